@@ -1,0 +1,156 @@
+/*
+ * mchap_hip.h -- C ABI of libmchap_hip.so: MI355X (gfx950) kernels for MCHap's per-locus
+ * MCMC haplotype assembler and exact genotype caller.
+ *
+ * The reference (PlantandFoodResearch/MCHap v0.11.1) has no FFI layer: its operator
+ * boundary is Python (paths relative to /root/reference/mchap/):
+ *   - DenovoMCMC.fit(reads, read_counts, initial) -> GenotypeMultiTrace   assemble/mcmc.py:24-161
+ *   - calling.exact.genotype_likelihoods / genotype_posteriors /
+ *     posterior_mode / posterior_allele_frequencies                      calling/exact.py:156-369
+ * Each entry point below names the reference interface it replaces.  INTEGRATION.md shows
+ * the ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions: plain pointers and sizes, caller allocates every output, the library never
+ * retains a pointer.  Return value 0 on success, negative MCHAP_ERR_* otherwise (see
+ * mchap_last_error()).  `*_device` entry points take DEVICE pointers and a hipStream_t
+ * (passed as void*), enqueue work and return without synchronising; the plain entry points
+ * take HOST pointers and are synchronous.
+ */
+#ifndef MCHAP_HIP_H
+#define MCHAP_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCHAP_MAX_TEMPS 16
+#define MCHAP_MAX_PLOIDY 8   /* nibble-packed labels; reference has no limit */
+#define MCHAP_MAX_ALLELE 8
+#define MCHAP_MAX_READS 1024 /* rows per unit after de-duplication */
+
+enum {
+  MCHAP_OK = 0,
+  MCHAP_ERR_NAN_LLK = -1,   /* ValueError("Encountered log likelihood of nan"), assemble/mcmc.py:330-331 */
+  MCHAP_ERR_BAD_ARG = -2,   /* AssertionError family: shapes, temperatures (assemble/mcmc.py:134,207,220,225-226) */
+  MCHAP_ERR_BREAKS = -3,    /* ValueError("breaks must be smaller then n"), assemble/structural.py:49-50 */
+  MCHAP_ERR_LIMIT = -4,     /* shape exceeds what the kernels support (ploidy, packed haplotype width, LDS) */
+  MCHAP_ERR_HIP = -5,       /* HIP runtime failure */
+  MCHAP_ERR_NO_DEVICE = -6
+};
+
+/* per-unit status written by the sampler kernel */
+enum {
+  MCHAP_UNIT_OK = 0,
+  MCHAP_UNIT_ALL_FIXED = 1, /* every position fixed homozygous: constant trace, llk = NaN (assemble/mcmc.py:189-199) */
+  MCHAP_UNIT_NAN_LLK = 2,
+  MCHAP_UNIT_BREAKS = 3
+};
+
+/* The fields of the DenovoMCMC dataclass (assemble/mcmc.py:24-40) that are common to a batch. */
+typedef struct mchap_denovo_cfg {
+  int32_t steps;                            /* steps */
+  int32_t chains;                           /* chains */
+  int32_t n_temps;                          /* len(temperatures) */
+  int32_t n_intervals;                      /* n_intervals, 0 == None */
+  double temperatures[MCHAP_MAX_TEMPS];     /* ascending, last == 1.0 (assemble/mcmc.py:224-226) */
+  double fix_homozygous;                    /* fix_homozygous */
+  double p_recomb;                          /* recombination_step_probability */
+  double p_partial_dosage;                  /* partial_dosage_step_probability */
+  double p_dosage;                          /* dosage_step_probability */
+  uint64_t seed;                            /* random_seed: Philox4x32-10 key */
+  const double *break_table;                /* HOST pointer, [(max_pos+1) x max_pos]: row m = Beta(alpha,beta) CDF
+                                               increments over m het bases (assemble/mcmc.py:429-452) */
+  int32_t max_pos;                          /* leading dimension of break_table */
+  int32_t reserved;
+} mchap_denovo_cfg;
+
+/* One unit = one (locus x sample) call of DenovoMCMC.fit.  Offsets are in ELEMENTS of the
+ * corresponding batch buffer. */
+typedef struct mchap_unit {
+  int64_t reads_off;     /* into reads: this unit's float64 [n_reads][n_pos][max_allele] tensor, C order */
+  int64_t counts_off;    /* into read_counts, or -1 == None */
+  int64_t nalleles_off;  /* into n_alleles: int8 [n_pos] */
+  int64_t initial_off;   /* into initial: int8 [chains][ploidy][n_het], or -1 == None */
+  int64_t trace_off;     /* into trace_words: uint64 [chains][steps][ploidy] */
+  int64_t llk_off;       /* into llks: float64 [chains][steps] */
+  int64_t fixed_off;     /* into fixed_alleles: int8 [n_pos] */
+  int32_t n_reads;
+  int32_t n_pos;
+  int32_t max_allele;
+  int32_t ploidy;
+  double inbreeding;     /* NaN == None (flat prior) */
+  uint64_t stream_id;    /* RNG stream of the unit: results do not depend on batch order or sharding */
+} mchap_unit;
+
+/* Replaces DenovoMCMC.fit (assemble/mcmc.py:103-161) for a batch of units.
+ *
+ * Outputs per unit:
+ *   trace_words  uint64 [chains][steps][ploidy]: the cold-chain genotype of every step with its haplotypes
+ *                packed over the NON-fixed positions (position 0 most significant, `bits` bits per allele,
+ *                bits = 1/2/3 for max_allele <= 2/4/8) and sorted ascending -- i.e. already in the
+ *                canonical order GenotypeMultiTrace.__post_init__ produces (assemble/classes.py:265-278).
+ *   llks         float64 [chains][steps]  (assemble/mcmc.py:418-425)
+ *   fixed_alleles int8 [n_pos]: -1 for sampled positions, else the allele fixed as homozygous
+ *                (assemble/mcmc.py:168-182,251-265); together with trace_words this is the full trace.
+ *   status       int32 per unit, MCHAP_UNIT_*.
+ * All pointers are device pointers; `units` too.  `stream` is a hipStream_t. */
+int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
+                                  const mchap_unit *units_host, const double *reads, const int64_t *read_counts,
+                                  const int8_t *n_alleles, const int8_t *initial, uint64_t *trace_words,
+                                  double *llks, int8_t *fixed_alleles, int32_t *status, void *stream);
+
+/* Same with host pointers: allocates device buffers, copies, runs, synchronises, copies back. */
+int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units,
+                           const double *reads, int64_t reads_len, const int64_t *read_counts, int64_t counts_len,
+                           const int8_t *n_alleles, int64_t nalleles_len, const int8_t *initial, int64_t initial_len,
+                           uint64_t *trace_words, int64_t trace_len, double *llks, int64_t llks_len,
+                           int8_t *fixed_alleles, int64_t fixed_len, int32_t *status);
+
+/* Test hook: log_likelihood (assemble/likelihood.py:17-70) of n_genotypes genotypes of one unit.
+ * Host pointers. genotypes int8 [n_genotypes][ploidy][n_pos]. */
+int mchap_log_likelihood_batch(const double *reads, int n_reads, int n_pos, int max_allele,
+                               const int64_t *read_counts, const int8_t *genotypes, int n_genotypes, int ploidy,
+                               double *llks_out);
+
+/* Posterior summary of a batch of traces: replaces GenotypeMultiTrace.burn(n).posterior() and the
+ * mode/support statistics the assemble program reads from it (assemble/classes.py:280-325,87-128,194-205;
+ * application/assemble.py:144-157).  Device pointers.
+ *   post_words  uint64 [n_units][max_states][ploidy_max]  distinct genotypes, probability descending
+ *   post_counts int32  [n_units][max_states]              occurrences after burn-in over all chains
+ *   post_n      int32  [n_units]                          number of distinct genotypes (may exceed max_states)
+ *   mode_stats  float64 [n_units][2]                      (support probability SPM, mode genotype probability GPM)
+ *   mode_index  int32  [n_units]                          index into post_words of the mode genotype of the mode support */
+int mchap_trace_posterior_batch_device(int n_units, const mchap_unit *units_dev, int steps, int chains, int burn,
+                                       const uint64_t *trace_words, int max_states, int ploidy_max,
+                                       uint64_t *post_words, int32_t *post_counts, int32_t *post_n,
+                                       double *mode_stats, int32_t *mode_index, void *stream);
+
+/* Exact caller: replaces calling.exact.genotype_likelihoods (calling/exact.py:266-292, float32 store) and,
+ * when post_out != NULL, genotype_posteriors (295-329).  Host pointers, one unit.
+ * prior: has_prior == 0 -> None; else (inbreeding, frequencies or NULL). */
+int mchap_exact_genotype_likelihoods(const double *reads, int n_reads, int n_pos, int max_allele,
+                                     const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy,
+                                     float *llks_out, double *llks64_out);
+
+/* Exact caller, streaming form: replaces calling.exact.posterior_mode (calling/exact.py:156-249) for a batch
+ * of units that share (n_reads, n_pos, max_allele, n_haps, ploidy).  Host pointers. */
+int mchap_exact_posterior_mode_batch(int n_units, const double *reads, int n_reads, int n_pos, int max_allele,
+                                     const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy,
+                                     int has_prior, const double *inbreeding, const double *frequencies,
+                                     int64_t *mode_alleles, double *mode_llk, double *mode_prob, double *support_prob,
+                                     double *freqs, double *occur);
+
+/* Introspection */
+const char *mchap_version(void);
+const char *mchap_last_error(void);
+int mchap_device_count(void);
+/* bytes of LDS one block of the sampler needs for this shape, or <0 if unsupported */
+int64_t mchap_denovo_lds_bytes(int n_reads, int n_pos, int max_allele, int ploidy, int chains, int n_temps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

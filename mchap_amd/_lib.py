@@ -1,0 +1,141 @@
+"""ctypes loader for libmchap_hip.so (the C ABI declared in include/mchap_hip.h).
+
+There is no CPU fallback: if the library is missing, or no MI355X is visible when a compute
+entry point is called, an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(CSRC, "libmchap_hip.so")
+
+MAX_TEMPS = 16
+MAX_PLOIDY = 8
+MAX_ALLELE = 8
+MAX_READS = 1024
+
+OK = 0
+ERR_NAN_LLK = -1
+ERR_BAD_ARG = -2
+ERR_BREAKS = -3
+ERR_LIMIT = -4
+ERR_HIP = -5
+ERR_NO_DEVICE = -6
+
+UNIT_OK = 0
+UNIT_ALL_FIXED = 1
+UNIT_NAN_LLK = 2
+UNIT_BREAKS = 3
+
+
+class DenovoCfg(C.Structure):
+    _fields_ = [
+        ("steps", C.c_int32),
+        ("chains", C.c_int32),
+        ("n_temps", C.c_int32),
+        ("n_intervals", C.c_int32),
+        ("temperatures", C.c_double * MAX_TEMPS),
+        ("fix_homozygous", C.c_double),
+        ("p_recomb", C.c_double),
+        ("p_partial_dosage", C.c_double),
+        ("p_dosage", C.c_double),
+        ("seed", C.c_uint64),
+        ("break_table", C.c_void_p),
+        ("max_pos", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+UNIT_DTYPE = np.dtype(
+    [
+        ("reads_off", "<i8"),
+        ("counts_off", "<i8"),
+        ("nalleles_off", "<i8"),
+        ("initial_off", "<i8"),
+        ("trace_off", "<i8"),
+        ("llk_off", "<i8"),
+        ("fixed_off", "<i8"),
+        ("n_reads", "<i4"),
+        ("n_pos", "<i4"),
+        ("max_allele", "<i4"),
+        ("ploidy", "<i4"),
+        ("inbreeding", "<f8"),
+        ("stream_id", "<u8"),
+    ],
+    align=True,
+)
+assert UNIT_DTYPE.itemsize == 88
+
+
+class MchapLibraryError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libmchap_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise MchapLibraryError(
+                "libmchap_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mchap_amd/csrc`. There is no CPU fallback." % SO
+            )
+        L = C.CDLL(SO)
+        L.mchap_version.restype = C.c_char_p
+        L.mchap_last_error.restype = C.c_char_p
+        L.mchap_denovo_lds_bytes.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+EXPORTS = [
+    "mchap_denovo_fit_batch_device",
+    "mchap_denovo_fit_batch",
+    "mchap_log_likelihood_batch",
+    "mchap_trace_posterior_batch_device",
+    "mchap_exact_genotype_likelihoods",
+    "mchap_exact_posterior_mode_batch",
+    "mchap_version",
+    "mchap_last_error",
+    "mchap_device_count",
+    "mchap_denovo_lds_bytes",
+]
+
+
+def last_error():
+    return lib().mchap_last_error().decode()
+
+
+def check(rc):
+    """Map a library return code to the exception type the reference raises."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == ERR_NAN_LLK:
+        raise ValueError("Encountered log likelihood of nan")
+    if rc == ERR_BREAKS:
+        raise ValueError("breaks must be smaller then n")
+    if rc == ERR_BAD_ARG:
+        raise AssertionError(msg)
+    if rc == ERR_LIMIT:
+        raise NotImplementedError("mchap_hip: " + msg)
+    raise MchapLibraryError("mchap_hip error %d: %s" % (rc, msg))
+
+
+def ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)

@@ -1,0 +1,297 @@
+// libmchap_hip.so -- host side of the C ABI declared in include/mchap_hip.h (gfx950 only).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/mchap_hip.h"
+#include "denovo_kernel.hpp"
+#include "exact_kernel.hpp"
+#include "posterior_kernel.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(MCHAP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+std::mutex g_init_mu;
+bool g_init_done[64] = {false};
+
+int ensure_init() {
+  int dev = 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(MCHAP_ERR_NO_DEVICE, "no HIP device visible: the MCHap kernels need an MI355X (gfx950)");
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (dev < 64 && g_init_done[dev]) return MCHAP_OK;
+  double ln[260], ln_inv[260];
+  for (int i = 0; i < 260; i++) {
+    ln[i] = std::log((double)i);
+    ln_inv[i] = std::log(1.0 / (double)i);
+  }
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln), ln, sizeof(ln)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln_inv), ln_inv, sizeof(ln_inv)));
+  if (dev < 64) g_init_done[dev] = true;
+  return MCHAP_OK;
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  template <class T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+int rpl_for(int max_reads) {
+  const int need = (max_reads + 63) / 64;
+  for (int r : {1, 2, 4, 8, 16})
+    if (need <= r) return r;
+  return -1;
+}
+
+template <int RPL>
+int launch_denovo(const mchap::DenovoParams &P, int n_units, int chains, size_t lds, hipStream_t stream) {
+  auto kern = mchap::denovo_mcmc_kernel<RPL>;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int cpb = chains < mchap::CHAINS_PER_BLOCK ? chains : mchap::CHAINS_PER_BLOCK;
+  hipLaunchKernelGGL(kern, dim3(n_units, (chains + cpb - 1) / cpb), dim3(64 * cpb), lds, stream, P);
+  HIP_TRY(hipGetLastError());
+  return MCHAP_OK;
+}
+
+int validate_cfg(const mchap_denovo_cfg *cfg) {
+  if (!cfg) return fail(MCHAP_ERR_BAD_ARG, "cfg is NULL");
+  if (cfg->steps < 1 || cfg->chains < 1) return fail(MCHAP_ERR_BAD_ARG, "steps and chains must be >= 1");
+  if (cfg->chains > 65535) return fail(MCHAP_ERR_LIMIT, "chains > 65535");
+  if (cfg->n_temps < 1 || cfg->n_temps > MCHAP_MAX_TEMPS) return fail(MCHAP_ERR_LIMIT, "n_temps out of range");
+  // assemble/mcmc.py:224-226
+  for (int t = 1; t < cfg->n_temps; t++)
+    if (cfg->temperatures[t] < cfg->temperatures[t - 1]) return fail(MCHAP_ERR_BAD_ARG, "temperatures must be ascending");
+  if (cfg->temperatures[0] < 0.0) return fail(MCHAP_ERR_BAD_ARG, "temperatures must be >= 0");
+  if (cfg->temperatures[cfg->n_temps - 1] != 1.0) return fail(MCHAP_ERR_BAD_ARG, "last temperature must be 1.0");
+  if (cfg->n_intervals == 0 && !cfg->break_table) return fail(MCHAP_ERR_BAD_ARG, "break_table required when n_intervals is None");
+  return MCHAP_OK;
+}
+
+// cached device copy of the break table
+std::mutex g_bt_mu;
+double *g_bt_dev = nullptr;
+size_t g_bt_cap = 0;
+
+}  // namespace
+
+extern "C" {
+
+const char *mchap_version(void) { return "mchap-hip 0.1 (gfx950; restates MCHap v0.11.1 assemble + calling.exact)"; }
+const char *mchap_last_error(void) { return g_err; }
+
+int mchap_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int64_t mchap_denovo_lds_bytes(int n_reads, int n_pos, int max_allele, int ploidy, int chains, int n_temps) {
+  const int rpl = rpl_for(n_reads < 1 ? 1 : n_reads);
+  if (rpl < 0 || ploidy > MCHAP_MAX_PLOIDY || max_allele > MCHAP_MAX_ALLELE || n_pos < 1) return -1;
+  const mchap::WaveLayout L = mchap::wave_layout(ploidy, n_pos, max_allele, n_temps);
+  const int cpb = chains < mchap::CHAINS_PER_BLOCK ? chains : mchap::CHAINS_PER_BLOCK;
+  return (int64_t)n_pos * max_allele * 64 * rpl * 8 + (int64_t)cpb * L.total;
+}
+
+int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
+                                  const mchap_unit *units_host, const double *reads, const int64_t *read_counts,
+                                  const int8_t *n_alleles, const int8_t *initial, uint64_t *trace_words, double *llks,
+                                  int8_t *fixed_alleles, int32_t *status, void *stream_) {
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  if (n_units <= 0) return MCHAP_OK;
+  if (!units_dev || !units_host || !reads || !n_alleles || !trace_words || !llks || !fixed_alleles || !status)
+    return fail(MCHAP_ERR_BAD_ARG, "NULL buffer");
+  rc = ensure_init();
+  if (rc) return rc;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+
+  int max_reads = 1, max_pos = 1;
+  size_t lds = 0;
+  for (int u = 0; u < n_units; u++) {
+    const mchap_unit &U = units_host[u];
+    if (U.ploidy < 1 || U.ploidy > MCHAP_MAX_PLOIDY) return fail(MCHAP_ERR_LIMIT, "unit %d: ploidy %d not in 1..%d", u, U.ploidy, MCHAP_MAX_PLOIDY);
+    if (U.max_allele < 1 || U.max_allele > MCHAP_MAX_ALLELE) return fail(MCHAP_ERR_LIMIT, "unit %d: max_allele %d not in 1..%d", u, U.max_allele, MCHAP_MAX_ALLELE);
+    if (U.n_reads < 1 || U.n_reads > MCHAP_MAX_READS) return fail(MCHAP_ERR_LIMIT, "unit %d: n_reads %d not in 1..%d (zero reads are mocked by the caller as one NaN read)", u, U.n_reads, MCHAP_MAX_READS);
+    if (U.n_pos < 1 || U.n_pos > 62) return fail(MCHAP_ERR_LIMIT, "unit %d: n_pos %d not in 1..62", u, U.n_pos);
+    if (cfg->n_intervals == 0 && U.n_pos > cfg->max_pos) return fail(MCHAP_ERR_BAD_ARG, "unit %d: n_pos exceeds break_table", u);
+    if (U.n_reads > max_reads) max_reads = U.n_reads;
+    if (U.n_pos > max_pos) max_pos = U.n_pos;
+  }
+  const int rpl = rpl_for(max_reads);
+  const int rpad = 64 * rpl;
+  for (int u = 0; u < n_units; u++) {
+    const mchap_unit &U = units_host[u];
+    const mchap::WaveLayout L = mchap::wave_layout(U.ploidy, U.n_pos, U.max_allele, cfg->n_temps);
+    const int cpb = cfg->chains < mchap::CHAINS_PER_BLOCK ? cfg->chains : mchap::CHAINS_PER_BLOCK;
+    const size_t need = (size_t)U.n_pos * U.max_allele * rpad * 8 + (size_t)cpb * L.total;
+    if (need > lds) lds = need;
+  }
+  if (lds > 160 * 1024)
+    return fail(MCHAP_ERR_LIMIT, "a unit needs %zu bytes of LDS (> 160 KiB): dense float64 staging does not fit", lds);
+
+  mchap::DenovoParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.units = units_dev;
+  P.reads = reads;
+  P.counts = read_counts;
+  P.n_alleles = n_alleles;
+  P.initial = initial;
+  P.trace = trace_words;
+  P.llks = llks;
+  P.fixed = fixed_alleles;
+  P.status = status;
+  P.steps = cfg->steps;
+  P.chains = cfg->chains;
+  P.n_temps = cfg->n_temps;
+  P.n_intervals = cfg->n_intervals;
+  for (int t = 0; t < cfg->n_temps; t++) P.temps[t] = cfg->temperatures[t];
+  P.fix_hom = cfg->fix_homozygous;
+  P.p_recomb = cfg->p_recomb;
+  P.p_partial = cfg->p_partial_dosage;
+  P.p_dosage = cfg->p_dosage;
+  P.seed = cfg->seed;
+  P.rpad = rpad;
+  P.max_pos = cfg->max_pos > 0 ? cfg->max_pos : 1;
+  {
+    std::lock_guard<std::mutex> lk(g_bt_mu);
+    const size_t n = (size_t)(P.max_pos + 1) * P.max_pos;
+    if (n > g_bt_cap) {
+      if (g_bt_dev) (void)hipFree(g_bt_dev);
+      HIP_TRY(hipMalloc(&g_bt_dev, n * sizeof(double)));
+      g_bt_cap = n;
+    }
+    if (cfg->break_table)
+      HIP_TRY(hipMemcpyAsync(g_bt_dev, cfg->break_table, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    else
+      HIP_TRY(hipMemsetAsync(g_bt_dev, 0, n * sizeof(double), stream));
+    P.break_table = g_bt_dev;
+  }
+  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * n_units, stream));
+  switch (rpl) {
+    case 1: return launch_denovo<1>(P, n_units, cfg->chains, lds, stream);
+    case 2: return launch_denovo<2>(P, n_units, cfg->chains, lds, stream);
+    case 4: return launch_denovo<4>(P, n_units, cfg->chains, lds, stream);
+    case 8: return launch_denovo<8>(P, n_units, cfg->chains, lds, stream);
+    case 16: return launch_denovo<16>(P, n_units, cfg->chains, lds, stream);
+  }
+  return fail(MCHAP_ERR_LIMIT, "unsupported reads-per-lane");
+}
+
+int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units, const double *reads,
+                           int64_t reads_len, const int64_t *read_counts, int64_t counts_len, const int8_t *n_alleles,
+                           int64_t nalleles_len, const int8_t *initial, int64_t initial_len, uint64_t *trace_words,
+                           int64_t trace_len, double *llks, int64_t llks_len, int8_t *fixed_alleles, int64_t fixed_len,
+                           int32_t *status) {
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  rc = ensure_init();
+  if (rc) return rc;
+  if (n_units <= 0) return MCHAP_OK;
+  DevBuf d_units, d_reads, d_counts, d_nal, d_init, d_trace, d_llk, d_fixed, d_status;
+  HIP_TRY(hipMalloc(&d_units.p, sizeof(mchap_unit) * n_units));
+  HIP_TRY(hipMalloc(&d_reads.p, sizeof(double) * (size_t)reads_len));
+  HIP_TRY(hipMalloc(&d_nal.p, (size_t)nalleles_len));
+  HIP_TRY(hipMalloc(&d_trace.p, sizeof(uint64_t) * (size_t)trace_len));
+  HIP_TRY(hipMalloc(&d_llk.p, sizeof(double) * (size_t)llks_len));
+  HIP_TRY(hipMalloc(&d_fixed.p, (size_t)fixed_len));
+  HIP_TRY(hipMalloc(&d_status.p, sizeof(int32_t) * n_units));
+  HIP_TRY(hipMemcpy(d_units.p, units, sizeof(mchap_unit) * n_units, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_reads.p, reads, sizeof(double) * (size_t)reads_len, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_nal.p, n_alleles, (size_t)nalleles_len, hipMemcpyHostToDevice));
+  if (read_counts && counts_len > 0) {
+    HIP_TRY(hipMalloc(&d_counts.p, sizeof(int64_t) * (size_t)counts_len));
+    HIP_TRY(hipMemcpy(d_counts.p, read_counts, sizeof(int64_t) * (size_t)counts_len, hipMemcpyHostToDevice));
+  }
+  if (initial && initial_len > 0) {
+    HIP_TRY(hipMalloc(&d_init.p, (size_t)initial_len));
+    HIP_TRY(hipMemcpy(d_init.p, initial, (size_t)initial_len, hipMemcpyHostToDevice));
+  }
+  rc = mchap_denovo_fit_batch_device(cfg, n_units, d_units.as<mchap_unit>(), units, d_reads.as<double>(),
+                                     d_counts.as<int64_t>(), d_nal.as<int8_t>(), d_init.as<int8_t>(),
+                                     d_trace.as<uint64_t>(), d_llk.as<double>(), d_fixed.as<int8_t>(),
+                                     d_status.as<int32_t>(), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(trace_words, d_trace.p, sizeof(uint64_t) * (size_t)trace_len, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(llks, d_llk.p, sizeof(double) * (size_t)llks_len, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(fixed_alleles, d_fixed.p, (size_t)fixed_len, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(status, d_status.p, sizeof(int32_t) * n_units, hipMemcpyDeviceToHost));
+  return MCHAP_OK;
+}
+
+int mchap_log_likelihood_batch(const double *reads, int n_reads, int n_pos, int max_allele, const int64_t *read_counts,
+                               const int8_t *genotypes, int n_genotypes, int ploidy, double *llks_out) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (n_genotypes <= 0) return MCHAP_OK;
+  const int rpl = rpl_for(n_reads);
+  if (rpl < 0 || n_reads < 1) return fail(MCHAP_ERR_LIMIT, "n_reads %d not in 1..%d", n_reads, MCHAP_MAX_READS);
+  if (ploidy < 1 || ploidy > MCHAP_MAX_PLOIDY) return fail(MCHAP_ERR_LIMIT, "ploidy %d not supported", ploidy);
+  if (n_pos * mchap::allele_bits(max_allele) > 64) return fail(MCHAP_ERR_LIMIT, "n_pos * bits > 64");
+  const size_t lds = (size_t)n_pos * max_allele * 64 * rpl * 8 + 4 * (8 * ploidy + 4 * n_pos + 64);
+  if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "unit needs %zu bytes of LDS", lds);
+  DevBuf d_reads, d_counts, d_g, d_out;
+  const size_t nr = (size_t)n_reads * n_pos * max_allele;
+  HIP_TRY(hipMalloc(&d_reads.p, nr * 8));
+  HIP_TRY(hipMemcpy(d_reads.p, reads, nr * 8, hipMemcpyHostToDevice));
+  if (read_counts) {
+    HIP_TRY(hipMalloc(&d_counts.p, (size_t)n_reads * 8));
+    HIP_TRY(hipMemcpy(d_counts.p, read_counts, (size_t)n_reads * 8, hipMemcpyHostToDevice));
+  }
+  const size_t ng = (size_t)n_genotypes * ploidy * n_pos;
+  HIP_TRY(hipMalloc(&d_g.p, ng));
+  HIP_TRY(hipMemcpy(d_g.p, genotypes, ng, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&d_out.p, (size_t)n_genotypes * 8));
+  const int blocks = n_genotypes < 1024 ? (n_genotypes + 3) / 4 : 256;
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_reads.as<double>(), n_reads, n_pos, max_allele,
+                       d_counts.as<int64_t>(), d_g.as<int8_t>(), n_genotypes, ploidy, 64 * rpl, d_out.as<double>());
+    HIP_TRY(hipGetLastError());
+    return MCHAP_OK;
+  };
+  switch (rpl) {
+    case 1: rc = go(mchap::llk_batch_kernel<1>); break;
+    case 2: rc = go(mchap::llk_batch_kernel<2>); break;
+    case 4: rc = go(mchap::llk_batch_kernel<4>); break;
+    case 8: rc = go(mchap::llk_batch_kernel<8>); break;
+    default: rc = go(mchap::llk_batch_kernel<16>); break;
+  }
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(llks_out, d_out.p, (size_t)n_genotypes * 8, hipMemcpyDeviceToHost));
+  return MCHAP_OK;
+}
+
+#include "api_posterior_exact.inc"
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// Trace -> posterior summary on the device: replaces the host-side Python of the reference's
+// GenotypeMultiTrace.burn(n).posterior() (assemble/classes.py:280-325, mset.unique_counts mset.py:361-392)
+// and PosteriorGenotypeDistribution.mode_genotype_support() / GenotypeSupportDistribution.mode_genotype()
+// (assemble/classes.py:87-128,194-205) as read by application/assemble.py:144-157.
+//
+// One wavefront per unit.  States (sorted genotypes = K packed haplotype words, written by the sampler) are
+// visited in the reference's merged order (chain-major, steps ascending after burn-in), 64 at a time; a list of
+// distinct states is kept in LDS in order of first appearance with their counts, exactly the order
+// mset.unique_counts produces.  The list is then ranked by (count descending, first appearance descending):
+// the order np.flip(np.argsort(probs)) gives for tied probabilities.
+#pragma once
+#include "denovo_kernel.hpp"
+
+namespace mchap {
+
+constexpr int POST_CAP = 512;  // distinct states kept per unit; more -> overflow flag (post_n = -n)
+
+struct PosteriorParams {
+  const mchap_unit *units;
+  const uint64_t *trace;
+  int steps, chains, burn;
+  int max_states, ploidy_max;
+  uint64_t *post_words;
+  int32_t *post_counts;
+  int32_t *post_n;
+  double *mode_stats;
+  int32_t *mode_index;
+};
+
+__global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const mchap_unit U = P.units[blockIdx.x];
+  const int K = U.ploidy;
+  const int lane = threadIdx.x;
+  const int S = P.steps, C_ = P.chains, burn = P.burn;
+  const int per_chain = S - burn;
+  const int N = C_ * per_chain;
+
+  uint64_t *uw = reinterpret_cast<uint64_t *>(smem);                  // [POST_CAP][K]
+  int *ucount = reinterpret_cast<int *>(smem + (size_t)POST_CAP * K * 8);  // [POST_CAP]
+  int *order = ucount + POST_CAP;                                     // [POST_CAP] rank -> unique index
+  int *label = order + POST_CAP;                                      // [POST_CAP] support label by rank
+  for (int i = lane; i < POST_CAP; i += WAVE) ucount[i] = 0;
+  __syncthreads();
+
+  int n_u = 0;        // wave-uniform
+  int overflow = 0;
+  for (int base = 0; base < N; base += WAVE) {
+    const int n = base + lane;
+    const bool active = n < N;
+    uint64_t st[MCHAP_MAX_PLOIDY];
+    if (active) {
+      const int ch = n / per_chain, s = burn + n % per_chain;
+      const uint64_t *src = P.trace + U.trace_off + ((size_t)ch * S + s) * K;
+#pragma unroll
+      for (int h = 0; h < MCHAP_MAX_PLOIDY; h++) st[h] = h < K ? src[h] : 0ull;
+    } else {
+#pragma unroll
+      for (int h = 0; h < MCHAP_MAX_PLOIDY; h++) st[h] = 0ull;
+    }
+    // match against the distinct states found so far
+    int found = -1;
+    for (int e = 0; e < n_u; e++) {
+      bool eq = true;
+#pragma unroll
+      for (int h = 0; h < MCHAP_MAX_PLOIDY; h++)
+        if (h < K) eq = eq && (uw[(size_t)e * K + h] == st[h]);
+      if (eq && found < 0) found = e;
+    }
+    // unresolved states become new distinct states in lane (= appearance) order
+    unsigned long long pending = __ballot(active && found < 0);
+    while (pending) {
+      const int leader = __ffsll((long long)pending) - 1;
+      bool eq = true;
+#pragma unroll
+      for (int h = 0; h < MCHAP_MAX_PLOIDY; h++) {
+        if (h < K) {
+          const uint64_t lw = __shfl(st[h], leader, WAVE);
+          eq = eq && (lw == st[h]);
+          if (lane == leader && n_u < POST_CAP) uw[(size_t)n_u * K + h] = lw;
+        }
+      }
+      if (active && found < 0 && eq) found = n_u < POST_CAP ? n_u : POST_CAP;
+      if (n_u < POST_CAP) n_u++;
+      else overflow++;
+      pending = __ballot(active && found < 0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    if (active && found >= 0 && found < POST_CAP) atomicAdd(&ucount[found], 1);
+    __syncthreads();
+  }
+
+  // rank by (count desc, first appearance desc)
+  for (int e = lane; e < n_u; e += WAVE) {
+    const int ce = ucount[e];
+    int rank = 0;
+    for (int f = 0; f < n_u; f++) {
+      const int cf = ucount[f];
+      rank += (cf > ce || (cf == ce && f > e)) ? 1 : 0;
+    }
+    order[rank] = e;
+    if (rank < P.max_states) {
+      uint64_t *dst = P.post_words + ((size_t)blockIdx.x * P.max_states + rank) * P.ploidy_max;
+      for (int h = 0; h < P.ploidy_max; h++) dst[h] = h < K ? uw[(size_t)e * K + h] : 0ull;
+      P.post_counts[(size_t)blockIdx.x * P.max_states + rank] = ce;
+    }
+  }
+  for (int r = n_u + lane; r < P.max_states; r += WAVE) {
+    uint64_t *dst = P.post_words + ((size_t)blockIdx.x * P.max_states + r) * P.ploidy_max;
+    for (int h = 0; h < P.ploidy_max; h++) dst[h] = 0ull;
+    P.post_counts[(size_t)blockIdx.x * P.max_states + r] = 0;
+  }
+  __syncthreads();
+
+  // support labels in ranked order: label[r] = first rank with the same set of distinct haplotypes
+  for (int r = lane; r < n_u; r += WAVE) {
+    const uint64_t *a = uw + (size_t)order[r] * K;
+    int lab = r;
+    for (int q = 0; q < r; q++) {
+      const uint64_t *b = uw + (size_t)order[q] * K;
+      // sorted words: equal supports <=> equal sequences of distinct words
+      int ia = 0, ib = 0;
+      bool same = true;
+      while (same && (ia < K || ib < K)) {
+        if (ia >= K || ib >= K) {
+          same = false;
+          break;
+        }
+        if (a[ia] != b[ib]) {
+          same = false;
+          break;
+        }
+        const uint64_t v = a[ia];
+        while (ia < K && a[ia] == v) ia++;
+        while (ib < K && b[ib] == v) ib++;
+      }
+      if (same) {
+        lab = q;
+        break;
+      }
+    }
+    label[r] = lab;
+  }
+  __syncthreads();
+  // support sums (sequential in ranked order, as the reference's dict accumulation) and their arg max
+  double best = -1.0;
+  int best_r = 0x7fffffff;
+  const double total = (double)N;
+  for (int r = lane; r < n_u; r += WAVE) {
+    if (label[r] != r) continue;
+    double sum = 0.0;
+    bool first = true;
+    for (int q = r; q < n_u; q++) {
+      if (label[q] != r) continue;
+      const double p = (double)ucount[order[q]] / total;
+      sum = first ? p : sum + p;
+      first = false;
+    }
+    if (sum > best) {
+      best = sum;
+      best_r = r;
+    }
+  }
+  // wave arg max, ties -> smallest rank (np.argmax over supports in order of appearance)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double ob = __shfl_xor(best, o, WAVE);
+    const int orr = __shfl_xor(best_r, o, WAVE);
+    if (ob > best || (ob == best && orr < best_r)) {
+      best = ob;
+      best_r = orr;
+    }
+  }
+  if (lane == 0) {
+    P.post_n[blockIdx.x] = overflow ? -(n_u + overflow) : n_u;
+    if (n_u > 0) {
+      P.mode_stats[2 * (size_t)blockIdx.x + 0] = best;                                    // SPM
+      P.mode_stats[2 * (size_t)blockIdx.x + 1] = (double)ucount[order[best_r]] / total;   // GPM
+      P.mode_index[blockIdx.x] = best_r;
+    } else {
+      P.mode_stats[2 * (size_t)blockIdx.x + 0] = NAN;
+      P.mode_stats[2 * (size_t)blockIdx.x + 1] = NAN;
+      P.mode_index[blockIdx.x] = -1;
+    }
+  }
+}
+
+inline size_t posterior_lds_bytes(int K) { return (size_t)POST_CAP * K * 8 + (size_t)POST_CAP * 4 * 3; }
+
+}  // namespace mchap

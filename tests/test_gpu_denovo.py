@@ -1,0 +1,153 @@
+"""GPU parity: the HIP sampler against the CPU oracle on the same Philox streams.
+
+Integer traces must be bit-exact, log-likelihoods within 1e-10 relative (fp64; the kernel sums reads in a
+different order).  All calls go through the C ABI (libmchap_hip.so)."""
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from tests.helpers import beta_break_table
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_trace(model, reads, n_alleles, rc, stream_id, initial=None, inbreeding="model", ploidy=None):
+    F = model.inbreeding if inbreeding == "model" else inbreeding
+    M = reads.shape[1]
+    cfg = orc.make_cfg(model.ploidy if ploidy is None else ploidy, model.steps, model.chains, F, model.temperatures,
+                       fix_homozygous=model.fix_homozygous, p_recomb=model.recombination_step_probability,
+                       p_partial_dosage=model.partial_dosage_step_probability, p_dosage=model.dosage_step_probability,
+                       n_intervals=model.n_intervals, llk_cache_threshold=-1, rng_kind=orc.RNG_PHILOX,
+                       seed=model.random_seed, stream_id=stream_id, break_table=beta_break_table(M, model.alpha, model.beta))
+    g, l, code = orc.denovo_fit(cfg, reads, n_alleles, rc, initial)
+    assert code == 0
+    return g, l
+
+
+def _check(model, reads_list, counts_list=None, initial=None, **kw):
+    from mchap_amd.classes import sort_haplotypes
+
+    traces = model.fit_batch(reads_list, counts_list, initial, **kw)
+    for u, tr in enumerate(traces):
+        rc = None if counts_list is None else counts_list[u]
+        ini = None if initial is None else initial[u]
+        F = "model" if kw.get("inbreeding") is None else kw["inbreeding"][u]
+        K = None if kw.get("ploidy") is None else kw["ploidy"][u]
+        g, l = _oracle_trace(model, reads_list[u], model.n_alleles, rc, u, ini, F, K)
+        assert tr.genotypes.dtype == np.int8
+        assert np.array_equal(tr.genotypes, sort_haplotypes(g)), "unit %d" % u
+        np.testing.assert_allclose(tr.llks, l, rtol=1e-10, atol=1e-9, equal_nan=True)
+
+
+def test_config2_shape_small_batch():
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(6, ploidy=4, n_pos=8, n_reads=200)
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=150, chains=2, random_seed=42)
+    _check(model, list(reads))
+
+
+@pytest.mark.parametrize("F", [None, 0.0, 0.1])
+@pytest.mark.parametrize("temps", [(1.0,), (0.2, 0.6, 1.0)])
+def test_priors_and_tempering(F, temps):
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(3, ploidy=4, n_pos=6, n_reads=48, first_unit=100)
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 6, inbreeding=F, steps=120, chains=2, temperatures=temps, random_seed=7)
+    _check(model, list(reads))
+
+
+@pytest.mark.parametrize("K,M,A,R", [(2, 5, 2, 30), (6, 4, 2, 70), (8, 5, 2, 100), (4, 5, 3, 40), (3, 3, 4, 20), (4, 12, 2, 300)])
+def test_shapes(K, M, A, R):
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(2, ploidy=K, n_pos=M, n_reads=R, n_alleles=A, first_unit=7, window=(2, M))
+    model = DenovoMCMC(ploidy=K, n_alleles=[A] * M, inbreeding=0.05, steps=60, chains=3, random_seed=11)
+    _check(model, list(reads))
+
+
+def test_read_counts_dedup_and_ragged_batch():
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import dedup_unit, synth_units
+
+    reads, _, _ = synth_units(4, ploidy=4, n_pos=8, n_reads=200, dedup=True, first_unit=50)
+    rl, cl = zip(*[dedup_unit(r) for r in reads])
+    assert len({len(r) for r in rl}) > 1  # ragged
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=100, chains=2, random_seed=3)
+    _check(model, list(rl), list(cl))
+
+
+def test_fixed_homozygous_zero_reads_initial_and_options():
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import as_probabilistic, synth_units
+
+    reads, calls, _ = synth_units(3, ploidy=4, n_pos=6, n_reads=150, first_unit=9)
+    # unit 0: two positions made homozygous; unit 1: as is; unit 2: zero reads
+    c0 = calls[0].copy()
+    c0[:, 1] = np.where(c0[:, 1] >= 0, 0, -1)
+    c0[:, 4] = np.where(c0[:, 4] >= 0, 1, -1)
+    r0 = as_probabilistic(c0, np.full(6, 2), 0.99)
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 6, steps=80, chains=2, random_seed=5, n_intervals=2,
+                       recombination_step_probability=0.3, partial_dosage_step_probability=0.8, dosage_step_probability=0.6)
+    rl = [r0, reads[1], np.empty((0, 6, 2))]
+    traces = model.fit_batch(rl)
+    assert (traces[0].genotypes[..., 1] == 0).all() and (traces[0].genotypes[..., 4] == 1).all()
+    _check(model, rl)
+    # all positions fixed -> constant trace, NaN llks (reference assemble/mcmc.py:189-199)
+    c_all = np.zeros((100, 3), dtype=np.int8)
+    c_all[:, 1] = 1
+    tr = DenovoMCMC(ploidy=4, n_alleles=[2, 2, 2], steps=10, chains=2, random_seed=1).fit(as_probabilistic(c_all, np.full(3, 2), 0.99))
+    assert np.isnan(tr.llks).all()
+    assert (tr.genotypes == np.array([0, 1, 0], dtype=np.int8)).all()
+    # user-supplied initial state
+    rng = np.random.default_rng(0)
+    ini = rng.integers(0, 2, size=(2, 4, 6)).astype(np.int8)
+    model2 = DenovoMCMC(ploidy=4, n_alleles=[2] * 6, steps=50, chains=2, random_seed=9, fix_homozygous=2.0)
+    _check(model2, [reads[1]], None, [ini])
+
+
+def test_per_unit_ploidy_and_inbreeding_and_stream_ids():
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    r4, _, _ = synth_units(2, ploidy=4, n_pos=6, n_reads=60, first_unit=30)
+    r2, _, _ = synth_units(1, ploidy=2, n_pos=6, n_reads=60, first_unit=40)
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 6, steps=60, chains=2, random_seed=21)
+    rl = [r4[0], r2[0], r4[1]]
+    _check(model, rl, ploidy=[4, 2, 4], inbreeding=[None, 0.3, 0.0])
+    # results depend on (seed, stream id) only, not on batch composition
+    a = model.fit_batch(rl, ploidy=[4, 2, 4], inbreeding=[None, 0.3, 0.0])
+    b = model.fit_batch([rl[2]], ploidy=[4], inbreeding=[0.0], stream_ids=[2])
+    assert np.array_equal(a[2].genotypes, b[0].genotypes) and np.array_equal(a[2].llks, b[0].llks)
+
+
+def test_errors():
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(1, ploidy=4, n_pos=4, n_reads=20)
+    with pytest.raises(AssertionError):
+        DenovoMCMC(ploidy=4, n_alleles=[2] * 4, temperatures=(0.5, 0.9), random_seed=1).fit(reads[0])
+    with pytest.raises(ValueError):
+        DenovoMCMC(ploidy=4, n_alleles=[2] * 4, n_intervals=6, steps=5, random_seed=1).fit(reads[0])
+    with pytest.raises(NotImplementedError):
+        DenovoMCMC(ploidy=12, n_alleles=[2] * 4, steps=5, random_seed=1).fit(reads[0])
+
+
+def test_log_likelihood_hook():
+    import ctypes as C
+    from mchap_amd import _lib
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(1, ploidy=4, n_pos=8, n_reads=200)
+    rng = np.random.default_rng(1)
+    g = rng.integers(0, 2, size=(50, 4, 8)).astype(np.int8)
+    out = np.zeros(50)
+    rd = np.ascontiguousarray(reads[0])
+    rc = rng.integers(1, 5, size=200).astype(np.int64)
+    _lib.check(_lib.lib().mchap_log_likelihood_batch(_lib.ptr(rd), 200, 8, 2, _lib.ptr(rc), _lib.ptr(g), 50, 4, _lib.ptr(out)))
+    expect = np.array([orc.log_likelihood(rd, gi, rc) for gi in g])
+    np.testing.assert_allclose(out, expect, rtol=1e-12)
