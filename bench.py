@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- loci/sec of the MCMC haplotype assembler hot path on MI355X.
+
+A "step" is one pass of the hot path (DenovoMCMC.fit for every unit of the batch, burn-in, posterior
+summary) over one batch of synthetic loci already resident in HBM.  Workload at N=1 = BASELINE.json
+configs[1]: 10k synthetic tetraploid loci, 8 SNVs, 200 reads, 1000 MCMC steps (2 chains, burn 500).
+With --gpus N every rank runs the same number of loci (weak scaling; loci are independent, so there is
+no data-path collective: only the timing barrier / max-over-ranks).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how roofline / cpu_baseline are defined.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--loci", type=int, default=10000, help="loci per GPU")
+    ap.add_argument("--mcmc-steps", type=int, default=1000)
+    ap.add_argument("--chains", type=int, default=2)
+    ap.add_argument("--burn", type=int, default=500)
+    ap.add_argument("--reads", type=int, default=200)
+    ap.add_argument("--snvs", type=int, default=8)
+    ap.add_argument("--ploidy", type=int, default=4)
+    ap.add_argument("--no-cache", action="store_true", help="disable the per-chain llk cache")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="units for the CPU baseline (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, cores):
+    """The oracle (C restatement incl. the reference's llk trie cache at its default threshold 100) timed on
+    the host cores over a bounded sample of the same workload."""
+    from oracle import binding as orc
+    from mchap_amd.assemble import break_table
+    from mchap_amd.synth import synth_units
+
+    n = args.cpu_sample or min(2000, 48 * cores)
+    reads, _, _ = synth_units(n, ploidy=args.ploidy, n_pos=args.snvs, n_reads=args.reads, first_unit=0)
+    cfg = orc.make_cfg(args.ploidy, args.mcmc_steps, args.chains, None, (1.0,), llk_cache_threshold=100, seed=42,
+                       rng_kind=orc.RNG_PHILOX, break_table=break_table(args.snvs, 1.0, 3.0))
+    orc.denovo_fit_batch(cfg, reads[: min(n, cores)], [2] * args.snvs, n_threads=cores, keep_traces=False)  # warm
+    t = time.perf_counter()
+    _, _, code, st = orc.denovo_fit_batch(cfg, reads, [2] * args.snvs, n_threads=cores, keep_traces=False)
+    dt = time.perf_counter() - t
+    assert code == 0
+    return {
+        "value": n / dt, "unit": "loci/s", "cores": cores, "kind": "port",
+        "sample": "%d loci of the same workload, oracle/mchap_oracle.c with llk cache threshold 100, OpenMP over loci, %.2f s wall"
+                  % (n, dt),
+        "llk_evals_per_locus": st.llk_evals / n, "llk_cache_hits_per_locus": st.llk_cache_hits / n,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl")
+
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.device import DenovoDeviceBatch
+    from mchap_amd.synth import synth_units
+
+    U = args.loci
+    first = rank * U  # rank r owns loci [r*U, (r+1)*U): contiguous shard, RNG keyed by global locus id
+    reads, _, _ = synth_units(U, ploidy=args.ploidy, n_pos=args.snvs, n_reads=args.reads, first_unit=first)
+    model = DenovoMCMC(ploidy=args.ploidy, n_alleles=[2] * args.snvs, steps=args.mcmc_steps, chains=args.chains,
+                       random_seed=42, llk_cache_threshold=-1 if args.no_cache else 100)
+    batch = DenovoDeviceBatch(model, reads, first_stream=first)
+    del reads
+
+    def one_pass(events=None):
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        batch.run()
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
+        batch.posterior(args.burn)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass(events)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    status = batch.d_status.cpu().numpy()
+    if (status > 1).any() or (status < 0).any():
+        raise SystemExit("sampler reported errors: %s" % np.unique(status))
+
+    if rank == 0:
+        total_units = U * world * args.steps
+        value = total_units / dt
+        # algorithmic HBM bytes per locus: float64 read tensor in, packed trace + llk out
+        bytes_in = args.reads * args.snvs * 2 * 8
+        bytes_out = args.chains * args.mcmc_steps * (args.ploidy * 8 + 8)
+        bytes_per_launch = U * (bytes_in + bytes_out)
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "loci/sec (whole node) for 1000-step MCMC, tetraploid 8-SNV loci, 1/2/4/8 GPUs",
+            "value": value,
+            "unit": "loci/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d synthetic tetraploid loci per GPU, %d SNVs, %d reads, %d MCMC steps x %d chains, burn %d, "
+                            "posterior summary (BASELINE.json configs[1])" % (U, args.snvs, args.reads, args.mcmc_steps, args.chains, args.burn),
+                "loci_per_gpu": U, "ploidy": args.ploidy, "snvs": args.snvs, "reads": args.reads,
+                "mcmc_steps": args.mcmc_steps, "chains": args.chains, "burn": args.burn,
+                "llk_cache": not args.no_cache, "parallelism": "loci sharded contiguously, %d rank(s), no data-path collective" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "denovo_mcmc_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": kern_ms,
+                "note": "the sampler is latency/issue-bound, not HBM-bound (DESIGN.md): the HBM fraction is reported as the contract asks",
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, os.cpu_count() or 1)
+            out["gpu_over_cpu_allcores"] = value / world / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,7 +64,7 @@ typedef struct mchap_denovo_cfg {
   const double *break_table;                /* HOST pointer, [(max_pos+1) x max_pos]: row m = Beta(alpha,beta) CDF
                                                increments over m het bases (assemble/mcmc.py:429-452) */
   int32_t max_pos;                          /* leading dimension of break_table */
-  int32_t reserved;
+  int32_t llk_cache;                        /* llk_cache_threshold >= 0: 1 = cache likelihoods per chain, 0 = recompute */
 } mchap_denovo_cfg;
 
 /* One unit = one (locus x sample) call of DenovoMCMC.fit.  Offsets are in ELEMENTS of the
@@ -100,7 +100,13 @@ typedef struct mchap_unit {
 int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
                                   const mchap_unit *units_host, const double *reads, const int64_t *read_counts,
                                   const int8_t *n_alleles, const int8_t *initial, uint64_t *trace_words,
-                                  double *llks, int8_t *fixed_alleles, int32_t *status, void *stream);
+                                  double *llks, int8_t *fixed_alleles, int32_t *status, void *workspace,
+                                  int64_t workspace_bytes, void *stream);
+
+/* Bytes of device workspace the sampler wants for its per-chain likelihood caches (the counterpart of the
+ * reference's llk cache, assemble/likelihood.py:151-305; results-neutral).  workspace may be NULL / smaller:
+ * the cache is then reduced or disabled. */
+int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units);
 
 /* Same with host pointers: allocates device buffers, copies, runs, synchronises, copies back. */
 int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units,

@@ -46,7 +46,7 @@ class DenovoCfg(C.Structure):
         ("seed", C.c_uint64),
         ("break_table", C.c_void_p),
         ("max_pos", C.c_int32),
-        ("reserved", C.c_int32),
+        ("llk_cache", C.c_int32),
     ]
 
 
@@ -95,10 +95,18 @@ def lib():
                 "libmchap_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C mchap_amd/csrc`. There is no CPU fallback." % SO
             )
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; whichever HIP runtime is loaded first serves the whole
+        # process (same soname).  Load torch's first when torch is installed so that tensors handed to the
+        # *_device entry points and this library share one runtime.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional for the host-pointer entry points
+            pass
         L = C.CDLL(SO)
         L.mchap_version.restype = C.c_char_p
         L.mchap_last_error.restype = C.c_char_p
         L.mchap_denovo_lds_bytes.restype = C.c_int64
+        L.mchap_denovo_workspace_bytes.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -114,6 +122,7 @@ EXPORTS = [
     "mchap_last_error",
     "mchap_device_count",
     "mchap_denovo_lds_bytes",
+    "mchap_denovo_workspace_bytes",
 ]
 
 

@@ -60,8 +60,8 @@ class DenovoMCMC(Assembler):
     """De novo haplotype assembly by MCMC over probabilistically encoded reads.
 
     Fields as in the reference (assemble/mcmc.py:26-40).  `random_seed=None` draws a seed from numpy's
-    global generator; `llk_cache_threshold` is accepted and ignored (the reference's likelihood cache is
-    results-neutral and the kernels recompute)."""
+    global generator; `llk_cache_threshold < 0` disables the per-chain likelihood cache, any other value enables
+    it (the cache is results-neutral, as in the reference)."""
 
     ploidy: int
     n_alleles: list
@@ -105,6 +105,8 @@ class DenovoMCMC(Assembler):
         cfg._keep = bt
         cfg.break_table = bt.ctypes.data
         cfg.max_pos = bt.shape[1]
+        # reference assemble/mcmc.py:306-312: a negative threshold disables the likelihood cache
+        cfg.llk_cache = 0 if (self.llk_cache_threshold is not None and self.llk_cache_threshold < 0) else 1
         return cfg
 
     def fit(self, reads, read_counts=None, initial=None):

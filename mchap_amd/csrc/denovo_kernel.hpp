@@ -54,6 +54,9 @@ struct DenovoParams {
   double fix_hom, p_recomb, p_partial, p_dosage;
   uint64_t seed;
   int rpad;  // 64 * RPL
+  // optional per-chain likelihood cache in HBM/L2: [units*chains][cache_slots] of {tag, llk}; 0 slots = off
+  uint64_t *cache;
+  int cache_slots;  // power of two
 };
 
 // ---- wave-private LDS scratch -------------------------------------------------------------
@@ -233,7 +236,32 @@ struct Chain {
   double inbreeding;  // NaN == None
   double luh;
   Rng rng;
+  uint64_t *cache;   // this chain's {tag, value} table or nullptr
+  uint32_t cache_mask;
+  int key_bits;      // bits per haplotype word actually used (Mh * bits)
 };
+
+// Likelihood cache: the reference memoises log_likelihood per genotype in an array-backed trie
+// (assemble/likelihood.py:151-305, arraymap.py) because a converged chain keeps proposing the same
+// neighbours; it is results-neutral (identical output with the cache off).  Here: one direct-mapped
+// table per chain in global memory (L2 / Infinity Cache resident), keyed by the exact packed genotype
+// when it fits 63 bits, else by a 64-bit mix of the haplotype words; the stored value is the llk this
+// same kernel computed for that key, so hits return bit-identical values.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+__device__ __forceinline__ uint64_t genotype_tag(const Chain &c, const uint64_t *hw) {
+  uint64_t t = 0;
+  if (c.key_bits * c.K <= 63) {
+    for (int h = 0; h < c.K; h++) t = (t << c.key_bits) | hw[h];
+  } else {
+    for (int h = 0; h < c.K; h++) t = mix64(t ^ hw[h]) + 0x9E3779B97F4A7C15ull;
+  }
+  return (t << 1) | 1ull;
+}
 
 template <int RPL>
 __device__ __forceinline__ double eval_llk(const Chain &c, const uint64_t *hw, const double (&cnt)[RPL]) {
@@ -258,6 +286,19 @@ __device__ __forceinline__ double eval_llk(const Chain &c, const uint64_t *hw, c
 #pragma unroll
   for (int i = 0; i < RPL; i++) s += log(acc[i]) * cnt[i];
   return wave_sum(s);
+}
+
+template <int RPL>
+__device__ __forceinline__ double eval_llk_cached(const Chain &c, const uint64_t *hw, const double (&cnt)[RPL]) {
+  if (!c.cache) return eval_llk<RPL>(c, hw, cnt);
+  const uint64_t tag = genotype_tag(c, hw);
+  const uint64_t slot = (c.key_bits * c.K <= 63 ? mix64(tag) : tag >> 1) & c.cache_mask;
+  ulonglong2 *e = reinterpret_cast<ulonglong2 *>(c.cache) + slot;
+  const ulonglong2 got = *e;  // one 16-byte load: {tag, llk bits}
+  if (got.x == tag) return __longlong_as_double((long long)got.y);
+  const double v = eval_llk<RPL>(c, hw, cnt);
+  if (c.lane == 0) *e = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(v));
+  return v;
 }
 
 // dosage (first-occurrence convention, jitutils.py:378-422) of K haplotype words -> nibble pack
@@ -329,7 +370,7 @@ __device__ inline double base_step(Chain &c, uint64_t *wt, double llk, int h, in
     } else {
       n_options += 1;
       c.pw[h] = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)i << sh);
-      const double llk_i = eval_llk<RPL>(c, c.pw, cnt);
+      const double llk_i = eval_llk_cached<RPL>(c, c.pw, cnt);
       c.llks[i] = llk_i;
       const double llk_ratio = llk_i - llk;
       double lprior_ratio = 0.0;
@@ -415,7 +456,7 @@ __device__ inline double interval_step(Chain &c, uint64_t *wt, double llk, int s
   for (int i = 0; i < n_options; i++) {
     const uint32_t oin = c.optin[i];
     for (int h = 0; h < K; h++) c.pw[h] = (wt[h] & ~min_) | (wt[nib(oin, h)] & min_);
-    const double llk_i = eval_llk<RPL>(c, c.pw, cnt);
+    const double llk_i = eval_llk_cached<RPL>(c, c.pw, cnt);
     c.llks[i] = llk_i;
     const double llk_ratio = llk_i - llk;
     double lprior_ratio = 0.0;
@@ -682,6 +723,13 @@ __global__ __launch_bounds__(64 * CHAINS_PER_BLOCK) void denovo_mcmc_kernel(cons
     luh += c_ln[c.nal[j]];  // assemble/mcmc.py:294
   }
   c.luh = luh;
+  c.key_bits = c.bits * Mh;
+  c.cache = nullptr;
+  c.cache_mask = 0;
+  if (P.cache_slots > 0) {
+    c.cache = P.cache + ((size_t)blockIdx.x * P.chains + chain) * (size_t)P.cache_slots * 2;
+    c.cache_mask = (uint32_t)P.cache_slots - 1u;
+  }
   if (!isnan(U.inbreeding)) {
     // tables for assemble/prior.py:39-112
     double *t = c.prior_tab;

@@ -94,6 +94,8 @@ int validate_cfg(const mchap_denovo_cfg *cfg) {
   return MCHAP_OK;
 }
 
+constexpr int CACHE_SLOTS = 512;  // {tag, llk} entries per chain
+
 // cached device copy of the break table
 std::mutex g_bt_mu;
 double *g_bt_dev = nullptr;
@@ -120,10 +122,16 @@ int64_t mchap_denovo_lds_bytes(int n_reads, int n_pos, int max_allele, int ploid
   return (int64_t)n_pos * max_allele * 64 * rpl * 8 + (int64_t)cpb * L.total;
 }
 
+int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units) {
+  if (!cfg || !cfg->llk_cache || n_units <= 0) return 0;
+  return (int64_t)n_units * cfg->chains * CACHE_SLOTS * 16;
+}
+
 int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
                                   const mchap_unit *units_host, const double *reads, const int64_t *read_counts,
                                   const int8_t *n_alleles, const int8_t *initial, uint64_t *trace_words, double *llks,
-                                  int8_t *fixed_alleles, int32_t *status, void *stream_) {
+                                  int8_t *fixed_alleles, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                  void *stream_) {
   int rc = validate_cfg(cfg);
   if (rc) return rc;
   if (n_units <= 0) return MCHAP_OK;
@@ -195,6 +203,18 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
     P.break_table = g_bt_dev;
   }
   HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * n_units, stream));
+  P.cache = nullptr;
+  P.cache_slots = 0;
+  if (cfg->llk_cache && workspace && workspace_bytes > 0) {
+    const int64_t rows = (int64_t)n_units * cfg->chains;
+    int slots = CACHE_SLOTS;
+    while (slots >= 16 && rows * slots * 16 > workspace_bytes) slots >>= 1;
+    if (slots >= 16) {
+      P.cache = reinterpret_cast<uint64_t *>(workspace);
+      P.cache_slots = slots;
+      HIP_TRY(hipMemsetAsync(workspace, 0, (size_t)(rows * slots * 16), stream));
+    }
+  }
   switch (rpl) {
     case 1: return launch_denovo<1>(P, n_units, cfg->chains, lds, stream);
     case 2: return launch_denovo<2>(P, n_units, cfg->chains, lds, stream);
@@ -215,7 +235,9 @@ int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap
   rc = ensure_init();
   if (rc) return rc;
   if (n_units <= 0) return MCHAP_OK;
-  DevBuf d_units, d_reads, d_counts, d_nal, d_init, d_trace, d_llk, d_fixed, d_status;
+  DevBuf d_units, d_reads, d_counts, d_nal, d_init, d_trace, d_llk, d_fixed, d_status, d_ws;
+  const int64_t ws_bytes = mchap_denovo_workspace_bytes(cfg, n_units);
+  if (ws_bytes > 0) HIP_TRY(hipMalloc(&d_ws.p, (size_t)ws_bytes));
   HIP_TRY(hipMalloc(&d_units.p, sizeof(mchap_unit) * n_units));
   HIP_TRY(hipMalloc(&d_reads.p, sizeof(double) * (size_t)reads_len));
   HIP_TRY(hipMalloc(&d_nal.p, (size_t)nalleles_len));
@@ -237,7 +259,7 @@ int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap
   rc = mchap_denovo_fit_batch_device(cfg, n_units, d_units.as<mchap_unit>(), units, d_reads.as<double>(),
                                      d_counts.as<int64_t>(), d_nal.as<int8_t>(), d_init.as<int8_t>(),
                                      d_trace.as<uint64_t>(), d_llk.as<double>(), d_fixed.as<int8_t>(),
-                                     d_status.as<int32_t>(), nullptr);
+                                     d_status.as<int32_t>(), d_ws.p, ws_bytes, nullptr);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(trace_words, d_trace.p, sizeof(uint64_t) * (size_t)trace_len, hipMemcpyDeviceToHost));

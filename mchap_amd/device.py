@@ -1,0 +1,123 @@
+"""Device-resident batches: inputs and outputs stay in HBM, kernels are enqueued on the caller's
+torch stream through the `*_device` entry points of the C ABI.  torch is used for device memory,
+streams and (in bench.py) torch.distributed only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .assemble import DenovoMCMC, unpack_trace
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise _lib.MchapLibraryError("no MI355X visible to torch: the device path needs a GPU (no CPU fallback)")
+    return torch
+
+
+class DenovoDeviceBatch:
+    """A batch of uniformly shaped units resident on one GPU.
+
+    reads : float64 [U, R, M, A] (numpy, copied once) ; read_counts : int64 [U, R] or None."""
+
+    def __init__(self, model: DenovoMCMC, reads, read_counts=None, first_stream=0, device=None):
+        torch = _torch()
+        self.torch = torch
+        self.model = model
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        reads = np.ascontiguousarray(reads, dtype=np.float64)
+        U, R, M, A = reads.shape
+        self.shape = (U, R, M, A)
+        K, Cn, S = int(model.ploidy), int(model.chains), int(model.steps)
+        self.K, self.Cn, self.S = K, Cn, S
+        units = np.zeros(U, dtype=_lib.UNIT_DTYPE)
+        idx = np.arange(U, dtype=np.int64)
+        units["reads_off"] = idx * (R * M * A)
+        units["counts_off"] = idx * R if read_counts is not None else -1
+        units["nalleles_off"] = 0
+        units["initial_off"] = -1
+        units["trace_off"] = idx * (Cn * S * K)
+        units["llk_off"] = idx * (Cn * S)
+        units["fixed_off"] = idx * M
+        units["n_reads"], units["n_pos"], units["max_allele"], units["ploidy"] = R, M, A, K
+        units["inbreeding"] = np.nan if model.inbreeding is None else float(model.inbreeding)
+        units["stream_id"] = (first_stream + idx).astype(np.uint64)
+        self.units_host = units
+        dev = self.device
+        self.d_units = torch.from_numpy(units.view(np.uint8).reshape(-1)).to(dev)
+        self.d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+        self.d_counts = None if read_counts is None else torch.from_numpy(np.ascontiguousarray(read_counts, dtype=np.int64).reshape(-1)).to(dev)
+        self.d_nalleles = torch.from_numpy(np.asarray(model.n_alleles, dtype=np.int8)).to(dev)
+        self.d_trace = torch.empty(U * Cn * S * K, dtype=torch.int64, device=dev)
+        self.d_llks = torch.empty(U * Cn * S, dtype=torch.float64, device=dev)
+        self.d_fixed = torch.empty(U * M, dtype=torch.int8, device=dev)
+        self.d_status = torch.empty(U, dtype=torch.int32, device=dev)
+        self.cfg = model._cfg(M)
+        L = _lib.lib()
+        self.ws_bytes = int(L.mchap_denovo_workspace_bytes(C.byref(self.cfg), U))
+        self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
+        self.post = None
+
+    def _p(self, t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def run(self):
+        """Enqueue the sampler on torch's current stream (no synchronisation)."""
+        L = _lib.lib()
+        stream = self.torch.cuda.current_stream().cuda_stream
+        rc = L.mchap_denovo_fit_batch_device(
+            C.byref(self.cfg), self.shape[0], self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_reads),
+            self._p(self.d_counts), self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks),
+            self._p(self.d_fixed), self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream))
+        _lib.check(rc)
+
+    def posterior(self, burn, max_states=32):
+        """Enqueue the posterior summary of the traces written by run()."""
+        torch = self.torch
+        U = self.shape[0]
+        if self.post is None or self.post["max_states"] != max_states:
+            dev = self.device
+            self.post = dict(
+                max_states=max_states,
+                words=torch.empty(U * max_states * self.K, dtype=torch.int64, device=dev),
+                counts=torch.empty(U * max_states, dtype=torch.int32, device=dev),
+                n=torch.empty(U, dtype=torch.int32, device=dev),
+                stats=torch.empty(U * 2, dtype=torch.float64, device=dev),
+                mode=torch.empty(U, dtype=torch.int32, device=dev),
+            )
+        P = self.post
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _lib.lib().mchap_trace_posterior_batch_device(
+            U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), int(max_states), self.K,
+            self._p(P["words"]), self._p(P["counts"]), self._p(P["n"]), self._p(P["stats"]), self._p(P["mode"]),
+            C.c_void_p(stream))
+        _lib.check(rc)
+
+    # ---- results back on the host ----
+    def traces(self):
+        U, R, M, A = self.shape
+        w = self.d_trace.cpu().numpy().view(np.uint64).reshape(U, self.Cn, self.S, self.K)
+        fixed = self.d_fixed.cpu().numpy().reshape(U, M)
+        llks = self.d_llks.cpu().numpy().reshape(U, self.Cn, self.S)
+        status = self.d_status.cpu().numpy()
+        return w, fixed, llks, status
+
+    def genotypes(self, u, words=None, fixed=None):
+        if words is None:
+            words, fixed, _, _ = self.traces()
+        return unpack_trace(words[u], fixed[u], self.shape[3])
+
+    def posterior_host(self):
+        P = self.post
+        U = self.shape[0]
+        ms = P["max_states"]
+        return dict(
+            words=P["words"].cpu().numpy().view(np.uint64).reshape(U, ms, self.K),
+            counts=P["counts"].cpu().numpy().reshape(U, ms),
+            n=P["n"].cpu().numpy(),
+            stats=P["stats"].cpu().numpy().reshape(U, 2),
+            mode=P["mode"].cpu().numpy(),
+        )

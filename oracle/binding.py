@@ -303,8 +303,12 @@ def denovo_fit_batch(cfg, reads, n_alleles, read_counts=None, n_threads=0, keep_
     U, R, M, A = reads.shape
     na = _i8(n_alleles)
     rc = _i64(read_counts)
-    g = np.zeros((U, cfg.chains, cfg.steps, cfg.ploidy, M), np.int8)
-    l = np.zeros((U, cfg.chains, cfg.steps))
+    g = l = None
+    if keep_traces:
+        g = np.zeros((U, cfg.chains, cfg.steps, cfg.ploidy, M), np.int8)
+        l = np.zeros((U, cfg.chains, cfg.steps))
+        g.fill(0)
+        l.fill(0.0)  # touch the pages outside the timed parallel region
     st = Stats()
     code = lib().orc_denovo_fit_batch(C.byref(cfg), U, int(n_threads), _p(reads, f64p), R, M, A, _p(rc, i64p), _p(na, i8p),
                                       _p(g, i8p), _p(l, f64p), C.byref(st))

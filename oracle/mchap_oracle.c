@@ -1255,25 +1255,38 @@ int orc_denovo_fit_batch(const orc_denovo_cfg *cfg, int n_units, int n_threads,
   orc_stats total = {0, 0, 0, 0};
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel
 #endif
-  for (int u = 0; u < n_units; u++) {
-    orc_denovo_cfg c = *cfg;
-    c.stream_id = cfg->stream_id + (uint64_t)u;
-    orc_stats st = {0, 0, 0, 0};
-    int rc = orc_denovo_fit(&c, reads + (size_t)u * rsz, n_reads, n_pos, max_allele,
-                            read_counts ? read_counts + (size_t)u * n_reads : NULL, n_alleles, NULL,
-                            genotypes_out ? genotypes_out + (size_t)u * gsz : NULL, llks_out + (size_t)u * lsz, &st);
+  {
+    /* per-thread scratch when the caller does not want the traces (CPU-baseline timing) */
+    int8_t *gscratch = genotypes_out ? NULL : (int8_t *)malloc(gsz);
+    double *lscratch = llks_out ? NULL : (double *)malloc(lsz * sizeof(double));
+    orc_stats mine = {0, 0, 0, 0};
+    int rc_mine = ORC_OK;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (int u = 0; u < n_units; u++) {
+      orc_denovo_cfg c = *cfg;
+      c.stream_id = cfg->stream_id + (uint64_t)u;
+      int rc = orc_denovo_fit(&c, reads + (size_t)u * rsz, n_reads, n_pos, max_allele,
+                              read_counts ? read_counts + (size_t)u * n_reads : NULL, n_alleles, NULL,
+                              genotypes_out ? genotypes_out + (size_t)u * gsz : gscratch,
+                              llks_out ? llks_out + (size_t)u * lsz : lscratch, &mine);
+      if (rc != ORC_OK) rc_mine = rc;
+    }
 #ifdef _OPENMP
 #pragma omp critical
 #endif
     {
-      if (rc != ORC_OK) rc_all = rc;
-      total.llk_evals += st.llk_evals;
-      total.llk_cache_hits += st.llk_cache_hits;
-      total.mutation_evals += st.mutation_evals;
-      total.structural_evals += st.structural_evals;
+      if (rc_mine != ORC_OK) rc_all = rc_mine;
+      total.llk_evals += mine.llk_evals;
+      total.llk_cache_hits += mine.llk_cache_hits;
+      total.mutation_evals += mine.mutation_evals;
+      total.structural_evals += mine.structural_evals;
     }
+    free(gscratch);
+    free(lscratch);
   }
   if (stats) *stats = total;
   return rc_all;

@@ -151,3 +151,25 @@ def test_log_likelihood_hook():
     _lib.check(_lib.lib().mchap_log_likelihood_batch(_lib.ptr(rd), 200, 8, 2, _lib.ptr(rc), _lib.ptr(g), 50, 4, _lib.ptr(out)))
     expect = np.array([orc.log_likelihood(rd, gi, rc) for gi in g])
     np.testing.assert_allclose(out, expect, rtol=1e-12)
+
+
+def test_llk_cache_is_results_neutral():
+    """Reference tests/test_application_assemble.py:356,390: identical output with the llk cache on and off."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(4, ploidy=4, n_pos=8, n_reads=200, first_unit=77)
+    for F, temps in ((None, (1.0,)), (0.1, (0.3, 1.0))):
+        kw = dict(ploidy=4, n_alleles=[2] * 8, inbreeding=F, steps=200, chains=2, temperatures=temps, random_seed=13)
+        on = DenovoMCMC(llk_cache_threshold=100, **kw).fit_batch(list(reads))
+        off = DenovoMCMC(llk_cache_threshold=-1, **kw).fit_batch(list(reads))
+        for a, b in zip(on, off):
+            assert np.array_equal(a.genotypes, b.genotypes)
+            assert np.array_equal(a.llks, b.llks)
+    # wide genotypes take the hashed-key path (K * Mh * bits > 63)
+    reads, _, _ = synth_units(2, ploidy=6, n_pos=14, n_reads=120, first_unit=5, window=(5, 14))
+    kw = dict(ploidy=6, n_alleles=[2] * 14, steps=60, chains=2, random_seed=2)
+    on = DenovoMCMC(llk_cache_threshold=100, **kw).fit_batch(list(reads))
+    off = DenovoMCMC(llk_cache_threshold=-1, **kw).fit_batch(list(reads))
+    for a, b in zip(on, off):
+        assert np.array_equal(a.genotypes, b.genotypes) and np.array_equal(a.llks, b.llks)
