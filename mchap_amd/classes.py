@@ -109,12 +109,17 @@ class PosteriorGenotypeDistribution(object):
             labels[i] = seen.setdefault(s, i)
         return labels
 
-    def mode_genotype_support(self):
-        """Genotypes congruent with the posterior mode support (reference classes.py:87-128)."""
+    def _support_sums(self):
         labels = self._support_labels()
         firsts = np.unique(labels)  # ascending == order of first appearance
         # sequential accumulation in order of appearance, as the reference's dict does
-        sums = np.array([_seq_sum(self.probabilities[labels == f]) for f in firsts])
+        return np.array([_seq_sum(self.probabilities[labels == f]) for f in firsts])
+
+    def mode_genotype_support(self):
+        """Genotypes congruent with the posterior mode support (reference classes.py:87-128)."""
+        labels = self._support_labels()
+        firsts = np.unique(labels)
+        sums = self._support_sums()
         mode = firsts[np.argmax(sums)]
         idx = labels == mode
         return GenotypeSupportDistribution(self.genotypes[idx], self.probabilities[idx])
@@ -247,8 +252,10 @@ class GenotypeMultiTrace(object):
         return new
 
     def posterior(self):
-        """Posterior over phased genotypes: distinct states, probability descending; ties come out in
-        descending order of first appearance (np.flip(np.argsort(probs)), reference classes.py:316-325)."""
+        """Posterior over phased genotypes: distinct states, probability descending (reference classes.py:316-325,
+        np.flip(np.argsort(probs))).  The reference leaves the order of TIED probabilities to numpy's default,
+        unstable argsort (it varies with the SIMD sort numpy dispatches to); here ties come out in descending order
+        of first appearance, which is what a stable sort gives and what the device kernel implements."""
         n_chain, n_step, ploidy, n_base = self.genotypes.shape
         genotypes = self.genotypes.reshape(n_chain * n_step, ploidy, n_base)
         states, counts = unique_counts(genotypes)

@@ -1,6 +1,6 @@
 // Philox4x32-10 counter-based streams for the sampler kernels (gfx950).
 //
-// Stream contract (shared with the CPU oracle, oracle/mchap_oracle.c "RNG"):
+// Stream contract (DESIGN.md "Random numbers"; the CPU checker under oracle/ restates it):
 //   key     = (seed_lo, seed_hi ^ stream_id_hi)
 //   counter = (block_lo, block_hi, substream, stream_id_lo),  substream = chain << 16 | slot,
 //             slot = temperature index, or 0xFFFF for the chain's initial-genotype stream

@@ -1,0 +1,90 @@
+"""Host mirrors of the reference's trace/posterior classes against vectors captured from the reference
+(tests/golden/trace_posterior.json).  CPU only."""
+import json
+import os
+
+import numpy as np
+
+from mchap_amd.classes import GenotypeMultiTrace, PosteriorGenotypeDistribution, sort_haplotypes, unique_counts
+
+
+def test_trace_to_posterior_pipeline(golden_dir):
+    with open(os.path.join(golden_dir, "trace_posterior.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 5
+    for c in cases:
+        raw = np.array(c["raw"], dtype=np.int8)
+        llks = np.zeros(raw.shape[:2])
+        trace = GenotypeMultiTrace(raw, llks)
+        assert np.array_equal(trace.genotypes, np.array(c["sorted"]))
+        burned = trace.burn(c["burn"])
+        post = burned.posterior()
+        assert np.array_equal(post.genotypes, np.array(c["post_genotypes"]))
+        np.testing.assert_allclose(post.probabilities, c["post_probs"], rtol=1e-15)
+        mode_g, mode_p = post.mode()
+        assert np.array_equal(mode_g, np.array(c["mode"][0])) and mode_p == c["mode"][1]
+        sup = post.mode_genotype_support()
+        assert np.array_equal(sup.genotypes, np.array(c["support_genotypes"]))
+        np.testing.assert_allclose(sup.probabilities, c["support_probs"], rtol=1e-15)
+        mg, mp = sup.mode_genotype()
+        assert np.array_equal(mg, np.array(c["mode_genotype"])) and mp == c["mode_prob"]
+        assert np.array_equal(sup.alleles(), np.array(c["support_alleles"]))
+        haps, fr, oc = post.allele_frequencies()
+        assert np.array_equal(haps, np.array(c["af_haps"]))
+        np.testing.assert_allclose(fr, c["af_freqs"], rtol=1e-13)
+        np.testing.assert_allclose(oc, c["af_occur"], rtol=1e-13)
+        # np.argsort's order of TIED probabilities is not defined by the reference (default quicksort: the SIMD
+        # sort numpy dispatches to on this CPU is unstable), so chains whose two best supports tie are skipped.
+        tie = False
+        for ch in burned.split():
+            sp = ch.posterior()._support_sums()
+            top = np.sort(sp)[::-1]
+            tie = tie or (len(top) > 1 and top[0] == top[1])
+        if not tie:
+            for thr, expect in c["incongruence"].items():
+                assert burned.replicate_incongruence(float(thr)) == expect
+
+
+def test_posterior_tie_order():
+    # probs [.25, .25, .5, 0] come out in order [2, 1, 0, 3]
+    g = np.zeros((1, 4, 2, 1), dtype=np.int8)
+    g[0, 0] = [[0], [0]]
+    g[0, 1] = [[0], [1]]
+    g[0, 2] = [[1], [1]]
+    g[0, 3] = [[1], [1]]
+    post = GenotypeMultiTrace(g, np.zeros((1, 4))).posterior()
+    assert post.probabilities.tolist() == [0.5, 0.25, 0.25]
+    assert post.genotypes[:, :, 0].tolist() == [[1, 1], [0, 1], [0, 0]]
+
+
+def test_sort_haplotypes_matches_lexsort():
+    rng = np.random.default_rng(0)
+    g = rng.integers(0, 3, size=(7, 5, 6, 9)).astype(np.int8)
+    s = sort_haplotypes(g)
+    for idx in np.ndindex(7, 5):
+        x = g[idx]
+        assert np.array_equal(s[idx], x[np.lexsort(np.flip(x, axis=-1).T)])
+
+
+def test_unique_counts_first_occurrence_order():
+    a = np.array([[1, 1], [0, 0], [1, 1], [2, 2], [0, 0], [1, 1]], dtype=np.int8)
+    u, c = unique_counts(a)
+    assert u.tolist() == [[1, 1], [0, 0], [2, 2]] and c.tolist() == [3, 2, 1]
+
+
+def test_call_genotype_support():
+    # reference tests/test_assemble/test_classes.py:183-248 scenario shape: threshold not met -> intersection padded with -1
+    genotypes = np.array([
+        [[0, 0, 0], [0, 0, 0], [0, 1, 1], [1, 1, 1]],
+        [[0, 0, 0], [0, 1, 1], [0, 1, 1], [1, 1, 1]],
+        [[0, 0, 0], [0, 1, 1], [1, 1, 1], [1, 1, 1]],
+    ], dtype=np.int8)
+    probs = np.array([0.5, 0.3, 0.2])
+    from mchap_amd.classes import GenotypeSupportDistribution
+
+    dist = GenotypeSupportDistribution(genotypes, probs)
+    g, p = dist.call_genotype_support(0.4)
+    assert np.array_equal(g, genotypes[0]) and p == 0.5
+    g, p = dist.call_genotype_support(0.7)
+    assert p == 0.8
+    assert g.tolist() == [[0, 0, 0], [0, 1, 1], [1, 1, 1], [-1, -1, -1]]
