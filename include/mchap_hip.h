@@ -141,6 +141,12 @@ int mchap_exact_genotype_likelihoods(const double *reads, int n_reads, int n_pos
                                      const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy,
                                      float *llks_out, double *llks64_out);
 
+/* Replaces calling.exact.genotype_posteriors (calling/exact.py:295-329) on a stored likelihood array (float32 as
+ * genotype_likelihoods returns it, or float64): priors in VCF order, normalisation; float64 result array whose
+ * values carry float32 precision when the input is float32, as in the reference.  Host pointers. */
+int mchap_exact_genotype_posteriors(const void *llks, int is_f32, int64_t n_genotypes, int ploidy, int n_alleles,
+                                    int has_prior, double inbreeding, const double *frequencies, double *post_out);
+
 /* Exact caller, streaming form: replaces calling.exact.posterior_mode (calling/exact.py:156-249) for a batch
  * of units that share (n_reads, n_pos, max_allele, n_haps, ploidy).  Host pointers. */
 int mchap_exact_posterior_mode_batch(int n_units, const double *reads, int n_reads, int n_pos, int max_allele,

@@ -117,6 +117,7 @@ EXPORTS = [
     "mchap_log_likelihood_batch",
     "mchap_trace_posterior_batch_device",
     "mchap_exact_genotype_likelihoods",
+    "mchap_exact_genotype_posteriors",
     "mchap_exact_posterior_mode_batch",
     "mchap_version",
     "mchap_last_error",
