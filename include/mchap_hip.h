@@ -65,6 +65,9 @@ typedef struct mchap_denovo_cfg {
                                                increments over m het bases (assemble/mcmc.py:429-452) */
   int32_t max_pos;                          /* leading dimension of break_table */
   int32_t llk_cache;                        /* llk_cache_threshold >= 0: 1 = cache likelihoods per chain, 0 = recompute */
+  int32_t kernel;                           /* 0 = default (lanes over chains), 1 = wavefront per chain with LDS-staged
+                                               reads, 2 = lanes over chains ("SIMT chains").  Same results either way. */
+  int32_t reserved;
 } mchap_denovo_cfg;
 
 /* One unit = one (locus x sample) call of DenovoMCMC.fit.  Offsets are in ELEMENTS of the
@@ -103,10 +106,10 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
                                   double *llks, int8_t *fixed_alleles, int32_t *status, void *workspace,
                                   int64_t workspace_bytes, void *stream);
 
-/* Bytes of device workspace the sampler wants for its per-chain likelihood caches (the counterpart of the
- * reference's llk cache, assemble/likelihood.py:151-305; results-neutral).  workspace may be NULL / smaller:
- * the cache is then reduced or disabled. */
-int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units);
+/* Bytes of device workspace the sampler needs: per-chain likelihood caches (the counterpart of the reference's llk
+ * cache, assemble/likelihood.py:151-305; results-neutral) and, for kernel 0/2, the transposed read tensors and
+ * per-unit tables written by its prepare pass. */
+int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host);
 
 /* Same with host pointers: allocates device buffers, copies, runs, synchronises, copies back. */
 int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units,

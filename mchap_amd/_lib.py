@@ -47,6 +47,8 @@ class DenovoCfg(C.Structure):
         ("break_table", C.c_void_p),
         ("max_pos", C.c_int32),
         ("llk_cache", C.c_int32),
+        ("kernel", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -9,6 +9,8 @@ MI355X visible.
 from dataclasses import dataclass
 
 import ctypes as C
+import os
+
 import numpy as np
 from scipy import stats as _stats
 
@@ -78,6 +80,7 @@ class DenovoMCMC(Assembler):
     temperatures: tuple = (1.0,)
     random_seed: int = None
     llk_cache_threshold: int = 100
+    kernel: int = 0  # not a reference field: 0 default, 1 wavefront-per-chain, 2 lanes-over-chains (same results)
 
     # ---- configuration shared by a batch ----
     def _cfg(self, max_pos):
@@ -107,6 +110,7 @@ class DenovoMCMC(Assembler):
         cfg.max_pos = bt.shape[1]
         # reference assemble/mcmc.py:306-312: a negative threshold disables the likelihood cache
         cfg.llk_cache = 0 if (self.llk_cache_threshold is not None and self.llk_cache_threshold < 0) else 1
+        cfg.kernel = int(self.kernel) if self.kernel else int(os.environ.get("MCHAP_HIP_KERNEL", "0"))
         return cfg
 
     def fit(self, reads, read_counts=None, initial=None):

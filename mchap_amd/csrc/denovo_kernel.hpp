@@ -134,7 +134,7 @@ __device__ __forceinline__ int choose_from(const double *p, int n, double u) {
 
 // first-occurrence dosage of the rows (in[h], out[h]) (jitutils.py:378-422 on label rows);
 // a zero nibble marks a duplicate.
-__device__ inline uint32_t dosage_of_labels(uint32_t in, uint32_t out, int K, bool use_out) {
+__device__ __forceinline__ uint32_t dosage_of_labels(uint32_t in, uint32_t out, int K, bool use_out) {
   uint32_t d = 0;
   for (int h = 0; h < K; h++) d |= 1u << (4 * h);
   for (int h = 0; h < K; h++) {
@@ -151,7 +151,7 @@ __device__ inline uint32_t dosage_of_labels(uint32_t in, uint32_t out, int K, bo
 }
 
 // structural.py:74-118
-__device__ inline int recombination_n_options(uint32_t in, uint32_t out, int K) {
+__device__ __forceinline__ int recombination_n_options(uint32_t in, uint32_t out, int K) {
   const uint32_t d = dosage_of_labels(in, out, K, true);
   int n = 0;
   for (int h0 = 0; h0 < K; h0++) {
@@ -166,7 +166,7 @@ __device__ inline int recombination_n_options(uint32_t in, uint32_t out, int K) 
 }
 
 // structural.py:181-237
-__device__ inline int dosage_n_options(uint32_t in, uint32_t out, int K) {
+__device__ __forceinline__ int dosage_n_options(uint32_t in, uint32_t out, int K) {
   const uint32_t hd = dosage_of_labels(in, out, K, true);
   const uint32_t sd = dosage_of_labels(in, out, K, false);
   int n = 0;

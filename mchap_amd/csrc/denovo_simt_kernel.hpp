@@ -1,0 +1,935 @@
+// De-novo MCMC sampler, "SIMT chains" form for MI355X (gfx950): one LANE per chain, 64 chains per wavefront.
+//
+// Why.  On the benchmark shape (and on real pileups) a converged chain keeps proposing the same neighbour
+// genotypes: with the reference's own likelihood cache (assemble/likelihood.py:151-305) 99.6 % of the requested
+// likelihood evaluations are cache hits (69.2 k requests -> 280 evaluations per locus, measured with the CPU
+// port).  What remains is the sequential book-keeping of ~40 dependent sub-steps per MCMC step: integer label /
+// dosage logic, one exp, one uniform draw, one cache probe.  A wavefront per chain (denovo_kernel.hpp) executes
+// that scalar work on 1 of 64 lanes; here every lane runs its own chain, so the same instruction stream advances
+// 64 chains, and the wavefront only co-operates (lanes over reads, wave shuffle reduction) when a lane misses its
+// cache.
+//
+// Pipeline: denovo_prepare_kernel (one workgroup per unit: homozygous fix, read tensor transposed to
+// [M0*A][RPAD] with NaN -> 1 in the workspace, initial-genotype distribution, prior tables) ->
+// denovo_simt_kernel (one wavefront per 64 chains).  Same algorithm, same Philox streams and therefore the same
+// traces as denovo_mcmc_kernel; reference citations as in denovo_kernel.hpp.
+#pragma once
+#include "denovo_kernel.hpp"
+
+namespace mchap {
+
+// per-unit metadata written by the prepare kernel
+constexpr int META_I_MH = 0;      // number of sampled (non-fixed) positions
+constexpr int META_I_STATUS = 1;  // MCHAP_UNIT_*
+constexpr int META_I_COLS = 2;    // then [M]: column (j * A) of sampled position jj ; then [M]: n_alleles
+__host__ __device__ inline int meta_i_stride(int max_pos) { return 2 + 2 * max_pos; }
+// doubles: [0] luh, [1..] prior table (2K+5), then dist [M*A]
+__host__ __device__ inline int meta_f_prior(int) { return 1; }
+__host__ __device__ inline int meta_f_dist(int max_ploidy) { return 1 + 2 * max_ploidy + 5; }
+__host__ __device__ inline int meta_f_stride(int max_ploidy, int max_pos, int max_allele) {
+  return 1 + 2 * max_ploidy + 5 + max_pos * max_allele;
+}
+
+struct SimtParams {
+  DenovoParams d;
+  // workspace carved by the host
+  double *rt;        // [U][max_ma][rpad]
+  double *cntw;      // [U][rpad]
+  int32_t *meta_i;   // [U][meta_i_stride]
+  double *meta_f;    // [U][meta_f_stride]
+  int n_units;
+  int max_pos, max_allele, max_ploidy;
+  int max_ma;        // max over units of n_pos * max_allele
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// prepare: grid = units, block = 64
+// ---------------------------------------------------------------------------------------------------------
+template <int RPL>
+__global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const DenovoParams &D = P.d;
+  const int u = blockIdx.x;
+  const mchap_unit U = D.units[u];
+  const int lane = threadIdx.x;
+  const int R = U.n_reads, M0 = U.n_pos, A = U.max_allele, K = U.ploidy;
+  const int rpad = D.rpad;
+  const int MA = M0 * A;
+  double *rl = reinterpret_cast<double *>(smem);  // [MA][rpad]
+  double *lp = rl + (size_t)MA * rpad;            // snv posterior scratch
+  const double *gr = D.reads + U.reads_off;
+  double *rt = P.rt + (size_t)u * P.max_ma * rpad;
+  double *cw = P.cntw + (size_t)u * rpad;
+  int32_t *mi = P.meta_i + (size_t)u * meta_i_stride(P.max_pos);
+  double *mf = P.meta_f + (size_t)u * meta_f_stride(P.max_ploidy, P.max_pos, P.max_allele);
+
+  for (int r = lane; r < rpad; r += WAVE) {
+    for (int q = 0; q < MA; q++) {
+      double v = 1.0;
+      if (r < R) {
+        v = gr[(size_t)r * MA + q];
+        if (isnan(v)) v = 1.0;
+      }
+      rl[(size_t)q * rpad + r] = v;
+      rt[(size_t)q * rpad + r] = v;
+    }
+  }
+  double cnt[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; i++) {
+    const int r = lane + WAVE * i;
+    cnt[i] = (r < R) ? (U.counts_off >= 0 ? (double)D.counts[U.counts_off + r] : 1.0) : 0.0;
+    cw[r] = cnt[i];
+  }
+  __syncthreads();
+  const int8_t *nalleles = D.n_alleles + U.nalleles_off;
+  // homozygous fix (assemble/mcmc.py:168-182, 494-541; snpcalling.py:14-70)
+  int Mh = 0;
+  double luh = 0.0;
+  for (int j = 0; j < M0; j++) {
+    const int n = nalleles[j];
+    const int u_gens = snv_genotypes(n, K);
+    uint32_t g = 0;
+    for (int q = 0; q < u_gens; q++) {
+      double lprior = 0.0;
+      if (!isnan(U.inbreeding)) lprior = snv_log_prior(g, K, n, U.inbreeding);
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < RPL; i++) {
+        double rp = 0.0;
+        for (int h = 0; h < K; h++) rp += rl[(size_t)(j * A + nib(g, h)) * rpad + lane + WAVE * i] / (double)K;
+        s += log(rp) * cnt[i];
+      }
+      const double llk = wave_sum(s);
+      lp[q] = lprior + llk;
+      g = increment_snv_genotype(g, K);
+    }
+    double acc = lp[0];
+    for (int q = 1; q < u_gens; q++) acc = add_log_prob(acc, lp[q]);
+    int fixed_allele = -1;
+    for (int a = 0; a < n; a++) {
+      int idx = 0;
+      for (int i = 0; i < K; i++) idx += (a == 0) ? 0 : snv_genotypes(a, i + 1);
+      if (exp(lp[idx] - acc) >= D.fix_hom) fixed_allele = a;
+    }
+    if (lane == 0) D.fixed[U.fixed_off + j] = (int8_t)fixed_allele;
+    if (fixed_allele < 0) {
+      if (lane == 0) {
+        mi[META_I_COLS + Mh] = j * A;
+        mi[META_I_COLS + P.max_pos + Mh] = n;
+      }
+      luh += c_ln[n];  // assemble/mcmc.py:294
+      Mh++;
+    }
+  }
+  const int bits = allele_bits(A);
+  int status = MCHAP_UNIT_OK;
+  if (Mh == 0) status = MCHAP_UNIT_ALL_FIXED;
+  else if (Mh * bits > 64) status = MCHAP_ERR_LIMIT;
+  if (lane == 0) {
+    mi[META_I_MH] = Mh;
+    mi[META_I_STATUS] = status;
+    D.status[u] = status;
+    mf[0] = luh;
+  }
+  if (status != MCHAP_UNIT_OK) {
+    if (status == MCHAP_UNIT_ALL_FIXED) {
+      // assemble/mcmc.py:189-199: constant trace, NaN llks
+      const size_t tb = U.trace_off, lb = U.llk_off;
+      const int S = D.steps, C_ = D.chains;
+      for (int i = lane; i < C_ * S * K; i += WAVE) D.trace[tb + i] = 0ull;
+      for (int i = lane; i < C_ * S; i += WAVE) D.llks[lb + i] = NAN;
+    }
+    return;
+  }
+  // prior tables (assemble/prior.py:39-112), same layout as Chain::prior_tab
+  if (!isnan(U.inbreeding) && lane == 0) {
+    double *t = mf + meta_f_prior(0);
+    const double F = U.inbreeding;
+    for (int d = 0; d <= K; d++) t[K + 1 + d] = lgamma((double)d + 1.0);
+    t[2 * K + 3] = lgamma((double)K + 1.0);
+    t[2 * K + 4] = (double)K * luh;
+    if (F != 0.0) {
+      const double log_disp = log((1.0 - F) / F) - luh;
+      const double disp = exp(log_disp);
+      const double sum_disp = exp(log_disp + luh);
+      const double lg_disp = lgamma(disp);
+      t[0] = 0.0;
+      for (int d = 1; d <= K; d++) t[d] = lgamma((double)d + disp) - (lgamma((double)d + 1.0) + lg_disp);
+      t[2 * K + 2] = (lgamma((double)K + 1.0) + lgamma(sum_disp)) - lgamma((double)K + sum_disp);
+    }
+  }
+  // _read_mean_dist (assemble/mcmc.py:455-491) over the sampled positions, from the raw tensor
+  if (U.initial_off < 0) {
+    double *dist = mf + meta_f_dist(P.max_ploidy);
+    __syncthreads();
+    for (int jj = 0; jj < Mh; jj++) {
+      const int col = mi[META_I_COLS + jj];
+      int n_nonzero = 0;
+      uint32_t gapmask = 0;
+      double dv[MCHAP_MAX_ALLELE];
+      for (int a = 0; a < A; a++) {
+        double tot = 0.0;
+        int n_ok = 0, n_nz = 0;
+        for (int r = lane; r < R; r += WAVE) {
+          const double v = gr[(size_t)r * MA + col + a];
+          if (!isnan(v)) {
+            tot += v;
+            n_ok++;
+          }
+          if (!(v == 0.0)) n_nz++;
+        }
+        tot = wave_sum(tot);
+        n_ok = wave_sum_i(n_ok);
+        n_nz = wave_sum_i(n_nz);
+        if (n_ok == 0) {
+          gapmask |= 1u << a;
+          dv[a] = 1.0;
+          n_nonzero++;
+        } else {
+          dv[a] = tot / (double)n_ok;
+          if (n_nz > 0) n_nonzero++;
+        }
+      }
+      for (int a = 0; a < A; a++)
+        if (gapmask & (1u << a)) dv[a] = 1.0 / (double)n_nonzero;
+      double s = 0.0;
+      for (int a = 1; a < A; a++) s += dv[a];
+      s = (A > 1) ? dv[0] + s : dv[0];
+      if (lane == 0)
+        for (int a = 0; a < A; a++) dist[jj * A + a] = dv[a] / s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sampler: one lane per chain
+// ---------------------------------------------------------------------------------------------------------
+struct SimtLds {
+  uint64_t *w;      // [T*Kmax][64]
+  uint64_t *pw;     // [Kmax][64]
+  double *llk_t;    // [T][64]
+  uint64_t *rngn;   // [T][64]
+  double *prior;    // [2Kmax+5][64]
+  uint32_t *optin;  // [Kmax*Kmax][64]
+  uint16_t *sub;    // [Kmax*Mmax][64]
+  uint16_t *cols;   // [Mmax][64]
+  uint8_t *shift;   // [Mmax][64]
+  uint8_t *nal;     // [Mmax][64]
+};
+
+__host__ __device__ inline size_t simt_lds_bytes(int Kmax, int Mmax, int T) {
+  size_t b = 0;
+  b += (size_t)8 * T * Kmax * 64;
+  b += (size_t)8 * Kmax * 64;
+  b += (size_t)8 * T * 64 * 2;
+  b += (size_t)8 * (2 * Kmax + 5) * 64;
+  b += (size_t)4 * Kmax * Kmax * 64;
+  b += (size_t)2 * Kmax * Mmax * 64;
+  b += (size_t)2 * Mmax * 64;
+  b += (size_t)1 * Mmax * 64 * 2;
+  return (b + 15) & ~(size_t)15;
+}
+
+struct Lane {
+  int K, Mh, bits, key_bits;
+  uint32_t amask;
+  double invK, inbreeding;
+  bool alive;            // lane owns a chain that is still running
+  const double *rt;      // unit's transposed reads [ma][rpad]
+  const double *cw;      // unit's counts [rpad]
+  ulonglong2 *cache;
+  uint32_t cache_mask;
+  Rng rng;
+};
+
+#define L_(arr, i) (arr)[(size_t)(i) * WAVE + lane]
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+
+// per-lane helpers on the lane's haplotype words (row `base` .. base+K-1 of an LDS [..][64] array)
+// KT > 0: compile-time ploidy shared by every chain of the launch (loops unroll to exactly K); KT == 0: per-lane K
+template <int KT>
+__device__ __forceinline__ uint32_t lane_dosage_of_words(const uint64_t *arr, int base, int K, int lane) {
+  constexpr int KM = KT ? KT : MCHAP_MAX_PLOIDY;
+  uint64_t x[KM];
+#pragma unroll
+  for (int h = 0; h < KM; h++) x[h] = h < K ? L_(arr, base + h) : 0ull;
+  uint32_t d = 0;
+#pragma unroll
+  for (int h = 0; h < KM; h++)
+    if (h < K) d |= 1u << (4 * h);
+#pragma unroll
+  for (int h = 0; h < KM; h++) {
+    if (h >= K || nib(d, h) == 0) continue;
+#pragma unroll
+    for (int p = 0; p < KM; p++) {
+      if (p <= h || p >= K || nib(d, p) == 0) continue;
+      if (x[h] == x[p]) {
+        d += 1u << (4 * h);
+        d &= ~(15u << (4 * p));
+      }
+    }
+  }
+  return d;
+}
+
+template <int KT>
+__device__ __forceinline__ int lane_count_copies(const uint64_t *arr, int base, int K, int h, int lane) {
+  constexpr int KM = KT ? KT : MCHAP_MAX_PLOIDY;
+  const uint64_t x = L_(arr, base + h);
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < KM; i++)
+    if (i < K) n += (L_(arr, base + i) == x) ? 1 : 0;
+  return n;
+}
+
+__device__ inline double lane_prior_of_dosage(const SimtLds &S, const Lane &c, uint32_t d, int lane) {
+  const int K = c.K;
+  if (c.inbreeding == 0.0) {
+    double den = 0.0;
+    for (int i = 0; i < K; i++) den += L_(S.prior, K + 1 + nib(d, i));
+    return (L_(S.prior, 2 * K + 3) - den) - L_(S.prior, 2 * K + 4);
+  }
+  double prod = 0.0;
+  for (int i = 0; i < K; i++) {
+    const uint32_t dose = nib(d, i);
+    if (dose > 0) prod += L_(S.prior, dose);
+  }
+  return L_(S.prior, 2 * K + 2) + prod;
+}
+
+template <int KT>
+__device__ __forceinline__ double lane_words_prior(const SimtLds &S, const Lane &c, const uint64_t *arr, int base, int lane) {
+  if (isnan(c.inbreeding)) return 0.0;
+  return lane_prior_of_dosage(S, c, lane_dosage_of_words<KT>(arr, base, KT ? KT : c.K, lane), lane);
+}
+
+template <int KT>
+__device__ __forceinline__ uint32_t lane_segment_labels(const uint64_t *arr, int base, int K, uint64_t mask, int lane) {
+  constexpr int KM = KT ? KT : MCHAP_MAX_PLOIDY;
+  uint64_t x[KM];
+#pragma unroll
+  for (int h = 0; h < KM; h++) x[h] = h < K ? (L_(arr, base + h) & mask) : 0ull;
+  uint32_t lab = 0;
+#pragma unroll
+  for (int h = 1; h < KM; h++) {
+    if (h >= K) continue;
+    int l = h;
+#pragma unroll
+    for (int g = KM - 1; g >= 0; g--)
+      if (g < h && x[g] == x[h]) l = g;  // smallest matching index wins
+    lab |= (uint32_t)l << (4 * h);
+  }
+  return lab;
+}
+
+__device__ __forceinline__ uint64_t lane_interval_mask(const Lane &c, int start, int stop) {
+  const int nb = c.bits * (stop - start);
+  const uint64_t ones = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+  const int sh = c.bits * (c.Mh - stop);
+  return sh >= 64 ? 0ull : ones << sh;
+}
+
+// Co-operative likelihood evaluation of the proposals S.pw[.][src] of every lane `src` with need set:
+// lanes over reads, coalesced 512-byte row reads of the unit's transposed tensor, wave butterfly sum.
+// The K*Mh row indices of a request are first computed one per lane and then broadcast with readlane, so the
+// global loads depend on nothing but registers and are issued back to back (one exposed L2 latency per request
+// instead of one per position).
+// one request: RPL chunks of 64 reads per lane; the pair loop is unrolled so that UNR * RPL row loads are in
+// flight before the first multiply (one exposed memory latency per UNR pairs, not per pair)
+template <int RPL>
+__device__ __forceinline__ double coop_body(const SimtLds &S, int src, int K, int Mh, uint32_t amask, double invK,
+                                            const double *rt, const double *cw, int rpad, int lane) {
+  constexpr int UNR = RPL <= 4 ? 8 : (RPL == 8 ? 4 : 2);
+  const int n_pairs = K * Mh;
+  double acc[RPL], prod[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; i++) {
+    acc[i] = 0.0;
+    prod[i] = 1.0;
+  }
+  for (int base = 0; base < n_pairs; base += WAVE) {
+    int myrow = 0;  // lane l owns pair base + l = (h, j)
+    {
+      const int p = base + lane;
+      if (p < n_pairs) {
+        const int h = p / Mh, j = p - h * Mh;
+        const uint64_t wh = S.pw[(size_t)h * WAVE + src];
+        const uint32_t a = (uint32_t)(wh >> S.shift[(size_t)j * WAVE + src]) & amask;
+        myrow = (int)S.cols[(size_t)j * WAVE + src] + (int)a;
+      }
+    }
+    const int lim = min(WAVE, n_pairs - base);
+    int jj = base % Mh;  // position of pair `base` inside its haplotype
+    for (int q0 = 0; q0 < lim; q0 += UNR) {
+      double v[UNR][RPL];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const int q = q0 + u;
+        const int row = __builtin_amdgcn_readlane(myrow, q < lim ? q : 0);
+        const double *rp = rt + (size_t)row * rpad;
+#pragma unroll
+        for (int i = 0; i < RPL; i++) v[u][i] = rp[WAVE * i];
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        if (q0 + u < lim) {
+#pragma unroll
+          for (int i = 0; i < RPL; i++) prod[i] *= v[u][i];
+          if (++jj == Mh) {  // haplotype complete
+            jj = 0;
+#pragma unroll
+            for (int i = 0; i < RPL; i++) {
+              acc[i] += prod[i] * invK;
+              prod[i] = 1.0;
+            }
+          }
+        }
+      }
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
+  return wave_sum(s);
+}
+
+// Co-operative likelihood evaluation of the proposals S.pw[.][src] of every lane `src` with need set:
+// lanes over reads, coalesced 512-byte row reads of the unit's transposed tensor, wave butterfly sum.
+// The K*Mh row indices of a request are first computed one per lane and then broadcast with readlane, so the
+// global loads depend on nothing but registers.
+__device__ inline double coop_eval(bool need, const SimtLds &S, const Lane &c, int rpad, int lane) {
+  double result = 0.0;
+  const int nch = rpad / WAVE;  // wave-uniform number of 64-read chunks
+  unsigned long long todo = __ballot(need);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int K = __builtin_amdgcn_readfirstlane(__shfl(c.K, src, WAVE));
+    const int Mh = __builtin_amdgcn_readfirstlane(__shfl(c.Mh, src, WAVE));
+    const uint32_t amask = (uint32_t)__shfl((int)c.amask, src, WAVE);
+    const double invK = __shfl(c.invK, src, WAVE);
+    const unsigned long long rtb = __shfl((unsigned long long)(uintptr_t)c.rt, src, WAVE);
+    const unsigned long long cwb = __shfl((unsigned long long)(uintptr_t)c.cw, src, WAVE);
+    const double *rt = reinterpret_cast<const double *>((uintptr_t)rtb) + lane;
+    const double *cw = reinterpret_cast<const double *>((uintptr_t)cwb) + lane;
+    double s;
+    if (nch == 4) s = coop_body<4>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    else if (nch == 1) s = coop_body<1>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    else if (nch == 2) s = coop_body<2>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    else if (nch == 8) s = coop_body<8>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    else s = coop_body<16>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    if (lane == src) result = s;
+  }
+  return result;
+}
+
+__device__ __forceinline__ uint64_t lane_genotype_tag(const SimtLds &S, const Lane &c, int lane) {
+  uint64_t t = 0;
+  if (c.key_bits * c.K <= 63) {
+    for (int h = 0; h < c.K; h++) t = (t << c.key_bits) | L_(S.pw, h);
+  } else {
+    for (int h = 0; h < c.K; h++) t = mix64(t ^ L_(S.pw, h)) + 0x9E3779B97F4A7C15ull;
+  }
+  return (t << 1) | 1ull;
+}
+
+#ifdef MCHAP_STATS
+__device__ unsigned long long g_stats[8];
+#define STAT_ADD(i, pred)                                                         \
+  do {                                                                            \
+    const int n_ = __popcll(__ballot(pred));                                      \
+    if (n_ && (threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)n_); \
+  } while (0)
+#else
+#define STAT_ADD(i, pred) \
+  do {                    \
+  } while (0)
+#endif
+
+// likelihood of the lane's proposal S.pw[.][lane] (where need): cache probe, co-operative evaluation on a miss.
+// The per-chain table is 4-way set associative (one 64-byte line per set): a hit in way k > 0 moves the entry one
+// way towards the front, a miss inserts into the last way, so the ~40 neighbours a converged chain proposes every
+// step stay resident however their keys collide.
+template <int KT>
+__device__ inline double lane_eval_cached(bool need, const SimtLds &S, const Lane &c, int rpad, int lane) {
+  double val = 0.0;
+  bool miss = need;
+  uint64_t tag = 0;
+  ulonglong2 *set = nullptr;
+  if (need && c.cache) {
+    tag = lane_genotype_tag(S, c, lane);
+    const uint64_t si = (c.key_bits * c.K <= 63 ? mix64(tag) : tag >> 1) & c.cache_mask;
+    set = c.cache + 4 * si;
+    const ulonglong2 e0 = set[0], e1 = set[1], e2 = set[2], e3 = set[3];
+    if (e0.x == tag) {
+      val = __longlong_as_double((long long)e0.y);
+      miss = false;
+    } else if (e1.x == tag) {
+      val = __longlong_as_double((long long)e1.y);
+      miss = false;
+      set[0] = e1;
+      set[1] = e0;
+    } else if (e2.x == tag) {
+      val = __longlong_as_double((long long)e2.y);
+      miss = false;
+      set[1] = e2;
+      set[2] = e1;
+    } else if (e3.x == tag) {
+      val = __longlong_as_double((long long)e3.y);
+      miss = false;
+      set[2] = e3;
+      set[3] = e2;
+    }
+  }
+  STAT_ADD(0, need);
+  STAT_ADD(1, miss);
+  STAT_ADD(2, true);  // probe rounds x 64 lanes
+  const double v = coop_eval(miss, S, c, rpad, lane);
+  if (miss) {
+    val = v;
+    if (set) set[3] = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(v));
+  }
+  return val;
+}
+
+// mutation.py:14-161 for every lane with act set; all lanes must call (co-operative evaluation inside)
+template <int KT>
+__device__ inline double simt_base_step(bool act, const SimtLds &S, Lane &c, int wb, double llk, int h, int j, double temp,
+                                        int amax, int rpad, int lane) {
+  const int K = KT ? KT : c.K;
+  int n_alleles = 0, sh = 0, current = 0;
+  double lhapcount = 0.0, lprior = 0.0;
+  uint64_t wh = 0;
+  if (act) {
+    n_alleles = L_(S.nal, j);
+    sh = L_(S.shift, j);
+    lhapcount = c_ln[lane_count_copies<KT>(S.w, wb, K, h, lane)];
+    lprior = lane_words_prior<KT>(S, c, S.w, wb, lane);
+    wh = L_(S.w, wb + h);
+    current = (int)((wh >> sh) & c.amask);
+    for (int i = 0; i < K; i++) L_(S.pw, i) = L_(S.w, wb + i);
+  }
+  double la[MCHAP_MAX_ALLELE], lk[MCHAP_MAX_ALLELE];
+  int n_options = 0;
+#pragma unroll
+  for (int i = 0; i < MCHAP_MAX_ALLELE; i++) {
+    la[i] = -INFINITY;
+    lk[i] = llk;
+    if (i >= amax) continue;  // wave-uniform bound
+    const bool prop = act && i < n_alleles && i != current;
+    if (prop) {
+      n_options += 1;
+      L_(S.pw, h) = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)i << sh);
+    }
+    const double llk_i = lane_eval_cached<KT>(prop, S, c, rpad, lane);
+    if (prop) {
+      lk[i] = llk_i;
+      const double llk_ratio = llk_i - llk;
+      double lprior_ratio = 0.0;
+      if (!isnan(c.inbreeding)) lprior_ratio = lane_words_prior<KT>(S, c, S.pw, 0, lane) - lprior;
+      const double lproposal_ratio = c_ln[lane_count_copies<KT>(S.pw, 0, K, h, lane)] - lhapcount;
+      const double mh = (llk_ratio + lprior_ratio) * temp + lproposal_ratio;
+      la[i] = fmin(0.0, mh);
+    }
+  }
+  if (!act) return llk;
+  const double ln_opt = c_ln[n_options];
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < MCHAP_MAX_ALLELE; i++) {
+    if (i < n_alleles) {
+      la[i] = exp(la[i] - ln_opt);
+      sum += la[i];
+    }
+  }
+  const double stay = 1.0 - sum;
+  const double u = rng_double(c.rng);
+  double cacc = 0.0;
+  int choice = n_alleles;
+  double llk_new = llk;
+#pragma unroll
+  for (int i = 0; i < MCHAP_MAX_ALLELE; i++) {
+    if (i < n_alleles && choice == n_alleles) {
+      cacc += (i == current) ? stay : la[i];
+      if (cacc > u) {
+        choice = i;
+        llk_new = lk[i];
+      }
+    }
+  }
+  if (choice >= n_alleles) {
+    choice = n_alleles - 1;
+#pragma unroll
+    for (int i = 0; i < MCHAP_MAX_ALLELE; i++)
+      if (i == choice) llk_new = lk[i];
+  }
+  L_(S.w, wb + h) = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)choice << sh);
+  return llk_new;
+}
+
+// structural.py:433-587 for every lane with act set
+template <int KT>
+__device__ inline double simt_interval_step(bool act, const SimtLds &S, Lane &c, int wb, double llk, int start, int stop,
+                                            int step_type, double temp, int rpad, int lane) {
+  const int K = KT ? KT : c.K;
+  uint64_t min_ = 0;
+  uint32_t lout = 0;
+  int n_options = 0;
+  double lprior = 0.0, log_proposal_prob = 0.0, ln_opt = 0.0, u = 2.0;
+  if (act) {
+    const uint64_t full = lane_interval_mask(c, 0, c.Mh);
+    min_ = lane_interval_mask(c, start, stop);
+    const uint32_t lin = lane_segment_labels<KT>(S.w, wb, K, min_, lane);
+    lout = lane_segment_labels<KT>(S.w, wb, K, full & ~min_, lane);
+    // enumerate straight into the lane's LDS column
+    {
+      const uint32_t hd = dosage_of_labels(lin, lout, K, true);
+      if (step_type == 0) {
+        for (int h0 = 0; h0 < K; h0++) {
+          if (nib(hd, h0) == 0) continue;
+          for (int h1 = h0 + 1; h1 < K; h1++) {
+            if (nib(hd, h1) == 0) continue;
+            if (nib(lin, h0) == nib(lin, h1) || nib(lout, h0) == nib(lout, h1)) continue;
+            uint32_t o = nib_set(lin, h0, nib(lin, h1));
+            o = nib_set(o, h1, nib(lin, h0));
+            L_(S.optin, n_options) = o;
+            n_options++;
+          }
+        }
+      } else {
+        const uint32_t sd = dosage_of_labels(lin, lout, K, false);
+        for (int h0 = 0; h0 < K; h0++) {
+          if (nib(hd, h0) == 0) continue;
+          if (nib(sd, h0) == 1) continue;
+          for (int h1 = 0; h1 < K; h1++) {
+            if (nib(sd, h1) == 0) continue;
+            if (nib(lin, h0) == nib(lin, h1)) continue;
+            L_(S.optin, n_options) = nib_set(lin, h0, nib(lin, h1));
+            n_options++;
+          }
+        }
+      }
+    }
+    if (n_options > 0) {
+      log_proposal_prob = c_ln_inv[n_options];
+      ln_opt = c_ln[n_options];
+      if (!isnan(c.inbreeding)) lprior = lane_words_prior<KT>(S, c, S.w, wb, lane);
+      u = rng_double(c.rng);  // the only draw of this step; the evaluations below consume none
+    }
+  }
+  const int nmax = wave_max_i(n_options);
+  double cacc = 0.0;
+  int choice = -1;
+  double llk_choice = llk;
+  for (int i = 0; i < nmax; i++) {
+    const bool prop = act && i < n_options && choice < 0;  // options after the chosen one cannot matter
+    uint32_t oin = 0;
+    if (prop) {
+      oin = L_(S.optin, i);
+      for (int h = 0; h < K; h++) L_(S.pw, h) = (L_(S.w, wb + h) & ~min_) | (L_(S.w, wb + nib(oin, h)) & min_);
+    }
+    const double llk_i = lane_eval_cached<KT>(prop, S, c, rpad, lane);
+    if (prop) {
+      const double llk_ratio = llk_i - llk;
+      double lprior_ratio = 0.0;
+      if (!isnan(c.inbreeding)) lprior_ratio = lane_prior_of_dosage(S, c, dosage_of_labels(oin, lout, K, true), lane) - lprior;
+      const int n_return = step_type == 0 ? recombination_n_options(oin, lout, K) : dosage_n_options(oin, lout, K);
+      const double lproposal_ratio = c_ln_inv[n_return] - log_proposal_prob;
+      const double mh = (llk_ratio + lprior_ratio) * temp + lproposal_ratio;
+      cacc += exp(fmin(0.0, mh) - ln_opt);
+      if (cacc > u) {
+        choice = i;
+        llk_choice = llk_i;
+      }
+    }
+  }
+  if (act && choice >= 0) {
+    const uint32_t oin = L_(S.optin, choice);
+    for (int h = 0; h < K; h++) L_(S.pw, h) = (L_(S.w, wb + h) & ~min_) | (L_(S.w, wb + nib(oin, h)) & min_);
+    for (int h = 0; h < K; h++) L_(S.w, wb + h) = L_(S.pw, h);
+    llk = llk_choice;
+  }
+  return llk;
+}
+
+// structural.py:22-71 + 590-673 for every lane with act set.  Returns false for lanes that hit the ValueError.
+template <int KT>
+__device__ inline bool simt_structural_compound(bool act, const SimtLds &S, Lane &c, int wb, double &llk, int n_breaks,
+                                                bool whole, int step_type, double temp, int rpad, int lane) {
+  bool ok = true;
+  uint64_t zeros = 0;  // bit i set = interval end point i
+  int n_int = 0;
+  if (act) {
+    const int n = c.Mh;
+    if (whole) {
+      zeros = 1ull | (1ull << n);
+      n_int = 1;
+    } else if (n_breaks >= n) {
+      ok = false;
+      act = false;
+    } else {
+      uint64_t ind = 0;
+      for (int i = 1; i < n; i++) ind |= 1ull << i;
+      for (int b = 0; b < n_breaks; b++) {
+        const int no = __popcll(ind);
+        if (no == 0) break;
+        int k = (int)rng_interval(c.rng, (uint32_t)(no - 1));
+        uint64_t t = ind;
+        while (k-- > 0) t &= t - 1;
+        ind &= ~(t & (~t + 1));
+      }
+      zeros = ~ind & ((1ull << (n + 1)) - 1ull);
+      n_int = n_breaks + 1;
+    }
+    if (act) {
+      for (int i = 0; i < n_int; i++) L_(S.sub, i) = (uint16_t)i;
+      for (int i = n_int - 1; i >= 1; i--) {
+        const int k = (int)rng_interval(c.rng, (uint32_t)i);
+        const uint16_t a = L_(S.sub, i), b = L_(S.sub, k);
+        L_(S.sub, i) = b;
+        L_(S.sub, k) = a;
+      }
+    }
+  }
+  const int nmax = wave_max_i(act ? n_int : 0);
+  for (int i = 0; i < nmax; i++) {
+    const bool a2 = act && i < n_int;
+    int start = 0, stop = 0;
+    if (a2) {
+      const int iv = L_(S.sub, i);
+      // end points iv and iv+1 = the (iv)-th and (iv+1)-th set bits of zeros
+      uint64_t z = zeros;
+      for (int q = 0; q < iv; q++) z &= z - 1;
+      start = __ffsll((long long)z) - 1;
+      z &= z - 1;
+      stop = __ffsll((long long)z) - 1;
+    }
+    llk = simt_interval_step<KT>(a2, S, c, wb, llk, start, stop, step_type, temp, rpad, lane);
+  }
+  return ok;
+}
+
+template <int KT>
+__global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const DenovoParams &D = P.d;
+  const int lane = threadIdx.x;
+  const int T = D.n_temps, Cn = D.chains, Sn = D.steps;
+  const int Kmax = P.max_ploidy, Mmax = P.max_pos;
+  const int rpad = D.rpad;
+  // LDS carve (lane-strided arrays)
+  SimtLds S;
+  {
+    unsigned char *p = smem;
+    S.w = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * T * Kmax * 64;
+    S.pw = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * Kmax * 64;
+    S.llk_t = reinterpret_cast<double *>(p); p += (size_t)8 * T * 64;
+    S.rngn = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * T * 64;
+    S.prior = reinterpret_cast<double *>(p); p += (size_t)8 * (2 * Kmax + 5) * 64;
+    S.optin = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * Kmax * Kmax * 64;
+    S.sub = reinterpret_cast<uint16_t *>(p); p += (size_t)2 * Kmax * Mmax * 64;
+    S.cols = reinterpret_cast<uint16_t *>(p); p += (size_t)2 * Mmax * 64;
+    S.shift = p; p += (size_t)Mmax * 64;
+    S.nal = p;
+  }
+  const long long q = (long long)blockIdx.x * WAVE + lane;  // global chain index
+  const long long n_chains = (long long)P.n_units * Cn;
+  Lane c;
+  c.alive = q < n_chains;
+  const int u = c.alive ? (int)(q / Cn) : 0;
+  const int chain = c.alive ? (int)(q % Cn) : 0;
+  const mchap_unit U = D.units[u];
+  const int32_t *mi = P.meta_i + (size_t)u * meta_i_stride(P.max_pos);
+  const double *mf = P.meta_f + (size_t)u * meta_f_stride(P.max_ploidy, P.max_pos, P.max_allele);
+  if (c.alive && mi[META_I_STATUS] != MCHAP_UNIT_OK) c.alive = false;
+  const int A = U.max_allele;
+  c.K = c.alive ? U.ploidy : 1;
+  c.Mh = c.alive ? mi[META_I_MH] : 1;
+  c.bits = allele_bits(A);
+  c.amask = (1u << c.bits) - 1u;
+  c.invK = 1.0 / (double)c.K;
+  c.inbreeding = U.inbreeding;
+  c.key_bits = c.bits * c.Mh;
+  c.rt = P.rt + (size_t)u * P.max_ma * rpad;
+  c.cw = P.cntw + (size_t)u * rpad;
+  c.cache = nullptr;
+  c.cache_mask = 0;
+  if (D.cache_slots > 0) {
+    c.cache = reinterpret_cast<ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots;
+    c.cache_mask = (uint32_t)(D.cache_slots / 4) - 1u;  // sets of 4 ways
+  }
+  const int K = KT ? KT : c.K;
+  const int Mh = c.Mh;
+  for (int j = 0; j < Mh; j++) {
+    L_(S.cols, j) = (uint16_t)(c.alive ? mi[META_I_COLS + j] : 0);
+    L_(S.nal, j) = (uint8_t)(c.alive ? mi[META_I_COLS + P.max_pos + j] : 2);
+    L_(S.shift, j) = (uint8_t)(c.bits * (Mh - 1 - j));
+  }
+  if (c.alive && !isnan(c.inbreeding))
+    for (int i = 0; i < 2 * K + 5; i++) L_(S.prior, i) = mf[meta_f_prior(0) + i];
+  // wave-uniform loop bounds
+  const int amax = wave_max_i(c.alive ? A : 0);
+  // ---- initial genotype (assemble/mcmc.py:202-208) into temperature slot 0 ----
+  if (c.alive) {
+    if (U.initial_off >= 0) {
+      const int8_t *ini = D.initial + U.initial_off + (size_t)chain * K * Mh;
+      for (int h = 0; h < K; h++) {
+        uint64_t x = 0;
+        for (int j = 0; j < Mh; j++) x |= (uint64_t)(uint8_t)ini[h * Mh + j] << L_(S.shift, j);
+        L_(S.w, h) = x;
+      }
+    } else {
+      const double *dist = mf + meta_f_dist(P.max_ploidy);
+      rng_open(c.rng, D.seed, U.stream_id, (uint32_t)chain, SLOT_INIT, 0);
+      for (int h = 0; h < K; h++) {
+        uint64_t x = 0;
+        for (int j = 0; j < Mh; j++) {
+          double s = 0.0;
+          for (int a = 0; a < A; a++) s += dist[j * A + a];
+          double cacc = 0.0;
+          const double uu = rng_double(c.rng);
+          int ch = A;
+          for (int a = 0; a < A; a++) {
+            cacc += dist[j * A + a] / s;
+            if (cacc > uu) {
+              ch = a;
+              break;
+            }
+          }
+          if (ch >= A) ch = A - 1;
+          x |= (uint64_t)ch << L_(S.shift, j);
+        }
+        L_(S.w, h) = x;
+      }
+    }
+    for (int h = 0; h < K; h++) L_(S.pw, h) = L_(S.w, h);
+  }
+  {
+    const double llk0 = coop_eval(c.alive, S, c, rpad, lane);  // assemble/mcmc.py:303 (not cached there either)
+    if (c.alive) {
+      for (int t = T - 1; t >= 0; t--) {
+        for (int h = 0; h < K; h++) L_(S.w, t * Kmax + h) = L_(S.w, h);
+        L_(S.llk_t, t) = llk0;
+        L_(S.rngn, t) = 0;
+      }
+    }
+  }
+  const double *break_dist = D.break_table + (size_t)Mh * D.max_pos;
+  const int n_break_dist = D.n_intervals > 0 ? D.n_intervals : Mh;
+  const size_t trace_base = U.trace_off + (size_t)chain * Sn * K;
+  const size_t llk_base = U.llk_off + (size_t)chain * Sn;
+  int status = MCHAP_UNIT_OK;
+  const int nsub = K * Mh;
+
+  for (int step = 0; step < Sn; step++) {
+    for (int t = 0; t < T; t++) {
+      const int wb = t * Kmax;
+      double llk = 0.0;
+      const double temp = D.temps[t];
+      if (c.alive) {
+        llk = L_(S.llk_t, t);
+        if (isnan(llk)) {  // assemble/mcmc.py:330-331
+          status = MCHAP_UNIT_NAN_LLK;
+          c.alive = false;
+        }
+      }
+      if (c.alive) {
+        rng_open(c.rng, D.seed, U.stream_id, (uint32_t)chain, (uint32_t)t, L_(S.rngn, t));
+        // mutation.compound_step: shuffle (mutation.py:219-229)
+        // entry i = (h << 8) | j of sub-step h * Mh + j (no division when it is consumed)
+        for (int h = 0, i = 0; h < K; h++)
+          for (int j = 0; j < Mh; j++, i++) L_(S.sub, i) = (uint16_t)((h << 8) | j);
+        for (int i = nsub - 1; i >= 1; i--) {
+          const int k = (int)rng_interval(c.rng, (uint32_t)i);
+          const uint16_t a = L_(S.sub, i), b = L_(S.sub, k);
+          L_(S.sub, i) = b;
+          L_(S.sub, k) = a;
+        }
+      }
+      const int nsub_max = wave_max_i(c.alive ? nsub : 0);
+      for (int i = 0; i < nsub_max; i++) {
+        const bool act = c.alive && i < nsub;
+        int h = 0, j = 0;
+        if (act) {
+          const int s = L_(S.sub, i);
+          h = s >> 8;
+          j = s & 255;
+        }
+        llk = simt_base_step<KT>(act, S, c, wb, llk, h, j, temp, amax, rpad, lane);
+      }
+      for (int kind = 0; kind < 3; kind++) {
+        bool act = false;
+        int nb = 0;
+        if (c.alive) {
+          const double pstep = kind == 0 ? D.p_recomb : (kind == 1 ? D.p_partial : D.p_dosage);
+          act = rng_double(c.rng) <= pstep;
+          if (act && kind < 2) {
+            if (D.n_intervals > 0) {
+              (void)rng_double(c.rng);
+              nb = D.n_intervals - 1;
+            } else {
+              nb = choose_from(break_dist, n_break_dist, rng_double(c.rng));
+            }
+          }
+        }
+        const bool ok = simt_structural_compound<KT>(act, S, c, wb, llk, nb, kind == 2, kind == 2 ? 1 : kind, temp, rpad, lane);
+        if (!ok) {
+          status = MCHAP_UNIT_BREAKS;
+          c.alive = false;
+        }
+      }
+      if (c.alive) {
+        if (t > 0) {
+          // tempering.py:61-151
+          const int wj = (t - 1) * Kmax;
+          double llk_j = L_(S.llk_t, t - 1);
+          const double prior_i = lane_words_prior<KT>(S, c, S.w, wb, lane);
+          const double prior_j = lane_words_prior<KT>(S, c, S.w, wj, lane);
+          const double ui = llk + prior_i, uj = llk_j + prior_j;
+          double acc = exp((uj - ui) * temp + (ui - uj) * D.temps[t - 1]);
+          if (acc > 1.0) acc = 1.0;
+          const double val = rng_double(c.rng);
+          if (acc >= val) {
+            for (int h = 0; h < K; h++) {
+              const uint64_t x = L_(S.w, wb + h);
+              L_(S.w, wb + h) = L_(S.w, wj + h);
+              L_(S.w, wj + h) = x;
+            }
+            const double x = llk;
+            llk = llk_j;
+            llk_j = x;
+          }
+          L_(S.llk_t, t - 1) = llk_j;
+        }
+        L_(S.llk_t, t) = llk;
+        L_(S.rngn, t) = c.rng.n;
+      }
+    }
+    if (c.alive) {
+      // record the cold chain with its haplotypes in canonical order (assemble/classes.py:265-278)
+      const int wb = (T - 1) * Kmax;
+      for (int h = 0; h < K; h++) {
+        const uint64_t x = L_(S.w, wb + h);
+        int rank = 0;
+        for (int g = 0; g < K; g++) {
+          const uint64_t y = L_(S.w, wb + g);
+          rank += (y < x || (y == x && g < h)) ? 1 : 0;
+        }
+        D.trace[trace_base + (size_t)step * K + rank] = x;
+      }
+      D.llks[llk_base + step] = L_(S.llk_t, T - 1);
+    }
+  }
+  if (status != MCHAP_UNIT_OK) atomicMax(&D.status[u], status);
+}
+
+#undef L_
+
+}  // namespace mchap

@@ -5,11 +5,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
 #include "../../include/mchap_hip.h"
 #include "denovo_kernel.hpp"
+#include "denovo_simt_kernel.hpp"
 #include "exact_kernel.hpp"
 #include "posterior_kernel.hpp"
 
@@ -103,10 +105,90 @@ size_t g_bt_cap = 0;
 
 }  // namespace
 
+namespace {
+
+struct BatchDims {
+  int max_reads = 1, max_pos = 1, max_allele = 1, max_ploidy = 1, max_ma = 1, max_ugens = 1;
+  int uniform_ploidy = -1;  // the ploidy shared by all units, 0 if mixed
+};
+
+int batch_dims(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host, BatchDims &B) {
+  for (int u = 0; u < n_units; u++) {
+    const mchap_unit &U = units_host[u];
+    if (U.ploidy < 1 || U.ploidy > MCHAP_MAX_PLOIDY) return fail(MCHAP_ERR_LIMIT, "unit %d: ploidy %d not in 1..%d", u, U.ploidy, MCHAP_MAX_PLOIDY);
+    if (U.max_allele < 1 || U.max_allele > MCHAP_MAX_ALLELE) return fail(MCHAP_ERR_LIMIT, "unit %d: max_allele %d not in 1..%d", u, U.max_allele, MCHAP_MAX_ALLELE);
+    if (U.n_reads < 1 || U.n_reads > MCHAP_MAX_READS) return fail(MCHAP_ERR_LIMIT, "unit %d: n_reads %d not in 1..%d (zero reads are mocked by the caller as one NaN read)", u, U.n_reads, MCHAP_MAX_READS);
+    if (U.n_pos < 1 || U.n_pos > 62) return fail(MCHAP_ERR_LIMIT, "unit %d: n_pos %d not in 1..62", u, U.n_pos);
+    if (cfg->n_intervals == 0 && U.n_pos > cfg->max_pos) return fail(MCHAP_ERR_BAD_ARG, "unit %d: n_pos exceeds break_table", u);
+    B.max_reads = std::max(B.max_reads, U.n_reads);
+    B.max_pos = std::max(B.max_pos, U.n_pos);
+    B.max_allele = std::max(B.max_allele, U.max_allele);
+    B.max_ploidy = std::max(B.max_ploidy, U.ploidy);
+    B.uniform_ploidy = (B.uniform_ploidy < 0 || B.uniform_ploidy == U.ploidy) ? U.ploidy : 0;
+    B.max_ma = std::max(B.max_ma, U.n_pos * U.max_allele);
+    B.max_ugens = std::max(B.max_ugens, mchap::snv_genotypes(U.max_allele, U.ploidy));
+  }
+  return MCHAP_OK;
+}
+
+struct SimtCarve {
+  size_t cache = 0, rt = 0, cntw = 0, meta_i = 0, meta_f = 0, total = 0;
+};
+
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+SimtCarve simt_carve(const mchap_denovo_cfg *cfg, int n_units, const BatchDims &B, int rpad, int cache_slots) {
+  SimtCarve c;
+  size_t o = 0;
+  c.cache = o; o += up256((size_t)n_units * cfg->chains * cache_slots * 16);
+  c.rt = o; o += up256((size_t)n_units * B.max_ma * rpad * 8);
+  c.cntw = o; o += up256((size_t)n_units * rpad * 8);
+  c.meta_i = o; o += up256((size_t)n_units * mchap::meta_i_stride(B.max_pos) * 4);
+  c.meta_f = o; o += up256((size_t)n_units * mchap::meta_f_stride(B.max_ploidy, B.max_pos, B.max_allele) * 8);
+  c.total = o;
+  return c;
+}
+
+template <int RPL>
+int launch_prepare(const mchap::SimtParams &P, int n_units, size_t lds_prep, hipStream_t stream) {
+  auto kp = mchap::denovo_prepare_kernel<RPL>;
+  if (lds_prep > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
+  hipLaunchKernelGGL(kp, dim3(n_units), dim3(64), lds_prep, stream, P);
+  HIP_TRY(hipGetLastError());
+  return MCHAP_OK;
+}
+
+template <int KT>
+int launch_simt(const mchap::SimtParams &P, int n_units, int chains, size_t lds_simt, hipStream_t stream) {
+  auto ks = mchap::denovo_simt_kernel<KT>;
+  if (lds_simt > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_simt));
+  const long long n_chains = (long long)n_units * chains;
+  hipLaunchKernelGGL(ks, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), lds_simt, stream, P);
+  HIP_TRY(hipGetLastError());
+  return MCHAP_OK;
+}
+
+bool use_simt(const mchap_denovo_cfg *cfg) { return cfg->kernel != 1; }
+
+}  // namespace
+
 extern "C" {
 
 const char *mchap_version(void) { return "mchap-hip 0.1 (gfx950; restates MCHap v0.11.1 assemble + calling.exact)"; }
 const char *mchap_last_error(void) { return g_err; }
+
+#ifdef MCHAP_STATS
+/* profiling builds only (make STATS=1): [0] likelihood requests, [1] cache misses, [2] probe slots */
+int mchap_debug_stats(unsigned long long *out, int reset) {
+  unsigned long long z[8] = {0};
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_stats), sizeof(z)));
+  if (reset) HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::g_stats), z, sizeof(z)));
+  return MCHAP_OK;
+}
+#endif
 
 int mchap_device_count(void) {
   int n = 0;
@@ -122,9 +204,15 @@ int64_t mchap_denovo_lds_bytes(int n_reads, int n_pos, int max_allele, int ploid
   return (int64_t)n_pos * max_allele * 64 * rpl * 8 + (int64_t)cpb * L.total;
 }
 
-int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units) {
-  if (!cfg || !cfg->llk_cache || n_units <= 0) return 0;
-  return (int64_t)n_units * cfg->chains * CACHE_SLOTS * 16;
+int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host) {
+  if (!cfg || n_units <= 0) return 0;
+  const int slots = cfg->llk_cache ? CACHE_SLOTS : 0;
+  if (!use_simt(cfg)) return (int64_t)n_units * cfg->chains * slots * 16;
+  if (!units_host) return -1;
+  BatchDims B;
+  if (batch_dims(cfg, n_units, units_host, B)) return -1;
+  const int rpl = rpl_for(B.max_reads);
+  return (int64_t)simt_carve(cfg, n_units, B, 64 * rpl, slots).total;
 }
 
 int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
@@ -140,33 +228,15 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
   rc = ensure_init();
   if (rc) return rc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-
-  int max_reads = 1, max_pos = 1;
-  size_t lds = 0;
-  for (int u = 0; u < n_units; u++) {
-    const mchap_unit &U = units_host[u];
-    if (U.ploidy < 1 || U.ploidy > MCHAP_MAX_PLOIDY) return fail(MCHAP_ERR_LIMIT, "unit %d: ploidy %d not in 1..%d", u, U.ploidy, MCHAP_MAX_PLOIDY);
-    if (U.max_allele < 1 || U.max_allele > MCHAP_MAX_ALLELE) return fail(MCHAP_ERR_LIMIT, "unit %d: max_allele %d not in 1..%d", u, U.max_allele, MCHAP_MAX_ALLELE);
-    if (U.n_reads < 1 || U.n_reads > MCHAP_MAX_READS) return fail(MCHAP_ERR_LIMIT, "unit %d: n_reads %d not in 1..%d (zero reads are mocked by the caller as one NaN read)", u, U.n_reads, MCHAP_MAX_READS);
-    if (U.n_pos < 1 || U.n_pos > 62) return fail(MCHAP_ERR_LIMIT, "unit %d: n_pos %d not in 1..62", u, U.n_pos);
-    if (cfg->n_intervals == 0 && U.n_pos > cfg->max_pos) return fail(MCHAP_ERR_BAD_ARG, "unit %d: n_pos exceeds break_table", u);
-    if (U.n_reads > max_reads) max_reads = U.n_reads;
-    if (U.n_pos > max_pos) max_pos = U.n_pos;
-  }
-  const int rpl = rpl_for(max_reads);
+  BatchDims B;
+  rc = batch_dims(cfg, n_units, units_host, B);
+  if (rc) return rc;
+  const int rpl = rpl_for(B.max_reads);
   const int rpad = 64 * rpl;
-  for (int u = 0; u < n_units; u++) {
-    const mchap_unit &U = units_host[u];
-    const mchap::WaveLayout L = mchap::wave_layout(U.ploidy, U.n_pos, U.max_allele, cfg->n_temps);
-    const int cpb = cfg->chains < mchap::CHAINS_PER_BLOCK ? cfg->chains : mchap::CHAINS_PER_BLOCK;
-    const size_t need = (size_t)U.n_pos * U.max_allele * rpad * 8 + (size_t)cpb * L.total;
-    if (need > lds) lds = need;
-  }
-  if (lds > 160 * 1024)
-    return fail(MCHAP_ERR_LIMIT, "a unit needs %zu bytes of LDS (> 160 KiB): dense float64 staging does not fit", lds);
 
-  mchap::DenovoParams P;
-  std::memset(&P, 0, sizeof(P));
+  mchap::SimtParams SP;
+  std::memset(&SP, 0, sizeof(SP));
+  mchap::DenovoParams &P = SP.d;
   P.units = units_dev;
   P.reads = reads;
   P.counts = read_counts;
@@ -205,6 +275,70 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
   HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * n_units, stream));
   P.cache = nullptr;
   P.cache_slots = 0;
+
+  if (use_simt(cfg)) {
+    const int want_slots = cfg->llk_cache ? CACHE_SLOTS : 0;
+    int slots = want_slots;
+    SimtCarve cv = simt_carve(cfg, n_units, B, rpad, slots);
+    while (slots >= 32 && (int64_t)cv.total > workspace_bytes) {
+      slots >>= 1;
+      cv = simt_carve(cfg, n_units, B, rpad, slots);
+    }
+    if (slots < 32 && want_slots) {
+      slots = 0;
+      cv = simt_carve(cfg, n_units, B, rpad, 0);
+    }
+    if (!workspace || (int64_t)cv.total > workspace_bytes)
+      return fail(MCHAP_ERR_BAD_ARG, "workspace of %lld bytes is too small: kernel %d needs at least %zu (mchap_denovo_workspace_bytes)",
+                  (long long)workspace_bytes, cfg->kernel, cv.total);
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    if (slots > 0) {
+      P.cache = reinterpret_cast<uint64_t *>(ws + cv.cache);
+      P.cache_slots = slots;
+      HIP_TRY(hipMemsetAsync(ws + cv.cache, 0, (size_t)n_units * cfg->chains * slots * 16, stream));
+    }
+    SP.rt = reinterpret_cast<double *>(ws + cv.rt);
+    SP.cntw = reinterpret_cast<double *>(ws + cv.cntw);
+    SP.meta_i = reinterpret_cast<int32_t *>(ws + cv.meta_i);
+    SP.meta_f = reinterpret_cast<double *>(ws + cv.meta_f);
+    SP.n_units = n_units;
+    SP.max_pos = B.max_pos;
+    SP.max_allele = B.max_allele;
+    SP.max_ploidy = B.max_ploidy;
+    SP.max_ma = B.max_ma;
+    const size_t lds_prep = (size_t)B.max_ma * rpad * 8 + (size_t)B.max_ugens * 8 + 64;
+    const size_t lds_simt = mchap::simt_lds_bytes(B.max_ploidy, B.max_pos, cfg->n_temps);
+    if (lds_prep > 160 * 1024 || lds_simt > 160 * 1024)
+      return fail(MCHAP_ERR_LIMIT, "a unit needs %zu / %zu bytes of LDS (> 160 KiB)", lds_prep, lds_simt);
+    switch (rpl) {
+      case 1: rc = launch_prepare<1>(SP, n_units, lds_prep, stream); break;
+      case 2: rc = launch_prepare<2>(SP, n_units, lds_prep, stream); break;
+      case 4: rc = launch_prepare<4>(SP, n_units, lds_prep, stream); break;
+      case 8: rc = launch_prepare<8>(SP, n_units, lds_prep, stream); break;
+      default: rc = launch_prepare<16>(SP, n_units, lds_prep, stream); break;
+    }
+    if (rc) return rc;
+    // a launch whose units share one ploidy runs the kernel specialised for it
+    switch (B.uniform_ploidy) {
+      case 2: return launch_simt<2>(SP, n_units, cfg->chains, lds_simt, stream);
+      case 4: return launch_simt<4>(SP, n_units, cfg->chains, lds_simt, stream);
+      case 6: return launch_simt<6>(SP, n_units, cfg->chains, lds_simt, stream);
+      case 8: return launch_simt<8>(SP, n_units, cfg->chains, lds_simt, stream);
+      default: return launch_simt<0>(SP, n_units, cfg->chains, lds_simt, stream);
+    }
+  }
+
+  // ---- kernel 1: wavefront per chain, reads staged in LDS ----
+  size_t lds = 0;
+  for (int u = 0; u < n_units; u++) {
+    const mchap_unit &U = units_host[u];
+    const mchap::WaveLayout L = mchap::wave_layout(U.ploidy, U.n_pos, U.max_allele, cfg->n_temps);
+    const int cpb = cfg->chains < mchap::CHAINS_PER_BLOCK ? cfg->chains : mchap::CHAINS_PER_BLOCK;
+    const size_t need = (size_t)U.n_pos * U.max_allele * rpad * 8 + (size_t)cpb * L.total;
+    if (need > lds) lds = need;
+  }
+  if (lds > 160 * 1024)
+    return fail(MCHAP_ERR_LIMIT, "a unit needs %zu bytes of LDS (> 160 KiB): dense float64 staging does not fit", lds);
   if (cfg->llk_cache && workspace && workspace_bytes > 0) {
     const int64_t rows = (int64_t)n_units * cfg->chains;
     int slots = CACHE_SLOTS;
@@ -236,7 +370,8 @@ int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap
   if (rc) return rc;
   if (n_units <= 0) return MCHAP_OK;
   DevBuf d_units, d_reads, d_counts, d_nal, d_init, d_trace, d_llk, d_fixed, d_status, d_ws;
-  const int64_t ws_bytes = mchap_denovo_workspace_bytes(cfg, n_units);
+  const int64_t ws_bytes = mchap_denovo_workspace_bytes(cfg, n_units, units);
+  if (ws_bytes < 0) return fail(MCHAP_ERR_LIMIT, "unsupported unit shape");
   if (ws_bytes > 0) HIP_TRY(hipMalloc(&d_ws.p, (size_t)ws_bytes));
   HIP_TRY(hipMalloc(&d_units.p, sizeof(mchap_unit) * n_units));
   HIP_TRY(hipMalloc(&d_reads.p, sizeof(double) * (size_t)reads_len));

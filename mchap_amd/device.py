@@ -57,7 +57,9 @@ class DenovoDeviceBatch:
         self.d_status = torch.empty(U, dtype=torch.int32, device=dev)
         self.cfg = model._cfg(M)
         L = _lib.lib()
-        self.ws_bytes = int(L.mchap_denovo_workspace_bytes(C.byref(self.cfg), U))
+        self.ws_bytes = int(L.mchap_denovo_workspace_bytes(C.byref(self.cfg), U, _lib.ptr(units)))
+        if self.ws_bytes < 0:
+            raise NotImplementedError("mchap_hip: unsupported unit shape")
         self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
         self.post = None
 

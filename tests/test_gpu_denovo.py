@@ -11,6 +11,13 @@ from tests.helpers import beta_break_table
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[2, 1], ids=["lanes-over-chains", "wave-per-chain"])
+def sampler_kernel(request, monkeypatch):
+    """Every test runs against both sampler kernels; they must give identical traces."""
+    monkeypatch.setenv("MCHAP_HIP_KERNEL", str(request.param))
+    return request.param
+
+
 def _oracle_trace(model, reads, n_alleles, rc, stream_id, initial=None, inbreeding="model", ploidy=None):
     F = model.inbreeding if inbreeding == "model" else inbreeding
     M = reads.shape[1]
@@ -173,3 +180,16 @@ def test_llk_cache_is_results_neutral():
     off = DenovoMCMC(llk_cache_threshold=-1, **kw).fit_batch(list(reads))
     for a, b in zip(on, off):
         assert np.array_equal(a.genotypes, b.genotypes) and np.array_equal(a.llks, b.llks)
+
+
+def test_both_kernels_give_identical_traces():
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(70, ploidy=4, n_pos=8, n_reads=200, first_unit=500)  # > one wavefront of chains
+    kw = dict(ploidy=4, n_alleles=[2] * 8, steps=120, chains=2, random_seed=99)
+    a = DenovoMCMC(kernel=1, **kw).fit_batch(list(reads))
+    b = DenovoMCMC(kernel=2, **kw).fit_batch(list(reads))
+    for x, y in zip(a, b):
+        assert np.array_equal(x.genotypes, y.genotypes)
+        np.testing.assert_allclose(x.llks, y.llks, rtol=1e-12)

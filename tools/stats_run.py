@@ -1,0 +1,25 @@
+"""Profiling helper (not part of the product): run the sampler from the counters build and print event counts."""
+import ctypes as C
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mchap_amd import _lib
+_lib.SO = os.path.join(_lib.CSRC, "libmchap_hip_stats.so")
+from mchap_amd import DenovoMCMC
+from mchap_amd.device import DenovoDeviceBatch
+from mchap_amd.synth import synth_units
+
+U = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+reads, _, _ = synth_units(U)
+model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=steps, chains=2, random_seed=42)
+b = DenovoDeviceBatch(model, reads)
+out = (C.c_ulonglong * 8)()
+L = _lib.lib()
+L.mchap_debug_stats(out, 1)
+t = time.time(); b.run(); torch.cuda.synchronize(); dt = time.time() - t
+L.mchap_debug_stats(out, 1)
+print("units", U, "steps", steps, "time %.3f s" % dt)
+print("requests %d  misses %d (%.2f%%)  probe-slots %d  requests/probe-slot %.3f" % (out[0], out[1], 100.0 * out[1] / max(out[0], 1), out[2], out[0] / max(out[2], 1)))
+print("per chain-step: requests %.2f misses %.3f" % (out[0] / (U * 2 * steps), out[1] / (U * 2 * steps)))
