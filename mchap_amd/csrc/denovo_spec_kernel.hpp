@@ -1,0 +1,966 @@
+// De-novo MCMC sampler, speculative form for MI355X (gfx950): a GROUP of G lanes per chain (G = 16/32/64).
+//
+// The reference's step is a chain of ~40 dependent sub-steps (assemble/mutation.py:164-246,
+// assemble/structural.py:590-673): each proposes a few neighbours of the current genotype, accepts one with small
+// probability, and hands the (usually unchanged) genotype to the next.  Two facts make the chain parallel:
+//   * the random numbers are counter-based (philox.hpp): the uniform a sub-step will consume is known from its
+//     position alone, before any earlier sub-step has run;
+//   * a sub-step's proposal probabilities depend only on the current genotype.
+// So all pending sub-steps of a compound step are evaluated at once, one per lane, against the current genotype
+// (cache probe per lane, co-operative likelihood evaluation for the misses); the first sub-step in sequence order
+// that moves is applied, everything before it is thereby validated as "stay", and only the sub-steps after it are
+// evaluated again.  The result is bit-for-bit the sequential chain (same draws, same decisions); the number of
+// parallel rounds per compound step is 1 + the number of accepted moves instead of the number of sub-steps.
+// The Fisher-Yates shuffle of the sub-steps is done by every lane tracing its own element through the n-1
+// transpositions (draws computed in parallel).  Structural steps speculate over (interval, option) pairs the same
+// way; their draws are data dependent (structural.py:504-506) and are consumed in the sequential validation walk.
+//
+// Launch: one wavefront per 64/G chains, all units of a launch share the ploidy KT; prepare kernel and workspace
+// as for the lanes-over-chains kernel (denovo_simt_kernel.hpp).  Same traces as the other two kernels.
+#pragma once
+#include <type_traits>
+
+#include "denovo_simt_kernel.hpp"
+
+namespace mchap {
+
+constexpr int SPEC_MAX_IV = 64;  // intervals per structural compound step (<= n_pos)
+constexpr int SPEC_LN = 260;
+
+struct SpecLds {
+  uint64_t *pw;      // [K][64] request words of missing lanes (lane strided)
+  uint64_t *wst;     // [NG][T][K] genotype of every temperature
+  double *llk_t;     // [NG][T]
+  uint64_t *rngn;    // [NG][T]
+  double *prior;     // [NG][2K+5]
+  double *ptab;      // [64] per-slot move probability
+  double *ln;        // [SPEC_LN] log(n)
+  double *lninv;     // [SPEC_LN] log(1/n)
+  uint32_t *ivse;    // [NG][SPEC_MAX_IV] start | stop << 8, in visiting order
+  uint32_t *ivlin;   // [NG][SPEC_MAX_IV]
+  uint32_t *ivlout;  // [NG][SPEC_MAX_IV]
+  uint32_t *ivno;    // [NG][SPEC_MAX_IV] n_options
+  uint16_t *cols;    // [NG][Mmax]
+  uint16_t *permtab; // [NG][nmax] (h << 8) | j by order position
+  uint8_t *shift;    // [NG][Mmax]
+  uint8_t *nal;      // [NG][Mmax]
+  uint8_t *ktab;     // [NG][nmax]
+  uint8_t *ordtab;   // [NG][SPEC_MAX_IV]
+};
+
+__host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int T, int G) {
+  const int NG = 64 / G;
+  const int nmax = K * Mmax;
+  size_t b = 0;
+  b += (size_t)8 * K * 64;
+  b += (size_t)8 * NG * T * K;
+  b += (size_t)8 * NG * T * 2;
+  b += (size_t)8 * NG * (2 * K + 5);
+  b += (size_t)8 * 64;
+  b += (size_t)8 * SPEC_LN * 2;
+  b += (size_t)4 * NG * SPEC_MAX_IV * 4;
+  b += (size_t)2 * NG * Mmax;
+  b += (size_t)2 * NG * nmax;
+  b += (size_t)NG * Mmax * 2;
+  b += (size_t)NG * nmax;
+  b += (size_t)NG * SPEC_MAX_IV;
+  return (b + 63) & ~(size_t)63;
+}
+
+// stateless Philox draws of a stream (same contract as Rng in philox.hpp)
+struct Stream {
+  uint32_t k0, k1, c2, c3;
+};
+__device__ __forceinline__ void stream_words(const Stream &s, uint64_t n, uint32_t &a, uint32_t &b) {
+  uint32_t o[4];
+  const uint64_t blk = n >> 1;
+  philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), s.c2, s.c3, s.k0, s.k1, o);
+  a = (n & 1) ? o[2] : o[0];
+  b = (n & 1) ? o[3] : o[1];
+}
+__device__ __forceinline__ double stream_double(const Stream &s, uint64_t n) {
+  uint32_t a, b;
+  stream_words(s, n, a, b);
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ uint32_t stream_interval(const Stream &s, uint64_t n, uint32_t max) {
+  uint32_t a, b;
+  stream_words(s, n, a, b);
+  return __umulhi(a, max + 1u);
+}
+
+template <int G>
+__device__ __forceinline__ uint64_t grp_ballot(bool p, int gi) {
+  const unsigned long long m = __ballot(p);
+  if (G == 64) return m;
+  return (m >> (gi * G)) & ((1ull << G) - 1ull);
+}
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+__device__ __forceinline__ void lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int KT>
+struct GWords {
+  uint64_t w[KT];
+};
+
+template <int KT>
+__device__ __forceinline__ uint64_t sel_word(const GWords<KT> &g, int h) {
+  uint64_t x = g.w[0];
+#pragma unroll
+  for (int i = 1; i < KT; i++) x = (h == i) ? g.w[i] : x;
+  return x;
+}
+template <int KT>
+__device__ __forceinline__ void set_word(GWords<KT> &g, int h, uint64_t v) {
+#pragma unroll
+  for (int i = 0; i < KT; i++) g.w[i] = (h == i) ? v : g.w[i];
+}
+template <int KT>
+__device__ __forceinline__ int copies_of(const GWords<KT> &g, uint64_t x) {
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < KT; i++) n += (g.w[i] == x) ? 1 : 0;
+  return n;
+}
+template <int KT>
+__device__ __forceinline__ uint32_t dosage_words(const GWords<KT> &g) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int h = 0; h < KT; h++) d |= 1u << (4 * h);
+#pragma unroll
+  for (int h = 0; h < KT; h++) {
+    if (nib(d, h) == 0) continue;
+#pragma unroll
+    for (int p = h + 1; p < KT; p++) {
+      if (nib(d, p) == 0) continue;
+      if (g.w[h] == g.w[p]) {
+        d += 1u << (4 * h);
+        d &= ~(15u << (4 * p));
+      }
+    }
+  }
+  return d;
+}
+template <int KT>
+__device__ __forceinline__ uint32_t seg_labels(const GWords<KT> &g, uint64_t mask) {
+  uint32_t lab = 0;
+#pragma unroll
+  for (int h = 1; h < KT; h++) {
+    int l = h;
+#pragma unroll
+    for (int q = KT - 1; q >= 0; q--)
+      if (q < h && ((g.w[q] ^ g.w[h]) & mask) == 0) l = q;
+    lab |= (uint32_t)l << (4 * h);
+  }
+  return lab;
+}
+template <int KT>
+__device__ __forceinline__ double prior_of(const double *pt, double inbreeding, uint32_t d) {
+  if (inbreeding == 0.0) {
+    double den = 0.0;
+#pragma unroll
+    for (int i = 0; i < KT; i++) den += pt[KT + 1 + nib(d, i)];
+    return (pt[2 * KT + 3] - den) - pt[2 * KT + 4];
+  }
+  double prod = 0.0;
+#pragma unroll
+  for (int i = 0; i < KT; i++) {
+    const uint32_t dose = nib(d, i);
+    if (dose > 0) prod += pt[dose];
+  }
+  return pt[2 * KT + 2] + prod;
+}
+template <int KT>
+__device__ __forceinline__ uint64_t tag_of(const GWords<KT> &g, int key_bits) {
+  uint64_t t = 0;
+  if (key_bits * KT <= 63) {
+#pragma unroll
+    for (int h = 0; h < KT; h++) t = (t << key_bits) | g.w[h];
+  } else {
+#pragma unroll
+    for (int h = 0; h < KT; h++) t = mix64(t ^ g.w[h]) + 0x9E3779B97F4A7C15ull;
+  }
+  return (t << 1) | 1ull;
+}
+__device__ __forceinline__ uint64_t mask_of(int bits, int Mh, int start, int stop) {
+  const int nb = bits * (stop - start);
+  const uint64_t ones = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+  const int sh = bits * (Mh - stop);
+  return sh >= 64 ? 0ull : ones << sh;
+}
+
+// per-group chain context (identical in every lane of the group)
+template <int KT>
+struct Grp {
+  int Mh, bits, key_bits;
+  uint32_t amask;
+  double inbreeding;
+  bool alive;
+  const double *rt, *cw;
+  ulonglong2 *cache;
+  uint32_t cache_mask;
+  Stream st;
+  uint64_t ctr;  // next draw of the current stream
+  double llk;
+  GWords<KT> g;  // genotype of the current temperature
+};
+
+template <int KT, int RPL>
+__device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
+                                                 const double *rt, const double *cw, int rpad, int lane) {
+  constexpr int UNR = RPL <= 4 ? 8 : (RPL == 8 ? 4 : 2);
+  const int n_pairs = KT * Mh;
+  const double invK = 1.0 / (double)KT;
+  double acc[RPL], prod[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; i++) {
+    acc[i] = 0.0;
+    prod[i] = 1.0;
+  }
+  for (int base = 0; base < n_pairs; base += WAVE) {
+    int myrow = 0;  // lane l owns pair base + l = (h, j)
+    {
+      const int p = base + lane;
+      if (p < n_pairs) {
+        const int h = p / Mh, j = p - h * Mh;
+        const uint64_t wh = S.pw[(size_t)h * WAVE + src];
+        const uint32_t a = (uint32_t)(wh >> S.shift[(size_t)sg * mmax + j]) & amask;
+        myrow = (int)S.cols[(size_t)sg * mmax + j] + (int)a;
+      }
+    }
+    const int lim = min(WAVE, n_pairs - base);
+    int jj = base % Mh;
+    for (int q0 = 0; q0 < lim; q0 += UNR) {
+      double v[UNR][RPL];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const int q = q0 + u;
+        const int row = __builtin_amdgcn_readlane(myrow, q < lim ? q : 0);
+        const double *rp = rt + (size_t)row * rpad;
+#pragma unroll
+        for (int i = 0; i < RPL; i++) v[u][i] = rp[WAVE * i];
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        if (q0 + u < lim) {
+#pragma unroll
+          for (int i = 0; i < RPL; i++) prod[i] *= v[u][i];
+          if (++jj == Mh) {
+            jj = 0;
+#pragma unroll
+            for (int i = 0; i < RPL; i++) {
+              acc[i] += prod[i] * invK;
+              prod[i] = 1.0;
+            }
+          }
+        }
+      }
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
+  return wave_sum(s);
+}
+
+// Likelihood of the lane's proposal `pw` (where need): 4-way cache probe, then co-operative evaluation of the
+// misses by the whole wavefront (request words staged through LDS).  Every lane of the wave must call.
+template <int KT, int G>
+__device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, const Grp<KT> &c, const SpecLds &S, int mmax,
+                                            int rpad, int lane) {
+  double val = 0.0;
+  bool miss = need;
+  uint64_t tag = 0;
+  ulonglong2 *slot = nullptr;
+  if (need && c.cache) {
+    // 8-way sets (one 128-byte line).  The lanes of a group probe and fill the chain's table concurrently, so the
+    // policy must not depend on read-modify-write sequences: hits never move entries, a miss goes to the first
+    // empty way it saw (else to a way picked by the key); a lost race only costs one more evaluation later.
+    tag = tag_of<KT>(pw, c.key_bits);
+    const uint64_t key = tag >> 1;
+    // full-avalanche 32-bit mix: the keys probed together are single-field neighbours of one genotype, so a
+    // plain multiplicative hash would send all neighbours that differ in a high field to the same set
+    uint32_t hsh = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u);
+    hsh ^= hsh >> 16;
+    hsh *= 0x7FEB352Du;
+    hsh ^= hsh >> 15;
+    hsh *= 0x846CA68Bu;
+    hsh ^= hsh >> 16;
+    ulonglong2 *set = c.cache + 8 * (size_t)((hsh >> 12) & c.cache_mask);
+    int way = (int)((hsh >> 24) & 7u);
+    bool empty_seen = false;
+#pragma unroll
+    for (int w = 7; w >= 0; w--) {
+      const ulonglong2 e = set[w];
+      if (e.x == tag) {
+        val = __longlong_as_double((long long)e.y);
+        miss = false;
+      }
+      if (e.x == 0ull) {
+        way = w;  // lowest empty way wins
+        empty_seen = true;
+      }
+    }
+    (void)empty_seen;
+    slot = set + way;
+  }
+  STAT_ADD(0, need);
+  STAT_ADD(1, miss);
+  STAT_ADD(2, true);
+  unsigned long long todo = __ballot(miss);
+  if (todo) {
+    if (miss) {
+#pragma unroll
+      for (int h = 0; h < KT; h++) S.pw[(size_t)h * WAVE + lane] = pw.w[h];
+    }
+    lds_sync();
+    const int nch = rpad / WAVE;
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int sg = src / G;
+      const int Mh = __builtin_amdgcn_readfirstlane(__shfl(c.Mh, src, WAVE));
+      const uint32_t amask = (uint32_t)__shfl((int)c.amask, src, WAVE);
+      const unsigned long long rtb = __shfl((unsigned long long)(uintptr_t)c.rt, src, WAVE);
+      const unsigned long long cwb = __shfl((unsigned long long)(uintptr_t)c.cw, src, WAVE);
+      const double *rt = reinterpret_cast<const double *>((uintptr_t)rtb) + lane;
+      const double *cw = reinterpret_cast<const double *>((uintptr_t)cwb) + lane;
+      double s;
+      if (nch == 4) s = spec_coop_body<KT, 4>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
+      else if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
+      else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
+      else if (nch == 8) s = spec_coop_body<KT, 8>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
+      else s = spec_coop_body<KT, 16>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
+      if (lane == src) val = s;
+    }
+    if (miss && slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
+    lds_sync();
+  }
+  return val;
+}
+
+// mutation.compound_step (mutation.py:164-246) for the group's chain: shuffle, then speculative sub-steps.
+template <int KT, int G>
+__device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, int mmax, int nmax, int rpad,
+                                              int lane, int gi, int gl) {
+  const int Mh = c.Mh;
+  const int n = KT * Mh;  // sub-steps; position p of the sequence is held by lane p % G, slot p / G (n <= 2 G)
+  const uint64_t ctr0 = c.ctr;
+  uint8_t *ktab = S.ktab + (size_t)gi * nmax;
+  uint16_t *permtab = S.permtab + (size_t)gi * nmax;
+  const uint8_t *shift = S.shift + (size_t)gi * mmax;
+  const uint8_t *nal = S.nal + (size_t)gi * mmax;
+  const double *pt = S.prior + (size_t)gi * (2 * KT + 5);
+  const bool two = wave_any(c.alive && n > G);  // second slot in use anywhere in the wave
+  // (1) draws of the Fisher-Yates shuffle: swap(i, k_i) for i = n-1 .. 1, k_i = interval(i) is draw ctr0 + (n-1-i)
+  if (c.alive) {
+    for (int s = 0; s < 2; s++) {
+      const int p = gl + s * G;
+      if (p >= 1 && p < n) ktab[p] = (uint8_t)stream_interval(c.st, ctr0 + (uint64_t)(n - 1 - p), (uint32_t)p);
+    }
+  }
+  lds_sync();
+  // (2) every lane traces the element that starts at its position through the transpositions
+  int x0 = gl, x1 = gl + G;
+  {
+    const int nloop = c.alive ? n : 0;
+    int nl = nloop;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) nl = max(nl, __shfl_xor(nl, o, WAVE));
+    for (int i = nl - 1; i >= 1; i--) {
+      if (i < nloop) {
+        const int ki = ktab[i];
+        x0 = (x0 == i) ? ki : ((x0 == ki) ? i : x0);
+        x1 = (x1 == i) ? ki : ((x1 == ki) ? i : x1);
+      }
+    }
+  }
+  if (c.alive) {
+    // element e = h * Mh + j starts at position e
+    for (int s = 0; s < 2; s++) {
+      const int e = gl + s * G;
+      if (e < n) {
+        int h = 0, j = e;
+        while (j >= Mh) {
+          j -= Mh;
+          h++;
+        }
+        permtab[s ? x1 : x0] = (uint16_t)((h << 8) | j);
+      }
+    }
+  }
+  lds_sync();
+  // (3) my sub-steps and their uniforms (one draw per sub-step, after the n-1 shuffle draws)
+  int sh_[2] = {0, 0}, hh[2] = {0, 0}, na_[2] = {2, 2};
+  double uu[2] = {2.0, 2.0};
+  if (c.alive) {
+    for (int s = 0; s < 2; s++) {
+      const int p = gl + s * G;
+      if (p < n) {
+        const int e = permtab[p];
+        hh[s] = e >> 8;
+        const int j = e & 255;
+        sh_[s] = shift[j];
+        na_[s] = nal[j];
+        uu[s] = stream_double(c.st, ctr0 + (uint64_t)(n - 1) + (uint64_t)p);
+      }
+    }
+  }
+  c.ctr = ctr0 + (uint64_t)(n - 1) + (uint64_t)n;
+  // (4) speculate / validate
+  int start = 0;
+  bool done = !c.alive;
+  while (wave_any(!done)) {
+    bool changed[2] = {false, false};
+    uint64_t neww[2] = {0, 0};
+    double newllk[2] = {0.0, 0.0};
+    const double lprior = (!done && !isnan(c.inbreeding)) ? prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(c.g)) : 0.0;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      if (s == 1 && !two) continue;  // wave-uniform
+      const int p = gl + s * G;
+      const bool act = !done && p >= start && p < n;
+      const int h = hh[s], sh = sh_[s], n_alleles = na_[s];
+      const uint64_t wh = sel_word<KT>(c.g, h);
+      const int current = (int)((wh >> sh) & c.amask);
+      const double lhapcount = S.ln[copies_of<KT>(c.g, wh)];
+      double la[MCHAP_MAX_ALLELE - 1], lk[MCHAP_MAX_ALLELE - 1];
+#pragma unroll
+      for (int o = 0; o < MCHAP_MAX_ALLELE - 1; o++) {
+        la[o] = -INFINITY;
+        lk[o] = c.llk;
+        if (o >= amax - 1) continue;  // wave-uniform bound
+        const bool prop = act && o < n_alleles - 1;
+        const int i = o + (o >= current ? 1 : 0);
+        GWords<KT> pw = c.g;
+        const uint64_t nw = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)i << sh);
+        set_word<KT>(pw, h, nw);
+        const double llk_i = spec_eval<KT, G>(prop, pw, c, S, mmax, rpad, lane);
+        if (prop) {
+          lk[o] = llk_i;
+          double lprior_ratio = 0.0;
+          if (!isnan(c.inbreeding)) lprior_ratio = prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(pw)) - lprior;
+          const double lproposal_ratio = S.ln[copies_of<KT>(pw, nw)] - lhapcount;
+          la[o] = fmin(0.0, ((llk_i - c.llk) + lprior_ratio) * temp + lproposal_ratio);
+        }
+      }
+      if (act) {
+        const double ln_opt = S.ln[n_alleles - 1];
+        double sum = 0.0;
+#pragma unroll
+        for (int o = 0; o < MCHAP_MAX_ALLELE - 1; o++) {
+          if (o < n_alleles - 1) {
+            la[o] = exp(la[o] - ln_opt);
+            sum += la[o];
+          }
+        }
+        const double stay = 1.0 - sum;
+        double cacc = 0.0;
+        int choice = -1;
+        double cl = c.llk;
+#pragma unroll
+        for (int i = 0; i < MCHAP_MAX_ALLELE; i++) {
+          if (i < n_alleles && choice < 0) {
+            double pi = stay, li = c.llk;
+            if (i != current) {
+              const int o = i - (i > current ? 1 : 0);
+#pragma unroll
+              for (int z = 0; z < MCHAP_MAX_ALLELE - 1; z++)
+                if (z == o) {
+                  pi = la[z];
+                  li = lk[z];
+                }
+            }
+            cacc += pi;
+            if (cacc > uu[s]) {
+              choice = i;
+              cl = li;
+            }
+          }
+        }
+        if (choice < 0) {  // u beyond the last cumulative value: the reference's searchsorted returns n (clamped)
+          choice = n_alleles - 1;
+          if (choice != current) {
+            const int o = choice - (choice > current ? 1 : 0);
+#pragma unroll
+            for (int z = 0; z < MCHAP_MAX_ALLELE - 1; z++)
+              if (z == o) cl = lk[z];
+          }
+        }
+        if (choice != current) {
+          changed[s] = true;
+          neww[s] = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)choice << sh);
+          newllk[s] = cl;
+        }
+      }
+    }
+    // first sub-step (in sequence order) that moves
+    const uint64_t m0 = grp_ballot<G>(changed[0], gi);
+    const uint64_t m1 = two ? grp_ballot<G>(changed[1], gi) : 0ull;
+    if (!done) {
+      if ((m0 | m1) == 0ull) {
+        done = true;
+      } else {
+        const int slot = m0 ? 0 : 1;
+        const int fl = __ffsll((long long)(m0 ? m0 : m1)) - 1;
+        const int hsrc = __shfl(slot ? hh[1] : hh[0], fl, G);
+        const uint64_t wsrc = __shfl(slot ? neww[1] : neww[0], fl, G);
+        const double lsrc = __shfl(slot ? newllk[1] : newllk[0], fl, G);
+        set_word<KT>(c.g, hsrc, wsrc);
+        c.llk = lsrc;
+        start = fl + slot * G + 1;
+        if (start >= n) done = true;
+      }
+    }
+  }
+}
+
+// One structural compound step (structural.py:22-71, 433-673) of kind 0 recombination, 1 interval dosage,
+// 2 whole-haplotype dosage.  Returns false if the group hit the reference's "breaks" ValueError.
+template <int KT, int G>
+__device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D, int kind, double temp,
+                                                const double *break_dist, int n_break_dist, int mmax, int rpad, int lane,
+                                                int gi, int gl) {
+  const int Mh = c.Mh;
+  const int step_type = kind == 0 ? 0 : 1;
+  uint32_t *ivse = S.ivse + (size_t)gi * SPEC_MAX_IV;
+  uint32_t *ivlin = S.ivlin + (size_t)gi * SPEC_MAX_IV;
+  uint32_t *ivlout = S.ivlout + (size_t)gi * SPEC_MAX_IV;
+  uint32_t *ivno = S.ivno + (size_t)gi * SPEC_MAX_IV;
+  uint8_t *ord = S.ordtab + (size_t)gi * SPEC_MAX_IV;
+  const double *pt = S.prior + (size_t)gi * (2 * KT + 5);
+  bool ok = true;
+  bool doit = false;
+  int n_int = 0;
+  if (c.alive) {
+    const double pstep = kind == 0 ? D.p_recomb : (kind == 1 ? D.p_partial : D.p_dosage);
+    doit = stream_double(c.st, c.ctr++) <= pstep;
+    uint64_t zeros = 0;
+    if (doit && kind < 2) {
+      int nb;
+      if (D.n_intervals > 0) {
+        c.ctr++;  // break_dist = [0,...,0,1]: the draw is consumed (assemble/mcmc.py:214-217)
+        nb = D.n_intervals - 1;
+      } else {
+        nb = choose_from(break_dist, n_break_dist, stream_double(c.st, c.ctr++));
+      }
+      if (nb >= Mh) {
+        ok = false;
+        doit = false;
+      } else {
+        uint64_t ind = 0;
+        for (int i = 1; i < Mh; i++) ind |= 1ull << i;
+        for (int b = 0; b < nb; b++) {
+          const int no = __popcll(ind);
+          if (no == 0) break;
+          int k = 0;
+          if (no > 1) k = (int)stream_interval(c.st, c.ctr++, (uint32_t)(no - 1));
+          uint64_t t = ind;
+          while (k-- > 0) t &= t - 1;
+          ind &= ~(t & (~t + 1));
+        }
+        zeros = ~ind & ((1ull << (Mh + 1)) - 1ull);
+        n_int = nb + 1;
+      }
+    } else if (doit) {
+      zeros = 1ull | (1ull << Mh);
+      n_int = 1;
+    }
+    if (doit) {
+      // np.random.permutation(arange(n_int)) then intervals in that order
+      if (gl == 0)
+        for (int i = 0; i < n_int; i++) ord[i] = (uint8_t)i;
+    }
+    lds_sync();
+    if (doit) {
+      for (int i = n_int - 1; i >= 1; i--) {
+        const int k = (int)stream_interval(c.st, c.ctr++, (uint32_t)i);
+        const uint8_t a = ord[i], b = ord[k];
+        lds_sync();
+        if (gl == 0) {
+          ord[i] = b;
+          ord[k] = a;
+        }
+        lds_sync();
+      }
+      if (gl < n_int) {
+        const int iv = ord[gl];
+        uint64_t z = zeros;
+        for (int q = 0; q < iv; q++) z &= z - 1;
+        const int start = __ffsll((long long)z) - 1;
+        z &= z - 1;
+        const int stop = __ffsll((long long)z) - 1;
+        ivse[gl] = (uint32_t)start | ((uint32_t)stop << 8);
+      }
+      // n_int <= Mh <= 62 may exceed G for G = 16/32: remaining entries by a strided loop
+      for (int q = gl + G; q < n_int; q += G) {
+        const int iv = ord[q];
+        uint64_t z = zeros;
+        for (int r = 0; r < iv; r++) z &= z - 1;
+        const int start = __ffsll((long long)z) - 1;
+        z &= z - 1;
+        const int stop = __ffsll((long long)z) - 1;
+        ivse[q] = (uint32_t)start | ((uint32_t)stop << 8);
+      }
+    }
+  }
+  lds_sync();
+  // speculation rounds over the remaining intervals [ii0, n_int)
+  int ii0 = 0;
+  bool done = !doit;
+  const uint64_t full = mask_of(c.bits, Mh, 0, Mh);
+  while (wave_any(!done)) {
+    // (a) labels and option counts of the next (up to G) intervals, one interval per lane
+    if (!done) {
+      for (int ii = ii0 + gl; ii < n_int && ii < ii0 + G; ii += G) {
+        const uint32_t se = ivse[ii];
+        const uint64_t min_ = mask_of(c.bits, Mh, (int)(se & 255u), (int)(se >> 8));
+        const uint32_t lin = seg_labels<KT>(c.g, min_);
+        const uint32_t lout = seg_labels<KT>(c.g, full & ~min_);
+        ivlin[ii] = lin;
+        ivlout[ii] = lout;
+        ivno[ii] = (uint32_t)(step_type == 0 ? recombination_n_options(lin, lout, KT) : dosage_n_options(lin, lout, KT));
+      }
+    }
+    lds_sync();
+    // (b) slots: lane gl serves option (my_ii, my_o); intervals [ii0, ii1) fit into G slots
+    int ii1 = ii0, my_ii = -1, my_o = 0, my_no = 0;
+    if (!done) {
+      int off = 0;
+      while (ii1 < n_int && ii1 < ii0 + G) {
+        const int no = (int)ivno[ii1];
+        if (off + no > G && ii1 > ii0) break;
+        if (gl >= off && gl < off + no) {
+          my_ii = ii1;
+          my_o = gl - off;
+          my_no = no;
+        }
+        off += no;
+        ii1++;
+      }
+    }
+    // (c) evaluate my option
+    const bool prop = !done && my_ii >= 0;
+    GWords<KT> pw = c.g;
+    uint32_t oin = 0, lout = 0;
+    if (prop) {
+      const uint32_t se = ivse[my_ii];
+      const uint64_t min_ = mask_of(c.bits, Mh, (int)(se & 255u), (int)(se >> 8));
+      const uint32_t lin = ivlin[my_ii];
+      lout = ivlout[my_ii];
+      // the my_o-th option in the reference's enumeration order (structural.py:121-178 / 240-307)
+      const uint32_t hd = dosage_of_labels(lin, lout, KT, true);
+      int cnt = 0;
+      if (step_type == 0) {
+#pragma unroll
+        for (int h0 = 0; h0 < KT; h0++) {
+#pragma unroll
+          for (int h1 = h0 + 1; h1 < KT; h1++) {
+            const bool valid = nib(hd, h0) != 0 && nib(hd, h1) != 0 && nib(lin, h0) != nib(lin, h1) && nib(lout, h0) != nib(lout, h1);
+            if (valid) {
+              if (cnt == my_o) {
+                uint32_t o = nib_set(lin, h0, nib(lin, h1));
+                oin = nib_set(o, h1, nib(lin, h0));
+              }
+              cnt++;
+            }
+          }
+        }
+      } else {
+        const uint32_t sd = dosage_of_labels(lin, lout, KT, false);
+#pragma unroll
+        for (int h0 = 0; h0 < KT; h0++) {
+#pragma unroll
+          for (int h1 = 0; h1 < KT; h1++) {
+            const bool valid = nib(hd, h0) != 0 && nib(sd, h0) != 1 && nib(sd, h1) != 0 && nib(lin, h0) != nib(lin, h1);
+            if (valid) {
+              if (cnt == my_o) oin = nib_set(lin, h0, nib(lin, h1));
+              cnt++;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < KT; h++) pw.w[h] = (c.g.w[h] & ~min_) | (sel_word<KT>(c.g, (int)nib(oin, h)) & min_);
+    }
+    const double llk_i = spec_eval<KT, G>(prop, pw, c, S, mmax, rpad, lane);
+    if (prop) {
+      double lprior_ratio = 0.0;
+      if (!isnan(c.inbreeding))
+        lprior_ratio = prior_of<KT>(pt, c.inbreeding, dosage_of_labels(oin, lout, KT, true)) -
+                       prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(c.g));
+      const int n_return = step_type == 0 ? recombination_n_options(oin, lout, KT) : dosage_n_options(oin, lout, KT);
+      const double lproposal_ratio = S.lninv[n_return] - S.lninv[my_no];
+      const double mh = ((llk_i - c.llk) + lprior_ratio) * temp + lproposal_ratio;
+      S.ptab[lane] = exp(fmin(0.0, mh) - S.ln[my_no]);
+    }
+    lds_sync();
+    // (d) sequential validation walk over the intervals of this round
+    int acc_gl = -1;
+    if (!done) {
+      int off = 0;
+      int ii = ii0;
+      for (; ii < ii1; ii++) {
+        const int no = (int)ivno[ii];
+        if (no > 0) {
+          const double u = stream_double(c.st, c.ctr++);
+          double cacc = 0.0;
+          int choice = -1;
+          for (int o = 0; o < no; o++) {
+            cacc += S.ptab[gi * G + off + o];
+            if (cacc > u) {
+              choice = o;
+              break;
+            }
+          }
+          if (choice >= 0) {
+            acc_gl = off + choice;
+            ii++;
+            break;
+          }
+        }
+        off += no;
+      }
+      ii0 = ii;
+    }
+    // (e) apply the accepted move (if any): its words and llk come from the lane that evaluated it
+    {
+      const int src = acc_gl >= 0 ? acc_gl : 0;
+      GWords<KT> nw;
+#pragma unroll
+      for (int h = 0; h < KT; h++) nw.w[h] = __shfl(pw.w[h], src, G);
+      const double nl = __shfl(llk_i, src, G);
+      if (acc_gl >= 0) {
+        c.g = nw;
+        c.llk = nl;
+      }
+    }
+    if (!done && ii0 >= n_int) done = true;
+    lds_sync();
+  }
+  return ok;
+}
+
+template <int KT, int G>
+__global__ __launch_bounds__(64) void denovo_spec_kernel(const SimtParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NG = 64 / G;
+  const DenovoParams &D = P.d;
+  const int lane = threadIdx.x;
+  const int gi = lane / G, gl = lane % G;
+  const int T = D.n_temps, Cn = D.chains, Sn = D.steps;
+  const int mmax = P.max_pos, nmax = KT * P.max_pos;
+  const int rpad = D.rpad;
+  SpecLds S;
+  {
+    unsigned char *p = smem;
+    S.pw = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * KT * 64;
+    S.wst = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * NG * T * KT;
+    S.llk_t = reinterpret_cast<double *>(p); p += (size_t)8 * NG * T;
+    S.rngn = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * NG * T;
+    S.prior = reinterpret_cast<double *>(p); p += (size_t)8 * NG * (2 * KT + 5);
+    S.ptab = reinterpret_cast<double *>(p); p += (size_t)8 * 64;
+    S.ln = reinterpret_cast<double *>(p); p += (size_t)8 * SPEC_LN;
+    S.lninv = reinterpret_cast<double *>(p); p += (size_t)8 * SPEC_LN;
+    S.ivse = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
+    S.ivlin = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
+    S.ivlout = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
+    S.ivno = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
+    S.cols = reinterpret_cast<uint16_t *>(p); p += (size_t)2 * NG * mmax;
+    S.permtab = reinterpret_cast<uint16_t *>(p); p += (size_t)2 * NG * nmax;
+    S.shift = p; p += (size_t)NG * mmax;
+    S.nal = p; p += (size_t)NG * mmax;
+    S.ktab = p; p += (size_t)NG * nmax;
+    S.ordtab = p;
+  }
+  for (int i = lane; i < SPEC_LN; i += WAVE) {
+    S.ln[i] = c_ln[i];
+    S.lninv[i] = c_ln_inv[i];
+  }
+  const long long q = (long long)blockIdx.x * NG + gi;  // chain index of the group
+  const long long n_chains = (long long)P.n_units * Cn;
+  Grp<KT> c;
+  c.alive = q < n_chains;
+  const int u = c.alive ? (int)(q / Cn) : 0;
+  const int chain = c.alive ? (int)(q % Cn) : 0;
+  const mchap_unit U = D.units[u];
+  const int32_t *mi = P.meta_i + (size_t)u * meta_i_stride(P.max_pos);
+  const double *mf = P.meta_f + (size_t)u * meta_f_stride(P.max_ploidy, P.max_pos, P.max_allele);
+  if (c.alive && mi[META_I_STATUS] != MCHAP_UNIT_OK) c.alive = false;
+  const int A = U.max_allele;
+  c.Mh = c.alive ? mi[META_I_MH] : 1;
+  c.bits = allele_bits(A);
+  c.amask = (1u << c.bits) - 1u;
+  c.inbreeding = U.inbreeding;
+  c.key_bits = c.bits * c.Mh;
+  c.rt = P.rt + (size_t)u * P.max_ma * rpad;
+  c.cw = P.cntw + (size_t)u * rpad;
+  c.cache = nullptr;
+  c.cache_mask = 0;
+  if (D.cache_slots > 0) {
+    c.cache = reinterpret_cast<ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots;
+    c.cache_mask = (uint32_t)(D.cache_slots / 8) - 1u;  // sets of 8 ways
+  }
+  c.ctr = 0;
+  c.llk = 0.0;
+  const int Mh = c.Mh;
+  if (c.alive) {
+    for (int j = gl; j < Mh; j += G) {
+      S.cols[(size_t)gi * mmax + j] = (uint16_t)mi[META_I_COLS + j];
+      S.nal[(size_t)gi * mmax + j] = (uint8_t)mi[META_I_COLS + P.max_pos + j];
+      S.shift[(size_t)gi * mmax + j] = (uint8_t)(c.bits * (Mh - 1 - j));
+    }
+    if (!isnan(c.inbreeding))
+      for (int i = gl; i < 2 * KT + 5; i += G) S.prior[(size_t)gi * (2 * KT + 5) + i] = mf[meta_f_prior(0) + i];
+  }
+  lds_sync();
+  const int amax = [&] {
+    int v = c.alive ? A : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, WAVE));
+    return v;
+  }();
+  // ---- initial genotype (assemble/mcmc.py:202-208) ----
+#pragma unroll
+  for (int h = 0; h < KT; h++) c.g.w[h] = 0;
+  if (c.alive) {
+    const uint8_t *shift = S.shift + (size_t)gi * mmax;
+    if (U.initial_off >= 0) {
+      const int8_t *ini = D.initial + U.initial_off + (size_t)chain * KT * Mh;
+#pragma unroll
+      for (int h = 0; h < KT; h++) {
+        uint64_t x = 0;
+        for (int j = 0; j < Mh; j++) x |= (uint64_t)(uint8_t)ini[h * Mh + j] << shift[j];
+        c.g.w[h] = x;
+      }
+    } else {
+      const double *dist = mf + meta_f_dist(P.max_ploidy);
+      Stream si;
+      si.k0 = (uint32_t)D.seed;
+      si.k1 = (uint32_t)(D.seed >> 32) ^ (uint32_t)(U.stream_id >> 32);
+      si.c2 = ((uint32_t)chain << 16) | SLOT_INIT;
+      si.c3 = (uint32_t)U.stream_id;
+      uint64_t n = 0;
+#pragma unroll
+      for (int h = 0; h < KT; h++) {
+        uint64_t x = 0;
+        for (int j = 0; j < Mh; j++) {
+          double s = 0.0;
+          for (int a = 0; a < A; a++) s += dist[j * A + a];
+          double cacc = 0.0;
+          const double uu = stream_double(si, n++);
+          int ch = A;
+          for (int a = 0; a < A; a++) {
+            cacc += dist[j * A + a] / s;
+            if (cacc > uu) {
+              ch = a;
+              break;
+            }
+          }
+          if (ch >= A) ch = A - 1;
+          x |= (uint64_t)ch << shift[j];
+        }
+        c.g.w[h] = x;
+      }
+    }
+  }
+  {
+    const double v = spec_eval<KT, G>(c.alive && gl == 0, c.g, c, S, mmax, rpad, lane);  // assemble/mcmc.py:303
+    c.llk = __shfl(v, 0, G);
+    if (c.alive && gl == 0) {
+      for (int t = 0; t < T; t++) {
+#pragma unroll
+        for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t) * KT + h] = c.g.w[h];
+        S.llk_t[(size_t)gi * T + t] = c.llk;
+        S.rngn[(size_t)gi * T + t] = 0;
+      }
+    }
+  }
+  lds_sync();
+  const double *break_dist = D.break_table + (size_t)Mh * D.max_pos;
+  const int n_break_dist = D.n_intervals > 0 ? D.n_intervals : Mh;
+  const size_t trace_base = U.trace_off + (size_t)chain * Sn * KT;
+  const size_t llk_base = U.llk_off + (size_t)chain * Sn;
+  int status = MCHAP_UNIT_OK;
+  c.st.k0 = (uint32_t)D.seed;
+  c.st.k1 = (uint32_t)(D.seed >> 32) ^ (uint32_t)(U.stream_id >> 32);
+  c.st.c3 = (uint32_t)U.stream_id;
+
+  for (int step = 0; step < Sn; step++) {
+    for (int t = 0; t < T; t++) {
+      if (T > 1) {
+#pragma unroll
+        for (int h = 0; h < KT; h++) c.g.w[h] = S.wst[((size_t)gi * T + t) * KT + h];
+        c.llk = S.llk_t[(size_t)gi * T + t];
+        c.ctr = S.rngn[(size_t)gi * T + t];
+      }
+      const double temp = D.temps[t];
+      c.st.c2 = ((uint32_t)chain << 16) | (uint32_t)t;
+      if (c.alive && isnan(c.llk)) {  // assemble/mcmc.py:330-331
+        status = MCHAP_UNIT_NAN_LLK;
+        c.alive = false;
+      }
+      spec_mutation<KT, G>(c, S, temp, amax, mmax, nmax, rpad, lane, gi, gl);
+      for (int kind = 0; kind < 3; kind++) {
+        if (!spec_structural<KT, G>(c, S, D, kind, temp, break_dist, n_break_dist, mmax, rpad, lane, gi, gl)) {
+          status = MCHAP_UNIT_BREAKS;
+          c.alive = false;
+        }
+      }
+      if (T > 1) {
+        if (c.alive && t > 0) {
+          // tempering.py:61-151 with the previous (warmer) temperature
+          const double *pt = S.prior + (size_t)gi * (2 * KT + 5);
+          GWords<KT> gj;
+#pragma unroll
+          for (int h = 0; h < KT; h++) gj.w[h] = S.wst[((size_t)gi * T + t - 1) * KT + h];
+          double llk_j = S.llk_t[(size_t)gi * T + t - 1];
+          double prior_i = 0.0, prior_j = 0.0;
+          if (!isnan(c.inbreeding)) {
+            prior_i = prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(c.g));
+            prior_j = prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(gj));
+          }
+          const double ui = c.llk + prior_i, uj = llk_j + prior_j;
+          double acc = exp((uj - ui) * temp + (ui - uj) * D.temps[t - 1]);
+          if (acc > 1.0) acc = 1.0;
+          const double val = stream_double(c.st, c.ctr++);
+          lds_sync();
+          if (acc >= val) {
+            if (gl == 0) {
+#pragma unroll
+              for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t - 1) * KT + h] = c.g.w[h];
+              S.llk_t[(size_t)gi * T + t - 1] = c.llk;
+            }
+            c.g = gj;
+            c.llk = llk_j;
+          }
+        }
+        lds_sync();
+        if (c.alive && gl == 0) {
+#pragma unroll
+          for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t) * KT + h] = c.g.w[h];
+          S.llk_t[(size_t)gi * T + t] = c.llk;
+          S.rngn[(size_t)gi * T + t] = c.ctr;
+        }
+        lds_sync();
+      }
+    }
+    if (c.alive) {
+      // record the cold chain (held in registers after the last temperature) in canonical order
+      if (gl < KT) {
+        const uint64_t x = sel_word<KT>(c.g, gl);
+        int rank = 0;
+#pragma unroll
+        for (int h = 0; h < KT; h++) rank += (c.g.w[h] < x || (c.g.w[h] == x && h < gl)) ? 1 : 0;
+        D.trace[trace_base + (size_t)step * KT + rank] = x;
+      }
+      if (gl == 0) D.llks[llk_base + step] = c.llk;
+    }
+  }
+  if (status != MCHAP_UNIT_OK && gl == 0) atomicMax(&D.status[u], status);
+}
+
+}  // namespace mchap

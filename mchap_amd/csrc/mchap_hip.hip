@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <mutex>
@@ -12,6 +13,7 @@
 #include "../../include/mchap_hip.h"
 #include "denovo_kernel.hpp"
 #include "denovo_simt_kernel.hpp"
+#include "denovo_spec_kernel.hpp"
 #include "exact_kernel.hpp"
 #include "posterior_kernel.hpp"
 
@@ -96,7 +98,7 @@ int validate_cfg(const mchap_denovo_cfg *cfg) {
   return MCHAP_OK;
 }
 
-constexpr int CACHE_SLOTS = 512;  // {tag, llk} entries per chain
+constexpr int CACHE_SLOTS = 1024;  // {tag, llk} entries per chain (16 KiB)
 
 // cached device copy of the break table
 std::mutex g_bt_mu;
@@ -168,6 +170,35 @@ int launch_simt(const mchap::SimtParams &P, int n_units, int chains, size_t lds_
   hipLaunchKernelGGL(ks, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), lds_simt, stream, P);
   HIP_TRY(hipGetLastError());
   return MCHAP_OK;
+}
+
+template <int KT, int G>
+int launch_spec(const mchap::SimtParams &P, int n_units, int chains, int n_temps, hipStream_t stream) {
+  auto ks = mchap::denovo_spec_kernel<KT, G>;
+  const size_t lds = mchap::spec_lds_bytes(KT, P.max_pos, n_temps, G);
+  if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long long n_chains = (long long)n_units * chains;
+  const int per_wave = 64 / G;
+  hipLaunchKernelGGL(ks, dim3((unsigned)((n_chains + per_wave - 1) / per_wave)), dim3(64), lds, stream, P);
+  HIP_TRY(hipGetLastError());
+  return MCHAP_OK;
+}
+
+// lanes per chain for the speculative sampler: every option of an interval step (<= K(K-1)) and half the
+// sub-steps of a mutation step (K * n_pos) must fit; 0 if the shape is not supported by it
+int spec_group(int K, int max_pos) {
+  if (K != 2 && K != 4 && K != 6 && K != 8) return 0;
+  const int n = K * max_pos;
+  int g = 16;
+  if (const char *e = std::getenv("MCHAP_HIP_GROUP")) g = std::atoi(e);
+  if (g != 16 && g != 32 && g != 64) g = 16;
+  while (g < 64 && (g < K * (K - 1) || 2 * g < n)) g *= 2;
+  if (g < K * (K - 1) || 2 * g < n) return 0;
+  if (K == 6 && g < 32) g = 32;
+  if (K == 8) g = 64;
+  return g;
 }
 
 bool use_simt(const mchap_denovo_cfg *cfg) { return cfg->kernel != 1; }
@@ -318,6 +349,25 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
       default: rc = launch_prepare<16>(SP, n_units, lds_prep, stream); break;
     }
     if (rc) return rc;
+    // default: the speculative sampler when every unit shares a supported ploidy, else lanes over chains
+    if (cfg->kernel != 2) {
+      const int K = B.uniform_ploidy;
+      const int g = K > 0 ? spec_group(K, B.max_pos) : 0;
+      const int T = cfg->n_temps;
+      if (g) {
+        switch (K * 100 + g) {
+          case 216: return launch_spec<2, 16>(SP, n_units, cfg->chains, T, stream);
+          case 232: return launch_spec<2, 32>(SP, n_units, cfg->chains, T, stream);
+          case 264: return launch_spec<2, 64>(SP, n_units, cfg->chains, T, stream);
+          case 416: return launch_spec<4, 16>(SP, n_units, cfg->chains, T, stream);
+          case 432: return launch_spec<4, 32>(SP, n_units, cfg->chains, T, stream);
+          case 464: return launch_spec<4, 64>(SP, n_units, cfg->chains, T, stream);
+          case 632: return launch_spec<6, 32>(SP, n_units, cfg->chains, T, stream);
+          case 664: return launch_spec<6, 64>(SP, n_units, cfg->chains, T, stream);
+          case 864: return launch_spec<8, 64>(SP, n_units, cfg->chains, T, stream);
+        }
+      }
+    }
     // a launch whose units share one ploidy runs the kernel specialised for it
     switch (B.uniform_ploidy) {
       case 2: return launch_simt<2>(SP, n_units, cfg->chains, lds_simt, stream);

@@ -11,7 +11,7 @@ from tests.helpers import beta_break_table
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[2, 1], ids=["lanes-over-chains", "wave-per-chain"])
+@pytest.fixture(autouse=True, params=[3, 2, 1], ids=["speculative", "lanes-over-chains", "wave-per-chain"])
 def sampler_kernel(request, monkeypatch):
     """Every test runs against both sampler kernels; they must give identical traces."""
     monkeypatch.setenv("MCHAP_HIP_KERNEL", str(request.param))
@@ -189,7 +189,8 @@ def test_both_kernels_give_identical_traces():
     reads, _, _ = synth_units(70, ploidy=4, n_pos=8, n_reads=200, first_unit=500)  # > one wavefront of chains
     kw = dict(ploidy=4, n_alleles=[2] * 8, steps=120, chains=2, random_seed=99)
     a = DenovoMCMC(kernel=1, **kw).fit_batch(list(reads))
-    b = DenovoMCMC(kernel=2, **kw).fit_batch(list(reads))
-    for x, y in zip(a, b):
-        assert np.array_equal(x.genotypes, y.genotypes)
-        np.testing.assert_allclose(x.llks, y.llks, rtol=1e-12)
+    for k in (2, 3):
+        b = DenovoMCMC(kernel=k, **kw).fit_batch(list(reads))
+        for x, y in zip(a, b):
+            assert np.array_equal(x.genotypes, y.genotypes)
+            np.testing.assert_allclose(x.llks, y.llks, rtol=1e-12)
