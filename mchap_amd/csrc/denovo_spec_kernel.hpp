@@ -26,26 +26,39 @@ namespace mchap {
 
 constexpr int SPEC_MAX_IV = 64;  // intervals per structural compound step (<= n_pos)
 constexpr int SPEC_LN = 260;
+constexpr int SPEC_DRAWS = 128;  // draws of the current stream staged in LDS per group (Philox blocks computed in parallel)
+
+// LDS pointers carry their address space so that every access is a ds_* instruction (a pointer stored in a struct
+// otherwise degrades to a generic "flat" access)
+#define LDSP(T) __attribute__((address_space(3))) T *
+#define GLBP(T) __attribute__((address_space(1))) T *
+template <class T>
+__device__ __forceinline__ LDSP(T) lds_cast(void *p) {
+  return (LDSP(T))p;
+}
 
 struct SpecLds {
-  uint64_t *pw;      // [K][64] request words of missing lanes (lane strided)
-  uint64_t *wst;     // [NG][T][K] genotype of every temperature
-  double *llk_t;     // [NG][T]
-  uint64_t *rngn;    // [NG][T]
-  double *prior;     // [NG][2K+5]
-  double *ptab;      // [64] per-slot move probability
-  double *ln;        // [SPEC_LN] log(n)
-  double *lninv;     // [SPEC_LN] log(1/n)
-  uint32_t *ivse;    // [NG][SPEC_MAX_IV] start | stop << 8, in visiting order
-  uint32_t *ivlin;   // [NG][SPEC_MAX_IV]
-  uint32_t *ivlout;  // [NG][SPEC_MAX_IV]
-  uint32_t *ivno;    // [NG][SPEC_MAX_IV] n_options
-  uint16_t *cols;    // [NG][Mmax]
-  uint16_t *permtab; // [NG][nmax] (h << 8) | j by order position
-  uint8_t *shift;    // [NG][Mmax]
-  uint8_t *nal;      // [NG][Mmax]
-  uint8_t *ktab;     // [NG][nmax]
-  uint8_t *ordtab;   // [NG][SPEC_MAX_IV]
+  LDSP(uint64_t) pw;      // [K][64] request words of missing lanes (lane strided)
+  LDSP(uint64_t) wst;     // [NG][T][K] genotype of every temperature
+  LDSP(double) llk_t;     // [NG][T]
+  LDSP(uint64_t) rngn;    // [NG][T]
+  LDSP(double) prior;     // [NG][2K+5]
+  LDSP(double) ptab;      // [64] per-slot move probability
+  LDSP(double) optp;      // [MCHAP_MAX_ALLELE][64] mutation option probabilities of the lane
+  LDSP(double) optl;      // [MCHAP_MAX_ALLELE][64] ... and their log likelihoods
+  LDSP(double) ln;        // [SPEC_LN] log(n)
+  LDSP(double) lninv;     // [SPEC_LN] log(1/n)
+  LDSP(uint32_t) ivse;    // [NG][SPEC_MAX_IV] start | stop << 8, in visiting order
+  LDSP(uint32_t) ivlin;   // [NG][SPEC_MAX_IV]
+  LDSP(uint32_t) ivlout;  // [NG][SPEC_MAX_IV]
+  LDSP(uint32_t) ivno;    // [NG][SPEC_MAX_IV] n_options
+  LDSP(uint16_t) cols;    // [NG][Mmax]
+  LDSP(uint16_t) permtab; // [NG][nmax] (h << 8) | j by order position
+  LDSP(uint8_t) shift;    // [NG][Mmax]
+  LDSP(uint8_t) nal;      // [NG][Mmax]
+  LDSP(uint8_t) ktab;     // [NG][nmax]
+  LDSP(uint8_t) ordtab;   // [NG][SPEC_MAX_IV]
+  LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
 };
 
 __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int T, int G) {
@@ -57,6 +70,7 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int T, int G) 
   b += (size_t)8 * NG * T * 2;
   b += (size_t)8 * NG * (2 * K + 5);
   b += (size_t)8 * 64;
+  b += (size_t)8 * MCHAP_MAX_ALLELE * 64 * 2;
   b += (size_t)8 * SPEC_LN * 2;
   b += (size_t)4 * NG * SPEC_MAX_IV * 4;
   b += (size_t)2 * NG * Mmax;
@@ -64,6 +78,8 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int T, int G) 
   b += (size_t)NG * Mmax * 2;
   b += (size_t)NG * nmax;
   b += (size_t)NG * SPEC_MAX_IV;
+  b = (b + 15) & ~(size_t)15;
+  b += (size_t)8 * NG * SPEC_DRAWS;
   return (b + 63) & ~(size_t)63;
 }
 
@@ -88,6 +104,29 @@ __device__ __forceinline__ uint32_t stream_interval(const Stream &s, uint64_t n,
   stream_words(s, n, a, b);
   return __umulhi(a, max + 1u);
 }
+
+// Stage draws base .. base + count - 1 (count <= SPEC_DRAWS) of stream `s` into the group's LDS table: every lane
+// computes whole Philox blocks (two draws each), so a compound step costs count / (2 G) blocks per lane instead of
+// one block per draw.  Entry i holds the two words of draw base + i.
+template <int G>
+__device__ __forceinline__ void stage_draws(const Stream &s, uint64_t base, int count, LDSP(uint64_t) tab, int gl, bool active) {
+  if (active) {
+    const uint64_t b0 = base >> 1;
+    const int nblk = (int)(((base + (uint64_t)count + 1) >> 1) - b0);
+    for (int b = gl; b < nblk; b += G) {
+      uint32_t o[4];
+      const uint64_t blk = b0 + (uint64_t)b;
+      philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), s.c2, s.c3, s.k0, s.k1, o);
+      const long long i0 = (long long)(blk << 1) - (long long)base;  // table index of the block's first draw
+      if (i0 >= 0 && i0 < count) tab[i0] = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+      if (i0 + 1 >= 0 && i0 + 1 < count) tab[i0 + 1] = (uint64_t)o[2] | ((uint64_t)o[3] << 32);
+    }
+  }
+}
+__device__ __forceinline__ double draw_double(uint64_t w) {
+  return ((double)((uint32_t)w >> 5) * 67108864.0 + (double)((uint32_t)(w >> 32) >> 6)) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ uint32_t draw_interval(uint64_t w, uint32_t max) { return __umulhi((uint32_t)w, max + 1u); }
 
 template <int G>
 __device__ __forceinline__ uint64_t grp_ballot(bool p, int gi) {
@@ -158,7 +197,7 @@ __device__ __forceinline__ uint32_t seg_labels(const GWords<KT> &g, uint64_t mas
   return lab;
 }
 template <int KT>
-__device__ __forceinline__ double prior_of(const double *pt, double inbreeding, uint32_t d) {
+__device__ __forceinline__ double prior_of(LDSP(double) pt, double inbreeding, uint32_t d) {
   if (inbreeding == 0.0) {
     double den = 0.0;
 #pragma unroll
@@ -210,8 +249,9 @@ struct Grp {
 
 template <int KT, int RPL>
 __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
-                                                 const double *rt, const double *cw, int rpad, int lane) {
-  constexpr int UNR = RPL <= 4 ? 8 : (RPL == 8 ? 4 : 2);
+                                                 GLBP(const double) rt, GLBP(const double) cw, int rpad, int lane) {
+  // rt / cw already point at the lane's first read of the block of RPL chunks
+  constexpr int UNR = 8;
   const int n_pairs = KT * Mh;
   const double invK = 1.0 / (double)KT;
   double acc[RPL], prod[RPL];
@@ -239,7 +279,7 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
       for (int u = 0; u < UNR; u++) {
         const int q = q0 + u;
         const int row = __builtin_amdgcn_readlane(myrow, q < lim ? q : 0);
-        const double *rp = rt + (size_t)row * rpad;
+        GLBP(const double) rp = rt + (size_t)row * rpad;
 #pragma unroll
         for (int i = 0; i < RPL; i++) v[u][i] = rp[WAVE * i];
       }
@@ -263,7 +303,43 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
-  return wave_sum(s);
+  return s;  // per-lane partial sum; the caller reduces across the wave
+}
+
+// Serves every request of the wave (bit mask `todo`), one after the other, with all 64 lanes; kept out of line so
+// that its registers (RPL x UNR loads in flight) do not count against the sampler's main loop.
+template <int KT, int G>
+__device__ __noinline__ double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
+                                             LDSP(uint16_t) cols_tab, int mmax, int Mh_lane, uint32_t amask_lane,
+                                             const double *rt_lane, const double *cw_lane, int rpad, int lane) {
+  SpecLds S;
+  S.pw = pwbuf;
+  S.shift = shift_tab;
+  S.cols = cols_tab;
+  const int nch = rpad / WAVE;
+  double val = 0.0;
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int sg = src / G;
+    const int Mh = __builtin_amdgcn_readfirstlane(__shfl(Mh_lane, src, WAVE));
+    const uint32_t amask = (uint32_t)__shfl((int)amask_lane, src, WAVE);
+    const unsigned long long rtb = __shfl((unsigned long long)(uintptr_t)rt_lane, src, WAVE);
+    const unsigned long long cwb = __shfl((unsigned long long)(uintptr_t)cw_lane, src, WAVE);
+    GLBP(const double) rt = (GLBP(const double))(uintptr_t)rtb + lane;
+    GLBP(const double) cw = (GLBP(const double))(uintptr_t)cwb + lane;
+    // the lane's reads in blocks of at most 4 chunks of 64 (keeps the loads in flight, and this function's
+    // registers, bounded whatever the read depth)
+    double s = 0.0;
+    if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
+    else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
+    else
+      for (int cb = 0; cb < nch; cb += 4)
+        s += spec_coop_body<KT, 4>(S, src, sg, mmax, Mh, amask, rt + cb * WAVE, cw + cb * WAVE, rpad, lane);
+    s = wave_sum(s);
+    if (lane == src) val = s;
+  }
+  return val;
 }
 
 // Likelihood of the lane's proposal `pw` (where need): 4-way cache probe, then co-operative evaluation of the
@@ -317,49 +393,51 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
       for (int h = 0; h < KT; h++) S.pw[(size_t)h * WAVE + lane] = pw.w[h];
     }
     lds_sync();
-    const int nch = rpad / WAVE;
-    while (todo) {
-      const int src = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const int sg = src / G;
-      const int Mh = __builtin_amdgcn_readfirstlane(__shfl(c.Mh, src, WAVE));
-      const uint32_t amask = (uint32_t)__shfl((int)c.amask, src, WAVE);
-      const unsigned long long rtb = __shfl((unsigned long long)(uintptr_t)c.rt, src, WAVE);
-      const unsigned long long cwb = __shfl((unsigned long long)(uintptr_t)c.cw, src, WAVE);
-      const double *rt = reinterpret_cast<const double *>((uintptr_t)rtb) + lane;
-      const double *cw = reinterpret_cast<const double *>((uintptr_t)cwb) + lane;
-      double s;
-      if (nch == 4) s = spec_coop_body<KT, 4>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
-      else if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
-      else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
-      else if (nch == 8) s = spec_coop_body<KT, 8>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
-      else s = spec_coop_body<KT, 16>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
-      if (lane == src) val = s;
+    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
+    if (miss) {
+      val = v;
+      if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
     }
-    if (miss && slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
     lds_sync();
   }
   return val;
 }
 
 // mutation.compound_step (mutation.py:164-246) for the group's chain: shuffle, then speculative sub-steps.
+#ifndef MCHAP_SPEC_WPE
+#define MCHAP_SPEC_WPE 1
+#endif
+#ifdef MCHAP_SPEC_NOINLINE
+#define SPEC_FN __device__ __noinline__
+#else
+#define SPEC_FN __device__ __forceinline__
+#endif
+
 template <int KT, int G>
-__device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, int mmax, int nmax, int rpad,
+SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, int mmax, int nmax, int rpad,
                                               int lane, int gi, int gl) {
   const int Mh = c.Mh;
   const int n = KT * Mh;  // sub-steps; position p of the sequence is held by lane p % G, slot p / G (n <= 2 G)
   const uint64_t ctr0 = c.ctr;
-  uint8_t *ktab = S.ktab + (size_t)gi * nmax;
-  uint16_t *permtab = S.permtab + (size_t)gi * nmax;
-  const uint8_t *shift = S.shift + (size_t)gi * mmax;
-  const uint8_t *nal = S.nal + (size_t)gi * mmax;
-  const double *pt = S.prior + (size_t)gi * (2 * KT + 5);
+  LDSP(uint8_t) ktab = S.ktab + gi * nmax;
+  LDSP(uint16_t) permtab = S.permtab + gi * nmax;
+  LDSP(uint8_t) shift = S.shift + gi * mmax;
+  LDSP(uint8_t) nal = S.nal + gi * mmax;
+  LDSP(double) pt = S.prior + gi * (2 * KT + 5);
   const bool two = wave_any(c.alive && n > G);  // second slot in use anywhere in the wave
-  // (1) draws of the Fisher-Yates shuffle: swap(i, k_i) for i = n-1 .. 1, k_i = interval(i) is draw ctr0 + (n-1-i)
+  // (1) the 2n-1 draws of this compound step, staged through LDS; the Fisher-Yates shuffle is swap(i, k_i) for
+  //     i = n-1 .. 1 with k_i = interval(i) from draw ctr0 + (n-1-i)
+  LDSP(uint64_t) dtab = S.draws + gi * SPEC_DRAWS;
+  const bool staged = 2 * n - 1 <= SPEC_DRAWS;
+  stage_draws<G>(c.st, ctr0, 2 * n - 1, dtab, gl, c.alive && staged);
+  lds_sync();
   if (c.alive) {
+#pragma unroll
     for (int s = 0; s < 2; s++) {
       const int p = gl + s * G;
-      if (p >= 1 && p < n) ktab[p] = (uint8_t)stream_interval(c.st, ctr0 + (uint64_t)(n - 1 - p), (uint32_t)p);
+      if (p >= 1 && p < n)
+        ktab[p] = (uint8_t)(staged ? draw_interval(dtab[n - 1 - p], (uint32_t)p)
+                                   : stream_interval(c.st, ctr0 + (uint64_t)(n - 1 - p), (uint32_t)p));
     }
   }
   lds_sync();
@@ -380,6 +458,7 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
   }
   if (c.alive) {
     // element e = h * Mh + j starts at position e
+#pragma unroll
     for (int s = 0; s < 2; s++) {
       const int e = gl + s * G;
       if (e < n) {
@@ -393,46 +472,38 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
     }
   }
   lds_sync();
-  // (3) my sub-steps and their uniforms (one draw per sub-step, after the n-1 shuffle draws)
-  int sh_[2] = {0, 0}, hh[2] = {0, 0}, na_[2] = {2, 2};
-  double uu[2] = {2.0, 2.0};
-  if (c.alive) {
-    for (int s = 0; s < 2; s++) {
-      const int p = gl + s * G;
-      if (p < n) {
-        const int e = permtab[p];
-        hh[s] = e >> 8;
-        const int j = e & 255;
-        sh_[s] = shift[j];
-        na_[s] = nal[j];
-        uu[s] = stream_double(c.st, ctr0 + (uint64_t)(n - 1) + (uint64_t)p);
-      }
-    }
-  }
+  // (3) speculate / validate.  Position p = gl + s * G of the sequence is handled by slot s of lane gl; its
+  //     sub-step is permtab[p] and its uniform is draw ctr0 + (n-1) + p.
   c.ctr = ctr0 + (uint64_t)(n - 1) + (uint64_t)n;
-  // (4) speculate / validate
+  const int nslots = two ? 2 : 1;
   int start = 0;
   bool done = !c.alive;
   while (wave_any(!done)) {
-    bool changed[2] = {false, false};
-    uint64_t neww[2] = {0, 0};
-    double newllk[2] = {0.0, 0.0};
     const double lprior = (!done && !isnan(c.inbreeding)) ? prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(c.g)) : 0.0;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      if (s == 1 && !two) continue;  // wave-uniform
+    bool found = false;
+#pragma unroll 1
+    for (int s = 0; s < nslots; s++) {
       const int p = gl + s * G;
-      const bool act = !done && p >= start && p < n;
-      const int h = hh[s], sh = sh_[s], n_alleles = na_[s];
+      const bool act = !done && !found && p >= start && p < n;
+      int h = 0, sh = 0, n_alleles = 2;
+      double u = 2.0;
+      if (act) {
+        const int e = permtab[p];
+        h = e >> 8;
+        const int j = e & 255;
+        sh = shift[j];
+        n_alleles = nal[j];
+        u = staged ? draw_double(dtab[n - 1 + p]) : stream_double(c.st, ctr0 + (uint64_t)(n - 1) + (uint64_t)p);
+      }
       const uint64_t wh = sel_word<KT>(c.g, h);
       const int current = (int)((wh >> sh) & c.amask);
       const double lhapcount = S.ln[copies_of<KT>(c.g, wh)];
-      double la[MCHAP_MAX_ALLELE - 1], lk[MCHAP_MAX_ALLELE - 1];
-#pragma unroll
-      for (int o = 0; o < MCHAP_MAX_ALLELE - 1; o++) {
-        la[o] = -INFINITY;
-        lk[o] = c.llk;
-        if (o >= amax - 1) continue;  // wave-uniform bound
+      // options of the sub-step in allele order (current allele skipped); their move probabilities and likelihoods
+      // are parked in the lane's LDS column so that the loop needs no unrolling
+      const double ln_opt = S.ln[n_alleles - 1];
+      double sum = 0.0;
+#pragma unroll 1
+      for (int o = 0; o < amax - 1; o++) {  // wave-uniform trip count
         const bool prop = act && o < n_alleles - 1;
         const int i = o + (o >= current ? 1 : 0);
         GWords<KT> pw = c.g;
@@ -440,104 +511,100 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
         set_word<KT>(pw, h, nw);
         const double llk_i = spec_eval<KT, G>(prop, pw, c, S, mmax, rpad, lane);
         if (prop) {
-          lk[o] = llk_i;
           double lprior_ratio = 0.0;
           if (!isnan(c.inbreeding)) lprior_ratio = prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(pw)) - lprior;
           const double lproposal_ratio = S.ln[copies_of<KT>(pw, nw)] - lhapcount;
-          la[o] = fmin(0.0, ((llk_i - c.llk) + lprior_ratio) * temp + lproposal_ratio);
+          const double mh = ((llk_i - c.llk) + lprior_ratio) * temp + lproposal_ratio;
+          const double pr = exp(fmin(0.0, mh) - ln_opt);
+          S.optp[o * WAVE + lane] = pr;
+          S.optl[o * WAVE + lane] = llk_i;
+          sum += pr;
         }
       }
+      bool changed = false;
+      uint64_t neww = 0;
+      double newllk = 0.0;
       if (act) {
-        const double ln_opt = S.ln[n_alleles - 1];
-        double sum = 0.0;
-#pragma unroll
-        for (int o = 0; o < MCHAP_MAX_ALLELE - 1; o++) {
-          if (o < n_alleles - 1) {
-            la[o] = exp(la[o] - ln_opt);
-            sum += la[o];
-          }
-        }
         const double stay = 1.0 - sum;
         double cacc = 0.0;
         int choice = -1;
         double cl = c.llk;
-#pragma unroll
-        for (int i = 0; i < MCHAP_MAX_ALLELE; i++) {
-          if (i < n_alleles && choice < 0) {
-            double pi = stay, li = c.llk;
-            if (i != current) {
-              const int o = i - (i > current ? 1 : 0);
-#pragma unroll
-              for (int z = 0; z < MCHAP_MAX_ALLELE - 1; z++)
-                if (z == o) {
-                  pi = la[z];
-                  li = lk[z];
-                }
-            }
-            cacc += pi;
-            if (cacc > uu[s]) {
-              choice = i;
-              cl = li;
-            }
+        for (int i = 0; i < n_alleles && choice < 0; i++) {
+          double pi = stay, li = c.llk;
+          if (i != current) {
+            const int o = i - (i > current ? 1 : 0);
+            pi = S.optp[o * WAVE + lane];
+            li = S.optl[o * WAVE + lane];
+          }
+          cacc += pi;
+          if (cacc > u) {
+            choice = i;
+            cl = li;
           }
         }
         if (choice < 0) {  // u beyond the last cumulative value: the reference's searchsorted returns n (clamped)
           choice = n_alleles - 1;
-          if (choice != current) {
-            const int o = choice - (choice > current ? 1 : 0);
-#pragma unroll
-            for (int z = 0; z < MCHAP_MAX_ALLELE - 1; z++)
-              if (z == o) cl = lk[z];
-          }
+          if (choice != current) cl = S.optl[(choice - (choice > current ? 1 : 0)) * WAVE + lane];
         }
         if (choice != current) {
-          changed[s] = true;
-          neww[s] = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)choice << sh);
-          newllk[s] = cl;
+          changed = true;
+          neww = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)choice << sh);
+          newllk = cl;
         }
       }
-    }
-    // first sub-step (in sequence order) that moves
-    const uint64_t m0 = grp_ballot<G>(changed[0], gi);
-    const uint64_t m1 = two ? grp_ballot<G>(changed[1], gi) : 0ull;
-    if (!done) {
-      if ((m0 | m1) == 0ull) {
-        done = true;
-      } else {
-        const int slot = m0 ? 0 : 1;
-        const int fl = __ffsll((long long)(m0 ? m0 : m1)) - 1;
-        const int hsrc = __shfl(slot ? hh[1] : hh[0], fl, G);
-        const uint64_t wsrc = __shfl(slot ? neww[1] : neww[0], fl, G);
-        const double lsrc = __shfl(slot ? newllk[1] : newllk[0], fl, G);
+      // first sub-step (in sequence order) that moves: positions of slot 0 precede those of slot 1
+      const uint64_t m = grp_ballot<G>(changed, gi);
+      const int fl = m ? __ffsll((long long)m) - 1 : 0;
+      const int hsrc = __shfl(h, fl, G);
+      const uint64_t wsrc = __shfl(neww, fl, G);
+      const double lsrc = __shfl(newllk, fl, G);
+      if (!done && !found && m) {
         set_word<KT>(c.g, hsrc, wsrc);
         c.llk = lsrc;
-        start = fl + slot * G + 1;
-        if (start >= n) done = true;
+        start = fl + s * G + 1;
+        found = true;
       }
     }
+    if (!done && (!found || start >= n)) done = true;
   }
 }
 
 // One structural compound step (structural.py:22-71, 433-673) of kind 0 recombination, 1 interval dosage,
 // 2 whole-haplotype dosage.  Returns false if the group hit the reference's "breaks" ValueError.
 template <int KT, int G>
-__device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D, int kind, double temp,
+SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D, int kind, double temp,
                                                 const double *break_dist, int n_break_dist, int mmax, int rpad, int lane,
                                                 int gi, int gl) {
   const int Mh = c.Mh;
   const int step_type = kind == 0 ? 0 : 1;
-  uint32_t *ivse = S.ivse + (size_t)gi * SPEC_MAX_IV;
-  uint32_t *ivlin = S.ivlin + (size_t)gi * SPEC_MAX_IV;
-  uint32_t *ivlout = S.ivlout + (size_t)gi * SPEC_MAX_IV;
-  uint32_t *ivno = S.ivno + (size_t)gi * SPEC_MAX_IV;
-  uint8_t *ord = S.ordtab + (size_t)gi * SPEC_MAX_IV;
-  const double *pt = S.prior + (size_t)gi * (2 * KT + 5);
+  LDSP(uint32_t) ivse = S.ivse + gi * SPEC_MAX_IV;
+  LDSP(uint32_t) ivlin = S.ivlin + gi * SPEC_MAX_IV;
+  LDSP(uint32_t) ivlout = S.ivlout + gi * SPEC_MAX_IV;
+  LDSP(uint32_t) ivno = S.ivno + gi * SPEC_MAX_IV;
+  LDSP(uint8_t) ord = S.ordtab + gi * SPEC_MAX_IV;
+  LDSP(double) pt = S.prior + gi * (2 * KT + 5);
   bool ok = true;
   bool doit = false;
   int n_int = 0;
+  // the draws this compound step may consume (decision, break count, <= Mh-1 break points, <= Mh-1 order swaps,
+  // <= Mh interval choices) staged through LDS: next_double()/next_interval() below read them in sequence
+  LDSP(uint64_t) dtab = S.draws + gi * SPEC_DRAWS;
+  const uint64_t dbase = c.ctr;
+  const int dcount = min(SPEC_DRAWS, 3 * Mh + 2);
+  lds_sync();
+  stage_draws<G>(c.st, dbase, dcount, dtab, gl, c.alive);
+  lds_sync();
+  auto next_words = [&]() -> uint64_t {
+    const uint64_t i = c.ctr - dbase;
+    c.ctr++;
+    if (i < (uint64_t)dcount) return dtab[i];
+    uint32_t a, b;
+    stream_words(c.st, c.ctr - 1, a, b);
+    return (uint64_t)a | ((uint64_t)b << 32);
+  };
   if (c.alive) {
     const double pstep = kind == 0 ? D.p_recomb : (kind == 1 ? D.p_partial : D.p_dosage);
-    doit = stream_double(c.st, c.ctr++) <= pstep;
+    doit = draw_double(next_words()) <= pstep;
     uint64_t zeros = 0;
     if (doit && kind < 2) {
       int nb;
@@ -545,7 +612,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
         c.ctr++;  // break_dist = [0,...,0,1]: the draw is consumed (assemble/mcmc.py:214-217)
         nb = D.n_intervals - 1;
       } else {
-        nb = choose_from(break_dist, n_break_dist, stream_double(c.st, c.ctr++));
+        nb = choose_from(break_dist, n_break_dist, draw_double(next_words()));
       }
       if (nb >= Mh) {
         ok = false;
@@ -557,7 +624,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
           const int no = __popcll(ind);
           if (no == 0) break;
           int k = 0;
-          if (no > 1) k = (int)stream_interval(c.st, c.ctr++, (uint32_t)(no - 1));
+          if (no > 1) k = (int)draw_interval(next_words(), (uint32_t)(no - 1));
           uint64_t t = ind;
           while (k-- > 0) t &= t - 1;
           ind &= ~(t & (~t + 1));
@@ -577,7 +644,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
     lds_sync();
     if (doit) {
       for (int i = n_int - 1; i >= 1; i--) {
-        const int k = (int)stream_interval(c.st, c.ctr++, (uint32_t)i);
+        const int k = (int)draw_interval(next_words(), (uint32_t)i);
         const uint8_t a = ord[i], b = ord[k];
         lds_sync();
         if (gl == 0) {
@@ -706,7 +773,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
       for (; ii < ii1; ii++) {
         const int no = (int)ivno[ii];
         if (no > 0) {
-          const double u = stream_double(c.st, c.ctr++);
+          const double u = draw_double(next_words());
           double cacc = 0.0;
           int choice = -1;
           for (int o = 0; o < no; o++) {
@@ -744,8 +811,27 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
   return ok;
 }
 
+#ifdef MCHAP_STATS
+#define PHASE_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0_ = __builtin_amdgcn_s_memtime()
+#define PHASE(i)                                                  \
+  do {                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+    ph_[i] += t_ - pt0_;                                          \
+    pt0_ = t_;                                                    \
+  } while (0)
+#define PHASE_FLUSH                                               \
+  do {                                                            \
+    if (threadIdx.x == 0)                                         \
+      for (int i_ = 0; i_ < 5; i_++) atomicAdd(&g_stats[3 + i_], ph_[i_]); \
+  } while (0)
+#else
+#define PHASE_DECL
+#define PHASE(i)
+#define PHASE_FLUSH
+#endif
+
 template <int KT, int G>
-__global__ __launch_bounds__(64) void denovo_spec_kernel(const SimtParams P) {
+__global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const SimtParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NG = 64 / G;
   const DenovoParams &D = P.d;
@@ -757,24 +843,28 @@ __global__ __launch_bounds__(64) void denovo_spec_kernel(const SimtParams P) {
   SpecLds S;
   {
     unsigned char *p = smem;
-    S.pw = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * KT * 64;
-    S.wst = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * NG * T * KT;
-    S.llk_t = reinterpret_cast<double *>(p); p += (size_t)8 * NG * T;
-    S.rngn = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * NG * T;
-    S.prior = reinterpret_cast<double *>(p); p += (size_t)8 * NG * (2 * KT + 5);
-    S.ptab = reinterpret_cast<double *>(p); p += (size_t)8 * 64;
-    S.ln = reinterpret_cast<double *>(p); p += (size_t)8 * SPEC_LN;
-    S.lninv = reinterpret_cast<double *>(p); p += (size_t)8 * SPEC_LN;
-    S.ivse = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
-    S.ivlin = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
-    S.ivlout = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
-    S.ivno = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
-    S.cols = reinterpret_cast<uint16_t *>(p); p += (size_t)2 * NG * mmax;
-    S.permtab = reinterpret_cast<uint16_t *>(p); p += (size_t)2 * NG * nmax;
-    S.shift = p; p += (size_t)NG * mmax;
-    S.nal = p; p += (size_t)NG * mmax;
-    S.ktab = p; p += (size_t)NG * nmax;
-    S.ordtab = p;
+    S.pw = lds_cast<uint64_t>(p); p += (size_t)8 * KT * 64;
+    S.wst = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T * KT;
+    S.llk_t = lds_cast<double>(p); p += (size_t)8 * NG * T;
+    S.rngn = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T;
+    S.prior = lds_cast<double>(p); p += (size_t)8 * NG * (2 * KT + 5);
+    S.ptab = lds_cast<double>(p); p += (size_t)8 * 64;
+    S.optp = lds_cast<double>(p); p += (size_t)8 * MCHAP_MAX_ALLELE * 64;
+    S.optl = lds_cast<double>(p); p += (size_t)8 * MCHAP_MAX_ALLELE * 64;
+    S.ln = lds_cast<double>(p); p += (size_t)8 * SPEC_LN;
+    S.lninv = lds_cast<double>(p); p += (size_t)8 * SPEC_LN;
+    S.ivse = lds_cast<uint32_t>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
+    S.ivlin = lds_cast<uint32_t>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
+    S.ivlout = lds_cast<uint32_t>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
+    S.ivno = lds_cast<uint32_t>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
+    S.cols = lds_cast<uint16_t>(p); p += (size_t)2 * NG * mmax;
+    S.permtab = lds_cast<uint16_t>(p); p += (size_t)2 * NG * nmax;
+    S.shift = lds_cast<uint8_t>(p); p += (size_t)NG * mmax;
+    S.nal = lds_cast<uint8_t>(p); p += (size_t)NG * mmax;
+    S.ktab = lds_cast<uint8_t>(p); p += (size_t)NG * nmax;
+    S.ordtab = lds_cast<uint8_t>(p); p += (size_t)NG * SPEC_MAX_IV;
+    p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
+    S.draws = lds_cast<uint64_t>(p);
   }
   for (int i = lane; i < SPEC_LN; i += WAVE) {
     S.ln[i] = c_ln[i];
@@ -827,7 +917,7 @@ __global__ __launch_bounds__(64) void denovo_spec_kernel(const SimtParams P) {
 #pragma unroll
   for (int h = 0; h < KT; h++) c.g.w[h] = 0;
   if (c.alive) {
-    const uint8_t *shift = S.shift + (size_t)gi * mmax;
+    LDSP(uint8_t) shift = S.shift + gi * mmax;
     if (U.initial_off >= 0) {
       const int8_t *ini = D.initial + U.initial_off + (size_t)chain * KT * Mh;
 #pragma unroll
@@ -868,7 +958,14 @@ __global__ __launch_bounds__(64) void denovo_spec_kernel(const SimtParams P) {
     }
   }
   {
-    const double v = spec_eval<KT, G>(c.alive && gl == 0, c.g, c, S, mmax, rpad, lane);  // assemble/mcmc.py:303
+    const bool req = c.alive && gl == 0;  // assemble/mcmc.py:303
+    if (req) {
+#pragma unroll
+      for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = c.g.w[h];
+    }
+    lds_sync();
+    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
+    lds_sync();
     c.llk = __shfl(v, 0, G);
     if (c.alive && gl == 0) {
       for (int t = 0; t < T; t++) {
@@ -889,8 +986,10 @@ __global__ __launch_bounds__(64) void denovo_spec_kernel(const SimtParams P) {
   c.st.k1 = (uint32_t)(D.seed >> 32) ^ (uint32_t)(U.stream_id >> 32);
   c.st.c3 = (uint32_t)U.stream_id;
 
+  PHASE_DECL;
   for (int step = 0; step < Sn; step++) {
     for (int t = 0; t < T; t++) {
+      PHASE(4);
       if (T > 1) {
 #pragma unroll
         for (int h = 0; h < KT; h++) c.g.w[h] = S.wst[((size_t)gi * T + t) * KT + h];
@@ -903,17 +1002,24 @@ __global__ __launch_bounds__(64) void denovo_spec_kernel(const SimtParams P) {
         status = MCHAP_UNIT_NAN_LLK;
         c.alive = false;
       }
+#ifndef MCHAP_ABL_NO_MUT
       spec_mutation<KT, G>(c, S, temp, amax, mmax, nmax, rpad, lane, gi, gl);
+#endif
+      PHASE(0);
+#ifndef MCHAP_ABL_NO_STR
+#pragma unroll 1
       for (int kind = 0; kind < 3; kind++) {
         if (!spec_structural<KT, G>(c, S, D, kind, temp, break_dist, n_break_dist, mmax, rpad, lane, gi, gl)) {
           status = MCHAP_UNIT_BREAKS;
           c.alive = false;
         }
+        PHASE(1 + kind);
       }
+#endif
       if (T > 1) {
         if (c.alive && t > 0) {
           // tempering.py:61-151 with the previous (warmer) temperature
-          const double *pt = S.prior + (size_t)gi * (2 * KT + 5);
+          LDSP(double) pt = S.prior + gi * (2 * KT + 5);
           GWords<KT> gj;
 #pragma unroll
           for (int h = 0; h < KT; h++) gj.w[h] = S.wst[((size_t)gi * T + t - 1) * KT + h];
@@ -960,6 +1066,7 @@ __global__ __launch_bounds__(64) void denovo_spec_kernel(const SimtParams P) {
       if (gl == 0) D.llks[llk_base + step] = c.llk;
     }
   }
+  PHASE_FLUSH;
   if (status != MCHAP_UNIT_OK && gl == 0) atomicMax(&D.status[u], status);
 }
 

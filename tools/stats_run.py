@@ -23,3 +23,8 @@ L.mchap_debug_stats(out, 1)
 print("units", U, "steps", steps, "time %.3f s" % dt)
 print("requests %d  misses %d (%.2f%%)  probe-slots %d  requests/probe-slot %.3f" % (out[0], out[1], 100.0 * out[1] / max(out[0], 1), out[2], out[0] / max(out[2], 1)))
 print("per chain-step: requests %.2f misses %.3f" % (out[0] / (U * 2 * steps), out[1] / (U * 2 * steps)))
+names = ["mutation", "recomb", "partial dosage", "full dosage", "other (trace, state)"]
+tot = sum(out[3:8]) or 1
+waves = (U * 2 + (64 // int(os.environ.get("MCHAP_HIP_GROUP", "16"))) - 1) // (64 // int(os.environ.get("MCHAP_HIP_GROUP", "16")))
+for i, nm in enumerate(names):
+    print("  %-22s %5.1f%%   %.0f cycles per wave-step (100 MHz ticks x?)" % (nm, 100.0 * out[3 + i] / tot, out[3 + i] / max(waves * steps, 1)))
