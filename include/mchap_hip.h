@@ -159,6 +159,14 @@ int mchap_exact_posterior_mode_batch(int n_units, const double *reads, int n_rea
                                      int64_t *mode_alleles, double *mode_llk, double *mode_prob, double *support_prob,
                                      double *freqs, double *occur);
 
+/* Measurement hooks (bench.py): when enabled, mchap_denovo_fit_batch_device records HIP events on the launch
+ * stream right around its sampler kernel (not the prepare pass or the memsets); mchap_last_sampler_ms waits for
+ * that launch and returns its duration in milliseconds (< 0 if nothing was recorded). */
+int mchap_set_profiling(int enabled);
+double mchap_last_sampler_ms(void);
+/* name of the sampler kernel the last mchap_denovo_fit_batch_device call launched */
+const char *mchap_last_sampler_name(void);
+
 /* Introspection */
 const char *mchap_version(void);
 const char *mchap_last_error(void);

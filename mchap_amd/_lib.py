@@ -109,6 +109,8 @@ def lib():
         L.mchap_last_error.restype = C.c_char_p
         L.mchap_denovo_lds_bytes.restype = C.c_int64
         L.mchap_denovo_workspace_bytes.restype = C.c_int64
+        L.mchap_last_sampler_ms.restype = C.c_double
+        L.mchap_last_sampler_name.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -126,6 +128,9 @@ EXPORTS = [
     "mchap_device_count",
     "mchap_denovo_lds_bytes",
     "mchap_denovo_workspace_bytes",
+    "mchap_set_profiling",
+    "mchap_last_sampler_ms",
+    "mchap_last_sampler_name",
 ]
 
 

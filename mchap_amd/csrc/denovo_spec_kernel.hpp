@@ -59,7 +59,17 @@ struct SpecLds {
   LDSP(uint8_t) ktab;     // [NG][nmax]
   LDSP(uint8_t) ordtab;   // [NG][SPEC_MAX_IV]
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
+  LDSP(uint64_t) memo_meta;  // [NG][2][(Mmax+1)^2] generation << 32 | n_options of an interval step
+  LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] its total move probability
+  int memo_stride;           // 2 * (Mmax+1)^2, or 0 when the tables do not fit
 };
+
+// interval-step memo (see spec_structural): only for a single temperature and while it stays small
+__host__ __device__ inline size_t spec_memo_bytes(int Mmax, int T, int G) {
+  const size_t per_group = (size_t)2 * (Mmax + 1) * (Mmax + 1) * 16;
+  if (T != 1 || per_group > 16 * 1024) return 0;
+  return per_group * (64 / G);
+}
 
 __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int T, int G) {
   const int NG = 64 / G;
@@ -80,6 +90,7 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int T, int G) 
   b += (size_t)NG * SPEC_MAX_IV;
   b = (b + 15) & ~(size_t)15;
   b += (size_t)8 * NG * SPEC_DRAWS;
+  b += spec_memo_bytes(Mmax, T, G);
   return (b + 63) & ~(size_t)63;
 }
 
@@ -245,7 +256,18 @@ struct Grp {
   uint64_t ctr;  // next draw of the current stream
   double llk;
   GWords<KT> g;  // genotype of the current temperature
+  // memo of the current genotype (single temperature only): a mutation compound step moves nothing if every one
+  // of its uniforms u satisfies mlo <= u < mhi; gen tags the interval-step memo entries
+  bool memo_on, mvalid;
+  double mlo, mhi;
+  uint32_t gen;
 };
+
+template <int KT>
+__device__ __forceinline__ void genotype_changed(Grp<KT> &c) {
+  c.mvalid = false;
+  c.gen += 1;
+}
 
 template <int KT, int RPL>
 __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
@@ -419,6 +441,31 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   const int Mh = c.Mh;
   const int n = KT * Mh;  // sub-steps; position p of the sequence is held by lane p % G, slot p / G (n <= 2 G)
   const uint64_t ctr0 = c.ctr;
+  // Fast path.  For an unchanged genotype the outcome of sub-step e depends only on its uniform: it stays iff
+  // lo_e <= u < hi_e (the cumulative probabilities around the current allele).  With mlo = max lo_e and
+  // mhi = min hi_e remembered from the last full evaluation, a compound step whose n uniforms all fall in
+  // [mlo, mhi) moves nothing whatever the shuffle pairs them with: its 2n-1 draws are skipped over.
+  bool run = c.alive;
+  if (wave_any(c.alive && c.mvalid)) {
+    LDSP(uint64_t) utab = S.draws + gi * SPEC_DRAWS;
+    const bool fast = c.alive && c.mvalid && n <= SPEC_DRAWS;
+    stage_draws<G>(c.st, ctr0 + (uint64_t)(n - 1), n, utab, gl, fast);
+    lds_sync();
+    bool ok = true;
+    if (fast) {
+      for (int p = gl; p < n; p += G) {
+        const double u = draw_double(utab[p]);
+        ok = ok && (c.mlo <= u) && (u < c.mhi);
+      }
+    }
+    const bool bad = grp_ballot<G>(!ok, gi) != 0ull;
+    lds_sync();
+    if (fast && !bad) {
+      c.ctr = ctr0 + (uint64_t)(n - 1) + (uint64_t)n;
+      run = false;
+    }
+  }
+  if (!wave_any(run)) return;
   LDSP(uint8_t) ktab = S.ktab + gi * nmax;
   LDSP(uint16_t) permtab = S.permtab + gi * nmax;
   LDSP(uint8_t) shift = S.shift + gi * mmax;
@@ -429,9 +476,9 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   //     i = n-1 .. 1 with k_i = interval(i) from draw ctr0 + (n-1-i)
   LDSP(uint64_t) dtab = S.draws + gi * SPEC_DRAWS;
   const bool staged = 2 * n - 1 <= SPEC_DRAWS;
-  stage_draws<G>(c.st, ctr0, 2 * n - 1, dtab, gl, c.alive && staged);
+  stage_draws<G>(c.st, ctr0, 2 * n - 1, dtab, gl, run && staged);
   lds_sync();
-  if (c.alive) {
+  if (run) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       const int p = gl + s * G;
@@ -444,7 +491,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   // (2) every lane traces the element that starts at its position through the transpositions
   int x0 = gl, x1 = gl + G;
   {
-    const int nloop = c.alive ? n : 0;
+    const int nloop = run ? n : 0;
     int nl = nloop;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) nl = max(nl, __shfl_xor(nl, o, WAVE));
@@ -456,7 +503,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
       }
     }
   }
-  if (c.alive) {
+  if (run) {
     // element e = h * Mh + j starts at position e
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -474,10 +521,12 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   lds_sync();
   // (3) speculate / validate.  Position p = gl + s * G of the sequence is handled by slot s of lane gl; its
   //     sub-step is permtab[p] and its uniform is draw ctr0 + (n-1) + p.
-  c.ctr = ctr0 + (uint64_t)(n - 1) + (uint64_t)n;
+  if (run) c.ctr = ctr0 + (uint64_t)(n - 1) + (uint64_t)n;
   const int nslots = two ? 2 : 1;
   int start = 0;
-  bool done = !c.alive;
+  bool done = !run;
+  bool first_round = true;
+  double my_lo = 0.0, my_hi = 2.0;  // this lane's sub-steps: max lo_e, min hi_e (first round only)
   while (wave_any(!done)) {
     const double lprior = (!done && !isnan(c.inbreeding)) ? prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(c.g)) : 0.0;
     bool found = false;
@@ -535,6 +584,9 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
             const int o = i - (i > current ? 1 : 0);
             pi = S.optp[o * WAVE + lane];
             li = S.optl[o * WAVE + lane];
+          } else {
+            my_lo = fmax(my_lo, cacc);          // lo_e: cumulative probability below the current allele
+            my_hi = fmin(my_hi, cacc + stay);   // hi_e: ... including it
           }
           cacc += pi;
           if (cacc > u) {
@@ -561,10 +613,26 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
       if (!done && !found && m) {
         set_word<KT>(c.g, hsrc, wsrc);
         c.llk = lsrc;
+        genotype_changed<KT>(c);
         start = fl + s * G + 1;
         found = true;
       }
     }
+    // a first round without any move evaluated every sub-step against the current genotype: remember the bounds
+    {
+      double lo = my_lo, hi = my_hi;
+#pragma unroll
+      for (int o = G / 2; o >= 1; o >>= 1) {
+        lo = fmax(lo, __shfl_xor(lo, o, G));
+        hi = fmin(hi, __shfl_xor(hi, o, G));
+      }
+      if (!done && first_round && !found && c.memo_on) {
+        c.mvalid = true;
+        c.mlo = lo;
+        c.mhi = hi;
+      }
+    }
+    first_round = false;
     if (!done && (!found || start >= n)) done = true;
   }
 }
@@ -679,6 +747,36 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
   int ii0 = 0;
   bool done = !doit;
   const uint64_t full = mask_of(c.bits, Mh, 0, Mh);
+  // Memo.  For an unchanged genotype an interval step (type, start, stop) has a fixed option count and a fixed
+  // total move probability (the last cumulative sum of its options): it moves nothing iff its uniform is >= that
+  // total.  Entries are tagged with the genotype generation; intervals are skipped while the memo says "no move".
+  const int mrow = mmax + 1;
+  LDSP(uint64_t) mmeta = S.memo_meta + gi * S.memo_stride + step_type * mrow * mrow;
+  LDSP(double) mtot = S.memo_tot + gi * S.memo_stride + step_type * mrow * mrow;
+  const bool memo = c.memo_on && S.memo_stride != 0;
+  if (!done && memo) {
+    while (ii0 < n_int) {
+      const uint32_t se = ivse[ii0];
+      const int idx = (int)(se & 255u) * mrow + (int)(se >> 8);
+      const uint64_t meta = mmeta[idx];
+      if ((uint32_t)(meta >> 32) != c.gen) break;  // not evaluated for this genotype yet
+      if ((uint32_t)meta != 0u) {
+        const uint64_t i = c.ctr - dbase;
+        uint64_t w;
+        if (i < (uint64_t)dcount) {
+          w = dtab[i];
+        } else {
+          uint32_t a, b;
+          stream_words(c.st, c.ctr, a, b);
+          w = (uint64_t)a | ((uint64_t)b << 32);
+        }
+        if (!(draw_double(w) >= mtot[idx])) break;  // this interval moves: evaluate it for real
+        c.ctr++;
+      }
+      ii0++;
+    }
+    if (ii0 >= n_int) done = true;
+  }
   while (wave_any(!done)) {
     // (a) labels and option counts of the next (up to G) intervals, one interval per lane
     if (!done) {
@@ -772,9 +870,9 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
       int ii = ii0;
       for (; ii < ii1; ii++) {
         const int no = (int)ivno[ii];
+        double cacc = 0.0;
         if (no > 0) {
           const double u = draw_double(next_words());
-          double cacc = 0.0;
           int choice = -1;
           for (int o = 0; o < no; o++) {
             cacc += S.ptab[gi * G + off + o];
@@ -788,6 +886,12 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
             ii++;
             break;
           }
+        }
+        if (memo && gl == 0) {  // evaluated in full without a move: remember (count, total) for this genotype
+          const uint32_t se = ivse[ii];
+          const int idx = (int)(se & 255u) * mrow + (int)(se >> 8);
+          mtot[idx] = cacc;
+          mmeta[idx] = ((uint64_t)c.gen << 32) | (uint64_t)(uint32_t)no;
         }
         off += no;
       }
@@ -803,6 +907,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
       if (acc_gl >= 0) {
         c.g = nw;
         c.llk = nl;
+        genotype_changed<KT>(c);
       }
     }
     if (!done && ii0 >= n_int) done = true;
@@ -864,7 +969,11 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.ktab = lds_cast<uint8_t>(p); p += (size_t)NG * nmax;
     S.ordtab = lds_cast<uint8_t>(p); p += (size_t)NG * SPEC_MAX_IV;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
-    S.draws = lds_cast<uint64_t>(p);
+    S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * SPEC_DRAWS;
+    S.memo_stride = spec_memo_bytes(mmax, T, G) ? 2 * (mmax + 1) * (mmax + 1) : 0;
+    S.memo_meta = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.memo_stride;
+    S.memo_tot = lds_cast<double>(p);
+    for (int i = lane; i < NG * S.memo_stride; i += WAVE) S.memo_meta[i] = 0ull;  // generation 0 = unknown
   }
   for (int i = lane; i < SPEC_LN; i += WAVE) {
     S.ln[i] = c_ln[i];
@@ -896,6 +1005,11 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   }
   c.ctr = 0;
   c.llk = 0.0;
+  c.memo_on = (T == 1);
+  c.mvalid = false;
+  c.mlo = 0.0;
+  c.mhi = 0.0;
+  c.gen = 1;
   const int Mh = c.Mh;
   if (c.alive) {
     for (int j = gl; j < Mh; j += G) {

@@ -38,6 +38,32 @@ int fail(int code, const char *fmt, ...) {
 std::mutex g_init_mu;
 bool g_init_done[64] = {false};
 
+// measurement hooks
+bool g_profiling = false;
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+bool g_ev_valid = false;
+char g_sampler_name[96] = "";
+
+struct SamplerTimer {
+  hipStream_t stream;
+  explicit SamplerTimer(hipStream_t s, const char *name) : stream(s) {
+    snprintf(g_sampler_name, sizeof(g_sampler_name), "%s", name);
+    if (!g_profiling) return;
+    if (!g_ev0) {
+      (void)hipEventCreate(&g_ev0);
+      (void)hipEventCreate(&g_ev1);
+    }
+    (void)hipEventRecord(g_ev0, stream);
+  }
+  ~SamplerTimer() {
+    if (!g_profiling) return;
+    (void)hipEventRecord(g_ev1, stream);
+    g_ev_valid = true;
+  }
+};
+
+
+
 int ensure_init() {
   int dev = 0;
   int n = 0;
@@ -79,6 +105,9 @@ int launch_denovo(const mchap::DenovoParams &P, int n_units, int chains, size_t 
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int cpb = chains < mchap::CHAINS_PER_BLOCK ? chains : mchap::CHAINS_PER_BLOCK;
+  char name[96];
+  snprintf(name, sizeof(name), "denovo_mcmc_kernel<%d>", RPL);
+  SamplerTimer timer(stream, name);
   hipLaunchKernelGGL(kern, dim3(n_units, (chains + cpb - 1) / cpb), dim3(64 * cpb), lds, stream, P);
   HIP_TRY(hipGetLastError());
   return MCHAP_OK;
@@ -167,6 +196,9 @@ int launch_simt(const mchap::SimtParams &P, int n_units, int chains, size_t lds_
   if (lds_simt > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_simt));
   const long long n_chains = (long long)n_units * chains;
+  char name[96];
+  snprintf(name, sizeof(name), "denovo_simt_kernel<%d>", KT);
+  SamplerTimer timer(stream, name);
   hipLaunchKernelGGL(ks, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), lds_simt, stream, P);
   HIP_TRY(hipGetLastError());
   return MCHAP_OK;
@@ -181,6 +213,9 @@ int launch_spec(const mchap::SimtParams &P, int n_units, int chains, int n_temps
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long long n_chains = (long long)n_units * chains;
   const int per_wave = 64 / G;
+  char name[96];
+  snprintf(name, sizeof(name), "denovo_spec_kernel<%d, %d>", KT, G);
+  SamplerTimer timer(stream, name);
   hipLaunchKernelGGL(ks, dim3((unsigned)((n_chains + per_wave - 1) / per_wave)), dim3(64), lds, stream, P);
   HIP_TRY(hipGetLastError());
   return MCHAP_OK;
@@ -209,6 +244,22 @@ extern "C" {
 
 const char *mchap_version(void) { return "mchap-hip 0.1 (gfx950; restates MCHap v0.11.1 assemble + calling.exact)"; }
 const char *mchap_last_error(void) { return g_err; }
+
+int mchap_set_profiling(int enabled) {
+  g_profiling = enabled != 0;
+  g_ev_valid = false;
+  return MCHAP_OK;
+}
+
+double mchap_last_sampler_ms(void) {
+  if (!g_ev_valid) return -1.0;
+  if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+const char *mchap_last_sampler_name(void) { return g_sampler_name; }
 
 #ifdef MCHAP_STATS
 /* profiling builds only (make STATS=1): [0] likelihood requests, [1] cache misses, [2] probe slots */
