@@ -11,7 +11,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO = os.path.join(CSRC, "libmchap_hip.so")
+# MCHAP_HIP_LIB: an alternative build of the same library (debug variants made by tools/)
+SO = os.environ.get("MCHAP_HIP_LIB") or os.path.join(CSRC, "libmchap_hip.so")
 
 MAX_TEMPS = 16
 MAX_PLOIDY = 8

@@ -40,6 +40,7 @@ struct SimtParams {
   int n_units;
   int max_pos, max_allele, max_ploidy;
   int max_ma;        // max over units of n_pos * max_allele
+  int flags;         // debugging: bit 0 no mutation memo, bit 1 no interval memo (MCHAP_HIP_FLAGS)
 };
 
 // ---------------------------------------------------------------------------------------------------------

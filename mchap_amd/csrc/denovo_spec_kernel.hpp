@@ -25,8 +25,17 @@
 namespace mchap {
 
 constexpr int SPEC_MAX_IV = 64;  // intervals per structural compound step (<= n_pos)
-constexpr int SPEC_LN = 260;
-constexpr int SPEC_DRAWS = 128;  // draws of the current stream staged in LDS per group (Philox blocks computed in parallel)
+constexpr int SPEC_LN = 72;   // log tables: counts up to K(K-1) <= 56
+constexpr int SPEC_DRAWS_MAX = 128;  // draws of the current stream staged in LDS per group (Philox blocks in parallel)
+__host__ __device__ inline int spec_draws(int K, int Mmax) {
+  int d = 2 * K * Mmax - 1;
+  if (d < 3 * Mmax + 2) d = 3 * Mmax + 2;
+  d = (d + 1) & ~1;
+#ifdef MCHAP_FAT_DRAWS
+  return SPEC_DRAWS_MAX;
+#endif
+  return d < SPEC_DRAWS_MAX ? d : SPEC_DRAWS_MAX;
+}
 
 // LDS pointers carry their address space so that every access is a ds_* instruction (a pointer stored in a struct
 // otherwise degrades to a generic "flat" access)
@@ -59,38 +68,54 @@ struct SpecLds {
   LDSP(uint8_t) ktab;     // [NG][nmax]
   LDSP(uint8_t) ordtab;   // [NG][SPEC_MAX_IV]
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
-  LDSP(uint64_t) memo_meta;  // [NG][2][(Mmax+1)^2] generation << 32 | n_options of an interval step
-  LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] its total move probability
+  LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] total move probability of an interval step for the current
+                             // genotype; NaN = not evaluated yet, -1 = the step has no options
+  LDSP(double) bdist;        // [NG][Mmax] the chain's break-count distribution
   int memo_stride;           // 2 * (Mmax+1)^2, or 0 when the tables do not fit
+  int ndraws;                // staged draws per group
 };
 
 // interval-step memo (see spec_structural): only for a single temperature and while it stays small
 __host__ __device__ inline size_t spec_memo_bytes(int Mmax, int T, int G) {
-  const size_t per_group = (size_t)2 * (Mmax + 1) * (Mmax + 1) * 16;
+  const size_t per_group = (size_t)2 * (Mmax + 1) * (Mmax + 1) * 8;
   if (T != 1 || per_group > 16 * 1024) return 0;
   return per_group * (64 / G);
 }
 
-__host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int T, int G) {
+__host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int T, int G) {
   const int NG = 64 / G;
   const int nmax = K * Mmax;
+#ifdef MCHAP_FAT_OPT
+  const int nopt = 8;
+#else
+  const int nopt = Amax > 1 ? Amax - 1 : 1;
+#endif
+#ifdef MCHAP_FAT_IV
+  const int niv = 64;
+#else
+  const int niv = Mmax + 1;
+#endif
   size_t b = 0;
-  b += (size_t)8 * K * 64;
-  b += (size_t)8 * NG * T * K;
-  b += (size_t)8 * NG * T * 2;
-  b += (size_t)8 * NG * (2 * K + 5);
-  b += (size_t)8 * 64;
-  b += (size_t)8 * MCHAP_MAX_ALLELE * 64 * 2;
-  b += (size_t)8 * SPEC_LN * 2;
-  b += (size_t)4 * NG * SPEC_MAX_IV * 4;
-  b += (size_t)2 * NG * Mmax;
-  b += (size_t)2 * NG * nmax;
-  b += (size_t)NG * Mmax * 2;
-  b += (size_t)NG * nmax;
-  b += (size_t)NG * SPEC_MAX_IV;
+  b += (size_t)8 * K * 64;               // pw
+  b += (size_t)8 * NG * T * K;           // wst
+  b += (size_t)8 * NG * T * 2;           // llk_t, rngn
+  b += (size_t)8 * NG * (2 * K + 5);     // prior
+  b += (size_t)8 * 64;                   // ptab
+  b += (size_t)8 * nopt * 64 * 2;        // optp, optl
+  b += (size_t)8 * SPEC_LN * 2;          // ln, lninv
+  b += (size_t)8 * NG * Mmax;            // break distribution row
+  b += (size_t)4 * NG * niv * 4;         // ivse, ivlin, ivlout, ivno
+  b += (size_t)2 * NG * Mmax;            // cols
+  b += (size_t)2 * NG * nmax;            // permtab
+  b += (size_t)NG * Mmax * 2;            // shift, nal
+  b += (size_t)NG * nmax;                // ktab
+  b += (size_t)NG * niv;                 // ordtab
   b = (b + 15) & ~(size_t)15;
-  b += (size_t)8 * NG * SPEC_DRAWS;
+  b += (size_t)8 * NG * spec_draws(K, Mmax);
   b += spec_memo_bytes(Mmax, T, G);
+#ifdef MCHAP_LDS_GUARD
+  b += 64 * 32;
+#endif
   return (b + 63) & ~(size_t)63;
 }
 
@@ -147,8 +172,12 @@ __device__ __forceinline__ uint64_t grp_ballot(bool p, int gi) {
 }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 __device__ __forceinline__ void lds_sync() {
+#ifdef MCHAP_SYNC_BARRIER
+  __syncthreads();
+#else
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
+#endif
 }
 
 template <int KT>
@@ -260,13 +289,13 @@ struct Grp {
   // of its uniforms u satisfies mlo <= u < mhi; gen tags the interval-step memo entries
   bool memo_on, mvalid;
   double mlo, mhi;
-  uint32_t gen;
+  uint32_t gen, memo_gen;  // memo_gen: the generation the interval memo table currently describes
 };
 
 template <int KT>
 __device__ __forceinline__ void genotype_changed(Grp<KT> &c) {
   c.mvalid = false;
-  c.gen += 1;
+  c.gen += 1;  // the interval memo of the group is wiped by memo_wipe() before it is read again
 }
 
 template <int KT, int RPL>
@@ -330,8 +359,13 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
 
 // Serves every request of the wave (bit mask `todo`), one after the other, with all 64 lanes; kept out of line so
 // that its registers (RPL x UNR loads in flight) do not count against the sampler's main loop.
+#ifndef MCHAP_COOP_NOINLINE
+#define COOP_FN __device__ __forceinline__
+#else
+#define COOP_FN __device__ __noinline__
+#endif
 template <int KT, int G>
-__device__ __noinline__ double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
+COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
                                              LDSP(uint16_t) cols_tab, int mmax, int Mh_lane, uint32_t amask_lane,
                                              const double *rt_lane, const double *cw_lane, int rpad, int lane) {
   SpecLds S;
@@ -427,7 +461,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
 
 // mutation.compound_step (mutation.py:164-246) for the group's chain: shuffle, then speculative sub-steps.
 #ifndef MCHAP_SPEC_WPE
-#define MCHAP_SPEC_WPE 1
+#define MCHAP_SPEC_WPE 2
 #endif
 #ifdef MCHAP_SPEC_NOINLINE
 #define SPEC_FN __device__ __noinline__
@@ -447,8 +481,8 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   // [mlo, mhi) moves nothing whatever the shuffle pairs them with: its 2n-1 draws are skipped over.
   bool run = c.alive;
   if (wave_any(c.alive && c.mvalid)) {
-    LDSP(uint64_t) utab = S.draws + gi * SPEC_DRAWS;
-    const bool fast = c.alive && c.mvalid && n <= SPEC_DRAWS;
+    LDSP(uint64_t) utab = S.draws + gi * S.ndraws;
+    const bool fast = c.alive && c.mvalid && n <= S.ndraws;
     stage_draws<G>(c.st, ctr0 + (uint64_t)(n - 1), n, utab, gl, fast);
     lds_sync();
     bool ok = true;
@@ -474,8 +508,8 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   const bool two = wave_any(c.alive && n > G);  // second slot in use anywhere in the wave
   // (1) the 2n-1 draws of this compound step, staged through LDS; the Fisher-Yates shuffle is swap(i, k_i) for
   //     i = n-1 .. 1 with k_i = interval(i) from draw ctr0 + (n-1-i)
-  LDSP(uint64_t) dtab = S.draws + gi * SPEC_DRAWS;
-  const bool staged = 2 * n - 1 <= SPEC_DRAWS;
+  LDSP(uint64_t) dtab = S.draws + gi * S.ndraws;
+  const bool staged = 2 * n - 1 <= S.ndraws;
   stage_draws<G>(c.st, ctr0, 2 * n - 1, dtab, gl, run && staged);
   lds_sync();
   if (run) {
@@ -645,20 +679,25 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
                                                 int gi, int gl) {
   const int Mh = c.Mh;
   const int step_type = kind == 0 ? 0 : 1;
-  LDSP(uint32_t) ivse = S.ivse + gi * SPEC_MAX_IV;
-  LDSP(uint32_t) ivlin = S.ivlin + gi * SPEC_MAX_IV;
-  LDSP(uint32_t) ivlout = S.ivlout + gi * SPEC_MAX_IV;
-  LDSP(uint32_t) ivno = S.ivno + gi * SPEC_MAX_IV;
-  LDSP(uint8_t) ord = S.ordtab + gi * SPEC_MAX_IV;
+#ifdef MCHAP_FAT_IV
+  const int nivs = 64;
+#else
+  const int nivs = mmax + 1;
+#endif
+  LDSP(uint32_t) ivse = S.ivse + gi * nivs;
+  LDSP(uint32_t) ivlin = S.ivlin + gi * nivs;
+  LDSP(uint32_t) ivlout = S.ivlout + gi * nivs;
+  LDSP(uint32_t) ivno = S.ivno + gi * nivs;
+  LDSP(uint8_t) ord = S.ordtab + gi * nivs;
   LDSP(double) pt = S.prior + gi * (2 * KT + 5);
   bool ok = true;
   bool doit = false;
   int n_int = 0;
   // the draws this compound step may consume (decision, break count, <= Mh-1 break points, <= Mh-1 order swaps,
   // <= Mh interval choices) staged through LDS: next_double()/next_interval() below read them in sequence
-  LDSP(uint64_t) dtab = S.draws + gi * SPEC_DRAWS;
+  LDSP(uint64_t) dtab = S.draws + gi * S.ndraws;
   const uint64_t dbase = c.ctr;
-  const int dcount = min(SPEC_DRAWS, 3 * Mh + 2);
+  const int dcount = min(S.ndraws, 3 * Mh + 2);
   lds_sync();
   stage_draws<G>(c.st, dbase, dcount, dtab, gl, c.alive);
   lds_sync();
@@ -680,7 +719,19 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
         c.ctr++;  // break_dist = [0,...,0,1]: the draw is consumed (assemble/mcmc.py:214-217)
         nb = D.n_intervals - 1;
       } else {
-        nb = choose_from(break_dist, n_break_dist, draw_double(next_words()));
+        {
+          const double u = draw_double(next_words());
+          LDSP(double) bd = S.bdist + gi * mmax;
+          double cacc = 0.0;
+          nb = n_break_dist;
+          for (int i = 0; i < n_break_dist; i++) {
+            cacc += bd[i];
+            if (cacc > u) {
+              nb = i;
+              break;
+            }
+          }
+        }
       }
       if (nb >= Mh) {
         ok = false;
@@ -751,16 +802,22 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
   // total move probability (the last cumulative sum of its options): it moves nothing iff its uniform is >= that
   // total.  Entries are tagged with the genotype generation; intervals are skipped while the memo says "no move".
   const int mrow = mmax + 1;
-  LDSP(uint64_t) mmeta = S.memo_meta + gi * S.memo_stride + step_type * mrow * mrow;
   LDSP(double) mtot = S.memo_tot + gi * S.memo_stride + step_type * mrow * mrow;
-  const bool memo = c.memo_on && S.memo_stride != 0;
+  const bool memo = S.memo_stride != 0;
+  if (memo && c.alive && c.gen != c.memo_gen) {
+    // the genotype changed since the table was filled: forget everything
+    LDSP(double) all = S.memo_tot + gi * S.memo_stride;
+    for (int i = gl; i < S.memo_stride; i += G) all[i] = NAN;
+    c.memo_gen = c.gen;
+  }
+  lds_sync();
   if (!done && memo) {
     while (ii0 < n_int) {
       const uint32_t se = ivse[ii0];
       const int idx = (int)(se & 255u) * mrow + (int)(se >> 8);
-      const uint64_t meta = mmeta[idx];
-      if ((uint32_t)(meta >> 32) != c.gen) break;  // not evaluated for this genotype yet
-      if ((uint32_t)meta != 0u) {
+      const double tot = mtot[idx];
+      if (isnan(tot)) break;  // not evaluated for this genotype yet
+      if (tot >= 0.0) {       // -1: the step has no options and consumes no draw
         const uint64_t i = c.ctr - dbase;
         uint64_t w;
         if (i < (uint64_t)dcount) {
@@ -770,7 +827,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
           stream_words(c.st, c.ctr, a, b);
           w = (uint64_t)a | ((uint64_t)b << 32);
         }
-        if (!(draw_double(w) >= mtot[idx])) break;  // this interval moves: evaluate it for real
+        if (!(draw_double(w) >= tot)) break;  // this interval moves: evaluate it for real
         c.ctr++;
       }
       ii0++;
@@ -887,11 +944,10 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
             break;
           }
         }
-        if (memo && gl == 0) {  // evaluated in full without a move: remember (count, total) for this genotype
+        if (memo && gl == 0 && c.gen == c.memo_gen) {  // evaluated in full without a move: remember the total
           const uint32_t se = ivse[ii];
           const int idx = (int)(se & 255u) * mrow + (int)(se >> 8);
-          mtot[idx] = cacc;
-          mmeta[idx] = ((uint64_t)c.gen << 32) | (uint64_t)(uint32_t)no;
+          mtot[idx] = no > 0 ? cacc : -1.0;
         }
         off += no;
       }
@@ -916,6 +972,25 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
   return ok;
 }
 
+#ifdef MCHAP_SPEC_LOG
+constexpr int LOG_CHAINS = 8, LOG_STEPS = 64, LOG_EV = 4, LOG_F = 4;
+__device__ unsigned long long g_log[LOG_CHAINS * LOG_STEPS * LOG_EV * LOG_F];
+#define SPEC_LOG(ev)                                                                                 \
+  do {                                                                                               \
+    if (gl == 0 && q < LOG_CHAINS && step < LOG_STEPS) {                                             \
+      unsigned long long *L_ = g_log + (((size_t)q * LOG_STEPS + step) * LOG_EV + (ev)) * LOG_F;     \
+      unsigned long long hsh_ = 0;                                                                   \
+      for (int h_ = 0; h_ < KT; h_++) hsh_ = hsh_ * 1000003ull + c.g.w[h_];                          \
+      L_[0] = c.ctr;                                                                                 \
+      L_[1] = (unsigned long long)__double_as_longlong(c.llk);                                       \
+      L_[2] = hsh_;                                                                                  \
+      L_[3] = c.alive;                                                                               \
+    }                                                                                                \
+  } while (0)
+#else
+#define SPEC_LOG(ev)
+#endif
+
 #ifdef MCHAP_STATS
 #define PHASE_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0_ = __builtin_amdgcn_s_memtime()
 #define PHASE(i)                                                  \
@@ -935,6 +1010,19 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
 #define PHASE_FLUSH
 #endif
 
+#ifdef MCHAP_LDS_GUARD
+#define GUARD_BYTES 64
+#define GUARD_STEP                                                   \
+  do {                                                               \
+    const int lo_ = (P.flags >> 8) & 0xff, hi_ = (P.flags >> 16) & 0xff; \
+    if (n_guard >= lo_ && n_guard < hi_) p += GUARD_BYTES;           \
+    guard_off[n_guard++] = 0;                                        \
+  } while (0)
+#else
+#define GUARD_BYTES 0
+#define GUARD_STEP
+#endif
+
 template <int KT, int G>
 __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const SimtParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -945,35 +1033,58 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   const int T = D.n_temps, Cn = D.chains, Sn = D.steps;
   const int mmax = P.max_pos, nmax = KT * P.max_pos;
   const int rpad = D.rpad;
+#ifdef MCHAP_LDS_GUARD
+  int guard_off[32];
+  int n_guard = 0;
+#endif
+#ifdef MCHAP_LDS_ZERO
+  {
+    const int nb8 = (int)(spec_lds_bytes(KT, P.max_pos, P.max_allele, D.n_temps, G) / 8);
+    LDSP(uint64_t) z = lds_cast<uint64_t>(smem);
+    for (int i = threadIdx.x; i < nb8; i += WAVE) z[i] = MCHAP_LDS_ZERO;
+    lds_sync();
+  }
+#endif
   SpecLds S;
   {
+#ifdef MCHAP_FAT_OPT
+    const int nopt = 8;
+#else
+    const int nopt = P.max_allele > 1 ? P.max_allele - 1 : 1;
+#endif
+#ifdef MCHAP_FAT_IV
+    const int niv = 64;
+#else
+    const int niv = mmax + 1;
+#endif
     unsigned char *p = smem;
-    S.pw = lds_cast<uint64_t>(p); p += (size_t)8 * KT * 64;
-    S.wst = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T * KT;
-    S.llk_t = lds_cast<double>(p); p += (size_t)8 * NG * T;
-    S.rngn = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T;
-    S.prior = lds_cast<double>(p); p += (size_t)8 * NG * (2 * KT + 5);
-    S.ptab = lds_cast<double>(p); p += (size_t)8 * 64;
-    S.optp = lds_cast<double>(p); p += (size_t)8 * MCHAP_MAX_ALLELE * 64;
-    S.optl = lds_cast<double>(p); p += (size_t)8 * MCHAP_MAX_ALLELE * 64;
-    S.ln = lds_cast<double>(p); p += (size_t)8 * SPEC_LN;
-    S.lninv = lds_cast<double>(p); p += (size_t)8 * SPEC_LN;
-    S.ivse = lds_cast<uint32_t>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
-    S.ivlin = lds_cast<uint32_t>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
-    S.ivlout = lds_cast<uint32_t>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
-    S.ivno = lds_cast<uint32_t>(p); p += (size_t)4 * NG * SPEC_MAX_IV;
-    S.cols = lds_cast<uint16_t>(p); p += (size_t)2 * NG * mmax;
-    S.permtab = lds_cast<uint16_t>(p); p += (size_t)2 * NG * nmax;
-    S.shift = lds_cast<uint8_t>(p); p += (size_t)NG * mmax;
-    S.nal = lds_cast<uint8_t>(p); p += (size_t)NG * mmax;
-    S.ktab = lds_cast<uint8_t>(p); p += (size_t)NG * nmax;
-    S.ordtab = lds_cast<uint8_t>(p); p += (size_t)NG * SPEC_MAX_IV;
+    S.pw = lds_cast<uint64_t>(p); p += (size_t)8 * KT * 64; GUARD_STEP;
+    S.wst = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T * KT; GUARD_STEP;
+    S.llk_t = lds_cast<double>(p); p += (size_t)8 * NG * T; GUARD_STEP;
+    S.rngn = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T; GUARD_STEP;
+    S.prior = lds_cast<double>(p); p += (size_t)8 * NG * (2 * KT + 5); GUARD_STEP;
+    S.ptab = lds_cast<double>(p); p += (size_t)8 * 64; GUARD_STEP;
+    S.optp = lds_cast<double>(p); p += (size_t)8 * nopt * 64; GUARD_STEP;
+    S.optl = lds_cast<double>(p); p += (size_t)8 * nopt * 64; GUARD_STEP;
+    S.ln = lds_cast<double>(p); p += (size_t)8 * SPEC_LN; GUARD_STEP;
+    S.lninv = lds_cast<double>(p); p += (size_t)8 * SPEC_LN; GUARD_STEP;
+    S.bdist = lds_cast<double>(p); p += (size_t)8 * NG * mmax; GUARD_STEP;
+    S.ivse = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv; GUARD_STEP;
+    S.ivlin = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv; GUARD_STEP;
+    S.ivlout = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv; GUARD_STEP;
+    S.ivno = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv; GUARD_STEP;
+    S.cols = lds_cast<uint16_t>(p); p += (size_t)2 * NG * mmax; GUARD_STEP;
+    S.permtab = lds_cast<uint16_t>(p); p += (size_t)2 * NG * nmax; GUARD_STEP;
+    S.shift = lds_cast<uint8_t>(p); p += (size_t)NG * mmax; GUARD_STEP;
+    S.nal = lds_cast<uint8_t>(p); p += (size_t)NG * mmax; GUARD_STEP;
+    S.ktab = lds_cast<uint8_t>(p); p += (size_t)NG * nmax; GUARD_STEP;
+    S.ordtab = lds_cast<uint8_t>(p); p += (size_t)NG * niv; GUARD_STEP;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
-    S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * SPEC_DRAWS;
-    S.memo_stride = spec_memo_bytes(mmax, T, G) ? 2 * (mmax + 1) * (mmax + 1) : 0;
-    S.memo_meta = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.memo_stride;
+    S.ndraws = spec_draws(KT, mmax);
+    S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.ndraws; GUARD_STEP;
+    S.memo_stride = (spec_memo_bytes(mmax, T, G) && !(P.flags & 2)) ? 2 * (mmax + 1) * (mmax + 1) : 0;
     S.memo_tot = lds_cast<double>(p);
-    for (int i = lane; i < NG * S.memo_stride; i += WAVE) S.memo_meta[i] = 0ull;  // generation 0 = unknown
+    for (int i = lane; i < NG * S.memo_stride; i += WAVE) S.memo_tot[i] = NAN;  // nothing evaluated yet
   }
   for (int i = lane; i < SPEC_LN; i += WAVE) {
     S.ln[i] = c_ln[i];
@@ -1005,11 +1116,12 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   }
   c.ctr = 0;
   c.llk = 0.0;
-  c.memo_on = (T == 1);
+  c.memo_on = (T == 1) && !(P.flags & 1);
   c.mvalid = false;
   c.mlo = 0.0;
   c.mhi = 0.0;
   c.gen = 1;
+  c.memo_gen = 1;
   const int Mh = c.Mh;
   if (c.alive) {
     for (int j = gl; j < Mh; j += G) {
@@ -1019,6 +1131,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     }
     if (!isnan(c.inbreeding))
       for (int i = gl; i < 2 * KT + 5; i += G) S.prior[(size_t)gi * (2 * KT + 5) + i] = mf[meta_f_prior(0) + i];
+    if (D.n_intervals == 0)
+      for (int j = gl; j < Mh; j += G) S.bdist[gi * mmax + j] = D.break_table[(size_t)Mh * D.max_pos + j];
   }
   lds_sync();
   const int amax = [&] {
@@ -1120,6 +1234,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       spec_mutation<KT, G>(c, S, temp, amax, mmax, nmax, rpad, lane, gi, gl);
 #endif
       PHASE(0);
+      SPEC_LOG(0);
 #ifndef MCHAP_ABL_NO_STR
 #pragma unroll 1
       for (int kind = 0; kind < 3; kind++) {
@@ -1128,6 +1243,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
           c.alive = false;
         }
         PHASE(1 + kind);
+        SPEC_LOG(1 + kind);
       }
 #endif
       if (T > 1) {

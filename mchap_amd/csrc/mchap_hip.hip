@@ -207,7 +207,8 @@ int launch_simt(const mchap::SimtParams &P, int n_units, int chains, size_t lds_
 template <int KT, int G>
 int launch_spec(const mchap::SimtParams &P, int n_units, int chains, int n_temps, hipStream_t stream) {
   auto ks = mchap::denovo_spec_kernel<KT, G>;
-  const size_t lds = mchap::spec_lds_bytes(KT, P.max_pos, n_temps, G);
+  size_t lds = mchap::spec_lds_bytes(KT, P.max_pos, P.max_allele, n_temps, G);
+  if (const char *e = std::getenv("MCHAP_HIP_LDS_PAD")) lds += (size_t)std::atoi(e);  // debugging: lower occupancy
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -261,6 +262,12 @@ double mchap_last_sampler_ms(void) {
 
 const char *mchap_last_sampler_name(void) { return g_sampler_name; }
 
+#ifdef MCHAP_SPEC_LOG
+int mchap_debug_log(unsigned long long *out) {
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_log), sizeof(unsigned long long) * 8 * 64 * 4 * 4));
+  return 0;
+}
+#endif
 #ifdef MCHAP_STATS
 /* profiling builds only (make STATS=1): [0] likelihood requests, [1] cache misses, [2] probe slots */
 int mchap_debug_stats(unsigned long long *out, int reset) {
@@ -388,6 +395,8 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
     SP.max_allele = B.max_allele;
     SP.max_ploidy = B.max_ploidy;
     SP.max_ma = B.max_ma;
+    SP.flags = 0;
+    if (const char *e = std::getenv("MCHAP_HIP_FLAGS")) SP.flags = std::atoi(e);
     const size_t lds_prep = (size_t)B.max_ma * rpad * 8 + (size_t)B.max_ugens * 8 + 64;
     const size_t lds_simt = mchap::simt_lds_bytes(B.max_ploidy, B.max_pos, cfg->n_temps);
     if (lds_prep > 160 * 1024 || lds_simt > 160 * 1024)
@@ -407,15 +416,33 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
       const int T = cfg->n_temps;
       if (g) {
         switch (K * 100 + g) {
+#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 216
           case 216: return launch_spec<2, 16>(SP, n_units, cfg->chains, T, stream);
+#endif
+#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 232
           case 232: return launch_spec<2, 32>(SP, n_units, cfg->chains, T, stream);
+#endif
+#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 264
           case 264: return launch_spec<2, 64>(SP, n_units, cfg->chains, T, stream);
+#endif
+#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 416
           case 416: return launch_spec<4, 16>(SP, n_units, cfg->chains, T, stream);
+#endif
+#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 432
           case 432: return launch_spec<4, 32>(SP, n_units, cfg->chains, T, stream);
+#endif
+#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 464
           case 464: return launch_spec<4, 64>(SP, n_units, cfg->chains, T, stream);
+#endif
+#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 632
           case 632: return launch_spec<6, 32>(SP, n_units, cfg->chains, T, stream);
+#endif
+#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 664
           case 664: return launch_spec<6, 64>(SP, n_units, cfg->chains, T, stream);
+#endif
+#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 864
           case 864: return launch_spec<8, 64>(SP, n_units, cfg->chains, T, stream);
+#endif
         }
       }
     }

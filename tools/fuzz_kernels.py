@@ -1,0 +1,67 @@
+"""Differential fuzz: random shapes / sampler settings, every sampler kernel against the CPU oracle.
+
+    python tools/fuzz_kernels.py [n_cases] [seed]        (needs a GPU; test infrastructure, like tests/)
+"""
+import os
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+
+from mchap_amd import DenovoMCMC
+from mchap_amd.classes import sort_haplotypes
+from mchap_amd.synth import synth_units
+from test_gpu_denovo import _oracle_trace
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(n_cases):
+        K = int(rng.choice([2, 3, 4, 5, 6, 8]))
+        M = int(rng.integers(1, 13))
+        A = int(rng.choice([2, 2, 3, 4]))
+        R = int(rng.choice([1, 5, 30, 64, 70, 130, 200, 300]))
+        chains = int(rng.integers(1, 4))
+        U = int(rng.integers(1, 4))
+        temps = [(1.0,), (1.0,), (0.3, 1.0), (0.2, 0.6, 1.0)][int(rng.integers(0, 4))]
+        F = [None, None, 0.0, 0.15][int(rng.integers(0, 4))]
+        pr = [float(rng.choice([-1.0, 0.3, 0.5, 1.0])) for _ in range(3)]
+        if rng.random() < 0.3:
+            pr = [0.5, 0.5, 1.0]
+        steps = int(rng.choice([30, 80, 150]))
+        lo = int(rng.integers(1, M + 1))
+        reads, _, _ = synth_units(U, ploidy=K, n_pos=M, n_reads=R, n_alleles=A, first_unit=1000 + case,
+                                  window=(lo, M), qual=(5, 40))
+        kw = dict(ploidy=K, n_alleles=[A] * M, inbreeding=F, steps=steps, chains=chains, temperatures=temps,
+                  random_seed=int(rng.integers(0, 2 ** 31)), recombination_step_probability=pr[0],
+                  partial_dosage_step_probability=pr[1], dosage_step_probability=pr[2],
+                  llk_cache_threshold=int(rng.choice([-1, 100])))
+        m0 = DenovoMCMC(kernel=2, **kw)
+        ref = []
+        for u in range(U):
+            g, l = _oracle_trace(m0, reads[u], m0.n_alleles, None, u)
+            ref.append((sort_haplotypes(g), l))
+        res = []
+        for k in (1, 2, 3):
+            try:
+                tr = DenovoMCMC(kernel=k, **kw).fit_batch(list(reads))
+            except NotImplementedError:
+                res.append("n/a")
+                continue
+            ok = all(np.array_equal(tr[u].genotypes, ref[u][0]) and
+                     np.allclose(tr[u].llks, ref[u][1], rtol=1e-10, atol=1e-9, equal_nan=True) for u in range(U))
+            res.append("ok" if ok else "FAIL")
+            bad += not ok
+        print("case %3d K=%d M=%2d A=%d R=%3d C=%d U=%d T=%d F=%s p=%s steps=%d cache=%d : %s" % (
+            case, K, M, A, R, chains, U, len(temps), F, pr, steps, kw["llk_cache_threshold"], " ".join(res)), flush=True)
+    print("FAILURES: %d" % bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
