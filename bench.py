@@ -66,16 +66,19 @@ def cpu_baseline(args, cores):
 
 
 def pmc_traffic(args):
-    """HBM bytes per sampler launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.json, produced by
-    tools/pmc_traffic.sh with FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), if it matches this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("loci") == args.loci and t.get("mcmc_steps") == args.mcmc_steps and t.get("chains") == args.chains:
-            return t["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    """HBM bytes per sampler launch from the rocprofv3 PMC passes (profiles/*_pmc_traffic.json, produced by
+    tools/profile_round.sh + tools/pmc_traffic.py: FETCH_SIZE / WRITE_SIZE converted with factors calibrated in the
+    sampler's access width, MI355X_MICROARCH.md "HBM"); the newest summary that matches this workload, else None."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("loci") == args.loci and t.get("mcmc_steps") == args.mcmc_steps and t.get("chains") == args.chains:
+                return t["hbm_bytes_per_launch"]
+        except Exception:
+            pass
     return None
 
 

@@ -1,7 +1,12 @@
 """Turn the rocprofv3 --pmc CSVs of tools/profile_round.sh into profiles/<tag>_pmc_traffic.json.
 
-HBM bytes per sampler launch = 2 x FETCH_SIZE (gfx950 reports half the bytes of a read stream,
-/opt/skills/guides/MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB-units of the counter (x 1024)."""
+FETCH_SIZE / WRITE_SIZE are in KiB.  /opt/skills/guides/MI355X_MICROARCH.md ("HBM") calibrates them for 16-byte-
+per-lane streams only (FETCH_SIZE reports half of the bytes there) and asks for a calibration in one's own access
+pattern otherwise: tools/pmc_calib.hip streams 1 GiB with the sampler's width (8 bytes per lane) in the same
+profiling session, and the measured bytes-per-counter-unit factors are applied to the sampler's counters.
+
+    python tools/pmc_traffic.py <tag> <loci> <mcmc_steps> <chains>
+"""
 import collections
 import csv
 import glob
@@ -9,23 +14,44 @@ import json
 import sys
 
 tag, loci, steps, chains = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-vals = collections.defaultdict(list)
-for d in ("pmc_fetch", "pmc_write"):
-    for f in glob.glob("gpurun_out/%s_%s/*/*counter_collection.csv" % (tag, d)):
+SAMPLERS = ("denovo_spec", "denovo_simt_kernel", "denovo_mcmc")
+
+
+def per_launch(dirname, match):
+    vals = collections.defaultdict(list)
+    for f in glob.glob("gpurun_out/%s_%s/*/*counter_collection.csv" % (tag, dirname)):
         per_dispatch = collections.defaultdict(float)
         for row in csv.DictReader(open(f)):
-            if "denovo_spec" in row["Kernel_Name"] or "denovo_simt_kernel" in row["Kernel_Name"] or "denovo_mcmc" in row["Kernel_Name"]:
+            if any(m in row["Kernel_Name"] for m in match):
                 per_dispatch[(row["Counter_Name"], row["Dispatch_Id"])] += float(row["Counter_Value"])
         for (name, _), v in per_dispatch.items():
             vals[name].append(v)
-fetch = sum(vals["FETCH_SIZE"]) / max(len(vals["FETCH_SIZE"]), 1)
-write = sum(vals["WRITE_SIZE"]) / max(len(vals["WRITE_SIZE"]), 1)
+    return {k: sum(v) / len(v) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
+
+
+fetch, nf = per_launch("pmc_fetch", SAMPLERS)
+write, nw = per_launch("pmc_write", SAMPLERS)
+cal_bytes = float((1 << 27) * 8)
+cf, _ = per_launch("cal_fetch", ("calib_read_f64",))
+cw, _ = per_launch("cal_write", ("calib_write_f64",))
+f_factor = cal_bytes / (cf["FETCH_SIZE"] * 1024.0) if cf.get("FETCH_SIZE") else None
+w_factor = cal_bytes / (cw["WRITE_SIZE"] * 1024.0) if cw.get("WRITE_SIZE") else None
+fs, ws = fetch.get("FETCH_SIZE", 0.0), write.get("WRITE_SIZE", 0.0)
 out = {
     "loci": loci, "mcmc_steps": steps, "chains": chains,
-    "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
-    "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
-    "correction": "FETCH_SIZE doubled (gfx950 reports half of a coalesced read stream); WRITE_SIZE as is",
-    "launches_averaged": [len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"])],
+    "FETCH_SIZE_KiB_per_launch": fs, "WRITE_SIZE_KiB_per_launch": ws,
+    "calibration": {
+        "pattern": "8 bytes per lane, 512 contiguous bytes per wavefront, 1 GiB streamed (tools/pmc_calib.hip)",
+        "bytes_per_FETCH_SIZE_byte": f_factor, "bytes_per_WRITE_SIZE_byte": w_factor,
+    },
+    "hbm_bytes_per_launch": ((f_factor or 2.0) * fs + (w_factor or 1.0) * ws) * 1024.0,
+    "hbm_bytes_per_launch_guide_16B_rule": (2.0 * fs + ws) * 1024.0,
+    "launches_averaged": [nf.get("FETCH_SIZE", 0), nw.get("WRITE_SIZE", 0)],
 }
+sq = {}
+for d in ("pmc_sq1", "pmc_sq2"):
+    v, _ = per_launch(d, SAMPLERS)
+    sq.update(v)
+out["sq_counters_per_launch"] = sq
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
-print(out)
+print(json.dumps(out, indent=1))
