@@ -442,15 +442,22 @@ __device__ __forceinline__ uint64_t lane_genotype_tag(const SimtLds &S, const La
 }
 
 #ifdef MCHAP_STATS
-__device__ unsigned long long g_stats[8];
+__device__ unsigned long long g_stats[24];
 #define STAT_ADD(i, pred)                                                         \
   do {                                                                            \
     const int n_ = __popcll(__ballot(pred));                                      \
     if (n_ && (threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)n_); \
   } while (0)
+#define STAT_WAVE(i, n)                                                                     \
+  do {                                                                                      \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_stats[i], (unsigned long long)(n));           \
+  } while (0)
 #else
 #define STAT_ADD(i, pred) \
   do {                    \
+  } while (0)
+#define STAT_WAVE(i, n) \
+  do {                  \
   } while (0)
 #endif
 

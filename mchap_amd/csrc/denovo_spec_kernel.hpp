@@ -22,6 +22,13 @@
 
 #include "denovo_simt_kernel.hpp"
 
+#ifndef MCHAP_COOP_UNR
+#define MCHAP_COOP_UNR 2  // row loads in flight per lane and chunk
+#endif
+#ifndef MCHAP_COOP_RPL
+#define MCHAP_COOP_RPL 4  // read chunks (of 64) per pass for read depths above 128; rpad is a multiple of 64 * this
+#endif
+
 namespace mchap {
 
 constexpr int SPEC_MAX_IV = 64;  // intervals per structural compound step (<= n_pos)
@@ -302,7 +309,7 @@ template <int KT, int RPL>
 __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
                                                  GLBP(const double) rt, GLBP(const double) cw, int rpad, int lane) {
   // rt / cw already point at the lane's first read of the block of RPL chunks
-  constexpr int UNR = 8;
+  constexpr int UNR = MCHAP_COOP_UNR;
   const int n_pairs = KT * Mh;
   const double invK = 1.0 / (double)KT;
   double acc[RPL], prod[RPL];
@@ -390,8 +397,8 @@ COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP
     if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
     else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
     else
-      for (int cb = 0; cb < nch; cb += 4)
-        s += spec_coop_body<KT, 4>(S, src, sg, mmax, Mh, amask, rt + cb * WAVE, cw + cb * WAVE, rpad, lane);
+      for (int cb = 0; cb < nch; cb += MCHAP_COOP_RPL)
+        s += spec_coop_body<KT, MCHAP_COOP_RPL>(S, src, sg, mmax, Mh, amask, rt + cb * WAVE, cw + cb * WAVE, rpad, lane);
     s = wave_sum(s);
     if (lane == src) val = s;
   }
@@ -424,7 +431,11 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
     ulonglong2 *set = c.cache + 8 * (size_t)((hsh >> 12) & c.cache_mask);
     int way = (int)((hsh >> 24) & 7u);
     bool empty_seen = false;
+#ifdef MCHAP_PROBE_UNR
+#pragma unroll MCHAP_PROBE_UNR
+#else
 #pragma unroll
+#endif
     for (int w = 7; w >= 0; w--) {
       const ulonglong2 e = set[w];
       if (e.x == tag) {
@@ -499,7 +510,10 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
       run = false;
     }
   }
+  STAT_WAVE(8, 1);
   if (!wave_any(run)) return;
+  STAT_WAVE(9, 1);
+  STAT_ADD(10, run && gl == 0);
   LDSP(uint8_t) ktab = S.ktab + gi * nmax;
   LDSP(uint16_t) permtab = S.permtab + gi * nmax;
   LDSP(uint8_t) shift = S.shift + gi * mmax;
@@ -562,6 +576,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   bool first_round = true;
   double my_lo = 0.0, my_hi = 2.0;  // this lane's sub-steps: max lo_e, min hi_e (first round only)
   while (wave_any(!done)) {
+    STAT_WAVE(11, 1);
     const double lprior = (!done && !isnan(c.inbreeding)) ? prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(c.g)) : 0.0;
     bool found = false;
 #pragma unroll 1
@@ -834,7 +849,12 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
     }
     if (ii0 >= n_int) done = true;
   }
+  STAT_WAVE(12 + 4 * (kind > 0), 1);
+  STAT_ADD(13 + 4 * (kind > 0), doit && gl == 0);
+  STAT_ADD(14 + 4 * (kind > 0), !done && gl == 0);
+  if (wave_any(!done)) STAT_WAVE(20 + (kind > 0), 1);
   while (wave_any(!done)) {
+    STAT_WAVE(15 + 4 * (kind > 0), 1);
     // (a) labels and option counts of the next (up to G) intervals, one interval per lane
     if (!done) {
       for (int ii = ii0 + gl; ii < n_int && ii < ii0 + G; ii += G) {

@@ -271,7 +271,7 @@ int mchap_debug_log(unsigned long long *out) {
 #ifdef MCHAP_STATS
 /* profiling builds only (make STATS=1): [0] likelihood requests, [1] cache misses, [2] probe slots */
 int mchap_debug_stats(unsigned long long *out, int reset) {
-  unsigned long long z[8] = {0};
+  unsigned long long z[24] = {0};
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_stats), sizeof(z)));
   if (reset) HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::g_stats), z, sizeof(z)));

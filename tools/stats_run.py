@@ -15,7 +15,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 reads, _, _ = synth_units(U)
 model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=steps, chains=2, random_seed=42)
 b = DenovoDeviceBatch(model, reads)
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 24)()
 L = _lib.lib()
 L.mchap_debug_stats(out, 1)
 t = time.time(); b.run(); torch.cuda.synchronize(); dt = time.time() - t
@@ -28,3 +28,11 @@ tot = sum(out[3:8]) or 1
 waves = (U * 2 + (64 // int(os.environ.get("MCHAP_HIP_GROUP", "16"))) - 1) // (64 // int(os.environ.get("MCHAP_HIP_GROUP", "16")))
 for i, nm in enumerate(names):
     print("  %-22s %5.1f%%   %.0f cycles per wave-step (100 MHz ticks x?)" % (nm, 100.0 * out[3 + i] / tot, out[3 + i] / max(waves * steps, 1)))
+
+ws = max(waves * steps, 1)
+print("mutation: wave-calls %d  slow-path wave-calls %.3f  groups on slow path per wave-call %.3f  rounds per wave-call %.3f" % (
+    out[8], out[9] / max(out[8], 1), out[10] / max(out[8], 1), out[11] / max(out[8], 1)))
+for nm, b, w in (("recombination", 12, 20), ("dosage (both kinds)", 16, 21)):
+    n = max(out[b], 1)
+    print("%s: wave-calls %d  groups executing per wave-call %.3f  groups needing rounds %.3f  wave-calls with rounds %.3f  rounds per wave-call %.3f" % (
+        nm, out[b], out[b + 1] / n, out[b + 2] / n, out[w] / n, out[b + 3] / n))
