@@ -41,14 +41,37 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, cores):
+def usable_cores():
+    """Threads the CPU baseline may really use: the affinity mask, capped by the cgroup CPU quota when there is one
+    (the GPU boxes expose 256 hardware threads but grant a 16-CPU quota: more threads than that only spin)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
+def cpu_baseline(args, cores, quota=None):
     """The oracle (C restatement incl. the reference's llk trie cache at its default threshold 100) timed on
     the host cores over a bounded sample of the same workload."""
     from oracle import binding as orc
     from mchap_amd.assemble import break_table
     from mchap_amd.synth import synth_units
 
-    n = args.cpu_sample or min(2000, 48 * cores)
+    n = args.cpu_sample or min(4000, 160 * cores)  # about 10-30 s of CPU work in total
     reads, _, _ = synth_units(n, ploidy=args.ploidy, n_pos=args.snvs, n_reads=args.reads, first_unit=0)
     cfg = orc.make_cfg(args.ploidy, args.mcmc_steps, args.chains, None, (1.0,), llk_cache_threshold=100, seed=42,
                        rng_kind=orc.RNG_PHILOX, break_table=break_table(args.snvs, 1.0, 3.0))
@@ -59,8 +82,9 @@ def cpu_baseline(args, cores):
     assert code == 0
     return {
         "value": n / dt, "unit": "loci/s", "cores": cores, "kind": "port",
-        "sample": "%d loci of the same workload, oracle/mchap_oracle.c with llk cache threshold 100, OpenMP over loci, %.2f s wall"
-                  % (n, dt),
+        "sample": "%d loci of the same workload, oracle/mchap_oracle.c with llk cache threshold 100, OpenMP over loci "
+                  "(%d threads = affinity capped by the cgroup CPU quota %s), %.2f s wall"
+                  % (n, cores, "none" if quota is None else "%.1f" % quota, dt),
         "llk_evals_per_locus": st.llk_evals / n, "llk_cache_hits_per_locus": st.llk_cache_hits / n,
     }
 
@@ -192,8 +216,8 @@ def main():
             },
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, os.cpu_count() or 1)
-            out["gpu_over_cpu_allcores"] = value / world / out["cpu_baseline"]["value"]
+            cores, quota = usable_cores()
+            out["cpu_baseline"] = cpu_baseline(args, cores, quota)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

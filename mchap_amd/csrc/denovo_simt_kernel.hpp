@@ -441,8 +441,10 @@ __device__ __forceinline__ uint64_t lane_genotype_tag(const SimtLds &S, const La
   return (t << 1) | 1ull;
 }
 
-#ifdef MCHAP_STATS
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
 __device__ unsigned long long g_stats[24];
+#endif
+#ifdef MCHAP_STATS
 #define STAT_ADD(i, pred)                                                         \
   do {                                                                            \
     const int n_ = __popcll(__ballot(pred));                                      \

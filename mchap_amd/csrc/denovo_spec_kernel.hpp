@@ -77,7 +77,7 @@ struct SpecLds {
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
   LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] total move probability of an interval step for the current
                              // genotype; NaN = not evaluated yet, -1 = the step has no options
-  LDSP(double) bdist;        // [NG][Mmax] the chain's break-count distribution
+  LDSP(double) bdist;        // [NG][Mmax] the chain's cumulative break-count distribution
   int memo_stride;           // 2 * (Mmax+1)^2, or 0 when the tables do not fit
   int ndraws;                // staged draws per group
 };
@@ -290,6 +290,7 @@ struct Grp {
   uint32_t cache_mask;
   Stream st;
   uint64_t ctr;  // next draw of the current stream
+  int doff, dcount;  // staged window of the group's draw table: entry doff holds draw ctr, dcount entries are valid
   double llk;
   GWords<KT> g;  // genotype of the current temperature
   // memo of the current genotype (single temperature only): a mutation compound step moves nothing if every one
@@ -297,7 +298,26 @@ struct Grp {
   bool memo_on, mvalid;
   double mlo, mhi;
   uint32_t gen, memo_gen;  // memo_gen: the generation the interval memo table currently describes
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+  unsigned long long ph[12], pt0;
+#endif
 };
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+#define GPHASE(c, i)                                              \
+  do {                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+    (c).ph[i] += t_ - (c).pt0;                                    \
+    (c).pt0 = t_;                                                 \
+  } while (0)
+#define GSUB_T0() const unsigned long long gsub_t0_ = __builtin_amdgcn_s_memtime()
+#define GSUB(c, i) const_cast<unsigned long long &>((c).ph[i]) += __builtin_amdgcn_s_memtime() - gsub_t0_
+#define GCOUNT(c, i, n) const_cast<unsigned long long &>((c).ph[i]) += (n)
+#else
+#define GPHASE(c, i)
+#define GSUB_T0()
+#define GSUB(c, i)
+#define GCOUNT(c, i, n)
+#endif
 
 template <int KT>
 __device__ __forceinline__ void genotype_changed(Grp<KT> &c) {
@@ -414,6 +434,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
   bool miss = need;
   uint64_t tag = 0;
   ulonglong2 *slot = nullptr;
+  GSUB_T0();
   if (need && c.cache) {
     // 8-way sets (one 128-byte line).  The lanes of a group probe and fill the chain's table concurrently, so the
     // policy must not depend on read-modify-write sequences: hits never move entries, a miss goes to the first
@@ -454,7 +475,9 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
   STAT_ADD(1, miss);
   STAT_ADD(2, true);
   unsigned long long todo = __ballot(miss);
+  GSUB(c, 9);
   if (todo) {
+    GCOUNT(c, 11, __popcll(todo));
     if (miss) {
 #pragma unroll
       for (int h = 0; h < KT; h++) S.pw[(size_t)h * WAVE + lane] = pw.w[h];
@@ -466,6 +489,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
       if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
     }
     lds_sync();
+    GSUB(c, 10);
   }
   return val;
 }
@@ -494,7 +518,10 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   if (wave_any(c.alive && c.mvalid)) {
     LDSP(uint64_t) utab = S.draws + gi * S.ndraws;
     const bool fast = c.alive && c.mvalid && n <= S.ndraws;
-    stage_draws<G>(c.st, ctr0 + (uint64_t)(n - 1), n, utab, gl, fast);
+    // the n uniforms, plus as many of the following draws as the same number of Philox rounds per lane yields:
+    // they are the structural steps' draws if this step moves nothing
+    const int cnt = max(n, min(S.ndraws, 2 * G * ((n / 2 + G) / G) - 1));
+    stage_draws<G>(c.st, ctr0 + (uint64_t)(n - 1), cnt, utab, gl, fast);
     lds_sync();
     bool ok = true;
     if (fast) {
@@ -507,10 +534,14 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
     lds_sync();
     if (fast && !bad) {
       c.ctr = ctr0 + (uint64_t)(n - 1) + (uint64_t)n;
+      c.doff = n;
+      c.dcount = cnt;
       run = false;
     }
   }
+  if (run) c.dcount = 0;  // the slow path restages the table from ctr0 and uses all of it
   STAT_WAVE(8, 1);
+  GPHASE(c, 0);
   if (!wave_any(run)) return;
   STAT_WAVE(9, 1);
   STAT_ADD(10, run && gl == 0);
@@ -684,6 +715,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
     first_round = false;
     if (!done && (!found || start >= n)) done = true;
   }
+  GPHASE(c, 1);
 }
 
 // One structural compound step (structural.py:22-71, 433-673) of kind 0 recombination, 1 interval dosage,
@@ -708,45 +740,48 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
   bool ok = true;
   bool doit = false;
   int n_int = 0;
-  // the draws this compound step may consume (decision, break count, <= Mh-1 break points, <= Mh-1 order swaps,
-  // <= Mh interval choices) staged through LDS: next_double()/next_interval() below read them in sequence
+  // Draws come from the group's staged window (Grp::doff / dcount): table entry doff holds draw c.ctr.  The window
+  // left behind by the mutation step usually covers all three structural steps; it is refilled (for every group
+  // of the wave at once, one Philox block per lane) when a group runs low, and single draws beyond it are computed
+  // on the spot.
   LDSP(uint64_t) dtab = S.draws + gi * S.ndraws;
-  const uint64_t dbase = c.ctr;
-  const int dcount = min(S.ndraws, 3 * Mh + 2);
-  lds_sync();
-  stage_draws<G>(c.st, dbase, dcount, dtab, gl, c.alive);
-  lds_sync();
+  {
+    const int low = min(3 * Mh + 2, 12);
+    if (wave_any(c.alive && c.dcount - c.doff < low)) {
+      const int W = min(S.ndraws, 2 * G - 1);
+      lds_sync();
+      stage_draws<G>(c.st, c.ctr, W, dtab, gl, c.alive);
+      lds_sync();
+      c.doff = 0;
+      c.dcount = c.alive ? W : 0;
+    }
+  }
+  GPHASE(c, 2);
   auto next_words = [&]() -> uint64_t {
-    const uint64_t i = c.ctr - dbase;
+    const int i = c.doff;
+    c.doff++;
     c.ctr++;
-    if (i < (uint64_t)dcount) return dtab[i];
+    if (i < c.dcount) return dtab[i];
     uint32_t a, b;
     stream_words(c.st, c.ctr - 1, a, b);
     return (uint64_t)a | ((uint64_t)b << 32);
   };
+  uint64_t zeros = 0;
   if (c.alive) {
     const double pstep = kind == 0 ? D.p_recomb : (kind == 1 ? D.p_partial : D.p_dosage);
     doit = draw_double(next_words()) <= pstep;
-    uint64_t zeros = 0;
     if (doit && kind < 2) {
       int nb;
       if (D.n_intervals > 0) {
         c.ctr++;  // break_dist = [0,...,0,1]: the draw is consumed (assemble/mcmc.py:214-217)
+        c.doff++;
         nb = D.n_intervals - 1;
       } else {
-        {
-          const double u = draw_double(next_words());
-          LDSP(double) bd = S.bdist + gi * mmax;
-          double cacc = 0.0;
-          nb = n_break_dist;
-          for (int i = 0; i < n_break_dist; i++) {
-            cacc += bd[i];
-            if (cacc > u) {
-              nb = i;
-              break;
-            }
-          }
-        }
+        // first i with cumsum(break_dist)[i] > u (the cumulative sums were formed in the reference's order)
+        const double u = draw_double(next_words());
+        LDSP(double) bcum = S.bdist + gi * mmax;
+        const uint64_t hit = grp_ballot<G>(gl < n_break_dist && bcum[gl < n_break_dist ? gl : 0] > u, gi);
+        nb = hit ? __ffsll((long long)hit) - 1 : n_break_dist;
       }
       if (nb >= Mh) {
         ok = false;
@@ -770,13 +805,72 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
       zeros = 1ull | (1ull << Mh);
       n_int = 1;
     }
-    if (doit) {
-      // np.random.permutation(arange(n_int)) then intervals in that order
-      if (gl == 0)
-        for (int i = 0; i < n_int; i++) ord[i] = (uint8_t)i;
+  }
+  GPHASE(c, 3);
+  const uint64_t full = mask_of(c.bits, Mh, 0, Mh);
+  // Memo.  For an unchanged genotype an interval step (type, start, stop) has a fixed option count and a fixed
+  // total move probability (the last cumulative sum of its options): it moves nothing iff its uniform is >= that
+  // total.  The table describes genotype generation memo_gen and is wiped when the genotype has changed.
+  const int mrow = mmax + 1;
+  LDSP(double) mtot = S.memo_tot + gi * S.memo_stride + step_type * mrow * mrow;
+  const bool memo = S.memo_stride != 0;
+  if (memo && wave_any(c.alive && c.gen != c.memo_gen)) {
+    if (c.alive && c.gen != c.memo_gen) {
+      LDSP(double) all = S.memo_tot + gi * S.memo_stride;
+      for (int i = gl; i < S.memo_stride; i += G) all[i] = NAN;
+      c.memo_gen = c.gen;
     }
     lds_sync();
-    if (doit) {
+  }
+  GPHASE(c, 4);
+  bool done = !doit;
+  // Fast check, independent of the visiting order: if every interval of this compound step is in the memo, the
+  // step consumes n_int - 1 shuffle draws and one uniform per interval that has options; it moves nothing if all
+  // those uniforms are >= the largest total among its intervals, whichever interval each of them is paired with.
+  if (memo && wave_any(doit)) {
+    const bool mine = doit && gl < n_int;
+    double tot = -1.0;
+    if (mine) {
+      uint64_t z = zeros;
+      for (int q = 0; q < gl; q++) z &= z - 1;
+      const int start = __ffsll((long long)z) - 1;
+      z &= z - 1;
+      const int stop = __ffsll((long long)z) - 1;
+      tot = mtot[start * mrow + stop];
+    }
+    const uint64_t unknown = grp_ballot<G>(mine && isnan(tot), gi);
+    const int n_cons = __popcll(grp_ballot<G>(mine && tot >= 0.0, gi));
+    double mx = (mine && tot >= 0.0) ? tot : -1.0;
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, G));
+    bool low = false;
+    if (doit && gl < n_cons) {
+      const int i = c.doff + (n_int - 1) + gl;
+      uint64_t w;
+      if (i < c.dcount) {
+        w = dtab[i];
+      } else {
+        uint32_t a, b;
+        stream_words(c.st, c.ctr + (uint64_t)(n_int - 1 + gl), a, b);
+        w = (uint64_t)a | ((uint64_t)b << 32);
+      }
+      low = !(draw_double(w) >= mx);
+    }
+    const uint64_t anylow = grp_ballot<G>(low, gi);
+    if (doit && !unknown && !anylow) {
+      c.ctr += (uint64_t)(n_int - 1 + n_cons);
+      c.doff += n_int - 1 + n_cons;
+      done = true;
+    }
+  }
+  GPHASE(c, 5);
+  // Exact path: visiting order (np.random.permutation(arange(n_int))), then the intervals one after the other
+  int ii0 = 0;
+  if (wave_any(!done)) {
+    if (!done && gl == 0)
+      for (int i = 0; i < n_int; i++) ord[i] = (uint8_t)i;
+    lds_sync();
+    if (!done) {
       for (int i = n_int - 1; i >= 1; i--) {
         const int k = (int)draw_interval(next_words(), (uint32_t)i);
         const uint8_t a = ord[i], b = ord[k];
@@ -787,17 +881,8 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
         }
         lds_sync();
       }
-      if (gl < n_int) {
-        const int iv = ord[gl];
-        uint64_t z = zeros;
-        for (int q = 0; q < iv; q++) z &= z - 1;
-        const int start = __ffsll((long long)z) - 1;
-        z &= z - 1;
-        const int stop = __ffsll((long long)z) - 1;
-        ivse[gl] = (uint32_t)start | ((uint32_t)stop << 8);
-      }
-      // n_int <= Mh <= 62 may exceed G for G = 16/32: remaining entries by a strided loop
-      for (int q = gl + G; q < n_int; q += G) {
+      // n_int <= Mh may exceed G for G = 16/32: strided
+      for (int q = gl; q < n_int; q += G) {
         const int iv = ord[q];
         uint64_t z = zeros;
         for (int r = 0; r < iv; r++) z &= z - 1;
@@ -807,48 +892,34 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
         ivse[q] = (uint32_t)start | ((uint32_t)stop << 8);
       }
     }
-  }
-  lds_sync();
-  // speculation rounds over the remaining intervals [ii0, n_int)
-  int ii0 = 0;
-  bool done = !doit;
-  const uint64_t full = mask_of(c.bits, Mh, 0, Mh);
-  // Memo.  For an unchanged genotype an interval step (type, start, stop) has a fixed option count and a fixed
-  // total move probability (the last cumulative sum of its options): it moves nothing iff its uniform is >= that
-  // total.  Entries are tagged with the genotype generation; intervals are skipped while the memo says "no move".
-  const int mrow = mmax + 1;
-  LDSP(double) mtot = S.memo_tot + gi * S.memo_stride + step_type * mrow * mrow;
-  const bool memo = S.memo_stride != 0;
-  if (memo && c.alive && c.gen != c.memo_gen) {
-    // the genotype changed since the table was filled: forget everything
-    LDSP(double) all = S.memo_tot + gi * S.memo_stride;
-    for (int i = gl; i < S.memo_stride; i += G) all[i] = NAN;
-    c.memo_gen = c.gen;
-  }
-  lds_sync();
-  if (!done && memo) {
-    while (ii0 < n_int) {
-      const uint32_t se = ivse[ii0];
-      const int idx = (int)(se & 255u) * mrow + (int)(se >> 8);
-      const double tot = mtot[idx];
-      if (isnan(tot)) break;  // not evaluated for this genotype yet
-      if (tot >= 0.0) {       // -1: the step has no options and consumes no draw
-        const uint64_t i = c.ctr - dbase;
-        uint64_t w;
-        if (i < (uint64_t)dcount) {
-          w = dtab[i];
-        } else {
-          uint32_t a, b;
-          stream_words(c.st, c.ctr, a, b);
-          w = (uint64_t)a | ((uint64_t)b << 32);
+    lds_sync();
+    // intervals are skipped while the memo says "no move"
+    if (!done && memo) {
+      while (ii0 < n_int) {
+        const uint32_t se = ivse[ii0];
+        const int idx = (int)(se & 255u) * mrow + (int)(se >> 8);
+        const double tot = mtot[idx];
+        if (isnan(tot)) break;  // not evaluated for this genotype yet
+        if (tot >= 0.0) {       // -1: the step has no options and consumes no draw
+          const int i = c.doff;
+          uint64_t w;
+          if (i < c.dcount) {
+            w = dtab[i];
+          } else {
+            uint32_t a, b;
+            stream_words(c.st, c.ctr, a, b);
+            w = (uint64_t)a | ((uint64_t)b << 32);
+          }
+          if (!(draw_double(w) >= tot)) break;  // this interval moves: evaluate it for real
+          c.ctr++;
+          c.doff++;
         }
-        if (!(draw_double(w) >= tot)) break;  // this interval moves: evaluate it for real
-        c.ctr++;
+        ii0++;
       }
-      ii0++;
+      if (ii0 >= n_int) done = true;
     }
-    if (ii0 >= n_int) done = true;
   }
+  GPHASE(c, 6);
   STAT_WAVE(12 + 4 * (kind > 0), 1);
   STAT_ADD(13 + 4 * (kind > 0), doit && gl == 0);
   STAT_ADD(14 + 4 * (kind > 0), !done && gl == 0);
@@ -989,6 +1060,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
     if (!done && ii0 >= n_int) done = true;
     lds_sync();
   }
+  GPHASE(c, 7);
   return ok;
 }
 
@@ -1009,25 +1081,6 @@ __device__ unsigned long long g_log[LOG_CHAINS * LOG_STEPS * LOG_EV * LOG_F];
   } while (0)
 #else
 #define SPEC_LOG(ev)
-#endif
-
-#ifdef MCHAP_STATS
-#define PHASE_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0_ = __builtin_amdgcn_s_memtime()
-#define PHASE(i)                                                  \
-  do {                                                            \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
-    ph_[i] += t_ - pt0_;                                          \
-    pt0_ = t_;                                                    \
-  } while (0)
-#define PHASE_FLUSH                                               \
-  do {                                                            \
-    if (threadIdx.x == 0)                                         \
-      for (int i_ = 0; i_ < 5; i_++) atomicAdd(&g_stats[3 + i_], ph_[i_]); \
-  } while (0)
-#else
-#define PHASE_DECL
-#define PHASE(i)
-#define PHASE_FLUSH
 #endif
 
 #ifdef MCHAP_LDS_GUARD
@@ -1135,6 +1188,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     c.cache_mask = (uint32_t)(D.cache_slots / 8) - 1u;  // sets of 8 ways
   }
   c.ctr = 0;
+  c.doff = 0;
+  c.dcount = 0;
   c.llk = 0.0;
   c.memo_on = (T == 1) && !(P.flags & 1);
   c.mvalid = false;
@@ -1151,8 +1206,14 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     }
     if (!isnan(c.inbreeding))
       for (int i = gl; i < 2 * KT + 5; i += G) S.prior[(size_t)gi * (2 * KT + 5) + i] = mf[meta_f_prior(0) + i];
-    if (D.n_intervals == 0)
-      for (int j = gl; j < Mh; j += G) S.bdist[gi * mmax + j] = D.break_table[(size_t)Mh * D.max_pos + j];
+    if (D.n_intervals == 0 && gl == 0) {
+      // cumulative break-count distribution, summed in the reference's order (structural.py:44-49)
+      double cacc = 0.0;
+      for (int j = 0; j < Mh; j++) {
+        cacc += D.break_table[(size_t)Mh * D.max_pos + j];
+        S.bdist[gi * mmax + j] = cacc;
+      }
+    }
   }
   lds_sync();
   const int amax = [&] {
@@ -1234,15 +1295,19 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   c.st.k1 = (uint32_t)(D.seed >> 32) ^ (uint32_t)(U.stream_id >> 32);
   c.st.c3 = (uint32_t)U.stream_id;
 
-  PHASE_DECL;
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+  for (int i_ = 0; i_ < 12; i_++) c.ph[i_] = 0;
+  c.pt0 = __builtin_amdgcn_s_memtime();
+#endif
   for (int step = 0; step < Sn; step++) {
     for (int t = 0; t < T; t++) {
-      PHASE(4);
+      GPHASE(c, 8);
       if (T > 1) {
 #pragma unroll
         for (int h = 0; h < KT; h++) c.g.w[h] = S.wst[((size_t)gi * T + t) * KT + h];
         c.llk = S.llk_t[(size_t)gi * T + t];
         c.ctr = S.rngn[(size_t)gi * T + t];
+        c.dcount = 0;  // another stream: nothing staged
       }
       const double temp = D.temps[t];
       c.st.c2 = ((uint32_t)chain << 16) | (uint32_t)t;
@@ -1253,7 +1318,6 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
 #ifndef MCHAP_ABL_NO_MUT
       spec_mutation<KT, G>(c, S, temp, amax, mmax, nmax, rpad, lane, gi, gl);
 #endif
-      PHASE(0);
       SPEC_LOG(0);
 #ifndef MCHAP_ABL_NO_STR
 #pragma unroll 1
@@ -1262,7 +1326,6 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
           status = MCHAP_UNIT_BREAKS;
           c.alive = false;
         }
-        PHASE(1 + kind);
         SPEC_LOG(1 + kind);
       }
 #endif
@@ -1304,6 +1367,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
         lds_sync();
       }
     }
+#ifndef MCHAP_ABL_NO_TRACE
     if (c.alive) {
       // record the cold chain (held in registers after the last temperature) in canonical order
       if (gl < KT) {
@@ -1315,8 +1379,12 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       }
       if (gl == 0) D.llks[llk_base + step] = c.llk;
     }
+#endif
   }
-  PHASE_FLUSH;
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+  if (threadIdx.x == 0)
+    for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_stats[3 + i_], c.ph[i_]);
+#endif
   if (status != MCHAP_UNIT_OK && gl == 0) atomicMax(&D.status[u], status);
 }
 

@@ -268,7 +268,7 @@ int mchap_debug_log(unsigned long long *out) {
   return 0;
 }
 #endif
-#ifdef MCHAP_STATS
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
 /* profiling builds only (make STATS=1): [0] likelihood requests, [1] cache misses, [2] probe slots */
 int mchap_debug_stats(unsigned long long *out, int reset) {
   unsigned long long z[24] = {0};

@@ -41,7 +41,7 @@ def synth_units(n_units, ploidy=4, n_pos=8, n_reads=200, n_alleles=2, first_unit
         rng = np.random.default_rng([seed, first_unit + u])
         while True:
             haps = rng.integers(0, A, size=(ploidy, n_pos)).astype(np.int8)
-            if len(np.unique(haps, axis=0)) >= min(3, ploidy):
+            if len(np.unique(haps, axis=0)) >= min(3, ploidy, A ** n_pos):
                 break
         src = haps[rng.integers(0, ploidy, size=n_reads)]
         if dedup:

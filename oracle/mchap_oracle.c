@@ -22,6 +22,9 @@
 
 #include <math.h>
 #include <stdlib.h>
+#ifdef __GLIBC__
+#include <malloc.h>
+#endif
 #include <string.h>
 #include <stdio.h>
 #ifdef _OPENMP
@@ -1253,6 +1256,12 @@ int orc_denovo_fit_batch(const orc_denovo_cfg *cfg, int n_units, int n_threads,
   size_t gsz = (size_t)cfg->chains * cfg->steps * cfg->ploidy * n_pos;
   size_t lsz = (size_t)cfg->chains * cfg->steps;
   orc_stats total = {0, 0, 0, 0};
+#ifdef __GLIBC__
+  /* keep the per-chain tries and traces on the per-thread heaps: with the default thresholds every chain's
+     growing trie is mmap()ed / munmap()ed, and hundreds of threads then serialise on the process's mmap lock */
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+#endif
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
 #pragma omp parallel
