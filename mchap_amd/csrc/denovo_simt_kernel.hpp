@@ -40,8 +40,9 @@ struct SimtParams {
   int n_units;
   int max_pos, max_allele, max_ploidy;
   int max_ma;        // max over units of n_pos * max_allele
-  int flags;         // debugging: bit 0 no mutation memo, bit 1 no interval memo (MCHAP_HIP_FLAGS)
+  int flags;         // debugging: bit 0 no mutation memo, bit 1 no interval memo (MCHAP_HIP_FLAGS); bit 30 below
 };
+constexpr int SIMT_FLAG_PREP_GLOBAL = 1 << 30;  // table too large for the prepare pass's LDS copy
 
 // ---------------------------------------------------------------------------------------------------------
 // prepare: grid = units, block = 64
@@ -56,10 +57,13 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
   const int R = U.n_reads, M0 = U.n_pos, A = U.max_allele, K = U.ploidy;
   const int rpad = D.rpad;
   const int MA = M0 * A;
-  double *rl = reinterpret_cast<double *>(smem);  // [MA][rpad]
-  double *lp = rl + (size_t)MA * rpad;            // snv posterior scratch
-  const double *gr = D.reads + U.reads_off;
   double *rt = P.rt + (size_t)u * P.max_ma * rpad;
+  // [MA][rpad] copy for the homozygous fix: in LDS when it fits, else the global table itself (every lane only
+  // re-reads the reads r = lane + 64 i it stored, so program order makes its own stores visible)
+  const bool in_lds = !(P.flags & SIMT_FLAG_PREP_GLOBAL);
+  double *rl = in_lds ? reinterpret_cast<double *>(smem) : rt;
+  double *lp = reinterpret_cast<double *>(smem) + (in_lds ? (size_t)MA * rpad : 0);  // snv posterior scratch
+  const double *gr = D.reads + U.reads_off;
   double *cw = P.cntw + (size_t)u * rpad;
   int32_t *mi = P.meta_i + (size_t)u * meta_i_stride(P.max_pos);
   double *mf = P.meta_f + (size_t)u * meta_f_stride(P.max_ploidy, P.max_pos, P.max_allele);
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
         v = gr[(size_t)r * MA + q];
         if (isnan(v)) v = 1.0;
       }
-      rl[(size_t)q * rpad + r] = v;
+      if (in_lds) rl[(size_t)q * rpad + r] = v;
       rt[(size_t)q * rpad + r] = v;
     }
   }

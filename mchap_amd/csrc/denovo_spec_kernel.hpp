@@ -22,6 +22,11 @@
 
 #include "denovo_simt_kernel.hpp"
 
+#ifdef MCHAP_MASK_PADDING
+#define MCHAP_PAD_LANE(x) (x)
+#else
+#define MCHAP_PAD_LANE(x) true
+#endif
 #ifndef MCHAP_COOP_UNR
 #define MCHAP_COOP_UNR 2  // row loads in flight per lane and chunk
 #endif
@@ -74,6 +79,7 @@ struct SpecLds {
   LDSP(uint8_t) nal;      // [NG][Mmax]
   LDSP(uint8_t) ktab;     // [NG][nmax]
   LDSP(uint8_t) ordtab;   // [NG][SPEC_MAX_IV]
+  LDSP(uint16_t) nreads;  // [NG] reads of the group's unit (lanes beyond it do not load the table's padding)
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
   LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] total move probability of an interval step for the current
                              // genotype; NaN = not evaluated yet, -1 = the step has no options
@@ -117,6 +123,8 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int 
   b += (size_t)NG * Mmax * 2;            // shift, nal
   b += (size_t)NG * nmax;                // ktab
   b += (size_t)NG * niv;                 // ordtab
+  b = (b + 1) & ~(size_t)1;
+  b += (size_t)2 * NG;                   // nreads
   b = (b + 15) & ~(size_t)15;
   b += (size_t)8 * NG * spec_draws(K, Mmax);
   b += spec_memo_bytes(Mmax, T, G);
@@ -327,7 +335,11 @@ __device__ __forceinline__ void genotype_changed(Grp<KT> &c) {
 
 template <int KT, int RPL>
 __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
-                                                 GLBP(const double) rt, GLBP(const double) cw, int rpad, int lane) {
+                                                 GLBP(const double) rt, GLBP(const double) cw, int rpad, int lane,
+                                                 int nrd) {
+  // nrd: reads left from this block's first read on.  With -DMCHAP_MASK_PADDING lanes whose read is padding keep the
+  // neutral 1.0 / count 0 without loading the padded tail of the row: 33 % fewer HBM bytes at config #2 (R = 200 in
+  // rows of 256) but 2.5 % slower (a compare and an exec update per load), so it is off by default.
   // rt / cw already point at the lane's first read of the block of RPL chunks
   constexpr int UNR = MCHAP_COOP_UNR;
   const int n_pairs = KT * Mh;
@@ -359,7 +371,7 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
         const int row = __builtin_amdgcn_readlane(myrow, q < lim ? q : 0);
         GLBP(const double) rp = rt + (size_t)row * rpad;
 #pragma unroll
-        for (int i = 0; i < RPL; i++) v[u][i] = rp[WAVE * i];
+        for (int i = 0; i < RPL; i++) v[u][i] = MCHAP_PAD_LANE(lane + WAVE * i < nrd) ? rp[WAVE * i] : 1.0;
       }
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
@@ -380,7 +392,7 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
+  for (int i = 0; i < RPL; i++) s += log(acc[i]) * (MCHAP_PAD_LANE(lane + WAVE * i < nrd) ? cw[WAVE * i] : 0.0);
   return s;  // per-lane partial sum; the caller reduces across the wave
 }
 
@@ -393,7 +405,7 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
 #endif
 template <int KT, int G>
 COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
-                                             LDSP(uint16_t) cols_tab, int mmax, int Mh_lane, uint32_t amask_lane,
+                                             LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab, int mmax, int Mh_lane, uint32_t amask_lane,
                                              const double *rt_lane, const double *cw_lane, int rpad, int lane) {
   SpecLds S;
   S.pw = pwbuf;
@@ -414,11 +426,13 @@ COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP
     // the lane's reads in blocks of at most 4 chunks of 64 (keeps the loads in flight, and this function's
     // registers, bounded whatever the read depth)
     double s = 0.0;
-    if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
-    else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane);
+    const int nrd = (int)nreads_tab[sg];
+    if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
+    else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
     else
       for (int cb = 0; cb < nch; cb += MCHAP_COOP_RPL)
-        s += spec_coop_body<KT, MCHAP_COOP_RPL>(S, src, sg, mmax, Mh, amask, rt + cb * WAVE, cw + cb * WAVE, rpad, lane);
+        s += spec_coop_body<KT, MCHAP_COOP_RPL>(S, src, sg, mmax, Mh, amask, rt + cb * WAVE, cw + cb * WAVE, rpad, lane,
+                                                nrd - cb * WAVE);
     s = wave_sum(s);
     if (lane == src) val = s;
   }
@@ -483,7 +497,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
       for (int h = 0; h < KT; h++) S.pw[(size_t)h * WAVE + lane] = pw.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
+    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
     if (miss) {
       val = v;
       if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
@@ -1152,6 +1166,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.nal = lds_cast<uint8_t>(p); p += (size_t)NG * mmax; GUARD_STEP;
     S.ktab = lds_cast<uint8_t>(p); p += (size_t)NG * nmax; GUARD_STEP;
     S.ordtab = lds_cast<uint8_t>(p); p += (size_t)NG * niv; GUARD_STEP;
+    p = smem + (((size_t)(p - smem) + 1) & ~(size_t)1);
+    S.nreads = lds_cast<uint16_t>(p); p += (size_t)2 * NG; GUARD_STEP;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.ndraws = spec_draws(KT, mmax);
     S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.ndraws; GUARD_STEP;
@@ -1198,6 +1214,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   c.gen = 1;
   c.memo_gen = 1;
   const int Mh = c.Mh;
+  if (gl == 0) S.nreads[gi] = (uint16_t)(c.alive ? U.n_reads : 0);
   if (c.alive) {
     for (int j = gl; j < Mh; j += G) {
       S.cols[(size_t)gi * mmax + j] = (uint16_t)mi[META_I_COLS + j];
@@ -1273,7 +1290,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = c.g.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
+    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
     lds_sync();
     c.llk = __shfl(v, 0, G);
     if (c.alive && gl == 0) {

@@ -397,7 +397,12 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
     SP.max_ma = B.max_ma;
     SP.flags = 0;
     if (const char *e = std::getenv("MCHAP_HIP_FLAGS")) SP.flags = std::atoi(e);
-    const size_t lds_prep = (size_t)B.max_ma * rpad * 8 + (size_t)B.max_ugens * 8 + 64;
+    // the prepare pass keeps the transposed table in LDS when it fits, else it re-reads its own global copy
+    size_t lds_prep = (size_t)B.max_ma * rpad * 8 + (size_t)B.max_ugens * 8 + 64;
+    if (lds_prep > 160 * 1024) {
+      lds_prep = (size_t)B.max_ugens * 8 + 64;
+      SP.flags |= mchap::SIMT_FLAG_PREP_GLOBAL;
+    }
     const size_t lds_simt = mchap::simt_lds_bytes(B.max_ploidy, B.max_pos, cfg->n_temps);
     if (lds_prep > 160 * 1024 || lds_simt > 160 * 1024)
       return fail(MCHAP_ERR_LIMIT, "a unit needs %zu / %zu bytes of LDS (> 160 KiB)", lds_prep, lds_simt);

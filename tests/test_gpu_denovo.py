@@ -194,3 +194,14 @@ def test_both_kernels_give_identical_traces():
         for x, y in zip(a, b):
             assert np.array_equal(x.genotypes, y.genotypes)
             np.testing.assert_allclose(x.llks, y.llks, rtol=1e-12)
+
+
+def test_config5_shape_octoploid_deep_reads():
+    """BASELINE.json configs[4] shape: K=8, 20 SNVs, 1000 reads.  K*M > 128 sub-steps: served by the lanes-over-chains
+    kernel whatever `kernel` asks for; the transposed table (320 KB) exceeds the prepare pass's LDS copy."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(2, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20))
+    model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=25, chains=2, random_seed=5)
+    _check(model, list(reads))

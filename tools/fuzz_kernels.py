@@ -16,9 +16,7 @@ from mchap_amd.synth import synth_units
 from test_gpu_denovo import _oracle_trace
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(n_cases, seed):
     rng = np.random.default_rng(seed)
     bad = 0
     for case in range(n_cases):
@@ -60,8 +58,8 @@ def main():
         print("case %3d K=%d M=%2d A=%d R=%3d C=%d U=%d T=%d F=%s p=%s steps=%d cache=%d : %s" % (
             case, K, M, A, R, chains, U, len(temps), F, pr, steps, kw["llk_cache_threshold"], " ".join(res)), flush=True)
     print("FAILURES: %d" % bad)
-    return 1 if bad else 0
+    return bad
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
