@@ -21,8 +21,14 @@ namespace mchap {
 // per-unit metadata written by the prepare kernel
 constexpr int META_I_MH = 0;      // number of sampled (non-fixed) positions
 constexpr int META_I_STATUS = 1;  // MCHAP_UNIT_*
-constexpr int META_I_COLS = 2;    // then [M]: column (j * A) of sampled position jj ; then [M]: n_alleles
-__host__ __device__ inline int meta_i_stride(int max_pos) { return 2 + 2 * max_pos; }
+constexpr int META_I_NDICT = 2;   // distinct values of the unit's table (0: more than DICT_MAX, no coded table)
+constexpr int META_I_COLS = 3;    // then [M]: column (j * A) of sampled position jj ; then [M]: n_alleles
+__host__ __device__ inline int meta_i_stride(int max_pos) { return 3 + 2 * max_pos; }
+// Coded read table (speculative sampler): a unit's table usually holds a few dozen distinct probabilities
+// (one per base quality, its error share, 1.0 for gaps), so it is also stored as uint8 codes into a per-unit
+// dictionary of float64 values: lossless, 8x smaller, and what the likelihood evaluation then streams stays in L2.
+constexpr int DICT_MAX = 256;
+constexpr int DICT_HASH = 1024;  // open-addressing slots of the prepare pass's LDS set
 // doubles: [0] luh, [1..] prior table (2K+5), then dist [M*A]
 __host__ __device__ inline int meta_f_prior(int) { return 1; }
 __host__ __device__ inline int meta_f_dist(int max_ploidy) { return 1 + 2 * max_ploidy + 5; }
@@ -35,11 +41,14 @@ struct SimtParams {
   // workspace carved by the host
   double *rt;        // [U][max_ma][rpad]
   double *cntw;      // [U][rpad]
+  uint8_t *codes;    // [U][max_ma][64][rpad / 64]: code of read lane + 64 i at byte i of the lane's group
+  double *dict;      // [U][DICT_MAX]
   int32_t *meta_i;   // [U][meta_i_stride]
   double *meta_f;    // [U][meta_f_stride]
   int n_units;
   int max_pos, max_allele, max_ploidy;
   int max_ma;        // max over units of n_pos * max_allele
+  int max_ugens_pad; // doubles reserved for the SNV posterior scratch of the prepare pass
   int flags;         // debugging: bit 0 no mutation memo, bit 1 no interval memo (MCHAP_HIP_FLAGS); bit 30 below
 };
 constexpr int SIMT_FLAG_PREP_GLOBAL = 1 << 30;  // table too large for the prepare pass's LDS copy
@@ -87,6 +96,57 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
     cw[r] = cnt[i];
   }
   __syncthreads();
+  // ---- dictionary + coded table ----
+  {
+    unsigned long long *hkeys = reinterpret_cast<unsigned long long *>(lp + P.max_ugens_pad);  // [DICT_HASH]
+    uint16_t *hcode = reinterpret_cast<uint16_t *>(hkeys + DICT_HASH);                         // [DICT_HASH]
+    int *ndist = reinterpret_cast<int *>(hcode + DICT_HASH);
+    const unsigned long long EMPTY = ~0ull;  // a NaN pattern: table entries are never NaN
+    for (int i = lane; i < DICT_HASH; i += WAVE) hkeys[i] = EMPTY;
+    if (lane == 0) *ndist = 0;
+    __syncthreads();
+    const int RPLT = rpad / WAVE;
+    for (int q = 0; q < MA; q++) {
+      for (int r = lane; r < rpad; r += WAVE) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(rt[(size_t)q * rpad + r]);
+        unsigned slot = (unsigned)(mix64(key) & (DICT_HASH - 1));
+        while (*(volatile int *)ndist <= DICT_MAX) {
+          const unsigned long long old = atomicCAS(&hkeys[slot], EMPTY, key);
+          if (old == EMPTY) atomicAdd(ndist, 1);
+          if (old == EMPTY || old == key) break;
+          slot = (slot + 1) & (DICT_HASH - 1);
+        }
+      }
+    }
+    __syncthreads();
+    const int nd = *ndist;
+    uint8_t *ct = P.codes + (size_t)u * P.max_ma * rpad;
+    double *dict = P.dict + (size_t)u * DICT_MAX;
+    if (nd <= DICT_MAX) {
+      int base = 0;
+      for (int s0 = 0; s0 < DICT_HASH; s0 += WAVE) {
+        const unsigned long long key = hkeys[s0 + lane];
+        const bool occ = key != EMPTY;
+        const unsigned long long m = __ballot(occ);
+        const int code = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (occ) {
+          hcode[s0 + lane] = (uint16_t)code;
+          dict[code] = __longlong_as_double((long long)key);
+        }
+        base += __popcll(m);
+      }
+      __syncthreads();
+      for (int q = 0; q < MA; q++) {
+        for (int r = lane; r < rpad; r += WAVE) {
+          const unsigned long long key = (unsigned long long)__double_as_longlong(rt[(size_t)q * rpad + r]);
+          unsigned slot = (unsigned)(mix64(key) & (DICT_HASH - 1));
+          while (hkeys[slot] != key) slot = (slot + 1) & (DICT_HASH - 1);
+          ct[((size_t)q * WAVE + lane) * RPLT + r / WAVE] = (uint8_t)hcode[slot];
+        }
+      }
+    }
+    if (lane == 0) mi[META_I_NDICT] = nd <= DICT_MAX ? nd : 0;
+  }
   const int8_t *nalleles = D.n_alleles + U.nalleles_off;
   // homozygous fix (assemble/mcmc.py:168-182, 494-541; snpcalling.py:14-70)
   int Mh = 0;

@@ -80,6 +80,8 @@ struct SpecLds {
   LDSP(uint8_t) ktab;     // [NG][nmax]
   LDSP(uint8_t) ordtab;   // [NG][SPEC_MAX_IV]
   LDSP(uint16_t) nreads;  // [NG] reads of the group's unit (lanes beyond it do not load the table's padding)
+  LDSP(uint16_t) ndict;   // [NG] entries of the unit's dictionary (0: no coded table, float64 rows are read)
+  LDSP(double) dict;      // [NG][DICT_MAX] the unit's distinct table values
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
   LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] total move probability of an interval step for the current
                              // genotype; NaN = not evaluated yet, -1 = the step has no options
@@ -124,8 +126,9 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int 
   b += (size_t)NG * nmax;                // ktab
   b += (size_t)NG * niv;                 // ordtab
   b = (b + 1) & ~(size_t)1;
-  b += (size_t)2 * NG;                   // nreads
+  b += (size_t)2 * NG * 2;               // nreads, ndict
   b = (b + 15) & ~(size_t)15;
+  b += (size_t)8 * NG * DICT_MAX;        // dict
   b += (size_t)8 * NG * spec_draws(K, Mmax);
   b += spec_memo_bytes(Mmax, T, G);
 #ifdef MCHAP_LDS_GUARD
@@ -294,6 +297,7 @@ struct Grp {
   double inbreeding;
   bool alive;
   const double *rt, *cw;
+  const uint8_t *ct;  // the unit's coded table
   ulonglong2 *cache;
   uint32_t cache_mask;
   Stream st;
@@ -396,6 +400,67 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
   return s;  // per-lane partial sum; the caller reduces across the wave
 }
 
+// The same evaluation from the coded table: one load per (haplotype, position) pair fetches the codes of the
+// lane's RPL reads (RPL bytes, lane-major layout), the float64 factors come from the unit's dictionary in LDS.
+// Same factors in the same order, hence the same value as spec_coop_body.
+template <int KT, int RPL, class CT>
+__device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
+                                                  GLBP(const uint8_t) ct, GLBP(const double) cw, int rpad, int lane) {
+  // ct points at the lane's first code of the block of RPL chunks; cw at the lane's first read of the block
+  constexpr int UNR = 4 * MCHAP_COOP_UNR;
+  LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
+  const int n_pairs = KT * Mh;
+  const double invK = 1.0 / (double)KT;
+  double acc[RPL], prod[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; i++) {
+    acc[i] = 0.0;
+    prod[i] = 1.0;
+  }
+  for (int base = 0; base < n_pairs; base += WAVE) {
+    int myrow = 0;  // lane l owns pair base + l = (h, j)
+    {
+      const int p = base + lane;
+      if (p < n_pairs) {
+        const int h = p / Mh, j = p - h * Mh;
+        const uint64_t wh = S.pw[(size_t)h * WAVE + src];
+        const uint32_t a = (uint32_t)(wh >> S.shift[(size_t)sg * mmax + j]) & amask;
+        myrow = (int)S.cols[(size_t)sg * mmax + j] + (int)a;
+      }
+    }
+    const int lim = min(WAVE, n_pairs - base);
+    int jj = base % Mh;
+    for (int q0 = 0; q0 < lim; q0 += UNR) {
+      CT cd[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const int q = q0 + u;
+        const int row = __builtin_amdgcn_readlane(myrow, q < lim ? q : 0);
+        cd[u] = *reinterpret_cast<GLBP(const CT)>(ct + (size_t)row * rpad);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        if (q0 + u < lim) {
+#pragma unroll
+          for (int i = 0; i < RPL; i++) prod[i] *= dict[((uint32_t)cd[u] >> (8 * i)) & 255u];
+          if (++jj == Mh) {
+            jj = 0;
+#pragma unroll
+            for (int i = 0; i < RPL; i++) {
+              acc[i] += prod[i] * invK;
+              prod[i] = 1.0;
+            }
+          }
+        }
+      }
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
+  return s;
+}
+
 // Serves every request of the wave (bit mask `todo`), one after the other, with all 64 lanes; kept out of line so
 // that its registers (RPL x UNR loads in flight) do not count against the sampler's main loop.
 #ifndef MCHAP_COOP_NOINLINE
@@ -405,12 +470,14 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
 #endif
 template <int KT, int G>
 COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
-                                             LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab, int mmax, int Mh_lane, uint32_t amask_lane,
+                                             LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab,
+                                             LDSP(uint16_t) ndict_tab, LDSP(double) dict_tab, const uint8_t *ct_lane, int mmax, int Mh_lane, uint32_t amask_lane,
                                              const double *rt_lane, const double *cw_lane, int rpad, int lane) {
   SpecLds S;
   S.pw = pwbuf;
   S.shift = shift_tab;
   S.cols = cols_tab;
+  S.dict = dict_tab;
   const int nch = rpad / WAVE;
   double val = 0.0;
   while (todo) {
@@ -427,7 +494,15 @@ COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP
     // registers, bounded whatever the read depth)
     double s = 0.0;
     const int nrd = (int)nreads_tab[sg];
-    if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
+    if (ndict_tab[sg] != 0) {
+      const unsigned long long ctb = __shfl((unsigned long long)(uintptr_t)ct_lane, src, WAVE);
+      GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)ctb + (size_t)lane * nch;
+      if (nch == 1) s = spec_coop_coded<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
+      else if (nch == 2) s = spec_coop_coded<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
+      else
+        for (int cb = 0; cb < nch; cb += 4)
+          s += spec_coop_coded<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cw + cb * WAVE, rpad, lane);
+    } else if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
     else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
     else
       for (int cb = 0; cb < nch; cb += MCHAP_COOP_RPL)
@@ -497,7 +572,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
       for (int h = 0; h < KT; h++) S.pw[(size_t)h * WAVE + lane] = pw.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
+    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, c.ct, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
     if (miss) {
       val = v;
       if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
@@ -1168,7 +1243,9 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.ordtab = lds_cast<uint8_t>(p); p += (size_t)NG * niv; GUARD_STEP;
     p = smem + (((size_t)(p - smem) + 1) & ~(size_t)1);
     S.nreads = lds_cast<uint16_t>(p); p += (size_t)2 * NG; GUARD_STEP;
+    S.ndict = lds_cast<uint16_t>(p); p += (size_t)2 * NG; GUARD_STEP;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
+    S.dict = lds_cast<double>(p); p += (size_t)8 * NG * DICT_MAX; GUARD_STEP;
     S.ndraws = spec_draws(KT, mmax);
     S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.ndraws; GUARD_STEP;
     S.memo_stride = (spec_memo_bytes(mmax, T, G) && !(P.flags & 2)) ? 2 * (mmax + 1) * (mmax + 1) : 0;
@@ -1197,6 +1274,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   c.key_bits = c.bits * c.Mh;
   c.rt = P.rt + (size_t)u * P.max_ma * rpad;
   c.cw = P.cntw + (size_t)u * rpad;
+  c.ct = P.codes + (size_t)u * P.max_ma * rpad;
   c.cache = nullptr;
   c.cache_mask = 0;
   if (D.cache_slots > 0) {
@@ -1215,6 +1293,12 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   c.memo_gen = 1;
   const int Mh = c.Mh;
   if (gl == 0) S.nreads[gi] = (uint16_t)(c.alive ? U.n_reads : 0);
+  {
+    const int nd = (c.alive && !(P.flags & 4)) ? mi[META_I_NDICT] : 0;
+    if (gl == 0) S.ndict[gi] = (uint16_t)nd;
+    const double *du = P.dict + (size_t)u * DICT_MAX;
+    for (int i = gl; i < nd; i += G) S.dict[(size_t)gi * DICT_MAX + i] = du[i];
+  }
   if (c.alive) {
     for (int j = gl; j < Mh; j += G) {
       S.cols[(size_t)gi * mmax + j] = (uint16_t)mi[META_I_COLS + j];
@@ -1290,7 +1374,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = c.g.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
+    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, c.ct, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
     lds_sync();
     c.llk = __shfl(v, 0, G);
     if (c.alive && gl == 0) {

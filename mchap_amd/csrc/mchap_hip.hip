@@ -163,7 +163,7 @@ int batch_dims(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units
 }
 
 struct SimtCarve {
-  size_t cache = 0, rt = 0, cntw = 0, meta_i = 0, meta_f = 0, total = 0;
+  size_t cache = 0, rt = 0, cntw = 0, codes = 0, dict = 0, meta_i = 0, meta_f = 0, total = 0;
 };
 
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -174,6 +174,8 @@ SimtCarve simt_carve(const mchap_denovo_cfg *cfg, int n_units, const BatchDims &
   c.cache = o; o += up256((size_t)n_units * cfg->chains * cache_slots * 16);
   c.rt = o; o += up256((size_t)n_units * B.max_ma * rpad * 8);
   c.cntw = o; o += up256((size_t)n_units * rpad * 8);
+  c.codes = o; o += up256((size_t)n_units * B.max_ma * rpad);
+  c.dict = o; o += up256((size_t)n_units * mchap::DICT_MAX * 8);
   c.meta_i = o; o += up256((size_t)n_units * mchap::meta_i_stride(B.max_pos) * 4);
   c.meta_f = o; o += up256((size_t)n_units * mchap::meta_f_stride(B.max_ploidy, B.max_pos, B.max_allele) * 8);
   c.total = o;
@@ -388,6 +390,8 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
     }
     SP.rt = reinterpret_cast<double *>(ws + cv.rt);
     SP.cntw = reinterpret_cast<double *>(ws + cv.cntw);
+    SP.codes = ws + cv.codes;
+    SP.dict = reinterpret_cast<double *>(ws + cv.dict);
     SP.meta_i = reinterpret_cast<int32_t *>(ws + cv.meta_i);
     SP.meta_f = reinterpret_cast<double *>(ws + cv.meta_f);
     SP.n_units = n_units;
@@ -398,9 +402,11 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
     SP.flags = 0;
     if (const char *e = std::getenv("MCHAP_HIP_FLAGS")) SP.flags = std::atoi(e);
     // the prepare pass keeps the transposed table in LDS when it fits, else it re-reads its own global copy
-    size_t lds_prep = (size_t)B.max_ma * rpad * 8 + (size_t)B.max_ugens * 8 + 64;
+    SP.max_ugens_pad = (B.max_ugens + 8) & ~7;
+    const size_t lds_dict = (size_t)mchap::DICT_HASH * (8 + 2) + 64;  // hash set of the dictionary pass
+    size_t lds_prep = (size_t)B.max_ma * rpad * 8 + (size_t)SP.max_ugens_pad * 8 + lds_dict;
     if (lds_prep > 160 * 1024) {
-      lds_prep = (size_t)B.max_ugens * 8 + 64;
+      lds_prep = (size_t)SP.max_ugens_pad * 8 + lds_dict;
       SP.flags |= mchap::SIMT_FLAG_PREP_GLOBAL;
     }
     const size_t lds_simt = mchap::simt_lds_bytes(B.max_ploidy, B.max_pos, cfg->n_temps);

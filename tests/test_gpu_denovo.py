@@ -196,12 +196,34 @@ def test_both_kernels_give_identical_traces():
             np.testing.assert_allclose(x.llks, y.llks, rtol=1e-12)
 
 
-def test_config5_shape_octoploid_deep_reads():
-    """BASELINE.json configs[4] shape: K=8, 20 SNVs, 1000 reads.  K*M > 128 sub-steps: served by the lanes-over-chains
-    kernel whatever `kernel` asks for; the transposed table (320 KB) exceeds the prepare pass's LDS copy."""
+def test_config5_shape_octoploid_deep_reads(sampler_kernel):
+    """BASELINE.json configs[4] shape: K=8, 20 SNVs, 1000 reads.  K*M > 128 sub-steps: kernel 3 hands over to the
+    lanes-over-chains kernel; the transposed table (320 KB) exceeds the prepare pass's LDS copy, and the LDS-staged
+    kernel 1 cannot hold it at all (it must say so)."""
     from mchap_amd import DenovoMCMC
     from mchap_amd.synth import synth_units
+
+    if sampler_kernel == 1:
+        reads, _, _ = synth_units(1, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20))
+        with pytest.raises(NotImplementedError):
+            DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=5, chains=2, random_seed=5).fit_batch(list(reads))
+        return
 
     reads, _, _ = synth_units(2, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20))
     model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=25, chains=2, random_seed=5)
     _check(model, list(reads))
+
+
+def test_continuous_probabilities_fall_back_to_float64_rows():
+    """More than 256 distinct values in a unit's table: no dictionary, the evaluation reads float64 rows; a unit with
+    few distinct values in the same batch uses its coded table.  Both must match the oracle."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    rng = np.random.default_rng(3)
+    reads, _, _ = synth_units(3, ploidy=4, n_pos=6, n_reads=90, window=(3, 6))
+    noisy = reads.copy()
+    jitter = rng.uniform(0.9, 1.0, size=noisy.shape)
+    noisy[1] = np.where(np.isnan(noisy[1]), np.nan, noisy[1] * jitter[1])  # unit 1: thousands of distinct values
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 6, steps=120, chains=2, random_seed=9)
+    _check(model, list(noisy))
