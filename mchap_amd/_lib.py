@@ -80,7 +80,7 @@ class MchapLibraryError(RuntimeError):
 
 def build(force=False):
     """Compile libmchap_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    args = ["make", "-C", CSRC]
+    args = ["make", "-C", CSRC, "-j%d" % max(1, min(16, os.cpu_count() or 1))]
     if force:
         args.append("-B")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)

@@ -34,8 +34,8 @@ constexpr int WAVE = 64;
 constexpr uint32_t SLOT_INIT = 0xFFFFu;
 
 // log(n), log(1/n) for small n, computed by the host's libm at library load.
-__constant__ double c_ln[260];
-__constant__ double c_ln_inv[260];
+static __constant__ double c_ln[260];      // per translation unit (the library is built from several)
+static __constant__ double c_ln_inv[260];
 
 struct DenovoParams {
   const mchap_unit *units;

@@ -506,7 +506,7 @@ __device__ __forceinline__ uint64_t lane_genotype_tag(const SimtLds &S, const La
 }
 
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
-__device__ unsigned long long g_stats[24];
+static __device__ unsigned long long g_stats[24];
 #endif
 #ifdef MCHAP_STATS
 #define STAT_ADD(i, pred)                                                         \

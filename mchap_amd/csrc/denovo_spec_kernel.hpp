@@ -1155,7 +1155,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
 
 #ifdef MCHAP_SPEC_LOG
 constexpr int LOG_CHAINS = 8, LOG_STEPS = 64, LOG_EV = 4, LOG_F = 4;
-__device__ unsigned long long g_log[LOG_CHAINS * LOG_STEPS * LOG_EV * LOG_F];
+static __device__ unsigned long long g_log[LOG_CHAINS * LOG_STEPS * LOG_EV * LOG_F];
 #define SPEC_LOG(ev)                                                                                 \
   do {                                                                                               \
     if (gl == 0 && q < LOG_CHAINS && step < LOG_STEPS) {                                             \

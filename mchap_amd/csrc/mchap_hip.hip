@@ -17,6 +17,47 @@
 #include "exact_kernel.hpp"
 #include "posterior_kernel.hpp"
 
+// entry points of the speculative sampler's object files (spec_inst.hip), internal to the library
+extern "C" int mchap_spec_init_2_16(const double *, const double *);
+extern "C" int mchap_spec_launch_2_16(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_2_32(const double *, const double *);
+extern "C" int mchap_spec_launch_2_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_2_64(const double *, const double *);
+extern "C" int mchap_spec_launch_2_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_4_16(const double *, const double *);
+extern "C" int mchap_spec_launch_4_16(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_4_32(const double *, const double *);
+extern "C" int mchap_spec_launch_4_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_4_64(const double *, const double *);
+extern "C" int mchap_spec_launch_4_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_6_32(const double *, const double *);
+extern "C" int mchap_spec_launch_6_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_6_64(const double *, const double *);
+extern "C" int mchap_spec_launch_6_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_8_64(const double *, const double *);
+extern "C" int mchap_spec_launch_8_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+
+extern "C" int mchap_simt_init_0(const double *, const double *);
+extern "C" int mchap_simt_launch_0(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_simt_init_2(const double *, const double *);
+extern "C" int mchap_simt_launch_2(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_simt_init_4(const double *, const double *);
+extern "C" int mchap_simt_launch_4(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_simt_init_6(const double *, const double *);
+extern "C" int mchap_simt_launch_6(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_simt_init_8(const double *, const double *);
+extern "C" int mchap_simt_launch_8(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_v1_init_1(const double *, const double *);
+extern "C" int mchap_v1_launch_1(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
+extern "C" int mchap_v1_init_2(const double *, const double *);
+extern "C" int mchap_v1_launch_2(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
+extern "C" int mchap_v1_init_4(const double *, const double *);
+extern "C" int mchap_v1_launch_4(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
+extern "C" int mchap_v1_init_8(const double *, const double *);
+extern "C" int mchap_v1_launch_8(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
+extern "C" int mchap_v1_init_16(const double *, const double *);
+extern "C" int mchap_v1_launch_16(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -64,6 +105,14 @@ struct SamplerTimer {
 
 
 
+// the speculative sampler's instantiations live in their own object files (spec_inst.hip)
+struct SpecInst {
+  int K, G;
+  int (*init)(const double *, const double *);
+  int (*launch)(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+};
+const SpecInst *spec_insts(int *n);
+
 int ensure_init() {
   int dev = 0;
   int n = 0;
@@ -79,6 +128,19 @@ int ensure_init() {
   }
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln), ln, sizeof(ln)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln_inv), ln_inv, sizeof(ln_inv)));
+  {
+    int n = 0;
+    const SpecInst *insts = spec_insts(&n);  // every object file has its own copy of the tables
+    for (int i = 0; i < n; i++)
+      if (insts[i].init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the speculative sampler <%d, %d>", insts[i].K, insts[i].G);
+  }
+  {
+    int (*inits[])(const double *, const double *) = {mchap_simt_init_0, mchap_simt_init_2, mchap_simt_init_4, mchap_simt_init_6,
+                                                      mchap_simt_init_8, mchap_v1_init_1,   mchap_v1_init_2,   mchap_v1_init_4,
+                                                      mchap_v1_init_8,   mchap_v1_init_16};
+    for (auto f : inits)
+      if (f(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of a sampler object");
+  }
   if (dev < 64) g_init_done[dev] = true;
   return MCHAP_OK;
 }
@@ -99,17 +161,15 @@ int rpl_for(int max_reads) {
   return -1;
 }
 
-template <int RPL>
-int launch_denovo(const mchap::DenovoParams &P, int n_units, int chains, size_t lds, hipStream_t stream) {
-  auto kern = mchap::denovo_mcmc_kernel<RPL>;
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+int launch_denovo(int rpl, const mchap::DenovoParams &P, int n_units, int chains, size_t lds, hipStream_t stream) {
+  int (*launch)(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t) =
+      rpl == 1 ? mchap_v1_launch_1 : rpl == 2 ? mchap_v1_launch_2 : rpl == 4 ? mchap_v1_launch_4 : rpl == 8 ? mchap_v1_launch_8 : mchap_v1_launch_16;
   const int cpb = chains < mchap::CHAINS_PER_BLOCK ? chains : mchap::CHAINS_PER_BLOCK;
   char name[96];
-  snprintf(name, sizeof(name), "denovo_mcmc_kernel<%d>", RPL);
+  snprintf(name, sizeof(name), "denovo_mcmc_kernel<%d>", rpl);
   SamplerTimer timer(stream, name);
-  hipLaunchKernelGGL(kern, dim3(n_units, (chains + cpb - 1) / cpb), dim3(64 * cpb), lds, stream, P);
-  HIP_TRY(hipGetLastError());
+  const int e = launch(&P, (unsigned)n_units, (unsigned)((chains + cpb - 1) / cpb), (unsigned)(64 * cpb), lds, stream);
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
 }
 
@@ -192,35 +252,35 @@ int launch_prepare(const mchap::SimtParams &P, int n_units, size_t lds_prep, hip
   return MCHAP_OK;
 }
 
-template <int KT>
-int launch_simt(const mchap::SimtParams &P, int n_units, int chains, size_t lds_simt, hipStream_t stream) {
-  auto ks = mchap::denovo_simt_kernel<KT>;
-  if (lds_simt > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_simt));
+int launch_simt(int KT, const mchap::SimtParams &P, int n_units, int chains, size_t lds_simt, hipStream_t stream) {
+  int (*launch)(const mchap::SimtParams *, unsigned, size_t, hipStream_t) =
+      KT == 2 ? mchap_simt_launch_2 : KT == 4 ? mchap_simt_launch_4 : KT == 6 ? mchap_simt_launch_6 : KT == 8 ? mchap_simt_launch_8 : mchap_simt_launch_0;
   const long long n_chains = (long long)n_units * chains;
   char name[96];
   snprintf(name, sizeof(name), "denovo_simt_kernel<%d>", KT);
   SamplerTimer timer(stream, name);
-  hipLaunchKernelGGL(ks, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), lds_simt, stream, P);
-  HIP_TRY(hipGetLastError());
+  const int e = launch(&P, (unsigned)((n_chains + 63) / 64), lds_simt, stream);
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
 }
 
-template <int KT, int G>
-int launch_spec(const mchap::SimtParams &P, int n_units, int chains, int n_temps, hipStream_t stream) {
-  auto ks = mchap::denovo_spec_kernel<KT, G>;
-  size_t lds = mchap::spec_lds_bytes(KT, P.max_pos, P.max_allele, n_temps, G);
+int launch_spec(int K, int G, const mchap::SimtParams &P, int n_units, int chains, int n_temps, hipStream_t stream) {
+  int n = 0;
+  const SpecInst *insts = spec_insts(&n);
+  const SpecInst *inst = nullptr;
+  for (int i = 0; i < n; i++)
+    if (insts[i].K == K && insts[i].G == G) inst = &insts[i];
+  if (!inst) return fail(MCHAP_ERR_LIMIT, "speculative sampler: no instantiation for ploidy %d with %d lanes per chain", K, G);
+  size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, n_temps, G);
   if (const char *e = std::getenv("MCHAP_HIP_LDS_PAD")) lds += (size_t)std::atoi(e);  // debugging: lower occupancy
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long long n_chains = (long long)n_units * chains;
   const int per_wave = 64 / G;
   char name[96];
-  snprintf(name, sizeof(name), "denovo_spec_kernel<%d, %d>", KT, G);
+  snprintf(name, sizeof(name), "denovo_spec_kernel<%d, %d>", K, G);
   SamplerTimer timer(stream, name);
-  hipLaunchKernelGGL(ks, dim3((unsigned)((n_chains + per_wave - 1) / per_wave)), dim3(64), lds, stream, P);
-  HIP_TRY(hipGetLastError());
+  const int e = inst->launch(&P, (unsigned)((n_chains + per_wave - 1) / per_wave), lds, stream);
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
 }
 
@@ -237,6 +297,22 @@ int spec_group(int K, int max_pos) {
   if (K == 6 && g < 32) g = 32;
   if (K == 8) g = 64;
   return g;
+}
+
+const SpecInst *spec_insts(int *n) {
+  static const SpecInst insts[] = {
+    {2, 16, mchap_spec_init_2_16, mchap_spec_launch_2_16},
+    {2, 32, mchap_spec_init_2_32, mchap_spec_launch_2_32},
+    {2, 64, mchap_spec_init_2_64, mchap_spec_launch_2_64},
+    {4, 16, mchap_spec_init_4_16, mchap_spec_launch_4_16},
+    {4, 32, mchap_spec_init_4_32, mchap_spec_launch_4_32},
+    {4, 64, mchap_spec_init_4_64, mchap_spec_launch_4_64},
+    {6, 32, mchap_spec_init_6_32, mchap_spec_launch_6_32},
+    {6, 64, mchap_spec_init_6_64, mchap_spec_launch_6_64},
+    {8, 64, mchap_spec_init_8_64, mchap_spec_launch_8_64},
+  };
+  *n = (int)(sizeof(insts) / sizeof(insts[0]));
+  return insts;
 }
 
 bool use_simt(const mchap_denovo_cfg *cfg) { return cfg->kernel != 1; }
@@ -426,44 +502,16 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
       const int g = K > 0 ? spec_group(K, B.max_pos) : 0;
       const int T = cfg->n_temps;
       if (g) {
-        switch (K * 100 + g) {
-#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 216
-          case 216: return launch_spec<2, 16>(SP, n_units, cfg->chains, T, stream);
-#endif
-#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 232
-          case 232: return launch_spec<2, 32>(SP, n_units, cfg->chains, T, stream);
-#endif
-#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 264
-          case 264: return launch_spec<2, 64>(SP, n_units, cfg->chains, T, stream);
-#endif
-#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 416
-          case 416: return launch_spec<4, 16>(SP, n_units, cfg->chains, T, stream);
-#endif
-#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 432
-          case 432: return launch_spec<4, 32>(SP, n_units, cfg->chains, T, stream);
-#endif
-#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 464
-          case 464: return launch_spec<4, 64>(SP, n_units, cfg->chains, T, stream);
-#endif
-#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 632
-          case 632: return launch_spec<6, 32>(SP, n_units, cfg->chains, T, stream);
-#endif
-#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 664
-          case 664: return launch_spec<6, 64>(SP, n_units, cfg->chains, T, stream);
-#endif
-#if !defined(MCHAP_SPEC_ONLY) || MCHAP_SPEC_ONLY == 864
-          case 864: return launch_spec<8, 64>(SP, n_units, cfg->chains, T, stream);
-#endif
-        }
+        return launch_spec(K, g, SP, n_units, cfg->chains, T, stream);
       }
     }
     // a launch whose units share one ploidy runs the kernel specialised for it
     switch (B.uniform_ploidy) {
-      case 2: return launch_simt<2>(SP, n_units, cfg->chains, lds_simt, stream);
-      case 4: return launch_simt<4>(SP, n_units, cfg->chains, lds_simt, stream);
-      case 6: return launch_simt<6>(SP, n_units, cfg->chains, lds_simt, stream);
-      case 8: return launch_simt<8>(SP, n_units, cfg->chains, lds_simt, stream);
-      default: return launch_simt<0>(SP, n_units, cfg->chains, lds_simt, stream);
+      case 2: return launch_simt(2, SP, n_units, cfg->chains, lds_simt, stream);
+      case 4: return launch_simt(4, SP, n_units, cfg->chains, lds_simt, stream);
+      case 6: return launch_simt(6, SP, n_units, cfg->chains, lds_simt, stream);
+      case 8: return launch_simt(8, SP, n_units, cfg->chains, lds_simt, stream);
+      default: return launch_simt(0, SP, n_units, cfg->chains, lds_simt, stream);
     }
   }
 
@@ -489,11 +537,11 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
     }
   }
   switch (rpl) {
-    case 1: return launch_denovo<1>(P, n_units, cfg->chains, lds, stream);
-    case 2: return launch_denovo<2>(P, n_units, cfg->chains, lds, stream);
-    case 4: return launch_denovo<4>(P, n_units, cfg->chains, lds, stream);
-    case 8: return launch_denovo<8>(P, n_units, cfg->chains, lds, stream);
-    case 16: return launch_denovo<16>(P, n_units, cfg->chains, lds, stream);
+    case 1: return launch_denovo(1, P, n_units, cfg->chains, lds, stream);
+    case 2: return launch_denovo(2, P, n_units, cfg->chains, lds, stream);
+    case 4: return launch_denovo(4, P, n_units, cfg->chains, lds, stream);
+    case 8: return launch_denovo(8, P, n_units, cfg->chains, lds, stream);
+    case 16: return launch_denovo(16, P, n_units, cfg->chains, lds, stream);
   }
   return fail(MCHAP_ERR_LIMIT, "unsupported reads-per-lane");
 }

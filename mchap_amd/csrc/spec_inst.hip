@@ -1,0 +1,28 @@
+// One instantiation of the speculative sampler per object file (-DSPEC_K=.. -DSPEC_G=..), so that the nine
+// instantiations compile in parallel (each takes 20-60 s; in one translation unit the library took five minutes).
+// The host API in mchap_hip.hip calls the two entry points below; they are not part of the C ABI.
+#include <hip/hip_runtime.h>
+
+#include "../../include/mchap_hip.h"
+#include "denovo_spec_kernel.hpp"
+
+#define SPEC_CAT_(a, k, g) a##k##_##g
+#define SPEC_CAT(a, k, g) SPEC_CAT_(a, k, g)
+
+extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_init_, SPEC_K, SPEC_G)(const double *ln,
+                                                                                                const double *ln_inv) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln), ln, sizeof(double) * 260) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln_inv), ln_inv, sizeof(double) * 260) != hipSuccess) return 1;
+  return 0;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_launch_, SPEC_K, SPEC_G)(
+    const mchap::SimtParams *P, unsigned grid, size_t lds, hipStream_t stream) {
+  auto ks = mchap::denovo_spec_kernel<SPEC_K, SPEC_G>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(ks, dim3(grid), dim3(64), lds, stream, *P);
+  return (int)hipGetLastError();
+}
