@@ -58,6 +58,8 @@ __device__ __forceinline__ LDSP(T) lds_cast(void *p) {
   return (LDSP(T))p;
 }
 
+enum { GP_RT = 0, GP_CW, GP_CT, GP_CACHE, GP_TRACE, GP_LLK, GP_N };
+enum { GV_INB = 0, GV_MLO, GV_MHI, GV_N };
 struct SpecLds {
   LDSP(uint64_t) pw;      // [K][64] request words of missing lanes (lane strided)
   LDSP(uint64_t) wst;     // [NG][T][K] genotype of every temperature
@@ -82,6 +84,11 @@ struct SpecLds {
   LDSP(uint16_t) nreads;  // [NG] reads of the group's unit (lanes beyond it do not load the table's padding)
   LDSP(uint16_t) ndict;   // [NG] entries of the unit's dictionary (0: no coded table, float64 rows are read)
   LDSP(double) dict;      // [NG][DICT_MAX] the unit's distinct table values
+  LDSP(uint64_t) gptr;    // [NG][GP_N] cold per-chain pointers (kept out of the registers): see GP_*
+  LDSP(double) gval;      // [NG][GV_N] cold per-chain values: inbreeding, mutation memo bounds
+  LDSP(uint32_t) gstream; // [NG][4] Philox key and counter words of the chain's current stream (Stream)
+  uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
+  bool cache_on;
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
   LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] total move probability of an interval step for the current
                              // genotype; NaN = not evaluated yet, -1 = the step has no options
@@ -129,6 +136,10 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int 
   b += (size_t)2 * NG * 2;               // nreads, ndict
   b = (b + 15) & ~(size_t)15;
   b += (size_t)8 * NG * DICT_MAX;        // dict
+  b += (size_t)8 * NG * GP_N;            // gptr
+  b += (size_t)8 * NG * GV_N;            // gval
+  b = (b + 15) & ~(size_t)15;
+  b += (size_t)16 * NG;                  // gstream
   b += (size_t)8 * NG * spec_draws(K, Mmax);
   b += spec_memo_bytes(Mmax, T, G);
 #ifdef MCHAP_LDS_GUARD
@@ -292,23 +303,15 @@ __device__ __forceinline__ uint64_t mask_of(int bits, int Mh, int start, int sto
 // per-group chain context (identical in every lane of the group)
 template <int KT>
 struct Grp {
-  int Mh, bits, key_bits;
-  uint32_t amask;
-  double inbreeding;
+  int Mh, bits;
   bool alive;
-  const double *rt, *cw;
-  const uint8_t *ct;  // the unit's coded table
-  ulonglong2 *cache;
-  uint32_t cache_mask;
-  Stream st;
-  uint64_t ctr;  // next draw of the current stream
+  uint64_t ctr;  // next draw of the current stream (Philox words of the stream: SpecLds::gstream)
   int doff, dcount;  // staged window of the group's draw table: entry doff holds draw ctr, dcount entries are valid
   double llk;
   GWords<KT> g;  // genotype of the current temperature
   // memo of the current genotype (single temperature only): a mutation compound step moves nothing if every one
   // of its uniforms u satisfies mlo <= u < mhi; gen tags the interval-step memo entries
-  bool memo_on, mvalid;
-  double mlo, mhi;
+  bool memo_on, mvalid;  // bounds mlo / mhi: SpecLds::gval
   uint32_t gen, memo_gen;  // memo_gen: the generation the interval memo table currently describes
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
   unsigned long long ph[12], pt0;
@@ -330,6 +333,20 @@ struct Grp {
 #define GSUB(c, i)
 #define GCOUNT(c, i, n)
 #endif
+
+// cold per-chain state kept in LDS (every lane of the group reads the same word: a broadcast)
+__device__ __forceinline__ Stream ld_stream(const SpecLds &S, int gi) {
+  LDSP(uint32_t) w = S.gstream + gi * 4;
+  Stream st;
+  st.k0 = w[0];
+  st.k1 = w[1];
+  st.c2 = w[2];
+  st.c3 = w[3];
+  return st;
+}
+#define C_INB(S, gi) ((S).gval[(gi) * GV_N + GV_INB])
+#define C_AMASK(c) ((1u << (c).bits) - 1u)
+#define C_KEYBITS(c) ((c).bits * (c).Mh)
 
 template <int KT>
 __device__ __forceinline__ void genotype_changed(Grp<KT> &c) {
@@ -471,8 +488,8 @@ __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int
 template <int KT, int G>
 COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
                                              LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab,
-                                             LDSP(uint16_t) ndict_tab, LDSP(double) dict_tab, const uint8_t *ct_lane, int mmax, int Mh_lane, uint32_t amask_lane,
-                                             const double *rt_lane, const double *cw_lane, int rpad, int lane) {
+                                             LDSP(uint16_t) ndict_tab, LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, int mmax, int Mh_lane, uint32_t amask_lane,
+                                             int rpad, int lane) {
   SpecLds S;
   S.pw = pwbuf;
   S.shift = shift_tab;
@@ -486,17 +503,15 @@ COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP
     const int sg = src / G;
     const int Mh = __builtin_amdgcn_readfirstlane(__shfl(Mh_lane, src, WAVE));
     const uint32_t amask = (uint32_t)__shfl((int)amask_lane, src, WAVE);
-    const unsigned long long rtb = __shfl((unsigned long long)(uintptr_t)rt_lane, src, WAVE);
-    const unsigned long long cwb = __shfl((unsigned long long)(uintptr_t)cw_lane, src, WAVE);
-    GLBP(const double) rt = (GLBP(const double))(uintptr_t)rtb + lane;
-    GLBP(const double) cw = (GLBP(const double))(uintptr_t)cwb + lane;
+    LDSP(uint64_t) gp = gptr_tab + sg * GP_N;  // the requesting chain's pointers (wave-uniform)
+    GLBP(const double) rt = (GLBP(const double))(uintptr_t)gp[GP_RT] + lane;
+    GLBP(const double) cw = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;
     // the lane's reads in blocks of at most 4 chunks of 64 (keeps the loads in flight, and this function's
     // registers, bounded whatever the read depth)
     double s = 0.0;
     const int nrd = (int)nreads_tab[sg];
     if (ndict_tab[sg] != 0) {
-      const unsigned long long ctb = __shfl((unsigned long long)(uintptr_t)ct_lane, src, WAVE);
-      GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)ctb + (size_t)lane * nch;
+      GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * nch;
       if (nch == 1) s = spec_coop_coded<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
       else if (nch == 2) s = spec_coop_coded<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
       else
@@ -524,11 +539,11 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
   uint64_t tag = 0;
   ulonglong2 *slot = nullptr;
   GSUB_T0();
-  if (need && c.cache) {
+  if (need && S.cache_on) {
     // 8-way sets (one 128-byte line).  The lanes of a group probe and fill the chain's table concurrently, so the
     // policy must not depend on read-modify-write sequences: hits never move entries, a miss goes to the first
     // empty way it saw (else to a way picked by the key); a lost race only costs one more evaluation later.
-    tag = tag_of<KT>(pw, c.key_bits);
+    tag = tag_of<KT>(pw, C_KEYBITS(c));
     const uint64_t key = tag >> 1;
     // full-avalanche 32-bit mix: the keys probed together are single-field neighbours of one genotype, so a
     // plain multiplicative hash would send all neighbours that differ in a high field to the same set
@@ -538,7 +553,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
     hsh ^= hsh >> 15;
     hsh *= 0x846CA68Bu;
     hsh ^= hsh >> 16;
-    ulonglong2 *set = c.cache + 8 * (size_t)((hsh >> 12) & c.cache_mask);
+    ulonglong2 *set = reinterpret_cast<ulonglong2 *>((uintptr_t)S.gptr[(lane / G) * GP_N + GP_CACHE]) + 8 * (size_t)((hsh >> 12) & S.cache_mask);
     int way = (int)((hsh >> 24) & 7u);
     bool empty_seen = false;
 #ifdef MCHAP_PROBE_UNR
@@ -572,7 +587,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, con
       for (int h = 0; h < KT; h++) S.pw[(size_t)h * WAVE + lane] = pw.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, c.ct, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
+    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, mmax, c.Mh, C_AMASK(c), rpad, lane);
     if (miss) {
       val = v;
       if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
@@ -610,13 +625,14 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
     // the n uniforms, plus as many of the following draws as the same number of Philox rounds per lane yields:
     // they are the structural steps' draws if this step moves nothing
     const int cnt = max(n, min(S.ndraws, 2 * G * ((n / 2 + G) / G) - 1));
-    stage_draws<G>(c.st, ctr0 + (uint64_t)(n - 1), cnt, utab, gl, fast);
+    stage_draws<G>(ld_stream(S, gi), ctr0 + (uint64_t)(n - 1), cnt, utab, gl, fast);
     lds_sync();
     bool ok = true;
     if (fast) {
+      const double mlo = S.gval[gi * GV_N + GV_MLO], mhi = S.gval[gi * GV_N + GV_MHI];
       for (int p = gl; p < n; p += G) {
         const double u = draw_double(utab[p]);
-        ok = ok && (c.mlo <= u) && (u < c.mhi);
+        ok = ok && (mlo <= u) && (u < mhi);
       }
     }
     const bool bad = grp_ballot<G>(!ok, gi) != 0ull;
@@ -644,7 +660,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   //     i = n-1 .. 1 with k_i = interval(i) from draw ctr0 + (n-1-i)
   LDSP(uint64_t) dtab = S.draws + gi * S.ndraws;
   const bool staged = 2 * n - 1 <= S.ndraws;
-  stage_draws<G>(c.st, ctr0, 2 * n - 1, dtab, gl, run && staged);
+  stage_draws<G>(ld_stream(S, gi), ctr0, 2 * n - 1, dtab, gl, run && staged);
   lds_sync();
   if (run) {
 #pragma unroll
@@ -652,7 +668,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
       const int p = gl + s * G;
       if (p >= 1 && p < n)
         ktab[p] = (uint8_t)(staged ? draw_interval(dtab[n - 1 - p], (uint32_t)p)
-                                   : stream_interval(c.st, ctr0 + (uint64_t)(n - 1 - p), (uint32_t)p));
+                                   : stream_interval(ld_stream(S, gi), ctr0 + (uint64_t)(n - 1 - p), (uint32_t)p));
     }
   }
   lds_sync();
@@ -697,7 +713,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   double my_lo = 0.0, my_hi = 2.0;  // this lane's sub-steps: max lo_e, min hi_e (first round only)
   while (wave_any(!done)) {
     STAT_WAVE(11, 1);
-    const double lprior = (!done && !isnan(c.inbreeding)) ? prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(c.g)) : 0.0;
+    const double lprior = (!done && !isnan(C_INB(S, gi))) ? prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(c.g)) : 0.0;
     bool found = false;
 #pragma unroll 1
     for (int s = 0; s < nslots; s++) {
@@ -711,10 +727,10 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
         const int j = e & 255;
         sh = shift[j];
         n_alleles = nal[j];
-        u = staged ? draw_double(dtab[n - 1 + p]) : stream_double(c.st, ctr0 + (uint64_t)(n - 1) + (uint64_t)p);
+        u = staged ? draw_double(dtab[n - 1 + p]) : stream_double(ld_stream(S, gi), ctr0 + (uint64_t)(n - 1) + (uint64_t)p);
       }
       const uint64_t wh = sel_word<KT>(c.g, h);
-      const int current = (int)((wh >> sh) & c.amask);
+      const int current = (int)((wh >> sh) & C_AMASK(c));
       const double lhapcount = S.ln[copies_of<KT>(c.g, wh)];
       // options of the sub-step in allele order (current allele skipped); their move probabilities and likelihoods
       // are parked in the lane's LDS column so that the loop needs no unrolling
@@ -725,12 +741,12 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
         const bool prop = act && o < n_alleles - 1;
         const int i = o + (o >= current ? 1 : 0);
         GWords<KT> pw = c.g;
-        const uint64_t nw = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)i << sh);
+        const uint64_t nw = (wh & ~((uint64_t)C_AMASK(c) << sh)) | ((uint64_t)i << sh);
         set_word<KT>(pw, h, nw);
         const double llk_i = spec_eval<KT, G>(prop, pw, c, S, mmax, rpad, lane);
         if (prop) {
           double lprior_ratio = 0.0;
-          if (!isnan(c.inbreeding)) lprior_ratio = prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(pw)) - lprior;
+          if (!isnan(C_INB(S, gi))) lprior_ratio = prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(pw)) - lprior;
           const double lproposal_ratio = S.ln[copies_of<KT>(pw, nw)] - lhapcount;
           const double mh = ((llk_i - c.llk) + lprior_ratio) * temp + lproposal_ratio;
           const double pr = exp(fmin(0.0, mh) - ln_opt);
@@ -769,7 +785,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
         }
         if (choice != current) {
           changed = true;
-          neww = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)choice << sh);
+          neww = (wh & ~((uint64_t)C_AMASK(c) << sh)) | ((uint64_t)choice << sh);
           newllk = cl;
         }
       }
@@ -797,8 +813,10 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
       }
       if (!done && first_round && !found && c.memo_on) {
         c.mvalid = true;
-        c.mlo = lo;
-        c.mhi = hi;
+        if (gl == 0) {  // read again by the next mutation step, after several lds_sync()
+          S.gval[gi * GV_N + GV_MLO] = lo;
+          S.gval[gi * GV_N + GV_MHI] = hi;
+        }
       }
     }
     first_round = false;
@@ -839,7 +857,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
     if (wave_any(c.alive && c.dcount - c.doff < low)) {
       const int W = min(S.ndraws, 2 * G - 1);
       lds_sync();
-      stage_draws<G>(c.st, c.ctr, W, dtab, gl, c.alive);
+      stage_draws<G>(ld_stream(S, gi), c.ctr, W, dtab, gl, c.alive);
       lds_sync();
       c.doff = 0;
       c.dcount = c.alive ? W : 0;
@@ -852,7 +870,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
     c.ctr++;
     if (i < c.dcount) return dtab[i];
     uint32_t a, b;
-    stream_words(c.st, c.ctr - 1, a, b);
+    stream_words(ld_stream(S, gi), c.ctr - 1, a, b);
     return (uint64_t)a | ((uint64_t)b << 32);
   };
   uint64_t zeros = 0;
@@ -940,7 +958,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
         w = dtab[i];
       } else {
         uint32_t a, b;
-        stream_words(c.st, c.ctr + (uint64_t)(n_int - 1 + gl), a, b);
+        stream_words(ld_stream(S, gi), c.ctr + (uint64_t)(n_int - 1 + gl), a, b);
         w = (uint64_t)a | ((uint64_t)b << 32);
       }
       low = !(draw_double(w) >= mx);
@@ -996,7 +1014,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
             w = dtab[i];
           } else {
             uint32_t a, b;
-            stream_words(c.st, c.ctr, a, b);
+            stream_words(ld_stream(S, gi), c.ctr, a, b);
             w = (uint64_t)a | ((uint64_t)b << 32);
           }
           if (!(draw_double(w) >= tot)) break;  // this interval moves: evaluate it for real
@@ -1091,9 +1109,9 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
     const double llk_i = spec_eval<KT, G>(prop, pw, c, S, mmax, rpad, lane);
     if (prop) {
       double lprior_ratio = 0.0;
-      if (!isnan(c.inbreeding))
-        lprior_ratio = prior_of<KT>(pt, c.inbreeding, dosage_of_labels(oin, lout, KT, true)) -
-                       prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(c.g));
+      if (!isnan(C_INB(S, gi)))
+        lprior_ratio = prior_of<KT>(pt, C_INB(S, gi), dosage_of_labels(oin, lout, KT, true)) -
+                       prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(c.g));
       const int n_return = step_type == 0 ? recombination_n_options(oin, lout, KT) : dosage_n_options(oin, lout, KT);
       const double lproposal_ratio = S.lninv[n_return] - S.lninv[my_no];
       const double mh = ((llk_i - c.llk) + lprior_ratio) * temp + lproposal_ratio;
@@ -1246,6 +1264,10 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.ndict = lds_cast<uint16_t>(p); p += (size_t)2 * NG; GUARD_STEP;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.dict = lds_cast<double>(p); p += (size_t)8 * NG * DICT_MAX; GUARD_STEP;
+    S.gptr = lds_cast<uint64_t>(p); p += (size_t)8 * NG * GP_N; GUARD_STEP;
+    S.gval = lds_cast<double>(p); p += (size_t)8 * NG * GV_N; GUARD_STEP;
+    p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
+    S.gstream = lds_cast<uint32_t>(p); p += (size_t)16 * NG; GUARD_STEP;
     S.ndraws = spec_draws(KT, mmax);
     S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.ndraws; GUARD_STEP;
     S.memo_stride = (spec_memo_bytes(mmax, T, G) && !(P.flags & 2)) ? 2 * (mmax + 1) * (mmax + 1) : 0;
@@ -1269,17 +1291,25 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   const int A = U.max_allele;
   c.Mh = c.alive ? mi[META_I_MH] : 1;
   c.bits = allele_bits(A);
-  c.amask = (1u << c.bits) - 1u;
-  c.inbreeding = U.inbreeding;
-  c.key_bits = c.bits * c.Mh;
-  c.rt = P.rt + (size_t)u * P.max_ma * rpad;
-  c.cw = P.cntw + (size_t)u * rpad;
-  c.ct = P.codes + (size_t)u * P.max_ma * rpad;
-  c.cache = nullptr;
-  c.cache_mask = 0;
-  if (D.cache_slots > 0) {
-    c.cache = reinterpret_cast<ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots;
-    c.cache_mask = (uint32_t)(D.cache_slots / 8) - 1u;  // sets of 8 ways
+  if (gl == 0) {
+    S.gval[gi * GV_N + GV_INB] = U.inbreeding;
+    S.gval[gi * GV_N + GV_MLO] = 0.0;
+    S.gval[gi * GV_N + GV_MHI] = 0.0;
+    S.gstream[gi * 4 + 0] = (uint32_t)D.seed;
+    S.gstream[gi * 4 + 1] = (uint32_t)(D.seed >> 32) ^ (uint32_t)(U.stream_id >> 32);
+    S.gstream[gi * 4 + 2] = ((uint32_t)chain << 16) | 0u;
+    S.gstream[gi * 4 + 3] = (uint32_t)U.stream_id;
+  }
+  S.cache_on = D.cache_slots > 0;
+  S.cache_mask = S.cache_on ? (uint32_t)(D.cache_slots / 8) - 1u : 0u;  // sets of 8 ways
+  if (gl == 0) {
+    LDSP(uint64_t) gp = S.gptr + gi * GP_N;
+    gp[GP_RT] = (uint64_t)(uintptr_t)(P.rt + (size_t)u * P.max_ma * rpad);
+    gp[GP_CW] = (uint64_t)(uintptr_t)(P.cntw + (size_t)u * rpad);
+    gp[GP_CT] = (uint64_t)(uintptr_t)(P.codes + (size_t)u * P.max_ma * rpad);
+    gp[GP_CACHE] = S.cache_on ? (uint64_t)(uintptr_t)(reinterpret_cast<ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots) : 0ull;
+    gp[GP_TRACE] = (uint64_t)(uintptr_t)(D.trace + U.trace_off + (size_t)chain * D.steps * KT);
+    gp[GP_LLK] = (uint64_t)(uintptr_t)(D.llks + U.llk_off + (size_t)chain * D.steps);
   }
   c.ctr = 0;
   c.doff = 0;
@@ -1287,8 +1317,6 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   c.llk = 0.0;
   c.memo_on = (T == 1) && !(P.flags & 1);
   c.mvalid = false;
-  c.mlo = 0.0;
-  c.mhi = 0.0;
   c.gen = 1;
   c.memo_gen = 1;
   const int Mh = c.Mh;
@@ -1305,7 +1333,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       S.nal[(size_t)gi * mmax + j] = (uint8_t)mi[META_I_COLS + P.max_pos + j];
       S.shift[(size_t)gi * mmax + j] = (uint8_t)(c.bits * (Mh - 1 - j));
     }
-    if (!isnan(c.inbreeding))
+    if (!isnan(C_INB(S, gi)))
       for (int i = gl; i < 2 * KT + 5; i += G) S.prior[(size_t)gi * (2 * KT + 5) + i] = mf[meta_f_prior(0) + i];
     if (D.n_intervals == 0 && gl == 0) {
       // cumulative break-count distribution, summed in the reference's order (structural.py:44-49)
@@ -1374,7 +1402,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = c.g.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, c.ct, mmax, c.Mh, c.amask, c.rt, c.cw, rpad, lane);
+    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, mmax, c.Mh, C_AMASK(c), rpad, lane);
     lds_sync();
     c.llk = __shfl(v, 0, G);
     if (c.alive && gl == 0) {
@@ -1389,12 +1417,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   lds_sync();
   const double *break_dist = D.break_table + (size_t)Mh * D.max_pos;
   const int n_break_dist = D.n_intervals > 0 ? D.n_intervals : Mh;
-  const size_t trace_base = U.trace_off + (size_t)chain * Sn * KT;
-  const size_t llk_base = U.llk_off + (size_t)chain * Sn;
   int status = MCHAP_UNIT_OK;
-  c.st.k0 = (uint32_t)D.seed;
-  c.st.k1 = (uint32_t)(D.seed >> 32) ^ (uint32_t)(U.stream_id >> 32);
-  c.st.c3 = (uint32_t)U.stream_id;
 
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
   for (int i_ = 0; i_ < 12; i_++) c.ph[i_] = 0;
@@ -1411,7 +1434,11 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
         c.dcount = 0;  // another stream: nothing staged
       }
       const double temp = D.temps[t];
-      c.st.c2 = ((uint32_t)chain << 16) | (uint32_t)t;
+      if (T > 1) {  // the temperature's stream
+        lds_sync();
+        if (gl == 0) S.gstream[gi * 4 + 2] = ((uint32_t)chain << 16) | (uint32_t)t;
+        lds_sync();
+      }
       if (c.alive && isnan(c.llk)) {  // assemble/mcmc.py:330-331
         status = MCHAP_UNIT_NAN_LLK;
         c.alive = false;
@@ -1439,14 +1466,14 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
           for (int h = 0; h < KT; h++) gj.w[h] = S.wst[((size_t)gi * T + t - 1) * KT + h];
           double llk_j = S.llk_t[(size_t)gi * T + t - 1];
           double prior_i = 0.0, prior_j = 0.0;
-          if (!isnan(c.inbreeding)) {
-            prior_i = prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(c.g));
-            prior_j = prior_of<KT>(pt, c.inbreeding, dosage_words<KT>(gj));
+          if (!isnan(C_INB(S, gi))) {
+            prior_i = prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(c.g));
+            prior_j = prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(gj));
           }
           const double ui = c.llk + prior_i, uj = llk_j + prior_j;
           double acc = exp((uj - ui) * temp + (ui - uj) * D.temps[t - 1]);
           if (acc > 1.0) acc = 1.0;
-          const double val = stream_double(c.st, c.ctr++);
+          const double val = stream_double(ld_stream(S, gi), c.ctr++);
           lds_sync();
           if (acc >= val) {
             if (gl == 0) {
@@ -1476,9 +1503,9 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
         int rank = 0;
 #pragma unroll
         for (int h = 0; h < KT; h++) rank += (c.g.w[h] < x || (c.g.w[h] == x && h < gl)) ? 1 : 0;
-        D.trace[trace_base + (size_t)step * KT + rank] = x;
+        reinterpret_cast<uint64_t *>((uintptr_t)S.gptr[gi * GP_N + GP_TRACE])[(size_t)step * KT + rank] = x;
       }
-      if (gl == 0) D.llks[llk_base + step] = c.llk;
+      if (gl == 0) reinterpret_cast<double *>((uintptr_t)S.gptr[gi * GP_N + GP_LLK])[step] = c.llk;
     }
 #endif
   }
