@@ -37,6 +37,7 @@
 namespace mchap {
 
 constexpr int SPEC_MAX_IV = 64;  // intervals per structural compound step (<= n_pos)
+constexpr int SPEC_TB = 4;    // trace records per flush: K = 4 -> one 128-byte line of words + 32 bytes of llks
 constexpr int SPEC_LN = 72;   // log tables: counts up to K(K-1) <= 56
 constexpr int SPEC_DRAWS_MAX = 128;  // draws of the current stream staged in LDS per group (Philox blocks in parallel)
 __host__ __device__ inline int spec_draws(int K, int Mmax) {
@@ -87,6 +88,7 @@ struct SpecLds {
   LDSP(uint64_t) gptr;    // [NG][GP_N] cold per-chain pointers (kept out of the registers): see GP_*
   LDSP(double) gval;      // [NG][GV_N] cold per-chain values: inbreeding, mutation memo bounds
   LDSP(uint32_t) gstream; // [NG][4] Philox key and counter words of the chain's current stream (Stream)
+  LDSP(uint64_t) tbuf;    // [NG][SPEC_TB][K + 1] trace records (K sorted words + llk) waiting to be written as a line
   uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
   bool cache_on;
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
@@ -140,6 +142,8 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int 
   b += (size_t)8 * NG * GV_N;            // gval
   b = (b + 15) & ~(size_t)15;
   b += (size_t)16 * NG;                  // gstream
+  b += (size_t)8 * NG * SPEC_TB * (K + 1);   // tbuf
+  b = (b + 15) & ~(size_t)15;
   b += (size_t)8 * NG * spec_draws(K, Mmax);
   b += spec_memo_bytes(Mmax, T, G);
 #ifdef MCHAP_LDS_GUARD
@@ -209,32 +213,38 @@ __device__ __forceinline__ void lds_sync() {
 #endif
 }
 
+// The K haplotype words of a genotype.  The helpers take it BY VALUE and the kernel copies the chain's words into
+// a local before looping over them: an index that is only constant after loop unrolling, applied directly to a
+// member of the chain context (Grp), keeps the whole context in scratch memory (the early SROA pass runs before
+// unrolling, and instcombine then folds the selects over its loads into address arithmetic for good).
 template <int KT>
 struct GWords {
   uint64_t w[KT];
 };
 
 template <int KT>
-__device__ __forceinline__ uint64_t sel_word(const GWords<KT> &g, int h) {
+__device__ __forceinline__ uint64_t sel_word(const GWords<KT> g, int h) {
   uint64_t x = g.w[0];
 #pragma unroll
   for (int i = 1; i < KT; i++) x = (h == i) ? g.w[i] : x;
   return x;
 }
 template <int KT>
-__device__ __forceinline__ void set_word(GWords<KT> &g, int h, uint64_t v) {
+__device__ __forceinline__ void set_word(GWords<KT> &gref, int h, uint64_t v) {
+  GWords<KT> g = gref;
 #pragma unroll
   for (int i = 0; i < KT; i++) g.w[i] = (h == i) ? v : g.w[i];
+  gref = g;
 }
 template <int KT>
-__device__ __forceinline__ int copies_of(const GWords<KT> &g, uint64_t x) {
+__device__ __forceinline__ int copies_of(const GWords<KT> g, uint64_t x) {
   int n = 0;
 #pragma unroll
   for (int i = 0; i < KT; i++) n += (g.w[i] == x) ? 1 : 0;
   return n;
 }
 template <int KT>
-__device__ __forceinline__ uint32_t dosage_words(const GWords<KT> &g) {
+__device__ __forceinline__ uint32_t dosage_words(const GWords<KT> g) {
   uint32_t d = 0;
 #pragma unroll
   for (int h = 0; h < KT; h++) d |= 1u << (4 * h);
@@ -253,7 +263,7 @@ __device__ __forceinline__ uint32_t dosage_words(const GWords<KT> &g) {
   return d;
 }
 template <int KT>
-__device__ __forceinline__ uint32_t seg_labels(const GWords<KT> &g, uint64_t mask) {
+__device__ __forceinline__ uint32_t seg_labels(const GWords<KT> g, uint64_t mask) {
   uint32_t lab = 0;
 #pragma unroll
   for (int h = 1; h < KT; h++) {
@@ -282,7 +292,7 @@ __device__ __forceinline__ double prior_of(LDSP(double) pt, double inbreeding, u
   return pt[2 * KT + 2] + prod;
 }
 template <int KT>
-__device__ __forceinline__ uint64_t tag_of(const GWords<KT> &g, int key_bits) {
+__device__ __forceinline__ uint64_t tag_of(const GWords<KT> g, int key_bits) {
   uint64_t t = 0;
   if (key_bits * KT <= 63) {
 #pragma unroll
@@ -532,7 +542,7 @@ COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP
 // Likelihood of the lane's proposal `pw` (where need): 4-way cache probe, then co-operative evaluation of the
 // misses by the whole wavefront (request words staged through LDS).  Every lane of the wave must call.
 template <int KT, int G>
-__device__ __forceinline__ double spec_eval(bool need, const GWords<KT> &pw, const Grp<KT> &c, const SpecLds &S, int mmax,
+__device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, const Grp<KT> &c, const SpecLds &S, int mmax,
                                             int rpad, int lane) {
   double val = 0.0;
   bool miss = need;
@@ -1064,7 +1074,8 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
     }
     // (c) evaluate my option
     const bool prop = !done && my_ii >= 0;
-    GWords<KT> pw = c.g;
+    const GWords<KT> cg = c.g;
+    GWords<KT> pw = cg;
     uint32_t oin = 0, lout = 0;
     if (prop) {
       const uint32_t se = ivse[my_ii];
@@ -1104,7 +1115,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
         }
       }
 #pragma unroll
-      for (int h = 0; h < KT; h++) pw.w[h] = (c.g.w[h] & ~min_) | (sel_word<KT>(c.g, (int)nib(oin, h)) & min_);
+      for (int h = 0; h < KT; h++) pw.w[h] = (cg.w[h] & ~min_) | (sel_word<KT>(cg, (int)nib(oin, h)) & min_);
     }
     const double llk_i = spec_eval<KT, G>(prop, pw, c, S, mmax, rpad, lane);
     if (prop) {
@@ -1179,7 +1190,7 @@ static __device__ unsigned long long g_log[LOG_CHAINS * LOG_STEPS * LOG_EV * LOG
     if (gl == 0 && q < LOG_CHAINS && step < LOG_STEPS) {                                             \
       unsigned long long *L_ = g_log + (((size_t)q * LOG_STEPS + step) * LOG_EV + (ev)) * LOG_F;     \
       unsigned long long hsh_ = 0;                                                                   \
-      for (int h_ = 0; h_ < KT; h_++) hsh_ = hsh_ * 1000003ull + c.g.w[h_];                          \
+      for (int h_ = 0; h_ < KT; h_++) hsh_ = hsh_ * 1000003ull + sel_word<KT>(c.g, h_);                          \
       L_[0] = c.ctr;                                                                                 \
       L_[1] = (unsigned long long)__double_as_longlong(c.llk);                                       \
       L_[2] = hsh_;                                                                                  \
@@ -1268,6 +1279,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.gval = lds_cast<double>(p); p += (size_t)8 * NG * GV_N; GUARD_STEP;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.gstream = lds_cast<uint32_t>(p); p += (size_t)16 * NG; GUARD_STEP;
+    S.tbuf = lds_cast<uint64_t>(p); p += (size_t)8 * NG * SPEC_TB * (KT + 1); GUARD_STEP;
+    p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.ndraws = spec_draws(KT, mmax);
     S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.ndraws; GUARD_STEP;
     S.memo_stride = (spec_memo_bytes(mmax, T, G) && !(P.flags & 2)) ? 2 * (mmax + 1) * (mmax + 1) : 0;
@@ -1352,8 +1365,12 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     return v;
   }();
   // ---- initial genotype (assemble/mcmc.py:202-208) ----
+  {
+    GWords<KT> z;
 #pragma unroll
-  for (int h = 0; h < KT; h++) c.g.w[h] = 0;
+    for (int h = 0; h < KT; h++) z.w[h] = 0;
+    c.g = z;
+  }
   if (c.alive) {
     LDSP(uint8_t) shift = S.shift + gi * mmax;
     if (U.initial_off >= 0) {
@@ -1362,7 +1379,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       for (int h = 0; h < KT; h++) {
         uint64_t x = 0;
         for (int j = 0; j < Mh; j++) x |= (uint64_t)(uint8_t)ini[h * Mh + j] << shift[j];
-        c.g.w[h] = x;
+        set_word<KT>(c.g, h, x);  // no dynamic index into c.g: it must stay in registers (a loop that is not
+                                  // unrolled would otherwise put the whole chain context into scratch memory)
       }
     } else {
       const double *dist = mf + meta_f_dist(P.max_ploidy);
@@ -1372,7 +1390,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       si.c2 = ((uint32_t)chain << 16) | SLOT_INIT;
       si.c3 = (uint32_t)U.stream_id;
       uint64_t n = 0;
-#pragma unroll
+#pragma unroll 1
       for (int h = 0; h < KT; h++) {
         uint64_t x = 0;
         for (int j = 0; j < Mh; j++) {
@@ -1391,15 +1409,16 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
           if (ch >= A) ch = A - 1;
           x |= (uint64_t)ch << shift[j];
         }
-        c.g.w[h] = x;
+        set_word<KT>(c.g, h, x);
       }
     }
   }
   {
     const bool req = c.alive && gl == 0;  // assemble/mcmc.py:303
+    const GWords<KT> g0 = c.g;
     if (req) {
 #pragma unroll
-      for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = c.g.w[h];
+      for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = g0.w[h];
     }
     lds_sync();
     const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, mmax, c.Mh, C_AMASK(c), rpad, lane);
@@ -1408,7 +1427,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     if (c.alive && gl == 0) {
       for (int t = 0; t < T; t++) {
 #pragma unroll
-        for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t) * KT + h] = c.g.w[h];
+        for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t) * KT + h] = g0.w[h];
         S.llk_t[(size_t)gi * T + t] = c.llk;
         S.rngn[(size_t)gi * T + t] = 0;
       }
@@ -1427,8 +1446,10 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     for (int t = 0; t < T; t++) {
       GPHASE(c, 8);
       if (T > 1) {
+        GWords<KT> gt;
 #pragma unroll
-        for (int h = 0; h < KT; h++) c.g.w[h] = S.wst[((size_t)gi * T + t) * KT + h];
+        for (int h = 0; h < KT; h++) gt.w[h] = S.wst[((size_t)gi * T + t) * KT + h];
+        c.g = gt;
         c.llk = S.llk_t[(size_t)gi * T + t];
         c.ctr = S.rngn[(size_t)gi * T + t];
         c.dcount = 0;  // another stream: nothing staged
@@ -1476,9 +1497,10 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
           const double val = stream_double(ld_stream(S, gi), c.ctr++);
           lds_sync();
           if (acc >= val) {
+            const GWords<KT> gi_ = c.g;
             if (gl == 0) {
 #pragma unroll
-              for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t - 1) * KT + h] = c.g.w[h];
+              for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t - 1) * KT + h] = gi_.w[h];
               S.llk_t[(size_t)gi * T + t - 1] = c.llk;
             }
             c.g = gj;
@@ -1487,8 +1509,9 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
         }
         lds_sync();
         if (c.alive && gl == 0) {
+          const GWords<KT> gn = c.g;
 #pragma unroll
-          for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t) * KT + h] = c.g.w[h];
+          for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t) * KT + h] = gn.w[h];
           S.llk_t[(size_t)gi * T + t] = c.llk;
           S.rngn[(size_t)gi * T + t] = c.ctr;
         }
@@ -1496,16 +1519,34 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       }
     }
 #ifndef MCHAP_ABL_NO_TRACE
-    if (c.alive) {
-      // record the cold chain (held in registers after the last temperature) in canonical order
-      if (gl < KT) {
-        const uint64_t x = sel_word<KT>(c.g, gl);
-        int rank = 0;
+    // record the cold chain (held in registers after the last temperature) in canonical order: SPEC_TB records
+    // are collected in LDS and written together, the words as one contiguous run (a full line for K = 4)
+    {
+      LDSP(uint64_t) tb = S.tbuf + (size_t)gi * SPEC_TB * (KT + 1);
+      const int slot = step % SPEC_TB;
+      if (c.alive) {
+        if (gl < KT) {
+          const GWords<KT> gr = c.g;
+          const uint64_t x = sel_word<KT>(gr, gl);
+          int rank = 0;
 #pragma unroll
-        for (int h = 0; h < KT; h++) rank += (c.g.w[h] < x || (c.g.w[h] == x && h < gl)) ? 1 : 0;
-        reinterpret_cast<uint64_t *>((uintptr_t)S.gptr[gi * GP_N + GP_TRACE])[(size_t)step * KT + rank] = x;
+          for (int h = 0; h < KT; h++) rank += (gr.w[h] < x || (gr.w[h] == x && h < gl)) ? 1 : 0;
+          tb[slot * KT + rank] = x;
+        }
+        if (gl == 0) tb[SPEC_TB * KT + slot] = (uint64_t)__double_as_longlong(c.llk);
       }
-      if (gl == 0) reinterpret_cast<double *>((uintptr_t)S.gptr[gi * GP_N + GP_LLK])[step] = c.llk;
+      if (slot == SPEC_TB - 1 || step == Sn - 1) {
+        lds_sync();
+        if (c.alive) {
+          const int first = step - slot;  // first step of the block
+          const int nw = (slot + 1) * KT;
+          uint64_t *tp = reinterpret_cast<uint64_t *>((uintptr_t)S.gptr[gi * GP_N + GP_TRACE]) + (size_t)first * KT;
+          for (int i = gl; i < nw; i += G) tp[i] = tb[i];
+          if (gl <= slot)
+            reinterpret_cast<uint64_t *>((uintptr_t)S.gptr[gi * GP_N + GP_LLK])[first + gl] = tb[SPEC_TB * KT + gl];
+        }
+        lds_sync();
+      }
     }
 #endif
   }
