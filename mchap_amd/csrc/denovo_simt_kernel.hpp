@@ -111,8 +111,13 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
         const unsigned long long key = (unsigned long long)__double_as_longlong(rt[(size_t)q * rpad + r]);
         unsigned slot = (unsigned)(mix64(key) & (DICT_HASH - 1));
         while (*(volatile int *)ndist <= DICT_MAX) {
-          const unsigned long long old = atomicCAS(&hkeys[slot], EMPTY, key);
-          if (old == EMPTY) atomicAdd(ndist, 1);
+          // plain read first: most entries repeat a value that is already in the set (same-address LDS atomics of a
+          // whole wavefront serialise)
+          unsigned long long old = *(volatile unsigned long long *)&hkeys[slot];
+          if (old == EMPTY) {
+            old = atomicCAS(&hkeys[slot], EMPTY, key);
+            if (old == EMPTY) atomicAdd(ndist, 1);
+          }
           if (old == EMPTY || old == key) break;
           slot = (slot + 1) & (DICT_HASH - 1);
         }

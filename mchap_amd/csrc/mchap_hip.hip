@@ -315,6 +315,11 @@ const SpecInst *spec_insts(int *n) {
   return insts;
 }
 
+size_t prep_lds_copy_limit() {
+  if (const char *e = std::getenv("MCHAP_HIP_PREP_LDS")) return (size_t)std::atol(e);
+  return 8 * 1024;
+}
+
 bool use_simt(const mchap_denovo_cfg *cfg) { return cfg->kernel != 1; }
 
 }  // namespace
@@ -481,7 +486,8 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
     SP.max_ugens_pad = (B.max_ugens + 8) & ~7;
     const size_t lds_dict = (size_t)mchap::DICT_HASH * (8 + 2) + 64;  // hash set of the dictionary pass
     size_t lds_prep = (size_t)B.max_ma * rpad * 8 + (size_t)SP.max_ugens_pad * 8 + lds_dict;
-    if (lds_prep > 160 * 1024) {
+    // (an LDS copy of more than a few KB costs the prepare pass its occupancy: one wavefront per workgroup)
+    if (lds_prep > 160 * 1024 || (size_t)B.max_ma * rpad * 8 > (size_t)prep_lds_copy_limit()) {
       lds_prep = (size_t)SP.max_ugens_pad * 8 + lds_dict;
       SP.flags |= mchap::SIMT_FLAG_PREP_GLOBAL;
     }
