@@ -120,7 +120,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl")
+        # RCCL over xGMI; MCHAP_BENCH_BACKEND=gloo lets the N > 1 path be exercised by several ranks on ONE GPU
+        # (RCCL refuses two ranks on the same device), which is how it is tested on the 1-GPU boxes
+        dist.init_process_group(backend=os.environ.get("MCHAP_BENCH_BACKEND", "nccl"))
 
     from mchap_amd import DenovoMCMC
     from mchap_amd.device import DenovoDeviceBatch
@@ -168,7 +170,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     span_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # prepare pass + sampler + memsets
