@@ -1,0 +1,57 @@
+"""GPU: results do not depend on how the units are sharded over ranks, and bench.py's N > 1 path runs."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shards_reproduce_the_unsharded_batch():
+    """Rank r owns a contiguous block of units and keys every unit's RNG streams by its global id
+    (mchap_amd/shard.py, DenovoDeviceBatch(first_stream=...)): two half batches == one full batch, bit for bit."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.device import DenovoDeviceBatch
+    from mchap_amd.shard import shard_range
+    from mchap_amd.synth import synth_units
+
+    n = 7
+    reads, _, _ = synth_units(n, n_pos=6, n_reads=60, window=(3, 6))
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 6, steps=150, chains=2, random_seed=3)
+    full = DenovoDeviceBatch(model, reads)
+    full.run()
+    full.posterior(50)
+    w_full, fixed_full, llk_full, _ = full.traces()
+    post_full = full.posterior_host()
+    for rank in range(2):
+        a, b = shard_range(n, rank, 2)
+        part = DenovoDeviceBatch(model, reads[a:b], first_stream=a)
+        part.run()
+        part.posterior(50)
+        w, fixed, llk, _ = part.traces()
+        assert np.array_equal(w, w_full[a:b]) and np.array_equal(fixed, fixed_full[a:b])
+        assert np.array_equal(llk, llk_full[a:b])
+        post = part.posterior_host()
+        assert np.array_equal(post["mode"], post_full["mode"][a:b])
+        assert np.array_equal(post["stats"], post_full["stats"][a:b])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py under torch.distributed.run with two ranks (gloo rendezvous: RCCL refuses two ranks on one device);
+    the line must report the whole job."""
+    env = dict(os.environ, MCHAP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--loci", "512", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["kernel"].startswith("denovo_")
