@@ -30,6 +30,9 @@
 #ifndef MCHAP_COOP_UNR
 #define MCHAP_COOP_UNR 2  // row loads in flight per lane and chunk
 #endif
+#ifndef MCHAP_CODED_UNR
+#define MCHAP_CODED_UNR 16  // code loads (one register each) in flight per lane in the coded evaluation
+#endif
 #ifndef MCHAP_COOP_RPL
 #define MCHAP_COOP_RPL 4  // read chunks (of 64) per pass for read depths above 128; rpad is a multiple of 64 * this
 #endif
@@ -434,7 +437,7 @@ template <int KT, int RPL, class CT>
 __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
                                                   GLBP(const uint8_t) ct, GLBP(const double) cw, int rpad, int lane) {
   // ct points at the lane's first code of the block of RPL chunks; cw at the lane's first read of the block
-  constexpr int UNR = 4 * MCHAP_COOP_UNR;
+  constexpr int UNR = MCHAP_CODED_UNR;
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   const int n_pairs = KT * Mh;
   const double invK = 1.0 / (double)KT;

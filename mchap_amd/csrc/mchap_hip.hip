@@ -58,6 +58,17 @@ extern "C" int mchap_v1_launch_8(const mchap::DenovoParams *, unsigned, unsigned
 extern "C" int mchap_v1_init_16(const double *, const double *);
 extern "C" int mchap_v1_launch_16(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
 
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+extern "C" int mchap_spec_stats_2_16(unsigned long long *, int);
+extern "C" int mchap_spec_stats_2_32(unsigned long long *, int);
+extern "C" int mchap_spec_stats_2_64(unsigned long long *, int);
+extern "C" int mchap_spec_stats_4_16(unsigned long long *, int);
+extern "C" int mchap_spec_stats_4_32(unsigned long long *, int);
+extern "C" int mchap_spec_stats_4_64(unsigned long long *, int);
+extern "C" int mchap_spec_stats_6_32(unsigned long long *, int);
+extern "C" int mchap_spec_stats_6_64(unsigned long long *, int);
+extern "C" int mchap_spec_stats_8_64(unsigned long long *, int);
+#endif
 namespace {
 
 thread_local char g_err[512] = "";
@@ -358,6 +369,13 @@ int mchap_debug_stats(unsigned long long *out, int reset) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_stats), sizeof(z)));
   if (reset) HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::g_stats), z, sizeof(z)));
+  // plus the copies of the speculative sampler's object files
+  int (*fs[])(unsigned long long *, int) = {mchap_spec_stats_2_16, mchap_spec_stats_2_32, mchap_spec_stats_2_64, mchap_spec_stats_4_16, mchap_spec_stats_4_32, mchap_spec_stats_4_64, mchap_spec_stats_6_32, mchap_spec_stats_6_64, mchap_spec_stats_8_64};
+  for (auto f : fs) {
+    unsigned long long t[24];
+    if (f(t, reset) != 0) return fail(MCHAP_ERR_HIP, "reading the counters of a sampler object");
+    for (int i = 0; i < 24; i++) out[i] += t[i];
+  }
   return MCHAP_OK;
 }
 #endif

@@ -26,3 +26,13 @@ extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_launch_
   hipLaunchKernelGGL(ks, dim3(grid), dim3(64), lds, stream, *P);
   return (int)hipGetLastError();
 }
+
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+// profiling builds: this object's copy of the event counters
+extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_stats_, SPEC_K, SPEC_G)(unsigned long long *out, int reset) {
+  unsigned long long z[24] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_stats), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(mchap::g_stats), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif
