@@ -207,6 +207,26 @@ __device__ __forceinline__ uint64_t grp_ballot(bool p, int gi) {
   return (m >> (gi * G)) & ((1ull << G) - 1ull);
 }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
+// max over the G lanes of a group, in every lane.  Within a row of 16 lanes the partners come through DPP row
+// rotations (no LDS crossbar round trip per step, unlike __shfl_xor); max is exact, so the order does not matter.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+template <int G>
+__device__ __forceinline__ double grp_max_f64(double v) {
+#pragma unroll
+  for (int o = G / 2; o >= 16; o >>= 1) v = fmax(v, __shfl_xor(v, o, G));
+  v = fmax(v, dpp_f64<0x128>(v));  // row_ror:8
+  v = fmax(v, dpp_f64<0x124>(v));  // row_ror:4
+  v = fmax(v, dpp_f64<0x122>(v));  // row_ror:2
+  v = fmax(v, dpp_f64<0x121>(v));  // row_ror:1
+  return v;
+}
 __device__ __forceinline__ void lds_sync() {
 #ifdef MCHAP_SYNC_BARRIER
   __syncthreads();
@@ -960,9 +980,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
     }
     const uint64_t unknown = grp_ballot<G>(mine && isnan(tot), gi);
     const int n_cons = __popcll(grp_ballot<G>(mine && tot >= 0.0, gi));
-    double mx = (mine && tot >= 0.0) ? tot : -1.0;
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, G));
+    const double mx = grp_max_f64<G>((mine && tot >= 0.0) ? tot : -1.0);
     bool low = false;
     if (doit && gl < n_cons) {
       const int i = c.doff + (n_int - 1) + gl;
