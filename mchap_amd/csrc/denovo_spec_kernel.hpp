@@ -91,9 +91,11 @@ struct SpecLds {
   LDSP(uint64_t) gptr;    // [NG][GP_N] cold per-chain pointers (kept out of the registers): see GP_*
   LDSP(double) gval;      // [NG][GV_N] cold per-chain values: inbreeding, mutation memo bounds
   LDSP(uint32_t) gstream; // [NG][4] Philox key and counter words of the chain's current stream (Stream)
+  LDSP(uint64_t) bw;      // [NG][K] the chain's current genotype while its proposals are evaluated (base words)
   LDSP(uint64_t) tbuf;    // [NG][SPEC_TB][K + 1] trace records (K sorted words + llk) waiting to be written as a line
   uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
   bool cache_on;
+  bool reuse_on;          // haplotype products of the chain's current genotype are reused by its proposals
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
   LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] total move probability of an interval step for the current
                              // genotype; NaN = not evaluated yet, -1 = the step has no options
@@ -145,6 +147,7 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int 
   b += (size_t)8 * NG * GV_N;            // gval
   b = (b + 15) & ~(size_t)15;
   b += (size_t)16 * NG;                  // gstream
+  b += (size_t)8 * NG * K;               // bw
   b += (size_t)8 * NG * SPEC_TB * (K + 1);   // tbuf
   b = (b + 15) & ~(size_t)15;
   b += (size_t)8 * NG * spec_draws(K, Mmax);
@@ -511,6 +514,99 @@ __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int
   return s;
 }
 
+// ---- coded evaluation, one haplotype at a time ----
+// Row of pair p = h * Mh + j of the genotype whose words are words[h] (an LDS array), for the lane's pairs
+// p = lane and p = lane + 64 (K * Mh <= 128).
+template <int KT>
+__device__ __forceinline__ void spec_pair_rows(LDSP(const uint64_t) words, int wstride, int widx, const SpecLds &S, int sg, int mmax,
+                                               int Mh, uint32_t amask, int lane, int &row0, int &row1) {
+  const int n_pairs = KT * Mh;
+  row0 = 0;
+  row1 = 0;
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int p = lane + WAVE * t;
+    if (p < n_pairs) {
+      const int h = p / Mh, j = p - h * Mh;
+      const uint64_t wh = words[(size_t)h * wstride + widx];
+      const uint32_t a = (uint32_t)(wh >> S.shift[(size_t)sg * mmax + j]) & amask;
+      const int r = (int)S.cols[(size_t)sg * mmax + j] + (int)a;
+      if (t == 0) row0 = r;
+      else row1 = r;
+    }
+  }
+}
+// prod[i] = product over the Mh positions of haplotype h (pairs h*Mh .. h*Mh+Mh-1, rows in row0/row1), reads of
+// chunk i, in position order: the factors and their order are those of spec_coop_coded
+template <int RPL, class CT>
+__device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int row1, int p0, int Mh, GLBP(const uint8_t) ct,
+                                              int rpad, double (&prod)[RPL]) {
+  constexpr int UNR = 8;
+#pragma unroll
+  for (int i = 0; i < RPL; i++) prod[i] = 1.0;
+  for (int j0 = 0; j0 < Mh; j0 += UNR) {
+    CT cd[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const int p = __builtin_amdgcn_readfirstlane(p0 + min(j0 + u, Mh - 1));
+      const int row = p < WAVE ? __builtin_amdgcn_readlane(row0, p & (WAVE - 1)) : __builtin_amdgcn_readlane(row1, p & (WAVE - 1));
+      cd[u] = *reinterpret_cast<GLBP(const CT)>(ct + (size_t)row * rpad);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      if (j0 + u < Mh) {
+#pragma unroll
+        for (int i = 0; i < RPL; i++) prod[i] *= dict[((uint32_t)cd[u] >> (8 * i)) & 255u];
+      }
+    }
+  }
+}
+// One request with reuse: haplotypes whose word equals the base word take the base product bp[h].
+template <int KT, int RPL, class CT>
+__device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
+                                                  GLBP(const uint8_t) ct, GLBP(const double) cw, int rpad, int lane,
+                                                  const double (&bp)[KT][4], bool use_base) {
+  LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
+  const double invK = 1.0 / (double)KT;
+  int row0, row1;
+  spec_pair_rows<KT>(S.pw, WAVE, src, S, sg, mmax, Mh, amask, lane, row0, row1);
+  double acc[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; i++) acc[i] = 0.0;
+#pragma unroll
+  for (int h = 0; h < KT; h++) {
+    const uint64_t a = S.pw[(size_t)h * WAVE + src], b = S.bw[(size_t)sg * KT + h];
+    const bool same = use_base && __builtin_amdgcn_readfirstlane((int)(a == b)) != 0;
+    double ph[RPL];
+    if (same) {
+#pragma unroll
+      for (int i = 0; i < RPL; i++) ph[i] = bp[h][i];
+    } else {
+      spec_hap_prod<RPL, CT>(dict, row0, row1, h * Mh, Mh, ct, rpad, ph);
+    }
+#pragma unroll
+    for (int i = 0; i < RPL; i++) acc[i] += ph[i] * invK;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
+  return s;
+}
+template <int KT, int RPL, class CT>
+__device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int mmax, int Mh, uint32_t amask,
+                                                   GLBP(const uint8_t) ct, int rpad, int lane, double (&bp)[KT][4]) {
+  LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
+  int row0, row1;
+  spec_pair_rows<KT>(S.bw + (size_t)sg * KT, 1, 0, S, sg, mmax, Mh, amask, lane, row0, row1);
+#pragma unroll
+  for (int h = 0; h < KT; h++) {
+    double ph[RPL];
+    spec_hap_prod<RPL, CT>(dict, row0, row1, h * Mh, Mh, ct, rpad, ph);
+#pragma unroll
+    for (int i = 0; i < RPL; i++) bp[h][i] = ph[i];
+  }
+}
+
 // Serves every request of the wave (bit mask `todo`), one after the other, with all 64 lanes; kept out of line so
 // that its registers (RPL x UNR loads in flight) do not count against the sampler's main loop.
 #ifndef MCHAP_COOP_NOINLINE
@@ -521,43 +617,80 @@ __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int
 template <int KT, int G>
 COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
                                              LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab,
-                                             LDSP(uint16_t) ndict_tab, LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, int mmax, int Mh_lane, uint32_t amask_lane,
+                                             LDSP(uint16_t) ndict_tab, LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, LDSP(uint64_t) bw_tab, bool reuse, int mmax, int Mh_lane, uint32_t amask_lane,
                                              int rpad, int lane) {
   SpecLds S;
   S.pw = pwbuf;
   S.shift = shift_tab;
   S.cols = cols_tab;
   S.dict = dict_tab;
+  S.bw = bw_tab;
   const int nch = rpad / WAVE;
   double val = 0.0;
+  // Reuse: a chain's proposals differ from its current genotype (the base words in bw_tab) in one or two haplotype
+  // words; when a chain has several requests in this call, the products of the base haplotypes are formed once and a
+  // request only forms the products of the words it changed.  Same factors, same order: bit-identical values.
   while (todo) {
-    const int src = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const int sg = src / G;
-    const int Mh = __builtin_amdgcn_readfirstlane(__shfl(Mh_lane, src, WAVE));
-    const uint32_t amask = (uint32_t)__shfl((int)amask_lane, src, WAVE);
+    // all requests of one chain (the lanes of a group are contiguous)
+    const int sg = (__ffsll((long long)todo) - 1) / G;
+    const unsigned long long gmask = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << (sg * (G & 63)));
+    unsigned long long reqs = todo & gmask;
+    todo &= ~gmask;
+    const int first = __ffsll((long long)reqs) - 1;
+    const int Mh = __builtin_amdgcn_readfirstlane(__shfl(Mh_lane, first, WAVE));
+    const uint32_t amask = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)amask_lane, first, WAVE));
     LDSP(uint64_t) gp = gptr_tab + sg * GP_N;  // the requesting chain's pointers (wave-uniform)
     GLBP(const double) rt = (GLBP(const double))(uintptr_t)gp[GP_RT] + lane;
     GLBP(const double) cw = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;
-    // the lane's reads in blocks of at most 4 chunks of 64 (keeps the loads in flight, and this function's
-    // registers, bounded whatever the read depth)
-    double s = 0.0;
     const int nrd = (int)nreads_tab[sg];
-    if (ndict_tab[sg] != 0) {
+    if (ndict_tab[sg] != 0 && nch <= 4 && KT * Mh <= 2 * WAVE) {
+      // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped
       GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * nch;
-      if (nch == 1) s = spec_coop_coded<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
-      else if (nch == 2) s = spec_coop_coded<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
-      else
-        for (int cb = 0; cb < nch; cb += 4)
-          s += spec_coop_coded<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cw + cb * WAVE, rpad, lane);
-    } else if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
-    else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
-    else
-      for (int cb = 0; cb < nch; cb += MCHAP_COOP_RPL)
-        s += spec_coop_body<KT, MCHAP_COOP_RPL>(S, src, sg, mmax, Mh, amask, rt + cb * WAVE, cw + cb * WAVE, rpad, lane,
-                                                nrd - cb * WAVE);
-    s = wave_sum(s);
-    if (lane == src) val = s;
+      const bool use_base = reuse && __popcll(reqs) >= 3;
+      double bp[KT][4];
+#pragma unroll
+      for (int h = 0; h < KT; h++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) bp[h][i] = 0.0;
+      if (use_base) {
+        if (nch == 1) spec_base_products<KT, 1, uint8_t>(S, sg, mmax, Mh, amask, ct, rpad, lane, bp);
+        else if (nch == 2) spec_base_products<KT, 2, uint16_t>(S, sg, mmax, Mh, amask, ct, rpad, lane, bp);
+        else spec_base_products<KT, 4, uint32_t>(S, sg, mmax, Mh, amask, ct, rpad, lane, bp);
+      }
+      while (reqs) {
+        const int src = __ffsll((long long)reqs) - 1;
+        reqs &= reqs - 1;
+        double s;
+        if (nch == 1) s = spec_coop_reuse<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane, bp, use_base);
+        else if (nch == 2) s = spec_coop_reuse<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane, bp, use_base);
+        else s = spec_coop_reuse<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane, bp, use_base);
+        s = wave_sum(s);
+        if (lane == src) val = s;
+      }
+    } else {
+      while (reqs) {
+        const int src = __ffsll((long long)reqs) - 1;
+        reqs &= reqs - 1;
+        // the lane's reads in blocks of at most 4 chunks of 64 (keeps the loads in flight, and the registers,
+        // bounded whatever the read depth)
+        double s = 0.0;
+        if (ndict_tab[sg] != 0) {
+          GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * nch;
+          if (nch == 1) s = spec_coop_coded<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
+          else if (nch == 2) s = spec_coop_coded<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
+          else
+            for (int cb = 0; cb < nch; cb += 4)
+              s += spec_coop_coded<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cw + cb * WAVE, rpad, lane);
+        } else if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
+        else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
+        else
+          for (int cb = 0; cb < nch; cb += MCHAP_COOP_RPL)
+            s += spec_coop_body<KT, MCHAP_COOP_RPL>(S, src, sg, mmax, Mh, amask, rt + cb * WAVE, cw + cb * WAVE, rpad, lane,
+                                                    nrd - cb * WAVE);
+        s = wave_sum(s);
+        if (lane == src) val = s;
+      }
+    }
   }
   return val;
 }
@@ -619,8 +752,13 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
 #pragma unroll
       for (int h = 0; h < KT; h++) S.pw[(size_t)h * WAVE + lane] = pw.w[h];
     }
+    if (S.reuse_on && lane % G == 0) {  // the chain's current genotype: what its proposals are variations of
+      const GWords<KT> cg = c.g;
+#pragma unroll
+      for (int h = 0; h < KT; h++) S.bw[(size_t)(lane / G) * KT + h] = cg.w[h];
+    }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, mmax, c.Mh, C_AMASK(c), rpad, lane);
+    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, mmax, c.Mh, C_AMASK(c), rpad, lane);
     if (miss) {
       val = v;
       if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
@@ -1300,6 +1438,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.gval = lds_cast<double>(p); p += (size_t)8 * NG * GV_N; GUARD_STEP;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.gstream = lds_cast<uint32_t>(p); p += (size_t)16 * NG; GUARD_STEP;
+    S.bw = lds_cast<uint64_t>(p); p += (size_t)8 * NG * KT; GUARD_STEP;
     S.tbuf = lds_cast<uint64_t>(p); p += (size_t)8 * NG * SPEC_TB * (KT + 1); GUARD_STEP;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.ndraws = spec_draws(KT, mmax);
@@ -1334,6 +1473,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.gstream[gi * 4 + 2] = ((uint32_t)chain << 16) | 0u;
     S.gstream[gi * 4 + 3] = (uint32_t)U.stream_id;
   }
+  S.reuse_on = !(P.flags & 8);
   S.cache_on = D.cache_slots > 0;
   S.cache_mask = S.cache_on ? (uint32_t)(D.cache_slots / 8) - 1u : 0u;  // sets of 8 ways
   if (gl == 0) {
@@ -1442,7 +1582,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = g0.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, mmax, c.Mh, C_AMASK(c), rpad, lane);
+    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, mmax, c.Mh, C_AMASK(c), rpad, lane);
     lds_sync();
     c.llk = __shfl(v, 0, G);
     if (c.alive && gl == 0) {
