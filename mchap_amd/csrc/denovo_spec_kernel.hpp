@@ -30,6 +30,9 @@
 #ifndef MCHAP_COOP_UNR
 #define MCHAP_COOP_UNR 2  // row loads in flight per lane and chunk
 #endif
+#ifndef MCHAP_REUSE_MAXK
+#define MCHAP_REUSE_MAXK 8  // largest ploidy whose kernels carry the product-reuse path (K x 4 products in registers)
+#endif
 #ifndef MCHAP_CODED_UNR
 #define MCHAP_CODED_UNR 16  // code loads (one register each) in flight per lane in the coded evaluation
 #endif
@@ -643,10 +646,10 @@ COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP
     GLBP(const double) rt = (GLBP(const double))(uintptr_t)gp[GP_RT] + lane;
     GLBP(const double) cw = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;
     const int nrd = (int)nreads_tab[sg];
-    if (ndict_tab[sg] != 0 && nch <= 4 && KT * Mh <= 2 * WAVE) {
+    if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && nch <= 4 && KT * Mh <= 2 * WAVE) {
       // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped
       GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * nch;
-      const bool use_base = reuse && __popcll(reqs) >= 3;
+      const bool use_base = reuse && __popcll(reqs) >= 2;
       double bp[KT][4];
 #pragma unroll
       for (int h = 0; h < KT; h++)
