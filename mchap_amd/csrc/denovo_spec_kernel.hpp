@@ -45,7 +45,7 @@ namespace mchap {
 constexpr int SPEC_MAX_IV = 64;  // intervals per structural compound step (<= n_pos)
 constexpr int SPEC_TB = 4;    // trace records per flush: K = 4 -> one 128-byte line of words + 32 bytes of llks
 constexpr int SPEC_LN = 72;   // log tables: counts up to K(K-1) <= 56
-constexpr int SPEC_DRAWS_MAX = 128;  // draws of the current stream staged in LDS per group (Philox blocks in parallel)
+constexpr int SPEC_DRAWS_MAX = 384;  // draws of the current stream staged in LDS per group (Philox blocks in parallel)
 __host__ __device__ inline int spec_draws(int K, int Mmax) {
   int d = 2 * K * Mmax - 1;
   if (d < 3 * Mmax + 2) d = 3 * Mmax + 2;
@@ -829,6 +829,8 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   LDSP(uint8_t) shift = S.shift + gi * mmax;
   LDSP(uint8_t) nal = S.nal + gi * mmax;
   LDSP(double) pt = S.prior + gi * (2 * KT + 5);
+  // sub-steps per lane ("slots"): two, three for octoploids with up to 3 G = 192 sub-steps (20 SNVs and more)
+  constexpr int NS = (KT == 8 && G == 64) ? 3 : 2;
   const bool two = wave_any(c.alive && n > G);  // second slot in use anywhere in the wave
   // (1) the 2n-1 draws of this compound step, staged through LDS; the Fisher-Yates shuffle is swap(i, k_i) for
   //     i = n-1 .. 1 with k_i = interval(i) from draw ctr0 + (n-1-i)
@@ -838,7 +840,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   lds_sync();
   if (run) {
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < NS; s++) {
       const int p = gl + s * G;
       if (p >= 1 && p < n)
         ktab[p] = (uint8_t)(staged ? draw_interval(dtab[n - 1 - p], (uint32_t)p)
@@ -847,7 +849,9 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   }
   lds_sync();
   // (2) every lane traces the element that starts at its position through the transpositions
-  int x0 = gl, x1 = gl + G;
+  int xs[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) xs[s] = gl + s * G;
   {
     const int nloop = run ? n : 0;
     int nl = nloop;
@@ -856,15 +860,15 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
     for (int i = nl - 1; i >= 1; i--) {
       if (i < nloop) {
         const int ki = ktab[i];
-        x0 = (x0 == i) ? ki : ((x0 == ki) ? i : x0);
-        x1 = (x1 == i) ? ki : ((x1 == ki) ? i : x1);
+#pragma unroll
+        for (int s = 0; s < NS; s++) xs[s] = (xs[s] == i) ? ki : ((xs[s] == ki) ? i : xs[s]);
       }
     }
   }
   if (run) {
     // element e = h * Mh + j starts at position e
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < NS; s++) {
       const int e = gl + s * G;
       if (e < n) {
         int h = 0, j = e;
@@ -872,7 +876,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
           j -= Mh;
           h++;
         }
-        permtab[s ? x1 : x0] = (uint16_t)((h << 8) | j);
+        permtab[xs[s]] = (uint16_t)((h << 8) | j);
       }
     }
   }
@@ -880,7 +884,7 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
   // (3) speculate / validate.  Position p = gl + s * G of the sequence is handled by slot s of lane gl; its
   //     sub-step is permtab[p] and its uniform is draw ctr0 + (n-1) + p.
   if (run) c.ctr = ctr0 + (uint64_t)(n - 1) + (uint64_t)n;
-  const int nslots = two ? 2 : 1;
+  const int nslots = (NS > 2 && wave_any(c.alive && n > 2 * G)) ? 3 : (two ? 2 : 1);
   int start = 0;
   bool done = !run;
   bool first_round = true;

@@ -304,7 +304,8 @@ int spec_group(int K, int max_pos) {
   if (const char *e = std::getenv("MCHAP_HIP_GROUP")) g = std::atoi(e);
   if (g != 16 && g != 32 && g != 64) g = 16;
   while (g < 64 && (g < K * (K - 1) || 2 * g < n)) g *= 2;
-  if (g < K * (K - 1) || 2 * g < n) return 0;
+  const int slots = (K == 8) ? 3 : 2;  // sub-steps per lane the instantiation supports (denovo_spec_kernel.hpp)
+  if (g < K * (K - 1) || slots * g < n) return 0;
   if (K == 6 && g < 32) g = 32;
   if (K == 8) g = 64;
   return g;

@@ -197,9 +197,9 @@ def test_both_kernels_give_identical_traces():
 
 
 def test_config5_shape_octoploid_deep_reads(sampler_kernel):
-    """BASELINE.json configs[4] shape: K=8, 20 SNVs, 1000 reads.  K*M > 128 sub-steps: kernel 3 hands over to the
-    lanes-over-chains kernel; the transposed table (320 KB) exceeds the prepare pass's LDS copy, and the LDS-staged
-    kernel 1 cannot hold it at all (it must say so)."""
+    """BASELINE.json configs[4] shape: K=8, 20 SNVs, 1000 reads.  K*M = 160 sub-steps: three per lane in the
+    speculative kernel; the transposed table (320 KB) exceeds the prepare pass's LDS copy, and the LDS-staged kernel 1
+    cannot hold it at all (it must say so)."""
     from mchap_amd import DenovoMCMC
     from mchap_amd.synth import synth_units
 
@@ -227,3 +227,14 @@ def test_continuous_probabilities_fall_back_to_float64_rows():
     noisy[1] = np.where(np.isnan(noisy[1]), np.nan, noisy[1] * jitter[1])  # unit 1: thousands of distinct values
     model = DenovoMCMC(ploidy=4, n_alleles=[2] * 6, steps=120, chains=2, random_seed=9)
     _check(model, list(noisy))
+
+
+@pytest.mark.parametrize("n_pos", [17, 24])
+def test_octoploid_three_substeps_per_lane(n_pos):
+    """K = 8 with more than 128 sub-steps per mutation step (up to 192): third slot of the speculative kernel."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(2, ploidy=8, n_pos=n_pos, n_reads=90, window=(6, n_pos))
+    model = DenovoMCMC(ploidy=8, n_alleles=[2] * n_pos, steps=40, chains=2, random_seed=n_pos)
+    _check(model, list(reads))
