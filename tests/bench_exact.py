@@ -2,7 +2,7 @@
 genotypes per unit): units/s through mchap_exact_posterior_mode_batch (host buffers, so PCIe-inclusive), checked
 against the oracle on a few units, with the oracle timed beside it.  Measurement aid, not part of bench.py's contract.
 
-    python tools/bench_exact.py [units]
+    python tests/bench_exact.py [units]
 """
 import os
 import sys

@@ -1,6 +1,6 @@
 """Differential fuzz: random shapes / sampler settings, every sampler kernel against the CPU oracle.
 
-    python tools/fuzz_kernels.py [n_cases] [seed]        (needs a GPU; test infrastructure, like tests/)
+    python tests/fuzz_kernels.py [n_cases] [seed]        (needs a GPU; test infrastructure, like tests/)
 """
 import os
 import sys

@@ -1,5 +1,5 @@
 """GPU parity, randomised: shapes, priors, tempering ladders and step probabilities drawn at random; every sampler
-kernel that supports the shape must reproduce the oracle's trace step for step (tools/fuzz_kernels.py)."""
+kernel that supports the shape must reproduce the oracle's trace step for step (tests/fuzz_kernels.py)."""
 import os
 import sys
 
@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed", [11, 12])
