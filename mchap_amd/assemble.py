@@ -133,6 +133,17 @@ class DenovoMCMC(Assembler):
         if initial is None:
             initial = [None] * n_units
         n_alleles = np.asarray(self.n_alleles, dtype=np.int8)
+        if len(n_alleles) == 0:
+            # no SNVs in the locus (reference assemble/mcmc.py:189-199 with n_het_base == 0): the constant, empty
+            # genotype with nan likelihoods; nothing to sample
+            out = []
+            for u in range(n_units):
+                rd = np.asarray(reads[u])
+                assert rd.ndim == 3 and rd.shape[1] == 0  # reference assemble/mcmc.py:220
+                K = int(self.ploidy if ploidy is None else ploidy[u])
+                g = np.zeros((self.chains, self.steps, K, 0), dtype=np.int8)
+                out.append(GenotypeMultiTrace._from_sorted(g, np.full((self.chains, self.steps), np.nan)))
+            return out
         units = np.zeros(n_units, dtype=_lib.UNIT_DTYPE)
         r_parts, c_parts, i_parts = [], [], []
         r_off = c_off = i_off = t_off = l_off = f_off = 0
@@ -150,8 +161,6 @@ class DenovoMCMC(Assembler):
             else:
                 rc = read_counts[u]
             assert len(n_alleles) == n_pos  # reference assemble/mcmc.py:220
-            if n_pos == 0:
-                raise NotImplementedError("units without positions are answered on the host; use fit()")
             rd = np.ascontiguousarray(rd)
             r_parts.append(rd.reshape(-1))
             U = units[u]
