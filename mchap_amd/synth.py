@@ -66,6 +66,11 @@ def synth_units(n_units, ploidy=4, n_pos=8, n_reads=200, n_alleles=2, first_unit
 def dedup_unit(reads):
     """De-duplicate identical read rows (reference application/baseclass.py:207): rows in order of first
     appearance plus their counts."""
+    reads = np.asarray(reads)
+    if len(reads) == 0 or reads[0].size == 0:
+        # no reads, or a locus without positions: every row is the same (empty) row
+        n = len(reads)
+        return reads[: min(n, 1)], np.full(min(n, 1), n, dtype=np.int64)
     flat = np.ascontiguousarray(reads).reshape(len(reads), -1)
     keys = flat.view("V%d" % (flat.shape[1] * 8)).reshape(-1)
     _, first, inv = np.unique(keys, return_index=True, return_inverse=True)

@@ -231,3 +231,25 @@ def test_cache_is_results_neutral(golden_dir):
         assert np.array_equal(g0, g1)
         assert np.array_equal(l0, l1)
     assert np.array_equal(z["tetra_flat__genotypes"], z["nocache__genotypes"])
+
+
+def test_oracle_replays_the_call_exact_golden_vcfs():
+    """The reference's RNG-free `mchap call-exact` golden VCFs (real numba outputs,
+    tests/test_application_call_exact.py:16-216) replayed from its BAM / VCF test files through the ORACLE: every
+    sample column character for character.  The GPU twin is tests/test_gpu_call_exact_goldens.py."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import replay_call_exact as rp
+    from test_gpu_call_exact_goldens import HERE, SCENARIOS
+
+    backend = rp.OracleBackend()
+    for input_vcf, bam_files, kw, golden in SCENARIOS:
+        _, records = rp.read_vcf(os.path.join(HERE, input_vcf))
+        samples, expect = rp.read_vcf(os.path.join(HERE, golden))
+        bams = {s: rp.read_bam(os.path.join(HERE, f)) for s, f in zip(samples, bam_files)}
+        for rec, exp in zip(records, expect):
+            got = rp.call_record(rec, bams, samples, calling=backend, **kw)
+            for s in samples:
+                assert got[s] == exp["samples"][s], (golden, rec["chrom"], rec["pos"], s)
