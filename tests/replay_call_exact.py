@@ -3,7 +3,7 @@ a minimal BAM reader, a VCF text reader and the per-sample plumbing of applicati
 application/call_exact.py:52-199 restated over mchap_amd (GPU exact caller).  The goldens were produced by the real
 reference (numba), and are RNG-free, so the sample columns must agree character for character.
 
-Test infrastructure (used by tests/test_gpu_call_exact_goldens.py); data under tests/golden/call_exact are the
+Test infrastructure (used by tests/test_gpu_call_exact_goldens.py); data under tests/golden/reference_data are the
 reference's own test files.
 """
 import gzip
@@ -300,3 +300,47 @@ def call_record(rec, bams, sample_names, ploidy=4, report=(), error_rate=0.0024,
                 fields.append(vcfstr(np.asarray(extra[tag], float)))
         cols[sample] = ":".join(fields)
     return cols
+
+
+# ---- de novo assembly loci (mchap assemble): targets from a BED file, SNVs from a VCF (io/loci.py:94-135) ----
+class DenovoLocus:
+    def __init__(self, contig, start, stop, name, variant_records, sequence):
+        self.contig, self.start, self.stop, self.name, self.sequence = contig, start, stop, name, sequence
+        snps = {}
+        for r in variant_records:
+            alleles = (r["ref"],) + r["alts"]
+            if r["chrom"] != contig or not (start <= r["pos"] - 1 < stop) or any(len(a) != 1 for a in alleles):
+                continue
+            p = r["pos"] - 1
+            if p in snps:  # _merge_snps (io/loci.py:364-382)
+                assert snps[p][0] == alleles[0]
+                snps[p] = snps[p] + tuple(a for a in alleles if a not in snps[p])
+            else:
+                snps[p] = alleles
+        self.positions = list(snps)
+        self.alleles = [snps[p] for p in self.positions]
+        self.n_alleles = [len(a) for a in self.alleles]
+
+    def format_haplotype(self, alleles):
+        chars = list(self.sequence)
+        for p, tup, a in zip(self.positions, self.alleles, alleles):
+            chars[p - self.start] = tup[int(a)]
+        return "".join(chars)
+
+
+def read_bed4(path):
+    return [(f[0], int(f[1]), int(f[2]), f[3]) for f in (line.split() for line in open(path)) if len(f) >= 4]
+
+
+def sample_reads(locus, bam, sample, error_rate=0.0024):
+    """-> (calls int8 [R, M], distinct read distributions, counts) of one sample at a locus."""
+    from mchap_amd import encoding
+
+    chars, _ = extract_read_variants(locus, bam, sample)
+    calls = np.full(chars.shape, -1, dtype=np.int8)
+    for j in range(len(locus.positions)):
+        for a, c in enumerate(locus.alleles[j]):
+            calls[chars[:, j] == c, j] = a
+    dists = encoding.encode_read_distributions(locus.n_alleles, calls, None, error_rate=error_rate)
+    uniq, counts = encoding.unique_counts(dists)
+    return calls, uniq, counts

@@ -1,0 +1,59 @@
+"""GPU: the reference's `mchap assemble` golden VCFs (real numba runs: 500 steps, burn 100, 2 chains, seed 11;
+tests/test_application_assemble.py:254-440).  Their MCMC draws come from numba's generator, so the comparison is
+statistical where the posterior is diffuse (shallow BAMs: same mode genotype, GPM / SPM within the Monte-Carlo error
+of the golden's 800 correlated samples) and exact where it is concentrated (deep BAMs: GT, GQ, SQ, GPM, SPM all equal).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_data")
+SEQ = "A" * 60  # tests/test_io/data/simple.fasta: three contigs of 60 A
+
+
+def _run(bam_files, golden, inbreeding, steps, burn):
+    import replay_call_exact as rp
+    from mchap_amd import DenovoMCMC
+
+    samples, expect = rp.read_vcf(os.path.join(HERE, golden))
+    _, variants = rp.read_vcf(os.path.join(HERE, "simple.vcf"))
+    bams = {s: rp.read_bam(os.path.join(HERE, f)) for s, f in zip(samples, bam_files)}
+    out = []
+    for (contig, start, stop, name), exp in zip(rp.read_bed4(os.path.join(HERE, "simple.bed")), expect):
+        assert exp["id"] == name
+        locus = rp.DenovoLocus(contig, start, stop, name, variants, SEQ[start:stop])
+        gold_seqs = (exp["ref"],) + exp["alts"]
+        for s in samples:
+            f = dict(zip(exp["format"].split(":"), exp["samples"][s].split(":")))
+            calls, uniq, counts = rp.sample_reads(locus, bams[s], s)
+            assert str(len(calls)) == f["RCOUNT"] and str(int((calls >= 0).sum())) == f["RCALLS"]
+            model = DenovoMCMC(ploidy=4, n_alleles=locus.n_alleles, inbreeding=inbreeding, steps=steps, chains=2, random_seed=11)
+            post = model.fit(uniq, read_counts=counts).burn(burn).posterior()
+            mode = post.mode_genotype_support() if hasattr(post, "mode_genotype_support") else None
+            genotype, gpm = post.genotypes[0], float(post.probabilities[0])
+            spm = float(mode.probabilities.sum()) if mode is not None else np.nan
+            mine = sorted(locus.format_haplotype(h) for h in genotype)
+            gold = sorted(gold_seqs[int(a)] for a in f["GT"].split("/"))
+            out.append((name, s, mine, gold, gpm, float(f["GPM"]), spm, float(f["SPM"]), f))
+    return out
+
+
+@pytest.mark.parametrize("golden,inbreeding", [("simple.output.assemble.vcf", 0.0), ("simple.output.assemble.flatprior.vcf", None)])
+def test_shallow_assemble_goldens_statistically(golden, inbreeding):
+    res = _run(["simple.sample1.bam", "simple.sample2.bam", "simple.sample3.bam"], golden, inbreeding, steps=6000, burn=1000)
+    for name, s, mine, gold, gpm, gpm_gold, spm, spm_gold, _ in res:
+        assert mine == gold, (name, s)
+        assert abs(gpm - gpm_gold) < 0.08 and abs(spm - spm_gold) < 0.08, (name, s, gpm, gpm_gold, spm, spm_gold)
+
+
+def test_deep_assemble_golden_exactly():
+    import replay_call_exact as rp
+
+    res = _run(["simple.sample1.deep.bam", "simple.sample2.deep.bam", "simple.sample3.deep.bam"], "simple.output.deep.assemble.vcf",
+               0.0, steps=500, burn=100)
+    for name, s, mine, gold, gpm, gpm_gold, spm, spm_gold, f in res:
+        assert mine == gold, (name, s)
+        assert rp.vcfstr(gpm) == f["GPM"] and rp.vcfstr(spm) == f["SPM"], (name, s, gpm, spm)
+        assert str(rp.qual_of_prob(gpm)) == f["GQ"] and str(rp.qual_of_prob(spm)) == f["SQ"]

@@ -7,7 +7,7 @@ import os
 import pytest
 
 pytestmark = pytest.mark.gpu
-HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "call_exact")
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_data")
 
 SHALLOW = ["simple.sample1.bam", "simple.sample2.bam", "simple.sample3.bam"]
 MIXED = ["simple.sample1.bam", "simple.sample2.deep.bam", "simple.sample3.bam"]
