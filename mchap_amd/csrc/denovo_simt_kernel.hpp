@@ -78,14 +78,21 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
   double *mf = P.meta_f + (size_t)u * meta_f_stride(P.max_ploidy, P.max_pos, P.max_allele);
 
   for (int r = lane; r < rpad; r += WAVE) {
-    for (int q = 0; q < MA; q++) {
-      double v = 1.0;
-      if (r < R) {
-        v = gr[(size_t)r * MA + q];
-        if (isnan(v)) v = 1.0;
+    // eight entries of the read's row at a time: the loads are independent and issued together (the stores that
+    // follow could alias them as far as the compiler knows)
+    for (int q0 = 0; q0 < MA; q0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = (r < R && q0 + k < MA) ? gr[(size_t)r * MA + q0 + k] : 1.0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int q = q0 + k;
+        if (q < MA) {
+          const double x = isnan(v[k]) ? 1.0 : v[k];
+          if (in_lds) rl[(size_t)q * rpad + r] = x;
+          rt[(size_t)q * rpad + r] = x;
+        }
       }
-      if (in_lds) rl[(size_t)q * rpad + r] = v;
-      rt[(size_t)q * rpad + r] = v;
     }
   }
   double cnt[RPL];
