@@ -151,6 +151,14 @@ int mchap_exact_genotype_likelihoods(const double *reads, int n_reads, int n_pos
 int mchap_exact_genotype_posteriors(const void *llks, int is_f32, int64_t n_genotypes, int ploidy, int n_alleles,
                                     int has_prior, double inbreeding, const double *frequencies, double *post_out);
 
+/* Replicate incongruence of every unit's chains (the MCI field of `mchap assemble`): replaces
+ * GenotypeMultiTrace.replicate_incongruence(threshold) (assemble/classes.py:341-376) on the traces written by
+ * mchap_denovo_fit_batch_device.  mci[u] = 0 none, 1 incongruence, 2 incongruence with more than `ploidy` haplotypes
+ * (putative CNV), -1 if a chain visited more distinct genotypes than the kernel keeps (512).  Device pointers. */
+int mchap_trace_incongruence_batch_device(int n_units, const mchap_unit *units_dev, int steps, int chains, int burn,
+                                          const uint64_t *trace_words, int ploidy_max, double threshold, int32_t *mci,
+                                          void *stream);
+
 /* Exact caller, streaming form: replaces calling.exact.posterior_mode (calling/exact.py:156-249) for a batch
  * of units that share (n_reads, n_pos, max_allele, n_haps, ploidy).  Host pointers. */
 int mchap_exact_posterior_mode_batch(int n_units, const double *reads, int n_reads, int n_pos, int max_allele,

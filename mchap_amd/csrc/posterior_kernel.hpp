@@ -27,19 +27,19 @@ struct PosteriorParams {
   int32_t *mode_index;
 };
 
-__global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorParams P) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const mchap_unit U = P.units[blockIdx.x];
+// Distinct states of chains [ch_lo, ch_hi) after burn-in, ranked, with support labels and the mode support.
+// LDS: uw [POST_CAP][K], ucount / order / label [POST_CAP].  Every lane returns the same n_u, overflow, best, best_r.
+struct PostSummary {
+  int n_u, overflow, best_r;
+  double best;  // probability of the mode support (SPM)
+};
+
+__device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, const mchap_unit &U, int S, int burn, int ch_lo,
+                                                      int ch_hi, uint64_t *uw, int *ucount, int *order, int *label) {
   const int K = U.ploidy;
   const int lane = threadIdx.x;
-  const int S = P.steps, C_ = P.chains, burn = P.burn;
   const int per_chain = S - burn;
-  const int N = C_ * per_chain;
-
-  uint64_t *uw = reinterpret_cast<uint64_t *>(smem);                  // [POST_CAP][K]
-  int *ucount = reinterpret_cast<int *>(smem + (size_t)POST_CAP * K * 8);  // [POST_CAP]
-  int *order = ucount + POST_CAP;                                     // [POST_CAP] rank -> unique index
-  int *label = order + POST_CAP;                                      // [POST_CAP] support label by rank
+  const int N = (ch_hi - ch_lo) * per_chain;
   for (int i = lane; i < POST_CAP; i += WAVE) ucount[i] = 0;
   __syncthreads();
 
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
     const bool active = n < N;
     uint64_t st[MCHAP_MAX_PLOIDY];
     if (active) {
-      const int ch = n / per_chain, s = burn + n % per_chain;
-      const uint64_t *src = P.trace + U.trace_off + ((size_t)ch * S + s) * K;
+      const int ch = ch_lo + n / per_chain, s = burn + n % per_chain;
+      const uint64_t *src = trace + U.trace_off + ((size_t)ch * S + s) * K;
 #pragma unroll
       for (int h = 0; h < MCHAP_MAX_PLOIDY; h++) st[h] = h < K ? src[h] : 0ull;
     } else {
@@ -99,16 +99,6 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
       rank += (cf > ce || (cf == ce && f > e)) ? 1 : 0;
     }
     order[rank] = e;
-    if (rank < P.max_states) {
-      uint64_t *dst = P.post_words + ((size_t)blockIdx.x * P.max_states + rank) * P.ploidy_max;
-      for (int h = 0; h < P.ploidy_max; h++) dst[h] = h < K ? uw[(size_t)e * K + h] : 0ull;
-      P.post_counts[(size_t)blockIdx.x * P.max_states + rank] = ce;
-    }
-  }
-  for (int r = n_u + lane; r < P.max_states; r += WAVE) {
-    uint64_t *dst = P.post_words + ((size_t)blockIdx.x * P.max_states + r) * P.ploidy_max;
-    for (int h = 0; h < P.ploidy_max; h++) dst[h] = 0ull;
-    P.post_counts[(size_t)blockIdx.x * P.max_states + r] = 0;
   }
   __syncthreads();
 
@@ -171,12 +161,45 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
       best_r = orr;
     }
   }
+  PostSummary R;
+  R.n_u = n_u;
+  R.overflow = overflow;
+  R.best = best;
+  R.best_r = best_r;
+  return R;
+}
+
+__global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const mchap_unit U = P.units[blockIdx.x];
+  const int K = U.ploidy;
+  const int lane = threadIdx.x;
+  const int N = P.chains * (P.steps - P.burn);
+  uint64_t *uw = reinterpret_cast<uint64_t *>(smem);                  // [POST_CAP][K]
+  int *ucount = reinterpret_cast<int *>(smem + (size_t)POST_CAP * K * 8);  // [POST_CAP]
+  int *order = ucount + POST_CAP;                                     // [POST_CAP] rank -> unique index
+  int *label = order + POST_CAP;                                      // [POST_CAP] support label by rank
+  const PostSummary R = post_summarise(P.trace, U, P.steps, P.burn, 0, P.chains, uw, ucount, order, label);
+  const int n_u = R.n_u;
+  for (int r = lane; r < n_u; r += WAVE) {
+    if (r < P.max_states) {
+      const int e = order[r];
+      uint64_t *dst = P.post_words + ((size_t)blockIdx.x * P.max_states + r) * P.ploidy_max;
+      for (int h = 0; h < P.ploidy_max; h++) dst[h] = h < K ? uw[(size_t)e * K + h] : 0ull;
+      P.post_counts[(size_t)blockIdx.x * P.max_states + r] = ucount[e];
+    }
+  }
+  for (int r = n_u + lane; r < P.max_states; r += WAVE) {
+    uint64_t *dst = P.post_words + ((size_t)blockIdx.x * P.max_states + r) * P.ploidy_max;
+    for (int h = 0; h < P.ploidy_max; h++) dst[h] = 0ull;
+    P.post_counts[(size_t)blockIdx.x * P.max_states + r] = 0;
+  }
   if (lane == 0) {
-    P.post_n[blockIdx.x] = overflow ? -(n_u + overflow) : n_u;
+    P.post_n[blockIdx.x] = R.overflow ? -(n_u + R.overflow) : n_u;
     if (n_u > 0) {
-      P.mode_stats[2 * (size_t)blockIdx.x + 0] = best;                                    // SPM
-      P.mode_stats[2 * (size_t)blockIdx.x + 1] = (double)ucount[order[best_r]] / total;   // GPM
-      P.mode_index[blockIdx.x] = best_r;
+      P.mode_stats[2 * (size_t)blockIdx.x + 0] = R.best;                                            // SPM
+      P.mode_stats[2 * (size_t)blockIdx.x + 1] = (double)ucount[order[R.best_r]] / (double)N;       // GPM
+      P.mode_index[blockIdx.x] = R.best_r;
     } else {
       P.mode_stats[2 * (size_t)blockIdx.x + 0] = NAN;
       P.mode_stats[2 * (size_t)blockIdx.x + 1] = NAN;
@@ -185,6 +208,82 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
   }
 }
 
+// Replicate incongruence of the chains of a unit (GenotypeMultiTrace.replicate_incongruence, assemble/classes.py:341-376,
+// the MCI field of `mchap assemble`): per chain the mode support and its probability; among the chains whose mode
+// support reaches `threshold`, 0 if they agree on the support's set of haplotypes, else 1, or 2 if together they hold
+// more than `ploidy` distinct haplotypes.  -1 if a chain visited more than POST_CAP distinct states.
+constexpr int POST_MAX_CHAINS = 32;
+struct IncongruenceParams {
+  const mchap_unit *units;
+  const uint64_t *trace;
+  int steps, chains, burn;
+  double threshold;
+  int32_t *mci;
+};
+
+__global__ __launch_bounds__(64) void trace_incongruence_kernel(const IncongruenceParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const mchap_unit U = P.units[blockIdx.x];
+  const int K = U.ploidy;
+  const int lane = threadIdx.x;
+  uint64_t *uw = reinterpret_cast<uint64_t *>(smem);
+  int *ucount = reinterpret_cast<int *>(smem + (size_t)POST_CAP * K * 8);
+  int *order = ucount + POST_CAP;
+  int *label = order + POST_CAP;
+  uint64_t *sets = reinterpret_cast<uint64_t *>(label + POST_CAP);  // [chains][K] distinct words of the chain's mode support
+  int *nset = reinterpret_cast<int *>(sets + (size_t)POST_MAX_CHAINS * MCHAP_MAX_PLOIDY);  // [chains] size, 0 = below threshold
+  int bad = 0;
+  for (int ch = 0; ch < P.chains; ch++) {
+    const PostSummary R = post_summarise(P.trace, U, P.steps, P.burn, ch, ch + 1, uw, ucount, order, label);
+    if (R.overflow) bad = 1;
+    if (lane == 0) {
+      int n = 0;
+      if (R.n_u > 0 && R.best >= P.threshold) {
+        const uint64_t *g = uw + (size_t)order[R.best_r] * K;  // sorted words
+        for (int h = 0; h < K; h++)
+          if (h == 0 || g[h] != g[h - 1]) sets[(size_t)ch * MCHAP_MAX_PLOIDY + n++] = g[h];
+      }
+      nset[ch] = n;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    int out = 0;
+    int first = -1, modes = 0;
+    // number of distinct allele sets among the qualifying chains
+    for (int a = 0; a < P.chains; a++) {
+      if (nset[a] == 0) continue;
+      bool seen = false;
+      for (int b = 0; b < a && !seen; b++) {
+        if (nset[b] != nset[a]) continue;
+        bool eq = true;
+        for (int i = 0; i < nset[a]; i++) eq = eq && sets[(size_t)a * MCHAP_MAX_PLOIDY + i] == sets[(size_t)b * MCHAP_MAX_PLOIDY + i];
+        seen = eq;
+      }
+      if (!seen) modes++;
+      if (first < 0) first = a;
+    }
+    if (modes > 1) {
+      out = 1;
+      // size of the union of the sets
+      int total = 0;
+      for (int a = 0; a < P.chains; a++)
+        for (int i = 0; i < nset[a]; i++) {
+          const uint64_t w = sets[(size_t)a * MCHAP_MAX_PLOIDY + i];
+          bool dup = false;
+          for (int b = 0; b < a && !dup; b++)
+            for (int q = 0; q < nset[b] && !dup; q++) dup = sets[(size_t)b * MCHAP_MAX_PLOIDY + q] == w;
+          if (!dup) total++;
+        }
+      if (total > K) out = 2;
+    }
+    P.mci[blockIdx.x] = bad ? -1 : out;
+  }
+}
+
 inline size_t posterior_lds_bytes(int K) { return (size_t)POST_CAP * K * 8 + (size_t)POST_CAP * 4 * 3; }
+inline size_t incongruence_lds_bytes(int K) {
+  return posterior_lds_bytes(K) + (size_t)POST_MAX_CHAINS * MCHAP_MAX_PLOIDY * 8 + (size_t)POST_MAX_CHAINS * 4;
+}
 
 }  // namespace mchap

@@ -98,6 +98,20 @@ class DenovoDeviceBatch:
             C.c_void_p(stream))
         _lib.check(rc)
 
+    def incongruence(self, burn, threshold=0.6):
+        """Enqueue the replicate-incongruence code (MCI) of every unit's chains; returns the int32 device tensor
+        (0 none, 1 incongruence, 2 putative CNV; reference GenotypeMultiTrace.replicate_incongruence)."""
+        torch = self.torch
+        U = self.shape[0]
+        if getattr(self, "d_mci", None) is None:
+            self.d_mci = torch.empty(U, dtype=torch.int32, device=self.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _lib.lib().mchap_trace_incongruence_batch_device(
+            U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), self.K, C.c_double(float(threshold)),
+            self._p(self.d_mci), C.c_void_p(stream))
+        _lib.check(rc)
+        return self.d_mci
+
     # ---- results back on the host ----
     def traces(self):
         U, R, M, A = self.shape
