@@ -107,6 +107,21 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
                                   double *llks, int8_t *fixed_alleles, int32_t *status, void *workspace,
                                   int64_t workspace_bytes, void *stream);
 
+/* The same with the compact input the reference's encoders start from (encoding/integer/transcode.py:16-77,
+ * io/bam.py:251-289): `calls` int8 [n_reads][n_pos] per unit (allele index, < 0 = gap; mchap_unit.reads_off counts
+ * ELEMENTS of this array), `quals` int16 of the same shape or NULL, and `qual_prob[q]` = probability that a call with
+ * base quality q is correct, i.e. (1 - error_rate) * (1 - 10^(-q/10)), computed by the caller exactly as the
+ * reference does (qual_prob[0] = 1 - error_rate is used for every call when quals == NULL; qualities beyond the
+ * table use its last entry).  The probability tensor is formed on the device by the prepare pass: the called
+ * allele gets p, the others (1 - p) / 3, a gap NaN, alleles >= n_alleles[j] zero.  5x fewer input bytes than the
+ * float64 tensor; same traces.  Kernels 2 and 3 only. */
+int mchap_denovo_fit_batch_calls_device(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
+                                        const mchap_unit *units_host, const int8_t *calls, const int16_t *quals,
+                                        const double *qual_prob, int qual_prob_len, const int64_t *read_counts,
+                                        const int8_t *n_alleles, const int8_t *initial, uint64_t *trace_words,
+                                        double *llks, int8_t *fixed_alleles, int32_t *status, void *workspace,
+                                        int64_t workspace_bytes, void *stream);
+
 /* Bytes of device workspace the sampler needs: per-chain likelihood caches (the counterpart of the reference's llk
  * cache, assemble/likelihood.py:151-305; results-neutral) and, for kernel 0/2, the transposed read tensors and
  * per-unit tables written by its prepare pass. */

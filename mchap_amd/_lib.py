@@ -118,6 +118,7 @@ def lib():
 
 EXPORTS = [
     "mchap_denovo_fit_batch_device",
+    "mchap_denovo_fit_batch_calls_device",
     "mchap_denovo_fit_batch",
     "mchap_log_likelihood_batch",
     "mchap_trace_posterior_batch_device",

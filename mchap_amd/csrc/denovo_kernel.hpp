@@ -57,6 +57,12 @@ struct DenovoParams {
   // optional per-chain likelihood cache in HBM/L2: [units*chains][cache_slots] of {tag, llk}; 0 slots = off
   uint64_t *cache;
   int cache_slots;  // power of two
+  // compact input (kernels 2 / 3 only): int8 allele calls [R][M0] per unit instead of the float64 tensor, optional
+  // int16 base qualities, and the probability of a correct call per quality (qual_prob[0] when there are none)
+  const int8_t *calls;
+  const int16_t *quals;
+  const double *qual_prob;
+  int qual_prob_len;
 };
 
 // ---- wave-private LDS scratch -------------------------------------------------------------

@@ -72,7 +72,23 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
   const bool in_lds = !(P.flags & SIMT_FLAG_PREP_GLOBAL);
   double *rl = in_lds ? reinterpret_cast<double *>(smem) : rt;
   double *lp = reinterpret_cast<double *>(smem) + (in_lds ? (size_t)MA * rpad : 0);  // snv posterior scratch
-  const double *gr = D.reads + U.reads_off;
+  const double *gr = D.reads ? D.reads + U.reads_off : nullptr;
+  const int8_t *nal0 = D.n_alleles + U.nalleles_off;
+  // entry (r, q = j * A + a) of the unit's probability tensor: read from it, or formed from the allele calls as
+  // encoding/integer/transcode.py:16-77 does (called allele p, the others (1 - p) / 3, NaN for a gap, then 0 for
+  // alleles the position does not have)
+  auto rawv = [&](int r, int q) -> double {
+    if (gr) return gr[(size_t)r * MA + q];
+    const int j = q / A, a = q - j * A;
+    if (a >= nal0[j]) return 0.0;
+    const size_t e = (size_t)U.reads_off + (size_t)r * M0 + j;
+    const int call = D.calls[e];
+    if (call < 0) return NAN;
+    int qi = D.quals ? (int)D.quals[e] : 0;
+    qi = qi < 0 ? 0 : (qi >= D.qual_prob_len ? D.qual_prob_len - 1 : qi);
+    const double pc = D.qual_prob[qi];
+    return a == call ? pc : (1.0 - pc) / 3.0;
+  };
   double *cw = P.cntw + (size_t)u * rpad;
   int32_t *mi = P.meta_i + (size_t)u * meta_i_stride(P.max_pos);
   double *mf = P.meta_f + (size_t)u * meta_f_stride(P.max_ploidy, P.max_pos, P.max_allele);
@@ -83,7 +99,7 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
     for (int q0 = 0; q0 < MA; q0 += 8) {
       double v[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) v[k] = (r < R && q0 + k < MA) ? gr[(size_t)r * MA + q0 + k] : 1.0;
+      for (int k = 0; k < 8; k++) v[k] = (r < R && q0 + k < MA) ? rawv(r, q0 + k) : 1.0;
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const int q = q0 + k;
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
         double tot = 0.0;
         int n_ok = 0, n_nz = 0;
         for (int r = lane; r < R; r += WAVE) {
-          const double v = gr[(size_t)r * MA + col + a];
+          const double v = rawv(r, col + a);
           if (!isnan(v)) {
             tot += v;
             n_ok++;

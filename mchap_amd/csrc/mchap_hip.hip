@@ -406,15 +406,46 @@ int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units, c
   return (int64_t)simt_carve(cfg, n_units, B, 64 * rpl, slots).total;
 }
 
+static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
+                                 const mchap_unit *units_host, const double *reads, const int8_t *calls, const int16_t *quals,
+                                 const double *qual_prob, int qual_prob_len, const int64_t *read_counts,
+                                 const int8_t *n_alleles, const int8_t *initial, uint64_t *trace_words, double *llks,
+                                 int8_t *fixed_alleles, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                 void *stream_);
+
 int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
                                   const mchap_unit *units_host, const double *reads, const int64_t *read_counts,
                                   const int8_t *n_alleles, const int8_t *initial, uint64_t *trace_words, double *llks,
                                   int8_t *fixed_alleles, int32_t *status, void *workspace, int64_t workspace_bytes,
                                   void *stream_) {
+  if (n_units > 0 && !reads) return fail(MCHAP_ERR_BAD_ARG, "NULL buffer");
+  return fit_batch_device_impl(cfg, n_units, units_dev, units_host, reads, nullptr, nullptr, nullptr, 0, read_counts, n_alleles,
+                               initial, trace_words, llks, fixed_alleles, status, workspace, workspace_bytes, stream_);
+}
+
+int mchap_denovo_fit_batch_calls_device(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
+                                        const mchap_unit *units_host, const int8_t *calls, const int16_t *quals,
+                                        const double *qual_prob, int qual_prob_len, const int64_t *read_counts,
+                                        const int8_t *n_alleles, const int8_t *initial, uint64_t *trace_words, double *llks,
+                                        int8_t *fixed_alleles, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                        void *stream_) {
+  if (n_units > 0 && (!calls || !qual_prob || qual_prob_len < 1)) return fail(MCHAP_ERR_BAD_ARG, "NULL buffer");
+  if (cfg && cfg->kernel == 1)
+    return fail(MCHAP_ERR_BAD_ARG, "allele-call input is read by the prepare pass of kernels 2 and 3; kernel 1 has none");
+  return fit_batch_device_impl(cfg, n_units, units_dev, units_host, nullptr, calls, quals, qual_prob, qual_prob_len, read_counts,
+                               n_alleles, initial, trace_words, llks, fixed_alleles, status, workspace, workspace_bytes, stream_);
+}
+
+static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
+                                 const mchap_unit *units_host, const double *reads, const int8_t *calls, const int16_t *quals,
+                                 const double *qual_prob, int qual_prob_len, const int64_t *read_counts,
+                                 const int8_t *n_alleles, const int8_t *initial, uint64_t *trace_words, double *llks,
+                                 int8_t *fixed_alleles, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                 void *stream_) {
   int rc = validate_cfg(cfg);
   if (rc) return rc;
   if (n_units <= 0) return MCHAP_OK;
-  if (!units_dev || !units_host || !reads || !n_alleles || !trace_words || !llks || !fixed_alleles || !status)
+  if (!units_dev || !units_host || !n_alleles || !trace_words || !llks || !fixed_alleles || !status)
     return fail(MCHAP_ERR_BAD_ARG, "NULL buffer");
   rc = ensure_init();
   if (rc) return rc;
@@ -430,6 +461,10 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
   mchap::DenovoParams &P = SP.d;
   P.units = units_dev;
   P.reads = reads;
+  P.calls = calls;
+  P.quals = quals;
+  P.qual_prob = qual_prob;
+  P.qual_prob_len = qual_prob_len;
   P.counts = read_counts;
   P.n_alleles = n_alleles;
   P.initial = initial;

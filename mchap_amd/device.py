@@ -23,19 +23,30 @@ class DenovoDeviceBatch:
 
     reads : float64 [U, R, M, A] (numpy, copied once) ; read_counts : int64 [U, R] or None."""
 
-    def __init__(self, model: DenovoMCMC, reads, read_counts=None, first_stream=0, device=None):
+    def __init__(self, model: DenovoMCMC, reads, read_counts=None, first_stream=0, device=None, calls=None, quals=None,
+                 error_rate=0.0024):
+        """reads: float64 [U, R, M, A]; or reads=None with calls int8 [U, R, M] (< 0 = gap), optional quals int16 of the
+        same shape and the base error rate: the compact form the reference's encoders start from, turned into the
+        probability tensor on the device (5x fewer bytes to upload, same traces)."""
         torch = _torch()
         self.torch = torch
         self.model = model
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-        reads = np.ascontiguousarray(reads, dtype=np.float64)
-        U, R, M, A = reads.shape
+        self.d_calls = self.d_quals = self.d_qual_prob = None
+        if reads is None:
+            calls = np.ascontiguousarray(calls, dtype=np.int8)
+            U, R, M = calls.shape
+            A = int(np.max(model.n_alleles))
+            reads = None
+        else:
+            reads = np.ascontiguousarray(reads, dtype=np.float64)
+            U, R, M, A = reads.shape
         self.shape = (U, R, M, A)
         K, Cn, S = int(model.ploidy), int(model.chains), int(model.steps)
         self.K, self.Cn, self.S = K, Cn, S
         units = np.zeros(U, dtype=_lib.UNIT_DTYPE)
         idx = np.arange(U, dtype=np.int64)
-        units["reads_off"] = idx * (R * M * A)
+        units["reads_off"] = idx * (R * M * A) if reads is not None else idx * (R * M)
         units["counts_off"] = idx * R if read_counts is not None else -1
         units["nalleles_off"] = 0
         units["initial_off"] = -1
@@ -48,7 +59,22 @@ class DenovoDeviceBatch:
         self.units_host = units
         dev = self.device
         self.d_units = torch.from_numpy(units.view(np.uint8).reshape(-1)).to(dev)
-        self.d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+        if reads is not None:
+            self.d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+        else:
+            from .encoding import prob_of_qual
+
+            self.d_reads = None
+            self.d_calls = torch.from_numpy(calls.reshape(-1)).to(dev)
+            if quals is not None:
+                quals = np.ascontiguousarray(quals, dtype=np.int16)
+                assert quals.shape == calls.shape
+                self.d_quals = torch.from_numpy(quals.reshape(-1)).to(dev)
+                table = prob_of_qual(np.arange(int(quals.max(initial=0)) + 1)) * (1.0 - error_rate)  # reference io/bam.py:280-288
+            else:
+                table = np.array([1.0 - error_rate])
+            self.qual_prob_len = len(table)
+            self.d_qual_prob = torch.from_numpy(np.ascontiguousarray(table, dtype=np.float64)).to(dev)
         self.d_counts = None if read_counts is None else torch.from_numpy(np.ascontiguousarray(read_counts, dtype=np.int64).reshape(-1)).to(dev)
         self.d_nalleles = torch.from_numpy(np.asarray(model.n_alleles, dtype=np.int8)).to(dev)
         self.d_trace = torch.empty(U * Cn * S * K, dtype=torch.int64, device=dev)
@@ -70,6 +96,14 @@ class DenovoDeviceBatch:
         """Enqueue the sampler on torch's current stream (no synchronisation)."""
         L = _lib.lib()
         stream = self.torch.cuda.current_stream().cuda_stream
+        if self.d_reads is None:
+            rc = L.mchap_denovo_fit_batch_calls_device(
+                C.byref(self.cfg), self.shape[0], self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_calls),
+                self._p(self.d_quals), self._p(self.d_qual_prob), int(self.qual_prob_len), self._p(self.d_counts),
+                self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks), self._p(self.d_fixed),
+                self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream))
+            _lib.check(rc)
+            return
         rc = L.mchap_denovo_fit_batch_device(
             C.byref(self.cfg), self.shape[0], self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_reads),
             self._p(self.d_counts), self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks),
