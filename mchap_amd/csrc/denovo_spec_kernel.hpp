@@ -1109,11 +1109,34 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
   }
   GPHASE(c, 4);
   bool done = !doit;
+  // Single-interval steps (the whole-haplotype dosage step, or no break drawn): one memo entry and at most one
+  // uniform decide; no interval list, ballots or reduction needed.
+  if (memo && doit && n_int == 1) {
+    const double tot = mtot[Mh];  // (start, stop) = (0, Mh)
+    if (tot < 0.0) {
+      done = true;  // no options: no draw
+    } else if (!isnan(tot)) {
+      const int i = c.doff;
+      uint64_t w;
+      if (i < c.dcount) {
+        w = dtab[i];
+      } else {
+        uint32_t a, b;
+        stream_words(ld_stream(S, gi), c.ctr, a, b);
+        w = (uint64_t)a | ((uint64_t)b << 32);
+      }
+      if (draw_double(w) >= tot) {
+        c.ctr++;
+        c.doff++;
+        done = true;
+      }
+    }
+  }
   // Fast check, independent of the visiting order: if every interval of this compound step is in the memo, the
   // step consumes n_int - 1 shuffle draws and one uniform per interval that has options; it moves nothing if all
   // those uniforms are >= the largest total among its intervals, whichever interval each of them is paired with.
-  if (memo && wave_any(doit)) {
-    const bool mine = doit && gl < n_int;
+  if (memo && wave_any(doit && !done)) {
+    const bool mine = doit && !done && gl < n_int;
     double tot = -1.0;
     if (mine) {
       uint64_t z = zeros;
@@ -1140,7 +1163,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
       low = !(draw_double(w) >= mx);
     }
     const uint64_t anylow = grp_ballot<G>(low, gi);
-    if (doit && !unknown && !anylow) {
+    if (doit && !done && !unknown && !anylow) {
       c.ctr += (uint64_t)(n_int - 1 + n_cons);
       c.doff += n_int - 1 + n_cons;
       done = true;
