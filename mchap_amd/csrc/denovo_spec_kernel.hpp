@@ -30,6 +30,12 @@
 #ifndef MCHAP_COOP_UNR
 #define MCHAP_COOP_UNR 2  // row loads in flight per lane and chunk
 #endif
+#ifndef MCHAP_SPEC_TB
+#define MCHAP_SPEC_TB 4    // trace records per flush
+#endif
+#ifndef MCHAP_SPEC_LOW
+#define MCHAP_SPEC_LOW 8   // staged draws a structural step wants to find before it refills the window
+#endif
 #ifndef MCHAP_REUSE_MAXK
 #define MCHAP_REUSE_MAXK 8  // largest ploidy whose kernels carry the product-reuse path (K x 4 products in registers)
 #endif
@@ -43,7 +49,7 @@
 namespace mchap {
 
 constexpr int SPEC_MAX_IV = 64;  // intervals per structural compound step (<= n_pos)
-constexpr int SPEC_TB = 4;    // trace records per flush: K = 4 -> one 128-byte line of words + 32 bytes of llks
+constexpr int SPEC_TB = MCHAP_SPEC_TB;    // trace records per flush: K = 4 -> one 128-byte line of words + 32 bytes of llks
 constexpr int SPEC_LN = 72;   // log tables: counts up to K(K-1) <= 56
 constexpr int SPEC_DRAWS_MAX = 384;  // draws of the current stream staged in LDS per group (Philox blocks in parallel)
 __host__ __device__ inline int spec_draws(int K, int Mmax) {
@@ -1031,7 +1037,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
   // on the spot.
   LDSP(uint64_t) dtab = S.draws + gi * S.ndraws;
   {
-    const int low = min(3 * Mh + 2, 12);
+    const int low = min(3 * Mh + 2, MCHAP_SPEC_LOW);
     if (wave_any(c.alive && c.dcount - c.doff < low)) {
       const int W = min(S.ndraws, 2 * G - 1);
       lds_sync();
