@@ -64,6 +64,33 @@ def usable_cores():
     return n, quota
 
 
+def call_concordance(args, batch, n=64):
+    """Checker leg (rank 0, after the timed region): the first n loci of the batch through the oracle on the same
+    Philox streams (llk cache off); the posterior mode genotype and its probability must be those the device-side
+    summary of the timed passes reported.  Returns (fraction of equal mode genotypes, max |delta GPM|)."""
+    from oracle import binding as orc
+    from mchap_amd import GenotypeMultiTrace
+    from mchap_amd.assemble import break_table, unpack_trace
+    from mchap_amd.classes import sort_haplotypes
+    from mchap_amd.synth import synth_units
+
+    n = min(n, args.loci)
+    reads, _, _ = synth_units(n, ploidy=args.ploidy, n_pos=args.snvs, n_reads=args.reads, first_unit=0)
+    cfg = orc.make_cfg(args.ploidy, args.mcmc_steps, args.chains, None, (1.0,), llk_cache_threshold=-1, seed=42,
+                       rng_kind=orc.RNG_PHILOX, break_table=break_table(args.snvs, 1.0, 3.0))
+    g, l, code, _ = orc.denovo_fit_batch(cfg, reads, [2] * args.snvs, n_threads=0, keep_traces=True)
+    assert code == 0
+    post = batch.posterior_host()
+    fixed = batch.d_fixed.cpu().numpy().reshape(args.loci, args.snvs)
+    same, dmax = 0, 0.0
+    for u in range(n):
+        ref = GenotypeMultiTrace._from_sorted(sort_haplotypes(g[u]), l[u]).burn(args.burn).posterior().mode_genotype_support().mode_genotype()
+        mine = unpack_trace(post["words"][u][post["mode"][u]][None], fixed[u], 2)[0]
+        same += int(np.array_equal(mine, ref[0]))
+        dmax = max(dmax, abs(float(post["stats"][u][1]) - float(ref[1])))
+    return same / n, dmax
+
+
 def cpu_baseline(args, cores, quota=None):
     """The oracle (C restatement incl. the reference's llk trie cache at its default threshold 100) timed on
     the host cores over a bounded sample of the same workload."""
@@ -80,8 +107,12 @@ def cpu_baseline(args, cores, quota=None):
     _, _, code, st = orc.denovo_fit_batch(cfg, reads, [2] * args.snvs, n_threads=cores, keep_traces=False)
     dt = time.perf_counter() - t
     assert code == 0
+    n1 = min(n, 256)  # one thread, ~2 s
+    t = time.perf_counter()
+    orc.denovo_fit_batch(cfg, reads[:n1], [2] * args.snvs, n_threads=1, keep_traces=False)
+    dt1 = time.perf_counter() - t
     return {
-        "value": n / dt, "unit": "loci/s", "cores": cores, "kind": "port",
+        "value": n / dt, "unit": "loci/s", "cores": cores, "kind": "port", "value_1_thread": n1 / dt1,
         "sample": "%d loci of the same workload, oracle/mchap_oracle.c with llk cache threshold 100, OpenMP over loci "
                   "(%d threads = affinity capped by the cgroup CPU quota %s), %.2f s wall"
                   % (n, cores, "none" if quota is None else "%.1f" % quota, dt),
@@ -220,6 +251,10 @@ def main():
         if not args.no_cpu_baseline:
             cores, quota = usable_cores()
             out["cpu_baseline"] = cpu_baseline(args, cores, quota)
+            if args.ploidy * args.snvs <= 64:
+                conc, dgpm = call_concordance(args, batch)
+                out["cpu_baseline"]["mode_call_concordance"] = conc
+                out["cpu_baseline"]["max_abs_delta_gpm"] = dgpm
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
