@@ -248,7 +248,7 @@ def main():
                         "fraction is reported because the contract asks for it",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline leg runs at N = 1 only
             cores, quota = usable_cores()
             out["cpu_baseline"] = cpu_baseline(args, cores, quota)
             if args.ploidy * args.snvs <= 64:
