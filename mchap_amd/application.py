@@ -1,0 +1,168 @@
+"""Application layer over the kernels: the per-locus plumbing of `mchap call-exact` and `mchap assemble`
+(reference application/baseclass.py:140-302, application/call_exact.py:52-199, application/assemble.py:95-176) from
+BAM / VCF / BED files to VCF record lines, without pysam.  The compute goes through `mchap_amd.calling` (exact caller
+kernels) and `mchap_amd.DenovoMCMC` (sampler kernels); everything else here is host-side formatting.
+
+Parity: the reference's RNG-free `call-exact` golden VCFs are reproduced line for line (tests/test_gpu_call_exact_goldens.py).
+"""
+import numpy as np
+
+from . import encoding
+from .io import DenovoLocus, Locus, extract_read_variants, qual_of_prob, read_bam, read_bed4, read_vcf, vcfstr  # noqa: F401
+
+SAMPLE_FIELDS = ("GT", "GQ", "SQ", "DP", "RCOUNT", "RCALLS", "MEC", "MECP", "GPM", "SPM", "MCI")
+
+
+def sample_reads(locus, bam, sample, error_rate=0.0024, use_phred=False):
+    """encode_sample_reads (application/baseclass.py:140-210) for one sample:
+    -> dict(chars, calls, depth, dists (distinct rows), counts)."""
+    chars, quals = extract_read_variants(locus, bam, sample)
+    M = len(locus.positions)
+    calls = np.full(chars.shape, -1, dtype=np.int8)
+    for j in range(M):
+        for a, c in enumerate(locus.alleles[j]):
+            calls[chars[:, j] == c, j] = a
+    dists = encoding.encode_read_distributions(locus.n_alleles, calls, quals if use_phred else None, error_rate=error_rate)
+    uniq, counts = encoding.unique_counts(dists)
+    depth = (chars != "-").sum(axis=0) if M else np.array([])
+    return dict(chars=chars, calls=calls, depth=depth, dists=uniq, counts=counts)
+
+
+def _mec(calls, genotype):
+    """minimum_error_correction summed over reads (encoding/integer/stats.py:18-39)."""
+    if len(calls) == 0:
+        return 0
+    diff = (calls[:, None, :] != genotype[None]) & (calls[:, None, :] >= 0)
+    return int(diff.sum(axis=-1).min(axis=-1).sum())
+
+
+def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024, use_phred=False, prior_tag=None,
+                      inbreeding=None, calling=None):
+    """One record of the input VCF -> (FILTER, INFO string, FORMAT string, {sample: column}) as `mchap call-exact`
+    writes them.  `calling`: mchap_amd.calling (default, GPU) or an object with the same functions."""
+    if calling is None:
+        from . import calling
+
+    locus = Locus(rec, prior_tag)
+    haps = locus.haplotypes
+    H, M = haps.shape
+    full = ("GL" in report) or ("GP" in report)
+    invalid = None
+    if locus.mask_reference_allele and H == 1:
+        invalid = "NOA"
+    elif np.any(np.isnan(locus.frequencies)):
+        invalid = "AF0"
+    cols, gts = {}, {}
+    acp_sum = np.zeros(H)
+    aop_not = np.ones(H)
+    aop_sum = np.zeros(H)
+    snvdp_sum = np.zeros(M)
+    dps, rcounts = [], []
+    nan_arrays = False
+    for sample in samples:
+        sr = sample_reads(locus, bams[sample], sample, error_rate, use_phred)
+        calls, depth = sr["calls"], sr["depth"]
+        rcount = len(calls)
+        dp = np.round(np.mean(depth)) if len(depth) else np.nan
+        rcalls = int((calls >= 0).sum())
+        dps.append(dp)
+        rcounts.append(rcount)
+        if M:
+            snvdp_sum += np.round(depth)
+        if invalid:
+            gts[sample] = np.full(ploidy, -1, int)
+            fields = ["/".join(["."] * ploidy), ".", ".", vcfstr(float(dp)), str(rcount), str(rcalls), ".", ".", ".", ".", "."]
+            fields += ["."] * len(report)
+            cols[sample] = ":".join(fields)
+            nan_arrays = True
+            continue
+        prior = None if inbreeding is None else (inbreeding, locus.frequencies)
+        extra = {}
+        if M == 0 or H == 1:
+            # a single haplotype: one genotype with probability 1 (the reference's arithmetic gives exactly that)
+            alleles, gprob, sprob = np.zeros(ploidy, int), 1.0, 1.0
+            freqs, occur = np.ones(1), np.ones(1)
+            extra = dict(GL=np.zeros(1), GP=np.ones(1))
+        elif full:
+            llks = calling.genotype_likelihoods(sr["dists"], ploidy, haps, read_counts=sr["counts"])
+            probs = calling.genotype_posteriors(llks, ploidy, H, prior=prior)
+            idx = int(np.argmax(probs))
+            alleles = calling.index_as_genotype_alleles(idx, ploidy)
+            gprob = probs[idx]
+            sprob = calling.alternate_dosage_posteriors(alleles, probs)[1].sum()
+            freqs, _, occur = calling.posterior_allele_frequencies(probs, ploidy, H)
+            extra = dict(GL=llks.astype(np.float64) / np.log(10), GP=probs)
+        else:
+            alleles, _, gprob, sprob, freqs, occur = calling.posterior_mode(
+                sr["dists"], ploidy, haps, read_counts=sr["counts"], prior=prior, return_support_prob=True,
+                return_posterior_frequencies=True, return_posterior_occurrence=True)
+        gts[sample] = np.asarray(alleles)
+        freqs, occur = np.asarray(freqs, float), np.asarray(occur, float)
+        acp_sum += freqs * ploidy
+        aop_sum += occur
+        aop_not *= 1 - occur
+        mec = _mec(calls, haps[alleles])
+        denom = int((calls >= 0).sum())
+        mecp = mec / denom if denom > 0 else np.nan
+        fields = ["/".join(str(a) for a in alleles), vcfstr(qual_of_prob(gprob)), vcfstr(qual_of_prob(sprob)), vcfstr(float(dp)),
+                  str(rcount), str(rcalls), str(mec), vcfstr(float(mecp)), vcfstr(float(gprob)), vcfstr(float(sprob)), "."]
+        for tag in report:
+            if tag == "AFP":
+                fields.append(vcfstr(freqs))
+            elif tag == "ACP":
+                fields.append(vcfstr(freqs * ploidy))
+            elif tag == "AOP":
+                fields.append(vcfstr(occur))
+            elif tag == "SNVDP":
+                fields.append(vcfstr(np.round(depth).astype(float)) if len(depth) else ".")
+            elif tag in ("GL", "GP"):
+                fields.append(vcfstr(np.asarray(extra[tag], float)))
+        cols[sample] = ":".join(fields)
+    # ---- record level (application/baseclass.py:220-302) ----
+    counts = np.zeros(H, int)
+    for g in gts.values():
+        for a in g:
+            if a >= 0:
+                counts[a] += 1
+    info = [("AN", int(counts.sum())), ("UAN", int((counts > 0).sum())), ("AC", counts[1:])]
+    if locus.mask_reference_allele:
+        info.append(("REFMASKED", True))
+    info += [("NS", sum(int(np.any(g >= 0)) for g in gts.values())), ("MCI", 0),
+             ("DP", float(np.nansum(dps)) if M else np.nan), ("RCOUNT", int(np.nansum(rcounts))), ("END", locus.stop),
+             ("NVAR", M), ("SNVPOS", np.array(locus.positions, int) - locus.start + 1)]
+    null_r = np.full(H, np.nan)
+    if "AFPRIOR" in report or prior_tag is not None:
+        info.append(("AFPRIOR", locus.frequencies))
+    for tag in report:
+        if tag == "ACP":
+            info.append(("ACP", null_r if nan_arrays else acp_sum))
+        elif tag == "AFP":
+            info.append(("AFP", null_r if nan_arrays else acp_sum / (ploidy * len(samples))))
+        elif tag == "AOP":
+            info.append(("AOP", null_r if nan_arrays else 1 - aop_not))
+            info.append(("AOPSUM", null_r if nan_arrays else aop_sum))
+        elif tag == "SNVDP":
+            info.append(("SNVDP", snvdp_sum))
+    parts = []
+    for k, v in info:
+        if isinstance(v, bool):
+            if v:
+                parts.append(k)
+        else:
+            parts.append("%s=%s" % (k, vcfstr(np.asarray(v) if isinstance(v, np.ndarray) else v)))
+    fmt = ":".join(SAMPLE_FIELDS + tuple(t for t in report if t in ("AFP", "ACP", "AOP", "SNVDP", "GL", "GP")))
+    return invalid or "PASS", ";".join(parts), fmt, cols
+
+
+def call_exact(vcf_path, sample_bams, ploidy=4, report=(), base_error_rate=0.0024, use_base_phred_scores=False,
+               prior_frequencies_tag=None, inbreeding=None, calling=None):
+    """`mchap call-exact` over a VCF of known haplotypes: yields one VCF record line per input record (no header).
+    sample_bams: ordered mapping sample name -> BAM path."""
+    samples = list(sample_bams)
+    bams = {s: read_bam(p) for s, p in sample_bams.items()}
+    _, records = read_vcf(vcf_path)
+    for rec in records:
+        flt, info, fmt, cols = call_exact_record(rec, bams, samples, ploidy, tuple(report), base_error_rate, use_base_phred_scores,
+                                                 prior_frequencies_tag, inbreeding, calling)
+        alt = ",".join(rec["alts"]) if rec["alts"] else "."
+        yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])

@@ -1,209 +1,10 @@
-"""Replay of the reference's `mchap call-exact` golden VCFs (tests/test_application_call_exact.py:16-216) without pysam:
-a minimal BAM reader, a VCF text reader and the per-sample plumbing of application/baseclass.py:140-210 and
-application/call_exact.py:52-199 restated over mchap_amd (GPU exact caller).  The goldens were produced by the real
-reference (numba), and are RNG-free, so the sample columns must agree character for character.
-
-Test infrastructure (used by tests/test_gpu_call_exact_goldens.py); data under tests/golden/reference_data are the
-reference's own test files.
-"""
-import gzip
-import struct
-from itertools import combinations_with_replacement  # noqa: F401
-
-import numpy as np
-
-SEQ_CODE = "=ACMGRSVTWYHKDBN"
-CIGAR_OPS = "MIDNSHP=X"
-
-
-def read_bam(path):
-    """-> (ref_names, {RG id: SM}, [record dicts]) of a (small) BAM file."""
-    data = gzip.decompress(open(path, "rb").read())
-    assert data[:4] == b"BAM\1"
-    (l_text,) = struct.unpack_from("<i", data, 4)
-    text = data[8:8 + l_text].decode().rstrip("\0")
-    o = 8 + l_text
-    (n_ref,) = struct.unpack_from("<i", data, o)
-    o += 4
-    refs = []
-    for _ in range(n_ref):
-        (l_name,) = struct.unpack_from("<i", data, o)
-        o += 4
-        refs.append(data[o:o + l_name - 1].decode())
-        o += l_name + 4
-    rg = {}
-    for line in text.splitlines():
-        if line.startswith("@RG"):
-            f = dict(x.split(":", 1) for x in line.split("\t")[1:])
-            rg[f["ID"]] = f["SM"]
-    recs = []
-    while o < len(data):
-        (block,) = struct.unpack_from("<i", data, o)
-        o += 4
-        b = data[o:o + block]
-        o += block
-        ref_id, pos, l_name, mapq, _bin, n_cig, flag, l_seq, _nr, _np, _tl = struct.unpack_from("<iiBBHHHiiii", b, 0)
-        p = 32
-        qname = b[p:p + l_name - 1].decode()
-        p += l_name
-        cigar = [(v >> 4, CIGAR_OPS[v & 15]) for v in struct.unpack_from("<%dI" % n_cig, b, p)]
-        p += 4 * n_cig
-        sq = b[p:p + (l_seq + 1) // 2]
-        p += (l_seq + 1) // 2
-        seq = "".join(SEQ_CODE[(sq[i // 2] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(l_seq))
-        qual = list(b[p:p + l_seq])
-        p += l_seq
-        tags = {}
-        while p < len(b):
-            tag, typ = b[p:p + 2].decode(), chr(b[p + 2])
-            p += 3
-            if typ == "Z":
-                e = b.index(b"\0", p)
-                tags[tag] = b[p:e].decode()
-                p = e + 1
-            elif typ == "A":
-                tags[tag] = chr(b[p])
-                p += 1
-            elif typ in "cCsSiIf":
-                n = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[typ]
-                p += n
-            elif typ == "B":
-                sub = chr(b[p])
-                (cnt,) = struct.unpack_from("<i", b, p + 1)
-                p += 5 + cnt * {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
-            else:
-                raise ValueError(typ)
-        recs.append(dict(qname=qname, flag=flag, ref=refs[ref_id] if ref_id >= 0 else None, pos=pos, mapq=mapq, cigar=cigar,
-                         seq=seq, qual=qual, rg=tags.get("RG")))
-    return refs, rg, recs
-
-
-def read_vcf(path):
-    """-> (sample names, [record dicts]) of a VCF text file."""
-    samples, out = [], []
-    for line in open(path):
-        line = line.rstrip("\n")
-        if line.startswith("##") or not line:
-            continue
-        f = line.split("\t")
-        if line.startswith("#"):
-            samples = f[9:]
-            continue
-        info = {}
-        for kv in f[7].split(";"):
-            if "=" in kv:
-                k, v = kv.split("=", 1)
-                info[k] = v
-            else:
-                info[kv] = True
-        out.append(dict(chrom=f[0], pos=int(f[1]), id=f[2], ref=f[3], alts=() if f[4] == "." else tuple(f[4].split(",")),
-                        info=info, format=f[8] if len(f) > 8 else "", samples=dict(zip(samples, f[9:]))))
-    return samples, out
-
-
-class Locus:
-    """LocusPrior.from_variant_record (io/loci.py:193-303) without allele filters."""
-
-    def __init__(self, rec, frequency_tag=None):
-        self.contig, self.start, self.stop = rec["chrom"], rec["pos"] - 1, rec["pos"] - 1 + len(rec["ref"])
-        self.sequences = (rec["ref"],) + rec["alts"]
-        n = len(self.sequences)
-        if frequency_tag:
-            fr = np.array([float(x) for x in rec["info"][frequency_tag].split(",")])
-            assert len(fr) == n
-        else:
-            fr = np.ones(n) / n
-        self.mask_reference_allele = "REFMASKED" in rec["info"]
-        if self.mask_reference_allele:
-            fr[0] = 0
-        self.frequencies = fr / fr.sum() if fr.sum() > 0 else np.full(n, np.nan)
-        haps = np.array([list(s) for s in self.sequences])
-        offsets = np.where((haps != haps[0:1]).any(axis=0))[0]
-        self.positions = [int(o) + self.start for o in offsets]
-        self.alleles = []
-        for o in offsets:
-            col = haps[:, o]
-            _, idx = np.unique(col, return_index=True)
-            idx.sort()
-            self.alleles.append(tuple(col[idx]))
-        self.n_alleles = [len(a) for a in self.alleles]
-        # encode_haplotypes (io/loci.py:184-191)
-        self.haplotypes = np.zeros((n, len(offsets)), dtype=np.int8)
-        for j, o in enumerate(offsets):
-            lut = {c: i for i, c in enumerate(self.alleles[j])}
-            self.haplotypes[:, j] = [lut[c] for c in haps[:, o]]
-
-
-def extract_read_variants(locus, bam, sample, min_quality=20):
-    """io/bam.py:54-229 for one sample: chars [n_reads, n_snv] ('-' gap, 'N' conflict) and summed quals."""
-    _, rg, recs = bam
-    positions = {p: i for i, p in enumerate(locus.positions)}
-    n = len(locus.positions)
-    data = {}
-    for r in recs:
-        if r["ref"] != locus.contig or r["flag"] & 4:
-            continue
-        ref_len = sum(l for l, op in r["cigar"] if op in "MDN=X")
-        if not (r["pos"] < locus.stop and r["pos"] + ref_len > locus.start):
-            continue  # pysam fetch(contig, start, stop): overlapping reads
-        if r["mapq"] < min_quality or r["flag"] & (0x400 | 0x200 | 0x800):
-            continue
-        if rg.get(r["rg"]) != sample:
-            continue
-        if r["qname"] not in data:
-            data[r["qname"]] = [np.full(n, "-", dtype="U1"), np.zeros(n, dtype=np.int16)]
-        chars, quals = data[r["qname"]]
-        rp, gp = 0, r["pos"]
-        for l, op in r["cigar"]:
-            if op in "M=X":
-                for k in range(l):
-                    if gp + k in positions:
-                        i = positions[gp + k]
-                        c, q = r["seq"][rp + k], r["qual"][rp + k]
-                        if chars[i] == "-":
-                            chars[i], quals[i] = c, q
-                        elif chars[i] == c:
-                            quals[i] += q
-                        else:
-                            chars[i] = "N"
-                rp += l
-                gp += l
-            elif op in "IS":
-                rp += l
-            elif op in "DN":
-                gp += l
-    if not data:
-        return np.empty((0, n), dtype="U1"), np.empty((0, n), dtype=np.int16)
-    return np.array([v[0] for v in data.values()]), np.array([v[1] for v in data.values()])
-
-
-def qual_of_prob(prob, precision=6):
-    """io/util.py:56-89"""
-    maximum = 1 - 0.1 ** precision
-    prob = min(prob, maximum)
-    prob = np.floor(prob * 10 ** precision) / 10 ** precision
-    return int(np.round(-10 * np.log10(1 - prob)))
-
-
-def vcfstr(obj, precision=3):
-    """io/vcf/util.py:4-42"""
-    if isinstance(obj, np.ndarray):
-        if len(obj) == 0:
-            return "."
-        if np.issubdtype(obj.dtype, np.floating):
-            obj = obj.round(precision)
-            string = ",".join(obj.astype("U16")).replace("nan", ".").replace(".0,", ",")
-            return string[:-2] if string[-2:] == ".0" else string
-        return ",".join(obj.astype("U16"))
-    if obj is None:
-        return "."
-    if isinstance(obj, (float, np.floating)):
-        if np.isnan(obj):
-            return "."
-        obj = np.round(obj, precision)
-        i = int(obj)
-        return str(i) if i == obj else str(obj)
-    return str(obj)
+"""Test-side helpers around mchap_amd.application / mchap_amd.io (the replay of the reference's golden VCFs):
+the oracle behind the function names of mchap_amd.calling, so that the same plumbing can be driven by the CPU
+oracle (tests/test_oracle_golden.py) as well as by the GPU exact caller (tests/test_gpu_call_exact_goldens.py).
+Data under tests/golden/reference_data are the reference's own test files."""
+from mchap_amd.application import call_exact, call_exact_record, sample_reads as _sample_reads  # noqa: F401
+from mchap_amd.io import (DenovoLocus, Locus, extract_read_variants, qual_of_prob, read_bam, read_bed4, read_vcf,  # noqa: F401
+                          vcfstr)
 
 
 class OracleBackend:
@@ -230,117 +31,12 @@ class OracleBackend:
         return self.orc.posterior_mode(reads, ploidy, haplotypes, read_counts, prior)
 
 
-def call_record(rec, bams, sample_names, ploidy=4, report=(), error_rate=0.0024, use_phred=False, prior_tag=None,
-                inbreeding=None, calling=None):
-    """One input VCF record -> {sample: 'GT:GQ:...' column} as `mchap call-exact` writes it.  `calling`: the module
-    mchap_amd.calling (GPU, default) or an OracleBackend."""
-    from mchap_amd import encoding
-
-    if calling is None:
-        from mchap_amd import calling
-
-    locus = Locus(rec, prior_tag)
-    haps = locus.haplotypes
-    H, M = haps.shape
-    full = ("GL" in report) or ("GP" in report)
-    cols = {}
-    for sample in sample_names:
-        chars, quals = extract_read_variants(locus, bams[sample], sample)
-        rcount = chars.shape[0]
-        depth = (chars != "-").sum(axis=0) if M else np.array([])
-        dp = np.round(np.mean(depth)) if len(depth) else np.nan
-        calls = np.full(chars.shape, -1, dtype=np.int8)
-        for j in range(M):
-            for a, c in enumerate(locus.alleles[j]):
-                calls[chars[:, j] == c, j] = a
-        dists = encoding.encode_read_distributions(locus.n_alleles, calls, quals if use_phred else None, error_rate=error_rate)
-        rcalls = int((calls >= 0).sum())
-        uniq, counts = encoding.unique_counts(dists)
-        prior = None if inbreeding is None else (inbreeding, locus.frequencies)
-        extra = {}
-        # invalid scenarios (application/call_exact.py:78-107): only allele masked (NOA) / zero prior frequencies (AF0)
-        if (locus.mask_reference_allele and H == 1) or np.any(np.isnan(locus.frequencies)):
-            fields = ["/".join(["."] * ploidy), ".", ".", vcfstr(float(dp)), str(rcount), str(rcalls), ".", ".", ".", ".", "."]
-            fields += ["."] * len(report)
-            cols[sample] = ":".join(fields)
-            continue
-        if M == 0 or H == 1:
-            # a single haplotype: one genotype with probability 1 (the reference's arithmetic gives exactly that)
-            alleles, gprob, sprob = np.zeros(ploidy, int), 1.0, 1.0
-            freqs, occur = np.ones(1), np.ones(1)
-            extra = dict(GL=np.zeros(1), GP=np.ones(1))
-        elif full:
-            llks = calling.genotype_likelihoods(uniq, ploidy, haps, read_counts=counts)
-            probs = calling.genotype_posteriors(llks, ploidy, H, prior=prior)
-            idx = int(np.argmax(probs))
-            alleles = calling.index_as_genotype_alleles(idx, ploidy)
-            gprob = probs[idx]
-            sprob = calling.alternate_dosage_posteriors(alleles, probs)[1].sum()
-            freqs, _, occur = calling.posterior_allele_frequencies(probs, ploidy, H)
-            extra = dict(GL=llks.astype(np.float64) / np.log(10), GP=probs)
-        else:
-            alleles, _, gprob, sprob, freqs, occur = calling.posterior_mode(
-                uniq, ploidy, haps, read_counts=counts, prior=prior, return_support_prob=True,
-                return_posterior_frequencies=True, return_posterior_occurrence=True)
-        mec = int(np.sum((calls[:, None, :] != haps[alleles][None]) & (calls[:, None, :] >= 0), axis=-1).min(axis=-1).sum()) if rcount else 0
-        denom = int((calls >= 0).sum())
-        mecp = mec / denom if denom > 0 else np.nan
-        fields = ["/".join(str(a) for a in alleles), vcfstr(qual_of_prob(gprob)), vcfstr(qual_of_prob(sprob)), vcfstr(float(dp)),
-                  str(rcount), str(rcalls), str(mec), vcfstr(float(mecp)), vcfstr(float(gprob)), vcfstr(float(sprob)), "."]
-        for tag in report:
-            if tag == "AFP":
-                fields.append(vcfstr(np.asarray(freqs, float)))
-            elif tag == "ACP":
-                fields.append(vcfstr(np.asarray(freqs, float) * ploidy))
-            elif tag == "AOP":
-                fields.append(vcfstr(np.asarray(occur, float)))
-            elif tag == "SNVDP":
-                fields.append(vcfstr(np.round(depth).astype(float)) if len(depth) else ".")
-            elif tag in ("GL", "GP"):
-                fields.append(vcfstr(np.asarray(extra[tag], float)))
-        cols[sample] = ":".join(fields)
-    return cols
-
-
-# ---- de novo assembly loci (mchap assemble): targets from a BED file, SNVs from a VCF (io/loci.py:94-135) ----
-class DenovoLocus:
-    def __init__(self, contig, start, stop, name, variant_records, sequence):
-        self.contig, self.start, self.stop, self.name, self.sequence = contig, start, stop, name, sequence
-        snps = {}
-        for r in variant_records:
-            alleles = (r["ref"],) + r["alts"]
-            if r["chrom"] != contig or not (start <= r["pos"] - 1 < stop) or any(len(a) != 1 for a in alleles):
-                continue
-            p = r["pos"] - 1
-            if p in snps:  # _merge_snps (io/loci.py:364-382)
-                assert snps[p][0] == alleles[0]
-                snps[p] = snps[p] + tuple(a for a in alleles if a not in snps[p])
-            else:
-                snps[p] = alleles
-        self.positions = list(snps)
-        self.alleles = [snps[p] for p in self.positions]
-        self.n_alleles = [len(a) for a in self.alleles]
-
-    def format_haplotype(self, alleles):
-        chars = list(self.sequence)
-        for p, tup, a in zip(self.positions, self.alleles, alleles):
-            chars[p - self.start] = tup[int(a)]
-        return "".join(chars)
-
-
-def read_bed4(path):
-    return [(f[0], int(f[1]), int(f[2]), f[3]) for f in (line.split() for line in open(path)) if len(f) >= 4]
+def call_record(rec, bams, sample_names, calling=None, **kw):
+    """-> {sample: column} (the sample columns of one record)."""
+    return call_exact_record(rec, bams, sample_names, calling=calling, **kw)[3]
 
 
 def sample_reads(locus, bam, sample, error_rate=0.0024):
-    """-> (calls int8 [R, M], distinct read distributions, counts) of one sample at a locus."""
-    from mchap_amd import encoding
-
-    chars, _ = extract_read_variants(locus, bam, sample)
-    calls = np.full(chars.shape, -1, dtype=np.int8)
-    for j in range(len(locus.positions)):
-        for a, c in enumerate(locus.alleles[j]):
-            calls[chars[:, j] == c, j] = a
-    dists = encoding.encode_read_distributions(locus.n_alleles, calls, None, error_rate=error_rate)
-    uniq, counts = encoding.unique_counts(dists)
-    return calls, uniq, counts
+    """-> (calls, distinct read distributions, counts)"""
+    sr = _sample_reads(locus, bam, sample, error_rate)
+    return sr["calls"], sr["dists"], sr["counts"]

@@ -38,3 +38,20 @@ def test_call_exact_golden_vcf(input_vcf, bam_files, kw, golden):
         got = rp.call_record(rec, bams, samples, **kw)
         for s in samples:
             assert got[s] == exp["samples"][s], (golden, rec["chrom"], rec["pos"], s, exp["format"])
+
+
+def _golden_lines(path):
+    return [ln.rstrip("\n") for ln in open(path) if ln.strip() and not ln.startswith("#")]
+
+
+@pytest.mark.parametrize("input_vcf,bam_files,kw,golden", SCENARIOS)
+def test_call_exact_whole_records(input_vcf, bam_files, kw, golden):
+    """mchap_amd.application.call_exact: every record line (CHROM .. FILTER, INFO, FORMAT, samples) equals the golden's."""
+    from mchap_amd import application
+
+    args = dict(report=kw.get("report", ()), base_error_rate=kw.get("error_rate", 0.0024),
+                use_base_phred_scores=kw.get("use_phred", False), prior_frequencies_tag=kw.get("prior_tag"),
+                inbreeding=kw.get("inbreeding"))
+    bams = {s: os.path.join(HERE, f) for s, f in zip(["SAMPLE1", "SAMPLE2", "SAMPLE3"], bam_files)}
+    got = list(application.call_exact(os.path.join(HERE, input_vcf), bams, **args))
+    assert got == _golden_lines(os.path.join(HERE, golden))

@@ -253,3 +253,26 @@ def test_oracle_replays_the_call_exact_golden_vcfs():
             got = rp.call_record(rec, bams, samples, calling=backend, **kw)
             for s in samples:
                 assert got[s] == exp["samples"][s], (golden, rec["chrom"], rec["pos"], s)
+
+
+def test_application_call_exact_whole_records_with_the_oracle():
+    """mchap_amd.application.call_exact driven by the oracle: whole record lines of the eight golden VCFs."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import replay_call_exact as rp
+    from mchap_amd import application
+    from test_gpu_call_exact_goldens import HERE, SCENARIOS, _golden_lines
+
+    backend = rp.OracleBackend()
+    for input_vcf, bam_files, kw, golden in SCENARIOS:
+        args = dict(report=kw.get("report", ()), base_error_rate=kw.get("error_rate", 0.0024),
+                    use_base_phred_scores=kw.get("use_phred", False), prior_frequencies_tag=kw.get("prior_tag"),
+                    inbreeding=kw.get("inbreeding"), calling=backend)
+        bams = {s: os.path.join(HERE, f) for s, f in zip(["SAMPLE1", "SAMPLE2", "SAMPLE3"], bam_files)}
+        got = list(application.call_exact(os.path.join(HERE, input_vcf), bams, **args))
+        want = _golden_lines(os.path.join(HERE, golden))
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g == w, (golden, g, w)
