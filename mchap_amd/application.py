@@ -166,3 +166,112 @@ def call_exact(vcf_path, sample_bams, ploidy=4, report=(), base_error_rate=0.002
                                                  prior_frequencies_tag, inbreeding, calling)
         alt = ",".join(rec["alts"]) if rec["alts"] else "."
         yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mchap assemble (application/assemble.py:95-252, assemble/haplotype_calling.py:4-64)
+# ---------------------------------------------------------------------------------------------------------
+def call_posterior_haplotypes(posteriors, threshold=0.01):
+    """Haplotype alleles of the VCF record from the samples' posteriors: every haplotype whose occurrence probability
+    reaches `threshold` in some sample, ordered by summed dosage weight (descending), reference first."""
+    arrays, values = {}, {}
+    for post in posteriors:
+        haps, weights, probs = post.allele_frequencies(dosage=True)
+        keep = probs >= threshold
+        for h, w in zip(haps[keep], weights[keep]):
+            b = h.tobytes()
+            if b not in arrays:
+                arrays[b] = h
+                values[b] = 0
+            values[b] += w
+    ref = [b for b, h in arrays.items() if np.all(h == 0)]
+    ref_observed = bool(ref)
+    for b in ref:
+        arrays.pop(b)
+        values.pop(b)
+    n_base = posteriors[0].genotypes.shape[-1]
+    haplotypes = np.full((len(arrays) + 1, n_base), -1, np.int8)
+    vals = np.full(len(arrays) + 1, -1, float)
+    for i, (b, h) in enumerate(arrays.items()):
+        haplotypes[i] = h
+        vals[i] = values[b]
+    haplotypes[-1][:] = 0
+    vals[-1] = vals.max() + 1
+    order = np.flip(np.argsort(vals))
+    return haplotypes[order], ref_observed
+
+
+def assemble_record(locus, bams, samples, ploidy=4, inbreeding=None, steps=1000, burn=500, chains=2, seed=None,
+                    error_rate=0.0024, use_phred=False, haplotype_posterior_threshold=0.20, incongruence_threshold=0.60,
+                    **mcmc_kw):
+    """One target locus (DenovoLocus) -> the VCF record line of `mchap assemble` (no --report extras)."""
+    from .assemble import DenovoMCMC
+
+    M = len(locus.positions)
+    per = {}
+    posteriors = []
+    for sample in samples:
+        sr = sample_reads(locus, bams[sample], sample, error_rate, use_phred)
+        model = DenovoMCMC(ploidy=ploidy, n_alleles=locus.n_alleles, inbreeding=inbreeding, steps=steps, chains=chains,
+                           random_seed=seed, **mcmc_kw)
+        trace = model.fit(sr["dists"], read_counts=sr["counts"]).burn(burn)
+        post = trace.posterior()
+        posteriors.append(post)
+        support = post.mode_genotype_support()
+        sprob = float(support.probabilities.sum())
+        genotype, gprob = support.mode_genotype()
+        calls, depth = sr["calls"], sr["depth"]
+        mec = _mec(calls, genotype)
+        denom = int((calls >= 0).sum())
+        per[sample] = dict(genotype=genotype, gprob=float(gprob), sprob=sprob, mec=mec, mecp=mec / denom if denom > 0 else np.nan,
+                           mci=int(trace.replicate_incongruence(threshold=incongruence_threshold)), rcount=len(calls),
+                           rcalls=denom, dp=np.round(np.mean(depth)) if len(depth) else np.nan)
+    haplotypes, ref_called = call_posterior_haplotypes(posteriors, threshold=haplotype_posterior_threshold)
+    labels = {h.tobytes(): i for i, h in enumerate(haplotypes)}
+    flt = "PASS"
+    if not ref_called:
+        labels.pop(haplotypes[0].tobytes())
+        if len(haplotypes) == 1:
+            flt = "NOA"
+    alts = [locus.format_haplotype(h) for h in haplotypes[1:]]
+    counts = np.zeros(len(haplotypes), int)
+    cols = []
+    for sample in samples:
+        d = per[sample]
+        a = np.sort([labels.get(h.tobytes(), -1) for h in d["genotype"]])
+        a = np.append(a[a >= 0], a[a < 0])
+        for x in a:
+            if x >= 0:
+                counts[x] += 1
+        d["alleles"] = a
+        fields = ["/".join(str(x) if x >= 0 else "." for x in a), vcfstr(qual_of_prob(d["gprob"])), vcfstr(qual_of_prob(d["sprob"])),
+                  vcfstr(float(d["dp"])), str(d["rcount"]), str(d["rcalls"]), str(d["mec"]), vcfstr(float(d["mecp"])),
+                  vcfstr(d["gprob"]), vcfstr(d["sprob"]), str(d["mci"])]
+        cols.append(":".join(fields))
+    info = [("AN", int(counts.sum())), ("UAN", int((counts > 0).sum())), ("AC", counts[1:])]
+    if not ref_called:
+        info.append(("REFMASKED", True))
+    info += [("NS", sum(int(np.any(per[s]["alleles"] >= 0)) for s in samples)), ("MCI", sum(int(per[s]["mci"] > 0) for s in samples)),
+             ("DP", float(np.nansum([per[s]["dp"] for s in samples])) if M else np.nan),
+             ("RCOUNT", int(sum(per[s]["rcount"] for s in samples))), ("END", locus.stop), ("NVAR", M),
+             ("SNVPOS", np.array(locus.positions, int) - locus.start + 1)]
+    parts = []
+    for k, v in info:
+        if isinstance(v, bool):
+            if v:
+                parts.append(k)
+        else:
+            parts.append("%s=%s" % (k, vcfstr(v)))
+    return "\t".join([locus.contig, str(locus.start + 1), locus.name, locus.sequence, ",".join(alts) if alts else ".", ".", flt,
+                      ";".join(parts), ":".join(SAMPLE_FIELDS)] + cols)
+
+
+def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, **kw):
+    """`mchap assemble` over the targets of a BED4 file: yields one VCF record line per target (no header).
+    reference_sequences: {contig: sequence string}; sample_bams: ordered mapping sample name -> BAM path."""
+    samples = list(sample_bams)
+    bams = {s: read_bam(p) for s, p in sample_bams.items()}
+    _, variants = read_vcf(variants_vcf_path)
+    for contig, start, stop, name in read_bed4(bed_path):
+        locus = DenovoLocus(contig, start, stop, name, variants, reference_sequences[contig][start:stop])
+        yield assemble_record(locus, bams, samples, **kw)

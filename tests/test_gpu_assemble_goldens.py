@@ -57,3 +57,17 @@ def test_deep_assemble_golden_exactly():
         assert mine == gold, (name, s)
         assert rp.vcfstr(gpm) == f["GPM"] and rp.vcfstr(spm) == f["SPM"], (name, s, gpm, spm)
         assert str(rp.qual_of_prob(gpm)) == f["GQ"] and str(rp.qual_of_prob(spm)) == f["SQ"]
+
+
+def test_deep_assemble_golden_whole_records():
+    """mchap_amd.application.assemble on the deep BAMs (concentrated posteriors: nothing depends on the generator):
+    every record line of the reference's golden VCF, allele order, INFO and MCI included."""
+    from mchap_amd import application
+
+    bams = {s: os.path.join(HERE, f) for s, f in zip(["SAMPLE1", "SAMPLE2", "SAMPLE3"],
+                                                     ["simple.sample1.deep.bam", "simple.sample2.deep.bam", "simple.sample3.deep.bam"])}
+    ref = {c: SEQ for c in ("CHR1", "CHR2", "CHR3")}
+    got = list(application.assemble(os.path.join(HERE, "simple.bed"), os.path.join(HERE, "simple.vcf"), ref, bams, ploidy=4,
+                                    inbreeding=0.0, steps=500, burn=100, chains=2, seed=11))
+    want = [ln.rstrip("\n") for ln in open(os.path.join(HERE, "simple.output.deep.assemble.vcf")) if ln.strip() and not ln.startswith("#")]
+    assert got == want
