@@ -49,6 +49,7 @@ struct SimtParams {
   int max_pos, max_allele, max_ploidy;
   int max_ma;        // max over units of n_pos * max_allele
   int max_ugens_pad; // doubles reserved for the SNV posterior scratch of the prepare pass
+  int prep_rows_off; // byte offset of the prepare pass's per-position row staging in its LDS
   int flags;         // debugging: bit 0 no mutation memo, bit 1 no interval memo (MCHAP_HIP_FLAGS); bit 30 below
 };
 constexpr int SIMT_FLAG_PREP_GLOBAL = 1 << 30;  // table too large for the prepare pass's LDS copy
@@ -179,9 +180,19 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
   // homozygous fix (assemble/mcmc.py:168-182, 494-541; snpcalling.py:14-70)
   int Mh = 0;
   double luh = 0.0;
+  // without the LDS copy of the whole table, the A rows of the current position are staged in LDS (each lane its own
+  // reads): the genotype loop below re-reads them K times per genotype
+  double *pl = reinterpret_cast<double *>(smem + P.prep_rows_off);  // [A][rpad]
   for (int j = 0; j < M0; j++) {
     const int n = nalleles[j];
     const int u_gens = snv_genotypes(n, K);
+    const double *rowp = rl + (size_t)(j * A) * rpad;
+    if (!in_lds) {
+      for (int a = 0; a < A; a++)
+#pragma unroll
+        for (int i = 0; i < RPL; i++) pl[(size_t)a * rpad + lane + WAVE * i] = rt[(size_t)(j * A + a) * rpad + lane + WAVE * i];
+      rowp = pl;
+    }
     uint32_t g = 0;
     for (int q = 0; q < u_gens; q++) {
       double lprior = 0.0;
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
 #pragma unroll
       for (int i = 0; i < RPL; i++) {
         double rp = 0.0;
-        for (int h = 0; h < K; h++) rp += rl[(size_t)(j * A + nib(g, h)) * rpad + lane + WAVE * i] / (double)K;
+        for (int h = 0; h < K; h++) rp += rowp[(size_t)nib(g, h) * rpad + lane + WAVE * i] / (double)K;
         s += log(rp) * cnt[i];
       }
       const double llk = wave_sum(s);

@@ -541,8 +541,12 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     const size_t lds_dict = (size_t)mchap::DICT_HASH * (8 + 2) + 64;  // hash set of the dictionary pass
     size_t lds_prep = (size_t)B.max_ma * rpad * 8 + (size_t)SP.max_ugens_pad * 8 + lds_dict;
     // (an LDS copy of more than a few KB costs the prepare pass its occupancy: one wavefront per workgroup)
+    SP.prep_rows_off = 0;
     if (lds_prep > 160 * 1024 || (size_t)B.max_ma * rpad * 8 > (size_t)prep_lds_copy_limit()) {
       lds_prep = (size_t)SP.max_ugens_pad * 8 + lds_dict;
+      lds_prep = (lds_prep + 15) & ~(size_t)15;
+      SP.prep_rows_off = (int)lds_prep;  // the rows of one position: [max_allele][rpad] float64
+      lds_prep += (size_t)B.max_allele * rpad * 8;
       SP.flags |= mchap::SIMT_FLAG_PREP_GLOBAL;
     }
     const size_t lds_simt = mchap::simt_lds_bytes(B.max_ploidy, B.max_pos, cfg->n_temps);
