@@ -56,9 +56,6 @@ __host__ __device__ inline int spec_draws(int K, int Mmax) {
   int d = 2 * K * Mmax - 1;
   if (d < 3 * Mmax + 2) d = 3 * Mmax + 2;
   d = (d + 1) & ~1;
-#ifdef MCHAP_FAT_DRAWS
-  return SPEC_DRAWS_MAX;
-#endif
   return d < SPEC_DRAWS_MAX ? d : SPEC_DRAWS_MAX;
 }
 
@@ -123,16 +120,8 @@ __host__ __device__ inline size_t spec_memo_bytes(int Mmax, int T, int G) {
 __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int T, int G) {
   const int NG = 64 / G;
   const int nmax = K * Mmax;
-#ifdef MCHAP_FAT_OPT
-  const int nopt = 8;
-#else
   const int nopt = Amax > 1 ? Amax - 1 : 1;
-#endif
-#ifdef MCHAP_FAT_IV
-  const int niv = 64;
-#else
   const int niv = Mmax + 1;
-#endif
   size_t b = 0;
   b += (size_t)8 * K * 64;               // pw
   b += (size_t)8 * NG * T * K;           // wst
@@ -161,9 +150,6 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int 
   b = (b + 15) & ~(size_t)15;
   b += (size_t)8 * NG * spec_draws(K, Mmax);
   b += spec_memo_bytes(Mmax, T, G);
-#ifdef MCHAP_LDS_GUARD
-  b += 64 * 32;
-#endif
   return (b + 63) & ~(size_t)63;
 }
 
@@ -616,18 +602,13 @@ __device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int
   }
 }
 
-// Serves every request of the wave (bit mask `todo`), one after the other, with all 64 lanes; kept out of line so
-// that its registers (RPL x UNR loads in flight) do not count against the sampler's main loop.
-#ifndef MCHAP_COOP_NOINLINE
-#define COOP_FN __device__ __forceinline__
-#else
-#define COOP_FN __device__ __noinline__
-#endif
+// Serves every request of the wave (bit mask `todo`), chain by chain, with all 64 lanes.  Inlined on purpose: see the
+// note on device function calls in DESIGN.md section 4.1.
 template <int KT, int G>
-COOP_FN double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
-                                             LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab,
-                                             LDSP(uint16_t) ndict_tab, LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, LDSP(uint64_t) bw_tab, bool reuse, int mmax, int Mh_lane, uint32_t amask_lane,
-                                             int rpad, int lane) {
+__device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
+                                                LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab, LDSP(uint16_t) ndict_tab,
+                                                LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, LDSP(uint64_t) bw_tab,
+                                                bool reuse, int mmax, int Mh_lane, uint32_t amask_lane, int rpad, int lane) {
   SpecLds S;
   S.pw = pwbuf;
   S.shift = shift_tab;
@@ -731,11 +712,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
     ulonglong2 *set = reinterpret_cast<ulonglong2 *>((uintptr_t)S.gptr[(lane / G) * GP_N + GP_CACHE]) + 8 * (size_t)((hsh >> 12) & S.cache_mask);
     int way = (int)((hsh >> 24) & 7u);
     bool empty_seen = false;
-#ifdef MCHAP_PROBE_UNR
-#pragma unroll MCHAP_PROBE_UNR
-#else
 #pragma unroll
-#endif
     for (int w = 7; w >= 0; w--) {
       const ulonglong2 e = set[w];
       if (e.x == tag) {
@@ -782,14 +759,9 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
 #ifndef MCHAP_SPEC_WPE
 #define MCHAP_SPEC_WPE 2
 #endif
-#ifdef MCHAP_SPEC_NOINLINE
-#define SPEC_FN __device__ __noinline__
-#else
-#define SPEC_FN __device__ __forceinline__
-#endif
 
 template <int KT, int G>
-SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, int mmax, int nmax, int rpad,
+__device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, int mmax, int nmax, int rpad,
                                               int lane, int gi, int gl) {
   const int Mh = c.Mh;
   const int n = KT * Mh;  // sub-steps; position p of the sequence is held by lane p % G, slot p / G (n <= 2 G)
@@ -1012,16 +984,12 @@ SPEC_FN void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, 
 // One structural compound step (structural.py:22-71, 433-673) of kind 0 recombination, 1 interval dosage,
 // 2 whole-haplotype dosage.  Returns false if the group hit the reference's "breaks" ValueError.
 template <int KT, int G>
-SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D, int kind, double temp,
+__device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D, int kind, double temp,
                                                 const double *break_dist, int n_break_dist, int mmax, int rpad, int lane,
                                                 int gi, int gl) {
   const int Mh = c.Mh;
   const int step_type = kind == 0 ? 0 : 1;
-#ifdef MCHAP_FAT_IV
-  const int nivs = 64;
-#else
   const int nivs = mmax + 1;
-#endif
   LDSP(uint32_t) ivse = S.ivse + gi * nivs;
   LDSP(uint32_t) ivlin = S.ivlin + gi * nivs;
   LDSP(uint32_t) ivlout = S.ivlout + gi * nivs;
@@ -1377,37 +1345,7 @@ SPEC_FN bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D
   return ok;
 }
 
-#ifdef MCHAP_SPEC_LOG
-constexpr int LOG_CHAINS = 8, LOG_STEPS = 64, LOG_EV = 4, LOG_F = 4;
-static __device__ unsigned long long g_log[LOG_CHAINS * LOG_STEPS * LOG_EV * LOG_F];
-#define SPEC_LOG(ev)                                                                                 \
-  do {                                                                                               \
-    if (gl == 0 && q < LOG_CHAINS && step < LOG_STEPS) {                                             \
-      unsigned long long *L_ = g_log + (((size_t)q * LOG_STEPS + step) * LOG_EV + (ev)) * LOG_F;     \
-      unsigned long long hsh_ = 0;                                                                   \
-      for (int h_ = 0; h_ < KT; h_++) hsh_ = hsh_ * 1000003ull + sel_word<KT>(c.g, h_);                          \
-      L_[0] = c.ctr;                                                                                 \
-      L_[1] = (unsigned long long)__double_as_longlong(c.llk);                                       \
-      L_[2] = hsh_;                                                                                  \
-      L_[3] = c.alive;                                                                               \
-    }                                                                                                \
-  } while (0)
-#else
-#define SPEC_LOG(ev)
-#endif
 
-#ifdef MCHAP_LDS_GUARD
-#define GUARD_BYTES 64
-#define GUARD_STEP                                                   \
-  do {                                                               \
-    const int lo_ = (P.flags >> 8) & 0xff, hi_ = (P.flags >> 16) & 0xff; \
-    if (n_guard >= lo_ && n_guard < hi_) p += GUARD_BYTES;           \
-    guard_off[n_guard++] = 0;                                        \
-  } while (0)
-#else
-#define GUARD_BYTES 0
-#define GUARD_STEP
-#endif
 
 template <int KT, int G>
 __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const SimtParams P) {
@@ -1419,66 +1357,46 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   const int T = D.n_temps, Cn = D.chains, Sn = D.steps;
   const int mmax = P.max_pos, nmax = KT * P.max_pos;
   const int rpad = D.rpad;
-#ifdef MCHAP_LDS_GUARD
-  int guard_off[32];
-  int n_guard = 0;
-#endif
-#ifdef MCHAP_LDS_ZERO
-  {
-    const int nb8 = (int)(spec_lds_bytes(KT, P.max_pos, P.max_allele, D.n_temps, G) / 8);
-    LDSP(uint64_t) z = lds_cast<uint64_t>(smem);
-    for (int i = threadIdx.x; i < nb8; i += WAVE) z[i] = MCHAP_LDS_ZERO;
-    lds_sync();
-  }
-#endif
   SpecLds S;
   {
-#ifdef MCHAP_FAT_OPT
-    const int nopt = 8;
-#else
     const int nopt = P.max_allele > 1 ? P.max_allele - 1 : 1;
-#endif
-#ifdef MCHAP_FAT_IV
-    const int niv = 64;
-#else
     const int niv = mmax + 1;
-#endif
     unsigned char *p = smem;
-    S.pw = lds_cast<uint64_t>(p); p += (size_t)8 * KT * 64; GUARD_STEP;
-    S.wst = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T * KT; GUARD_STEP;
-    S.llk_t = lds_cast<double>(p); p += (size_t)8 * NG * T; GUARD_STEP;
-    S.rngn = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T; GUARD_STEP;
-    S.prior = lds_cast<double>(p); p += (size_t)8 * NG * (2 * KT + 5); GUARD_STEP;
-    S.ptab = lds_cast<double>(p); p += (size_t)8 * 64; GUARD_STEP;
-    S.optp = lds_cast<double>(p); p += (size_t)8 * nopt * 64; GUARD_STEP;
-    S.optl = lds_cast<double>(p); p += (size_t)8 * nopt * 64; GUARD_STEP;
-    S.ln = lds_cast<double>(p); p += (size_t)8 * SPEC_LN; GUARD_STEP;
-    S.lninv = lds_cast<double>(p); p += (size_t)8 * SPEC_LN; GUARD_STEP;
-    S.bdist = lds_cast<double>(p); p += (size_t)8 * NG * mmax; GUARD_STEP;
-    S.ivse = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv; GUARD_STEP;
-    S.ivlin = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv; GUARD_STEP;
-    S.ivlout = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv; GUARD_STEP;
-    S.ivno = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv; GUARD_STEP;
-    S.cols = lds_cast<uint16_t>(p); p += (size_t)2 * NG * mmax; GUARD_STEP;
-    S.permtab = lds_cast<uint16_t>(p); p += (size_t)2 * NG * nmax; GUARD_STEP;
-    S.shift = lds_cast<uint8_t>(p); p += (size_t)NG * mmax; GUARD_STEP;
-    S.nal = lds_cast<uint8_t>(p); p += (size_t)NG * mmax; GUARD_STEP;
-    S.ktab = lds_cast<uint8_t>(p); p += (size_t)NG * nmax; GUARD_STEP;
-    S.ordtab = lds_cast<uint8_t>(p); p += (size_t)NG * niv; GUARD_STEP;
+    S.pw = lds_cast<uint64_t>(p); p += (size_t)8 * KT * 64;
+    S.wst = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T * KT;
+    S.llk_t = lds_cast<double>(p); p += (size_t)8 * NG * T;
+    S.rngn = lds_cast<uint64_t>(p); p += (size_t)8 * NG * T;
+    S.prior = lds_cast<double>(p); p += (size_t)8 * NG * (2 * KT + 5);
+    S.ptab = lds_cast<double>(p); p += (size_t)8 * 64;
+    S.optp = lds_cast<double>(p); p += (size_t)8 * nopt * 64;
+    S.optl = lds_cast<double>(p); p += (size_t)8 * nopt * 64;
+    S.ln = lds_cast<double>(p); p += (size_t)8 * SPEC_LN;
+    S.lninv = lds_cast<double>(p); p += (size_t)8 * SPEC_LN;
+    S.bdist = lds_cast<double>(p); p += (size_t)8 * NG * mmax;
+    S.ivse = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv;
+    S.ivlin = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv;
+    S.ivlout = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv;
+    S.ivno = lds_cast<uint32_t>(p); p += (size_t)4 * NG * niv;
+    S.cols = lds_cast<uint16_t>(p); p += (size_t)2 * NG * mmax;
+    S.permtab = lds_cast<uint16_t>(p); p += (size_t)2 * NG * nmax;
+    S.shift = lds_cast<uint8_t>(p); p += (size_t)NG * mmax;
+    S.nal = lds_cast<uint8_t>(p); p += (size_t)NG * mmax;
+    S.ktab = lds_cast<uint8_t>(p); p += (size_t)NG * nmax;
+    S.ordtab = lds_cast<uint8_t>(p); p += (size_t)NG * niv;
     p = smem + (((size_t)(p - smem) + 1) & ~(size_t)1);
-    S.nreads = lds_cast<uint16_t>(p); p += (size_t)2 * NG; GUARD_STEP;
-    S.ndict = lds_cast<uint16_t>(p); p += (size_t)2 * NG; GUARD_STEP;
+    S.nreads = lds_cast<uint16_t>(p); p += (size_t)2 * NG;
+    S.ndict = lds_cast<uint16_t>(p); p += (size_t)2 * NG;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
-    S.dict = lds_cast<double>(p); p += (size_t)8 * NG * DICT_MAX; GUARD_STEP;
-    S.gptr = lds_cast<uint64_t>(p); p += (size_t)8 * NG * GP_N; GUARD_STEP;
-    S.gval = lds_cast<double>(p); p += (size_t)8 * NG * GV_N; GUARD_STEP;
+    S.dict = lds_cast<double>(p); p += (size_t)8 * NG * DICT_MAX;
+    S.gptr = lds_cast<uint64_t>(p); p += (size_t)8 * NG * GP_N;
+    S.gval = lds_cast<double>(p); p += (size_t)8 * NG * GV_N;
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
-    S.gstream = lds_cast<uint32_t>(p); p += (size_t)16 * NG; GUARD_STEP;
-    S.bw = lds_cast<uint64_t>(p); p += (size_t)8 * NG * KT; GUARD_STEP;
-    S.tbuf = lds_cast<uint64_t>(p); p += (size_t)8 * NG * SPEC_TB * (KT + 1); GUARD_STEP;
+    S.gstream = lds_cast<uint32_t>(p); p += (size_t)16 * NG;
+    S.bw = lds_cast<uint64_t>(p); p += (size_t)8 * NG * KT;
+    S.tbuf = lds_cast<uint64_t>(p); p += (size_t)8 * NG * SPEC_TB * (KT + 1);
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.ndraws = spec_draws(KT, mmax);
-    S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.ndraws; GUARD_STEP;
+    S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.ndraws;
     S.memo_stride = (spec_memo_bytes(mmax, T, G) && !(P.flags & 2)) ? 2 * (mmax + 1) * (mmax + 1) : 0;
     S.memo_tot = lds_cast<double>(p);
     for (int i = lane; i < NG * S.memo_stride; i += WAVE) S.memo_tot[i] = NAN;  // nothing evaluated yet
@@ -1661,20 +1579,14 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
         status = MCHAP_UNIT_NAN_LLK;
         c.alive = false;
       }
-#ifndef MCHAP_ABL_NO_MUT
       spec_mutation<KT, G>(c, S, temp, amax, mmax, nmax, rpad, lane, gi, gl);
-#endif
-      SPEC_LOG(0);
-#ifndef MCHAP_ABL_NO_STR
 #pragma unroll 1
       for (int kind = 0; kind < 3; kind++) {
         if (!spec_structural<KT, G>(c, S, D, kind, temp, break_dist, n_break_dist, mmax, rpad, lane, gi, gl)) {
           status = MCHAP_UNIT_BREAKS;
           c.alive = false;
         }
-        SPEC_LOG(1 + kind);
       }
-#endif
       if (T > 1) {
         if (c.alive && t > 0) {
           // tempering.py:61-151 with the previous (warmer) temperature
@@ -1715,7 +1627,6 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
         lds_sync();
       }
     }
-#ifndef MCHAP_ABL_NO_TRACE
     // record the cold chain (held in registers after the last temperature) in canonical order: SPEC_TB records
     // are collected in LDS and written together, the words as one contiguous run (a full line for K = 4)
     {
@@ -1745,7 +1656,6 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
         lds_sync();
       }
     }
-#endif
   }
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
   if (threadIdx.x == 0)

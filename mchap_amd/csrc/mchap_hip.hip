@@ -283,7 +283,6 @@ int launch_spec(int K, int G, const mchap::SimtParams &P, int n_units, int chain
     if (insts[i].K == K && insts[i].G == G) inst = &insts[i];
   if (!inst) return fail(MCHAP_ERR_LIMIT, "speculative sampler: no instantiation for ploidy %d with %d lanes per chain", K, G);
   size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, n_temps, G);
-  if (const char *e = std::getenv("MCHAP_HIP_LDS_PAD")) lds += (size_t)std::atoi(e);  // debugging: lower occupancy
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
   const long long n_chains = (long long)n_units * chains;
   const int per_wave = 64 / G;
@@ -357,12 +356,6 @@ double mchap_last_sampler_ms(void) {
 
 const char *mchap_last_sampler_name(void) { return g_sampler_name; }
 
-#ifdef MCHAP_SPEC_LOG
-int mchap_debug_log(unsigned long long *out) {
-  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_log), sizeof(unsigned long long) * 8 * 64 * 4 * 4));
-  return 0;
-}
-#endif
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
 /* profiling builds only (make STATS=1): [0] likelihood requests, [1] cache misses, [2] probe slots */
 int mchap_debug_stats(unsigned long long *out, int reset) {
