@@ -15,6 +15,11 @@
 // transpositions (draws computed in parallel).  Structural steps speculate over (interval, option) pairs the same
 // way; their draws are data dependent (structural.py:504-506) and are consumed in the sequential validation walk.
 //
+// On top of that (all results-neutral): memoised no-move outcomes per genotype (bounds of the
+// mutation step's uniforms, total move probability of every visited interval step), a window of staged draws shared
+// by the compound steps of one MCMC step, the read table as uint8 codes into a per-unit dictionary held in LDS, and
+// reuse of the current genotype's haplotype products by the requests of one chain.
+//
 // Launch: one wavefront per 64/G chains, all units of a launch share the ploidy KT; prepare kernel and workspace
 // as for the lanes-over-chains kernel (denovo_simt_kernel.hpp).  Same traces as the other two kernels.
 #pragma once
