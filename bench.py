@@ -188,7 +188,10 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -257,7 +260,7 @@ def main():
                 out["cpu_baseline"]["max_abs_delta_gpm"] = dgpm
         print(json.dumps(out))
     if dist is not None:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
