@@ -41,7 +41,7 @@ struct SimtParams {
   // workspace carved by the host
   double *rt;        // [U][max_ma][rpad]
   double *cntw;      // [U][rpad]
-  uint8_t *codes;    // [U][max_ma][64][rpad / 64]: code of read lane + 64 i at byte i of the lane's group
+  uint8_t *codes;    // [U][max_ma][64][cstride]: code of read lane + 64 i at byte i of the lane's group
   double *dict;      // [U][DICT_MAX]
   int32_t *meta_i;   // [U][meta_i_stride]
   double *meta_f;    // [U][meta_f_stride]
@@ -50,6 +50,7 @@ struct SimtParams {
   int max_ma;        // max over units of n_pos * max_allele
   int max_ugens_pad; // doubles reserved for the SNV posterior scratch of the prepare pass
   int prep_rows_off; // byte offset of the prepare pass's per-position row staging in its LDS
+  int cstride;       // bytes per lane and row of the coded table: rpad / 64 rounded up to 1, 2 or a multiple of 4
   int flags;         // debugging: bit 0 no mutation memo, bit 1 no interval memo (MCHAP_HIP_FLAGS); bit 30 below
 };
 constexpr int SIMT_FLAG_PREP_GLOBAL = 1 << 30;  // table too large for the prepare pass's LDS copy
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
     }
     __syncthreads();
     const int nd = *ndist;
-    uint8_t *ct = P.codes + (size_t)u * P.max_ma * rpad;
+    uint8_t *ct = P.codes + (size_t)u * P.max_ma * WAVE * P.cstride;
     double *dict = P.dict + (size_t)u * DICT_MAX;
     if (nd <= DICT_MAX) {
       int base = 0;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
           const unsigned long long key = (unsigned long long)__double_as_longlong(rt[(size_t)q * rpad + r]);
           unsigned slot = (unsigned)(mix64(key) & (DICT_HASH - 1));
           while (hkeys[slot] != key) slot = (slot + 1) & (DICT_HASH - 1);
-          ct[((size_t)q * WAVE + lane) * RPLT + r / WAVE] = (uint8_t)hcode[slot];
+          ct[((size_t)q * WAVE + lane) * P.cstride + r / WAVE] = (uint8_t)hcode[slot];
         }
       }
     }

@@ -47,9 +47,6 @@
 #ifndef MCHAP_CODED_UNR
 #define MCHAP_CODED_UNR 16  // code loads (one register each) in flight per lane in the coded evaluation
 #endif
-#ifndef MCHAP_COOP_RPL
-#define MCHAP_COOP_RPL 4  // read chunks (of 64) per pass for read depths above 128; rpad is a multiple of 64 * this
-#endif
 
 namespace mchap {
 
@@ -107,6 +104,7 @@ struct SpecLds {
   uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
   bool cache_on;
   bool reuse_on;          // haplotype products of the chain's current genotype are reused by its proposals
+  int crow;               // bytes per row of the coded table (64 lanes x SimtParams::cstride)
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
   LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] total move probability of an interval step for the current
                              // genotype; NaN = not evaluated yet, -1 = the step has no options
@@ -458,8 +456,9 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
 // Same factors in the same order, hence the same value as spec_coop_body.
 template <int KT, int RPL, class CT>
 __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
-                                                  GLBP(const uint8_t) ct, GLBP(const double) cw, int rpad, int lane) {
-  // ct points at the lane's first code of the block of RPL chunks; cw at the lane's first read of the block
+                                                  GLBP(const uint8_t) ct, GLBP(const double) cw, int crow, int lane) {
+  // ct points at the lane's first code of the block of RPL chunks; cw at the lane's first read of the block;
+  // crow = bytes per row of the coded table
   constexpr int UNR = MCHAP_CODED_UNR;
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   const int n_pairs = KT * Mh;
@@ -489,7 +488,7 @@ __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int
       for (int u = 0; u < UNR; u++) {
         const int q = q0 + u;
         const int row = __builtin_amdgcn_readlane(myrow, q < lim ? q : 0);
-        cd[u] = *reinterpret_cast<GLBP(const CT)>(ct + (size_t)row * rpad);
+        cd[u] = *reinterpret_cast<GLBP(const CT)>(ct + (size_t)row * crow);
       }
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
@@ -540,7 +539,7 @@ __device__ __forceinline__ void spec_pair_rows(LDSP(const uint64_t) words, int w
 // chunk i, in position order: the factors and their order are those of spec_coop_coded
 template <int RPL, class CT>
 __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int row1, int p0, int Mh, GLBP(const uint8_t) ct,
-                                              int rpad, double (&prod)[RPL]) {
+                                              int crow, double (&prod)[RPL]) {
   constexpr int UNR = 8;
 #pragma unroll
   for (int i = 0; i < RPL; i++) prod[i] = 1.0;
@@ -550,7 +549,7 @@ __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int r
     for (int u = 0; u < UNR; u++) {
       const int p = __builtin_amdgcn_readfirstlane(p0 + min(j0 + u, Mh - 1));
       const int row = p < WAVE ? __builtin_amdgcn_readlane(row0, p & (WAVE - 1)) : __builtin_amdgcn_readlane(row1, p & (WAVE - 1));
-      cd[u] = *reinterpret_cast<GLBP(const CT)>(ct + (size_t)row * rpad);
+      cd[u] = *reinterpret_cast<GLBP(const CT)>(ct + (size_t)row * crow);
     }
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
@@ -564,7 +563,7 @@ __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int r
 // One request with reuse: haplotypes whose word equals the base word take the base product bp[h].
 template <int KT, int RPL, class CT>
 __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
-                                                  GLBP(const uint8_t) ct, GLBP(const double) cw, int rpad, int lane,
+                                                  GLBP(const uint8_t) ct, GLBP(const double) cw, int crow, int lane,
                                                   const double (&bp)[KT][4], bool use_base) {
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   const double invK = 1.0 / (double)KT;
@@ -582,7 +581,7 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
 #pragma unroll
       for (int i = 0; i < RPL; i++) ph[i] = bp[h][i];
     } else {
-      spec_hap_prod<RPL, CT>(dict, row0, row1, h * Mh, Mh, ct, rpad, ph);
+      spec_hap_prod<RPL, CT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
     }
 #pragma unroll
     for (int i = 0; i < RPL; i++) acc[i] += ph[i] * invK;
@@ -594,14 +593,14 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
 }
 template <int KT, int RPL, class CT>
 __device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int mmax, int Mh, uint32_t amask,
-                                                   GLBP(const uint8_t) ct, int rpad, int lane, double (&bp)[KT][4]) {
+                                                   GLBP(const uint8_t) ct, int crow, int lane, double (&bp)[KT][4]) {
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   int row0, row1;
   spec_pair_rows<KT>(S.bw + (size_t)sg * KT, 1, 0, S, sg, mmax, Mh, amask, lane, row0, row1);
 #pragma unroll
   for (int h = 0; h < KT; h++) {
     double ph[RPL];
-    spec_hap_prod<RPL, CT>(dict, row0, row1, h * Mh, Mh, ct, rpad, ph);
+    spec_hap_prod<RPL, CT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
 #pragma unroll
     for (int i = 0; i < RPL; i++) bp[h][i] = ph[i];
   }
@@ -613,7 +612,8 @@ template <int KT, int G>
 __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
                                                 LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab, LDSP(uint16_t) ndict_tab,
                                                 LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, LDSP(uint64_t) bw_tab,
-                                                bool reuse, int mmax, int Mh_lane, uint32_t amask_lane, int rpad, int lane) {
+                                                bool reuse, int crow, int mmax, int Mh_lane, uint32_t amask_lane, int rpad,
+                                                int lane) {
   SpecLds S;
   S.pw = pwbuf;
   S.shift = shift_tab;
@@ -638,9 +638,10 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
     GLBP(const double) rt = (GLBP(const double))(uintptr_t)gp[GP_RT] + lane;
     GLBP(const double) cw = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;
     const int nrd = (int)nreads_tab[sg];
+    const int cstride = crow / WAVE;  // code bytes per lane and row
     if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && nch <= 4 && KT * Mh <= 2 * WAVE) {
       // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped
-      GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * nch;
+      GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
       const bool use_base = reuse && __popcll(reqs) >= 2;
       double bp[KT][4];
 #pragma unroll
@@ -648,17 +649,19 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
 #pragma unroll
         for (int i = 0; i < 4; i++) bp[h][i] = 0.0;
       if (use_base) {
-        if (nch == 1) spec_base_products<KT, 1, uint8_t>(S, sg, mmax, Mh, amask, ct, rpad, lane, bp);
-        else if (nch == 2) spec_base_products<KT, 2, uint16_t>(S, sg, mmax, Mh, amask, ct, rpad, lane, bp);
-        else spec_base_products<KT, 4, uint32_t>(S, sg, mmax, Mh, amask, ct, rpad, lane, bp);
+        if (nch == 1) spec_base_products<KT, 1, uint8_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        else if (nch == 2) spec_base_products<KT, 2, uint16_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        else if (nch == 3) spec_base_products<KT, 3, uint32_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        else spec_base_products<KT, 4, uint32_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
       }
       while (reqs) {
         const int src = __ffsll((long long)reqs) - 1;
         reqs &= reqs - 1;
         double s;
-        if (nch == 1) s = spec_coop_reuse<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane, bp, use_base);
-        else if (nch == 2) s = spec_coop_reuse<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane, bp, use_base);
-        else s = spec_coop_reuse<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane, bp, use_base);
+        if (nch == 1) s = spec_coop_reuse<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        else if (nch == 2) s = spec_coop_reuse<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        else if (nch == 3) s = spec_coop_reuse<KT, 3, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        else s = spec_coop_reuse<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
         s = wave_sum(s);
         if (lane == src) val = s;
       }
@@ -667,21 +670,26 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
         const int src = __ffsll((long long)reqs) - 1;
         reqs &= reqs - 1;
         // the lane's reads in blocks of at most 4 chunks of 64 (keeps the loads in flight, and the registers,
-        // bounded whatever the read depth)
+        // bounded whatever the read depth); the last block may hold 1-3 chunks
         double s = 0.0;
-        if (ndict_tab[sg] != 0) {
-          GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * nch;
-          if (nch == 1) s = spec_coop_coded<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
-          else if (nch == 2) s = spec_coop_coded<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, rpad, lane);
-          else
-            for (int cb = 0; cb < nch; cb += 4)
-              s += spec_coop_coded<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cw + cb * WAVE, rpad, lane);
-        } else if (nch == 1) s = spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
-        else if (nch == 2) s = spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rt, cw, rpad, lane, nrd);
-        else
-          for (int cb = 0; cb < nch; cb += MCHAP_COOP_RPL)
-            s += spec_coop_body<KT, MCHAP_COOP_RPL>(S, src, sg, mmax, Mh, amask, rt + cb * WAVE, cw + cb * WAVE, rpad, lane,
-                                                    nrd - cb * WAVE);
+        const bool coded = ndict_tab[sg] != 0;
+        GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
+        for (int cb = 0; cb < nch; cb += 4) {
+          const int rem = nch - cb;
+          GLBP(const double) cwb = cw + cb * WAVE;
+          if (coded) {
+            if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            else s += spec_coop_coded<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          } else {
+            GLBP(const double) rtb = rt + cb * WAVE;
+            if (rem >= 4) s += spec_coop_body<KT, 4>(S, src, sg, mmax, Mh, amask, rtb, cwb, rpad, lane, nrd - cb * WAVE);
+            else if (rem == 3) s += spec_coop_body<KT, 3>(S, src, sg, mmax, Mh, amask, rtb, cwb, rpad, lane, nrd - cb * WAVE);
+            else if (rem == 2) s += spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rtb, cwb, rpad, lane, nrd - cb * WAVE);
+            else s += spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rtb, cwb, rpad, lane, nrd - cb * WAVE);
+          }
+        }
         s = wave_sum(s);
         if (lane == src) val = s;
       }
@@ -749,7 +757,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
       for (int h = 0; h < KT; h++) S.bw[(size_t)(lane / G) * KT + h] = cg.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, mmax, c.Mh, C_AMASK(c), rpad, lane);
+    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane);
     if (miss) {
       val = v;
       if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
@@ -1433,13 +1441,14 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.gstream[gi * 4 + 3] = (uint32_t)U.stream_id;
   }
   S.reuse_on = !(P.flags & 8);
+  S.crow = WAVE * P.cstride;
   S.cache_on = D.cache_slots > 0;
   S.cache_mask = S.cache_on ? (uint32_t)(D.cache_slots / 8) - 1u : 0u;  // sets of 8 ways
   if (gl == 0) {
     LDSP(uint64_t) gp = S.gptr + gi * GP_N;
     gp[GP_RT] = (uint64_t)(uintptr_t)(P.rt + (size_t)u * P.max_ma * rpad);
     gp[GP_CW] = (uint64_t)(uintptr_t)(P.cntw + (size_t)u * rpad);
-    gp[GP_CT] = (uint64_t)(uintptr_t)(P.codes + (size_t)u * P.max_ma * rpad);
+    gp[GP_CT] = (uint64_t)(uintptr_t)(P.codes + (size_t)u * P.max_ma * WAVE * P.cstride);
     gp[GP_CACHE] = S.cache_on ? (uint64_t)(uintptr_t)(reinterpret_cast<ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots) : 0ull;
     gp[GP_TRACE] = (uint64_t)(uintptr_t)(D.trace + U.trace_off + (size_t)chain * D.steps * KT);
     gp[GP_LLK] = (uint64_t)(uintptr_t)(D.llks + U.llk_off + (size_t)chain * D.steps);
@@ -1541,7 +1550,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = g0.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, mmax, c.Mh, C_AMASK(c), rpad, lane);
+    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane);
     lds_sync();
     c.llk = __shfl(v, 0, G);
     if (c.alive && gl == 0) {

@@ -165,6 +165,9 @@ struct DevBuf {
   T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// bytes per lane and row of the coded table: 1, 2, or a multiple of 4 (the sampler loads 1 / 2 / 4 bytes at a time)
+int code_stride(int rpl) { return rpl <= 2 ? rpl : (rpl + 3) & ~3; }
+
 int rpl_for(int max_reads) {
   const int need = (max_reads + 63) / 64;
   for (int r : {1, 2, 4, 8, 16})
@@ -245,7 +248,7 @@ SimtCarve simt_carve(const mchap_denovo_cfg *cfg, int n_units, const BatchDims &
   c.cache = o; o += up256((size_t)n_units * cfg->chains * cache_slots * 16);
   c.rt = o; o += up256((size_t)n_units * B.max_ma * rpad * 8);
   c.cntw = o; o += up256((size_t)n_units * rpad * 8);
-  c.codes = o; o += up256((size_t)n_units * B.max_ma * rpad);
+  c.codes = o; o += up256((size_t)n_units * B.max_ma * 64 * code_stride(rpad / 64));
   c.dict = o; o += up256((size_t)n_units * mchap::DICT_MAX * 8);
   c.meta_i = o; o += up256((size_t)n_units * mchap::meta_i_stride(B.max_pos) * 4);
   c.meta_f = o; o += up256((size_t)n_units * mchap::meta_f_stride(B.max_ploidy, B.max_pos, B.max_allele) * 8);
@@ -331,6 +334,19 @@ size_t prep_lds_copy_limit() {
   return 8 * 1024;
 }
 
+int spec_group(int K, int max_pos);
+
+// Read chunks (of 64) per unit for the prepare pass and the sampler behind it.  The speculative sampler takes any
+// count up to 8 (then 12, 16); the lanes-over-chains kernel is instantiated for powers of two.
+int simt_rpl(const mchap_denovo_cfg *cfg, int uniform_ploidy, int max_pos, int max_reads) {
+  const bool spec = cfg->kernel != 1 && cfg->kernel != 2 && uniform_ploidy > 0 && spec_group(uniform_ploidy, max_pos) != 0;
+  if (!spec) return rpl_for(max_reads);
+  const int need = (max_reads + 63) / 64;
+  if (need <= 8) return need < 1 ? 1 : need;
+  if (need <= 12) return 12;
+  return need <= 16 ? 16 : -1;
+}
+
 bool use_simt(const mchap_denovo_cfg *cfg) { return cfg->kernel != 1; }
 
 }  // namespace
@@ -395,7 +411,8 @@ int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units, c
   if (!units_host) return -1;
   BatchDims B;
   if (batch_dims(cfg, n_units, units_host, B)) return -1;
-  const int rpl = rpl_for(B.max_reads);
+  const int rpl = simt_rpl(cfg, B.uniform_ploidy, B.max_pos, B.max_reads);
+  if (rpl < 0) return -1;
   return (int64_t)simt_carve(cfg, n_units, B, 64 * rpl, slots).total;
 }
 
@@ -446,7 +463,8 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
   BatchDims B;
   rc = batch_dims(cfg, n_units, units_host, B);
   if (rc) return rc;
-  const int rpl = rpl_for(B.max_reads);
+  const int rpl = use_simt(cfg) ? simt_rpl(cfg, B.uniform_ploidy, B.max_pos, B.max_reads) : rpl_for(B.max_reads);
+  if (rpl < 0) return fail(MCHAP_ERR_LIMIT, "n_reads %d not in 1..%d", B.max_reads, MCHAP_MAX_READS);
   const int rpad = 64 * rpl;
 
   mchap::SimtParams SP;
@@ -527,6 +545,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.max_allele = B.max_allele;
     SP.max_ploidy = B.max_ploidy;
     SP.max_ma = B.max_ma;
+    SP.cstride = code_stride(rpl);
     SP.flags = 0;
     if (const char *e = std::getenv("MCHAP_HIP_FLAGS")) SP.flags = std::atoi(e);
     // the prepare pass keeps the transposed table in LDS when it fits, else it re-reads its own global copy
@@ -548,8 +567,13 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     switch (rpl) {
       case 1: rc = launch_prepare<1>(SP, n_units, lds_prep, stream); break;
       case 2: rc = launch_prepare<2>(SP, n_units, lds_prep, stream); break;
+      case 3: rc = launch_prepare<3>(SP, n_units, lds_prep, stream); break;
       case 4: rc = launch_prepare<4>(SP, n_units, lds_prep, stream); break;
+      case 5: rc = launch_prepare<5>(SP, n_units, lds_prep, stream); break;
+      case 6: rc = launch_prepare<6>(SP, n_units, lds_prep, stream); break;
+      case 7: rc = launch_prepare<7>(SP, n_units, lds_prep, stream); break;
       case 8: rc = launch_prepare<8>(SP, n_units, lds_prep, stream); break;
+      case 12: rc = launch_prepare<12>(SP, n_units, lds_prep, stream); break;
       default: rc = launch_prepare<16>(SP, n_units, lds_prep, stream); break;
     }
     if (rc) return rc;
