@@ -639,8 +639,10 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
     GLBP(const double) cw = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;
     const int nrd = (int)nreads_tab[sg];
     const int cstride = crow / WAVE;  // code bytes per lane and row
-    if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && nch <= 4 && KT * Mh <= 2 * WAVE) {
-      // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped
+    if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && KT * Mh <= 2 * WAVE) {
+      // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped.
+      // The base products cover the first block of (up to) 4 chunks; deeper reads add their other blocks in full.
+      const int nb0 = nch < 4 ? nch : 4;
       GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
       const bool use_base = reuse && __popcll(reqs) >= 2;
       double bp[KT][4];
@@ -649,19 +651,27 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
 #pragma unroll
         for (int i = 0; i < 4; i++) bp[h][i] = 0.0;
       if (use_base) {
-        if (nch == 1) spec_base_products<KT, 1, uint8_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
-        else if (nch == 2) spec_base_products<KT, 2, uint16_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
-        else if (nch == 3) spec_base_products<KT, 3, uint32_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        if (nb0 == 1) spec_base_products<KT, 1, uint8_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        else if (nb0 == 2) spec_base_products<KT, 2, uint16_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        else if (nb0 == 3) spec_base_products<KT, 3, uint32_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
         else spec_base_products<KT, 4, uint32_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
       }
       while (reqs) {
         const int src = __ffsll((long long)reqs) - 1;
         reqs &= reqs - 1;
-        double s;
-        if (nch == 1) s = spec_coop_reuse<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
-        else if (nch == 2) s = spec_coop_reuse<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
-        else if (nch == 3) s = spec_coop_reuse<KT, 3, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
-        else s = spec_coop_reuse<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        double s = 0.0;
+        if (nb0 == 1) s += spec_coop_reuse<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        else if (nb0 == 2) s += spec_coop_reuse<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        else if (nb0 == 3) s += spec_coop_reuse<KT, 3, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        else s += spec_coop_reuse<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        for (int cb = 4; cb < nch; cb += 4) {
+          const int rem = nch - cb;
+          GLBP(const double) cwb = cw + cb * WAVE;
+          if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          else s += spec_coop_coded<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+        }
         s = wave_sum(s);
         if (lane == src) val = s;
       }
