@@ -109,13 +109,16 @@ struct SpecLds {
   LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] total move probability of an interval step for the current
                              // genotype; NaN = not evaluated yet, -1 = the step has no options
   LDSP(double) bdist;        // [NG][Mmax] the chain's cumulative break-count distribution
-  int memo_stride;           // 2 * (Mmax+1)^2, or 0 when the tables do not fit
+  int memo_stride;           // 2 * spec_memo_entries(Mmax), or 0 when the tables do not fit
   int ndraws;                // staged draws per group
 };
 
 // interval-step memo (see spec_structural): only for a single temperature and while it stays small
+// entries of one interval-step memo table: intervals (start, stop) with 0 <= start < stop <= Mmax, triangular
+__host__ __device__ inline int spec_memo_entries(int Mmax) { return Mmax * (Mmax + 1) / 2; }
+__host__ __device__ inline int spec_memo_index(int start, int stop) { return stop * (stop - 1) / 2 + start; }
 __host__ __device__ inline size_t spec_memo_bytes(int Mmax, int T, int G) {
-  const size_t per_group = (size_t)2 * (Mmax + 1) * (Mmax + 1) * 8;
+  const size_t per_group = (size_t)2 * spec_memo_entries(Mmax) * 8;
   if (T != 1 || per_group > 16 * 1024) return 0;
   return per_group * (64 / G);
 }
@@ -1093,8 +1096,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
   // Memo.  For an unchanged genotype an interval step (type, start, stop) has a fixed option count and a fixed
   // total move probability (the last cumulative sum of its options): it moves nothing iff its uniform is >= that
   // total.  The table describes genotype generation memo_gen and is wiped when the genotype has changed.
-  const int mrow = mmax + 1;
-  LDSP(double) mtot = S.memo_tot + gi * S.memo_stride + step_type * mrow * mrow;
+  LDSP(double) mtot = S.memo_tot + gi * S.memo_stride + step_type * spec_memo_entries(mmax);
   const bool memo = S.memo_stride != 0;
   if (memo && wave_any(c.alive && c.gen != c.memo_gen)) {
     if (c.alive && c.gen != c.memo_gen) {
@@ -1109,7 +1111,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
   // Single-interval steps (the whole-haplotype dosage step, or no break drawn): one memo entry and at most one
   // uniform decide; no interval list, ballots or reduction needed.
   if (memo && doit && n_int == 1) {
-    const double tot = mtot[Mh];  // (start, stop) = (0, Mh)
+    const double tot = mtot[spec_memo_index(0, Mh)];
     if (tot < 0.0) {
       done = true;  // no options: no draw
     } else if (!isnan(tot)) {
@@ -1141,7 +1143,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
       const int start = __ffsll((long long)z) - 1;
       z &= z - 1;
       const int stop = __ffsll((long long)z) - 1;
-      tot = mtot[start * mrow + stop];
+      tot = mtot[spec_memo_index(start, stop)];
     }
     const uint64_t unknown = grp_ballot<G>(mine && isnan(tot), gi);
     const int n_cons = __popcll(grp_ballot<G>(mine && tot >= 0.0, gi));
@@ -1200,7 +1202,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
     if (!done && memo) {
       while (ii0 < n_int) {
         const uint32_t se = ivse[ii0];
-        const int idx = (int)(se & 255u) * mrow + (int)(se >> 8);
+        const int idx = spec_memo_index((int)(se & 255u), (int)(se >> 8));
         const double tot = mtot[idx];
         if (isnan(tot)) break;  // not evaluated for this genotype yet
         if (tot >= 0.0) {       // -1: the step has no options and consumes no draw
@@ -1341,7 +1343,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
         }
         if (memo && gl == 0 && c.gen == c.memo_gen) {  // evaluated in full without a move: remember the total
           const uint32_t se = ivse[ii];
-          const int idx = (int)(se & 255u) * mrow + (int)(se >> 8);
+          const int idx = spec_memo_index((int)(se & 255u), (int)(se >> 8));
           mtot[idx] = no > 0 ? cacc : -1.0;
         }
         off += no;
@@ -1420,7 +1422,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.ndraws = spec_draws(KT, mmax);
     S.draws = lds_cast<uint64_t>(p); p += (size_t)8 * NG * S.ndraws;
-    S.memo_stride = (spec_memo_bytes(mmax, T, G) && !(P.flags & 2)) ? 2 * (mmax + 1) * (mmax + 1) : 0;
+    S.memo_stride = (spec_memo_bytes(mmax, T, G) && !(P.flags & 2)) ? 2 * spec_memo_entries(mmax) : 0;
     S.memo_tot = lds_cast<double>(p);
     for (int i = lane; i < NG * S.memo_stride; i += WAVE) S.memo_tot[i] = NAN;  // nothing evaluated yet
   }
