@@ -85,7 +85,7 @@ def call_concordance(args, batch, n=64):
     same, dmax = 0, 0.0
     for u in range(n):
         ref = GenotypeMultiTrace._from_sorted(sort_haplotypes(g[u]), l[u]).burn(args.burn).posterior().mode_genotype_support().mode_genotype()
-        mine = unpack_trace(post["words"][u][post["mode"][u]][None], fixed[u], 2)[0]
+        mine = unpack_trace(post["mode_words"][u][None], fixed[u], 2)[0]
         same += int(np.array_equal(mine, ref[0]))
         dmax = max(dmax, abs(float(post["stats"][u][1]) - float(ref[1])))
     return same / n, dmax

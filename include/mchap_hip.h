@@ -46,7 +46,8 @@ enum {
   MCHAP_UNIT_OK = 0,
   MCHAP_UNIT_ALL_FIXED = 1, /* every position fixed homozygous: constant trace, llk = NaN (assemble/mcmc.py:189-199) */
   MCHAP_UNIT_NAN_LLK = 2,
-  MCHAP_UNIT_BREAKS = 3
+  MCHAP_UNIT_BREAKS = 3,
+  MCHAP_UNIT_BAD_INITIAL = 4 /* initial.shape != (ploidy, n_het_base): AssertionError, assemble/mcmc.py:207 */
 };
 
 /* The fields of the DenovoMCMC dataclass (assemble/mcmc.py:24-40) that are common to a batch. */
@@ -87,6 +88,9 @@ typedef struct mchap_unit {
   int32_t ploidy;
   double inbreeding;     /* NaN == None (flat prior) */
   uint64_t stream_id;    /* RNG stream of the unit: results do not depend on batch order or sharding */
+  int32_t initial_n_het; /* last dimension of the caller's `initial` array; the unit ends with MCHAP_UNIT_BAD_INITIAL
+                            (nothing sampled, `initial` not read) unless it equals the number of non-fixed positions */
+  int32_t reserved;
 } mchap_unit;
 
 /* Replaces DenovoMCMC.fit (assemble/mcmc.py:103-161) for a batch of units.
@@ -147,11 +151,17 @@ int mchap_log_likelihood_batch(const double *reads, int n_reads, int n_pos, int 
  *   post_counts int32  [n_units][max_states]              occurrences after burn-in over all chains
  *   post_n      int32  [n_units]                          number of distinct genotypes (may exceed max_states)
  *   mode_stats  float64 [n_units][2]                      (support probability SPM, mode genotype probability GPM)
- *   mode_index  int32  [n_units]                          index into post_words of the mode genotype of the mode support */
+ *   mode_index  int32  [n_units]                          rank (row of post_words when < max_states) of the mode genotype
+ *                                                         of the mode support
+ *   mode_words  uint64 [n_units][ploidy_max] or NULL      that genotype itself, whatever its rank
+ *   mode_count  int32  [n_units] or NULL                  its occurrences
+ * post_n < 0: more than 512 distinct genotypes (-n: counts beyond the 512th are lost; fall back to the trace);
+ * INT32_MIN: the unit's ploidy exceeds ploidy_max. */
 int mchap_trace_posterior_batch_device(int n_units, const mchap_unit *units_dev, int steps, int chains, int burn,
                                        const uint64_t *trace_words, int max_states, int ploidy_max,
                                        uint64_t *post_words, int32_t *post_counts, int32_t *post_n,
-                                       double *mode_stats, int32_t *mode_index, void *stream);
+                                       double *mode_stats, int32_t *mode_index, uint64_t *mode_words,
+                                       int32_t *mode_count, void *stream);
 
 /* Exact caller: replaces calling.exact.genotype_likelihoods (calling/exact.py:266-292, float32 store) and,
  * when post_out != NULL, genotype_posteriors (295-329).  Host pointers, one unit.
@@ -168,8 +178,8 @@ int mchap_exact_genotype_posteriors(const void *llks, int is_f32, int64_t n_geno
 
 /* Replicate incongruence of every unit's chains (the MCI field of `mchap assemble`): replaces
  * GenotypeMultiTrace.replicate_incongruence(threshold) (assemble/classes.py:341-376) on the traces written by
- * mchap_denovo_fit_batch_device.  mci[u] = 0 none, 1 incongruence, 2 incongruence with more than `ploidy` haplotypes
- * (putative CNV), -1 if a chain visited more distinct genotypes than the kernel keeps (512).  Device pointers. */
+ * mchap_denovo_fit_batch_device.  mci[u] = 0 none, 1 incongruence, 2 incongruence whose union of haplotypes is larger
+ * than the first qualifying chain's support (putative CNV; the reference's `len(alleles[0])`, classes.py:371-375), -1 if a chain visited more distinct genotypes than the kernel keeps (512).  Device pointers. */
 int mchap_trace_incongruence_batch_device(int n_units, const mchap_unit *units_dev, int steps, int chains, int burn,
                                           const uint64_t *trace_words, int ploidy_max, double threshold, int32_t *mci,
                                           void *stream);

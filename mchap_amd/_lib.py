@@ -31,6 +31,7 @@ UNIT_OK = 0
 UNIT_ALL_FIXED = 1
 UNIT_NAN_LLK = 2
 UNIT_BREAKS = 3
+UNIT_BAD_INITIAL = 4
 
 
 class DenovoCfg(C.Structure):
@@ -68,10 +69,12 @@ UNIT_DTYPE = np.dtype(
         ("ploidy", "<i4"),
         ("inbreeding", "<f8"),
         ("stream_id", "<u8"),
+        ("initial_n_het", "<i4"),
+        ("reserved", "<i4"),
     ],
     align=True,
 )
-assert UNIT_DTYPE.itemsize == 88
+assert UNIT_DTYPE.itemsize == 96
 
 
 class MchapLibraryError(RuntimeError):

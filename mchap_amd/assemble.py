@@ -180,6 +180,7 @@ class DenovoMCMC(Assembler):
                 assert ini.ndim == 3 and ini.shape[0] == self.chains and ini.shape[1] == K
                 i_parts.append(ini.reshape(-1))
                 U["initial_off"] = i_off
+                U["initial_n_het"] = ini.shape[2]
                 i_off += ini.size
             else:
                 U["initial_off"] = -1
@@ -219,11 +220,11 @@ class DenovoMCMC(Assembler):
                 raise ValueError("breaks must be smaller then n")  # reference assemble/structural.py:49-50
             if st < 0:
                 raise NotImplementedError("mchap_hip: unit %d exceeds the packed haplotype width" % u)
+            # reference assemble/mcmc.py:207; checked on the device BEFORE `initial` is read
+            assert st != _lib.UNIT_BAD_INITIAL, "initial.shape != (ploidy, n_het_base)"
             n_pos, max_allele, K, ini_shape = shapes[u]
             U = units[u]
             fx = fixed[U["fixed_off"]: U["fixed_off"] + n_pos]
-            if ini_shape is not None:
-                assert ini_shape[2] == int(np.sum(fx < 0))  # reference assemble/mcmc.py:207
             w = trace[U["trace_off"]: U["trace_off"] + self.chains * self.steps * K].reshape(self.chains, self.steps, K)
             g = unpack_trace(w, fx, max_allele)
             lk = llks[U["llk_off"]: U["llk_off"] + self.chains * self.steps].reshape(self.chains, self.steps).copy()

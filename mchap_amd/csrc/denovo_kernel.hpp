@@ -723,6 +723,10 @@ __global__ __launch_bounds__(64 * CHAINS_PER_BLOCK) void denovo_mcmc_kernel(cons
     if (chain == 0 && lane == 0) P.status[blockIdx.x] = MCHAP_ERR_LIMIT;
     return;
   }
+  if (U.initial_off >= 0 && U.initial_n_het != Mh) {  // assemble/mcmc.py:207
+    if (chain == 0 && lane == 0) P.status[blockIdx.x] = MCHAP_UNIT_BAD_INITIAL;
+    return;
+  }
   double luh = 0.0;
   for (int j = 0; j < Mh; j++) {
     c.shift[j] = (uint8_t)(c.bits * (Mh - 1 - j));

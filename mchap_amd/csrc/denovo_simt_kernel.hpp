@@ -231,6 +231,7 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
   int status = MCHAP_UNIT_OK;
   if (Mh == 0) status = MCHAP_UNIT_ALL_FIXED;
   else if (Mh * bits > 64) status = MCHAP_ERR_LIMIT;
+  else if (U.initial_off >= 0 && U.initial_n_het != Mh) status = MCHAP_UNIT_BAD_INITIAL;  // assemble/mcmc.py:207
   if (lane == 0) {
     mi[META_I_MH] = Mh;
     mi[META_I_STATUS] = status;

@@ -203,10 +203,12 @@ int validate_cfg(const mchap_denovo_cfg *cfg) {
 
 constexpr int CACHE_SLOTS = 1024;  // {tag, llk} entries per chain (16 KiB)
 
-// cached device copy of the break table
-std::mutex g_bt_mu;
-double *g_bt_dev = nullptr;
-size_t g_bt_cap = 0;
+// The break table of a call lives at the head of the CALLER's workspace (no library-owned device state: two fits
+// on different streams, threads or devices never share a buffer).
+size_t break_table_bytes(const mchap_denovo_cfg *cfg) {
+  const size_t mp = cfg->max_pos > 0 ? (size_t)cfg->max_pos : 1;
+  return ((mp + 1) * mp * sizeof(double) + 255) & ~(size_t)255;
+}
 
 }  // namespace
 
@@ -407,13 +409,14 @@ int64_t mchap_denovo_lds_bytes(int n_reads, int n_pos, int max_allele, int ploid
 int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host) {
   if (!cfg || n_units <= 0) return 0;
   const int slots = cfg->llk_cache ? CACHE_SLOTS : 0;
-  if (!use_simt(cfg)) return (int64_t)n_units * cfg->chains * slots * 16;
+  const int64_t bt = (int64_t)break_table_bytes(cfg);
+  if (!use_simt(cfg)) return bt + (int64_t)n_units * cfg->chains * slots * 16;
   if (!units_host) return -1;
   BatchDims B;
   if (batch_dims(cfg, n_units, units_host, B)) return -1;
   const int rpl = simt_rpl(cfg, B.uniform_ploidy, B.max_pos, B.max_reads);
   if (rpl < 0) return -1;
-  return (int64_t)simt_carve(cfg, n_units, B, 64 * rpl, slots).total;
+  return bt + (int64_t)simt_carve(cfg, n_units, B, 64 * rpl, slots).total;
 }
 
 static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
@@ -496,18 +499,19 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
   P.rpad = rpad;
   P.max_pos = cfg->max_pos > 0 ? cfg->max_pos : 1;
   {
-    std::lock_guard<std::mutex> lk(g_bt_mu);
+    // head of the caller's workspace: this call's break table, copied on this call's stream
     const size_t n = (size_t)(P.max_pos + 1) * P.max_pos;
-    if (n > g_bt_cap) {
-      if (g_bt_dev) (void)hipFree(g_bt_dev);
-      HIP_TRY(hipMalloc(&g_bt_dev, n * sizeof(double)));
-      g_bt_cap = n;
-    }
+    const size_t bt_bytes = break_table_bytes(cfg);
+    if (!workspace || workspace_bytes < (int64_t)bt_bytes)
+      return fail(MCHAP_ERR_BAD_ARG, "workspace of %lld bytes is too small (mchap_denovo_workspace_bytes)", (long long)workspace_bytes);
+    double *bt_dev = reinterpret_cast<double *>(workspace);
     if (cfg->break_table)
-      HIP_TRY(hipMemcpyAsync(g_bt_dev, cfg->break_table, n * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(bt_dev, cfg->break_table, n * sizeof(double), hipMemcpyHostToDevice, stream));
     else
-      HIP_TRY(hipMemsetAsync(g_bt_dev, 0, n * sizeof(double), stream));
-    P.break_table = g_bt_dev;
+      HIP_TRY(hipMemsetAsync(bt_dev, 0, n * sizeof(double), stream));
+    P.break_table = bt_dev;
+    workspace = reinterpret_cast<unsigned char *>(workspace) + bt_bytes;
+    workspace_bytes -= (int64_t)bt_bytes;
   }
   HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t) * n_units, stream));
   P.cache = nullptr;

@@ -9,6 +9,8 @@
 // mset.unique_counts produces.  The list is then ranked by (count descending, first appearance descending):
 // the order np.flip(np.argsort(probs)) gives for tied probabilities.
 #pragma once
+#include <limits.h>
+
 #include "denovo_kernel.hpp"
 
 namespace mchap {
@@ -25,6 +27,8 @@ struct PosteriorParams {
   int32_t *post_n;
   double *mode_stats;
   int32_t *mode_index;
+  uint64_t *mode_words;   // [U][ploidy_max] or null: the mode genotype itself (its rank may exceed max_states)
+  int32_t *mode_count;    // [U] or null
 };
 
 // Distinct states of chains [ch_lo, ch_hi) after burn-in, ranked, with support labels and the mode support.
@@ -175,6 +179,16 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
   const int K = U.ploidy;
   const int lane = threadIdx.x;
   const int N = P.chains * (P.steps - P.burn);
+  if (K > P.ploidy_max || K < 1) {  // the LDS tables are sized for ploidy_max: refuse instead of overrunning them
+    if (lane == 0) {
+      P.post_n[blockIdx.x] = INT_MIN;
+      P.mode_stats[2 * (size_t)blockIdx.x + 0] = NAN;
+      P.mode_stats[2 * (size_t)blockIdx.x + 1] = NAN;
+      P.mode_index[blockIdx.x] = -1;
+      if (P.mode_count) P.mode_count[blockIdx.x] = 0;
+    }
+    return;
+  }
   uint64_t *uw = reinterpret_cast<uint64_t *>(smem);                  // [POST_CAP][K]
   int *ucount = reinterpret_cast<int *>(smem + (size_t)POST_CAP * K * 8);  // [POST_CAP]
   int *order = ucount + POST_CAP;                                     // [POST_CAP] rank -> unique index
@@ -200,7 +214,12 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
       P.mode_stats[2 * (size_t)blockIdx.x + 0] = R.best;                                            // SPM
       P.mode_stats[2 * (size_t)blockIdx.x + 1] = (double)ucount[order[R.best_r]] / (double)N;       // GPM
       P.mode_index[blockIdx.x] = R.best_r;
+      if (P.mode_words)
+        for (int h = 0; h < P.ploidy_max; h++)
+          P.mode_words[(size_t)blockIdx.x * P.ploidy_max + h] = h < K ? uw[(size_t)order[R.best_r] * K + h] : 0ull;
+      if (P.mode_count) P.mode_count[blockIdx.x] = ucount[order[R.best_r]];
     } else {
+      if (P.mode_count) P.mode_count[blockIdx.x] = 0;
       P.mode_stats[2 * (size_t)blockIdx.x + 0] = NAN;
       P.mode_stats[2 * (size_t)blockIdx.x + 1] = NAN;
       P.mode_index[blockIdx.x] = -1;
@@ -211,13 +230,14 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
 // Replicate incongruence of the chains of a unit (GenotypeMultiTrace.replicate_incongruence, assemble/classes.py:341-376,
 // the MCI field of `mchap assemble`): per chain the mode support and its probability; among the chains whose mode
 // support reaches `threshold`, 0 if they agree on the support's set of haplotypes, else 1, or 2 if together they hold
-// more than `ploidy` distinct haplotypes.  -1 if a chain visited more than POST_CAP distinct states.
+// more distinct haplotypes than the first of those chains' supports.  -1 if a chain visited more than POST_CAP distinct states.
 constexpr int POST_MAX_CHAINS = 32;
 struct IncongruenceParams {
   const mchap_unit *units;
   const uint64_t *trace;
   int steps, chains, burn;
   double threshold;
+  int ploidy_max;
   int32_t *mci;
 };
 
@@ -226,6 +246,10 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
   const mchap_unit U = P.units[blockIdx.x];
   const int K = U.ploidy;
   const int lane = threadIdx.x;
+  if (K > P.ploidy_max || K < 1) {
+    if (lane == 0) P.mci[blockIdx.x] = -1;
+    return;
+  }
   uint64_t *uw = reinterpret_cast<uint64_t *>(smem);
   int *ucount = reinterpret_cast<int *>(smem + (size_t)POST_CAP * K * 8);
   int *order = ucount + POST_CAP;
@@ -275,7 +299,9 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
             for (int q = 0; q < nset[b] && !dup; q++) dup = sets[(size_t)b * MCHAP_MAX_PLOIDY + q] == w;
           if (!dup) total++;
         }
-      if (total > K) out = 2;
+      // the reference compares with the size of the FIRST qualifying chain's allele set, not with the ploidy
+      // (assemble/classes.py:371-375: `ploidy = len(alleles[0])`)
+      if (total > nset[first]) out = 2;
     }
     P.mci[blockIdx.x] = bad ? -1 : out;
   }

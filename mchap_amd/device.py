@@ -123,13 +123,15 @@ class DenovoDeviceBatch:
                 n=torch.empty(U, dtype=torch.int32, device=dev),
                 stats=torch.empty(U * 2, dtype=torch.float64, device=dev),
                 mode=torch.empty(U, dtype=torch.int32, device=dev),
+                mode_words=torch.empty(U * self.K, dtype=torch.int64, device=dev),
+                mode_count=torch.empty(U, dtype=torch.int32, device=dev),
             )
         P = self.post
         stream = torch.cuda.current_stream().cuda_stream
         rc = _lib.lib().mchap_trace_posterior_batch_device(
             U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), int(max_states), self.K,
             self._p(P["words"]), self._p(P["counts"]), self._p(P["n"]), self._p(P["stats"]), self._p(P["mode"]),
-            C.c_void_p(stream))
+            self._p(P["mode_words"]), self._p(P["mode_count"]), C.c_void_p(stream))
         _lib.check(rc)
 
     def incongruence(self, burn, threshold=0.6):
@@ -164,10 +166,18 @@ class DenovoDeviceBatch:
         P = self.post
         U = self.shape[0]
         ms = P["max_states"]
+        n = P["n"].cpu().numpy()
+        if (n < 0).any():
+            # more distinct genotypes than the kernel keeps (counts were dropped): the summary is not the posterior
+            raise _lib.MchapLibraryError(
+                "posterior summary overflow in %d unit(s): more than 512 distinct genotypes after burn-in; "
+                "summarise those units from traces() instead" % int((n < 0).sum()))
         return dict(
             words=P["words"].cpu().numpy().view(np.uint64).reshape(U, ms, self.K),
             counts=P["counts"].cpu().numpy().reshape(U, ms),
-            n=P["n"].cpu().numpy(),
+            n=n,
             stats=P["stats"].cpu().numpy().reshape(U, 2),
             mode=P["mode"].cpu().numpy(),
+            mode_words=P["mode_words"].cpu().numpy().view(np.uint64).reshape(U, self.K),
+            mode_count=P["mode_count"].cpu().numpy(),
         )

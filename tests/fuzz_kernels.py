@@ -16,17 +16,22 @@ from mchap_amd.synth import synth_units
 from test_gpu_denovo import _oracle_trace
 
 
-def run(n_cases, seed):
+def run(n_cases, seed, ploidies=(2, 3, 4, 5, 6, 8), read_depths=(1, 5, 30, 64, 70, 130, 200, 300), tempering=None, max_pos=12):
+    """ploidies / read_depths: what the cases draw from; tempering: None = random, True = always a ladder, False = never."""
     rng = np.random.default_rng(seed)
     bad = 0
     for case in range(n_cases):
-        K = int(rng.choice([2, 3, 4, 5, 6, 8]))
-        M = int(rng.integers(1, 13))
+        K = int(rng.choice(ploidies))
+        M = int(rng.integers(1, max_pos + 1))
         A = int(rng.choice([2, 2, 3, 4]))
-        R = int(rng.choice([1, 5, 30, 64, 70, 130, 200, 300]))
+        R = int(rng.choice(read_depths))
         chains = int(rng.integers(1, 4))
         U = int(rng.integers(1, 4))
         temps = [(1.0,), (1.0,), (0.3, 1.0), (0.2, 0.6, 1.0)][int(rng.integers(0, 4))]
+        if tempering:
+            temps = [(0.3, 1.0), (0.2, 0.6, 1.0), (0.001, 0.01, 0.1, 1.0)][int(rng.integers(0, 3))]
+        elif tempering is False:
+            temps = (1.0,)
         F = [None, None, 0.0, 0.15][int(rng.integers(0, 4))]
         pr = [float(rng.choice([-1.0, 0.3, 0.5, 1.0])) for _ in range(3)]
         if rng.random() < 0.3:

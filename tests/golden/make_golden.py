@@ -407,6 +407,44 @@ def gen_trace_posterior():
                 mode=[post.mode()[0].tolist(), float(post.mode()[1])],
             )
         )
+    # constructed chains that sit on chosen supports: the three incongruence codes, including the reference's
+    # `len(alleles[0])` rule (classes.py:371-375: the union of the supports is compared with the size of the FIRST
+    # qualifying chain's support, not with the ploidy)
+    a, b, c_, d, e = [np.array(x, np.int8) for x in ([0, 0, 0, 1], [0, 1, 1, 0], [1, 0, 1, 1], [1, 1, 0, 0], [1, 1, 1, 1])]
+    designs = [
+        ([[a, a, b, c_], [a, a, b, b]], 0.85),            # {a,b,c} then {a,b}: union 3 == 3 -> 1
+        ([[a, a, b, b], [a, a, b, c_]], 0.85),            # {a,b} then {a,b,c}: union 3 > 2 -> 2
+        ([[a, a, b, b], [a, b, b, b]], 0.7),              # same support, different dosage -> 0
+        ([[a, b, c_, d], [a, b, c_, e], [a, b, c_, d]], 0.8),  # 4 + 1 = 5 > 4 -> 2
+        ([[a, a, a, b], [a, a, a, c_], [b, b, b, b]], 0.75),   # {a,b}, {a,c}, {b}: union 3 > 2 -> 2
+        ([[a, b, c_, c_], [a, a, b, b], [a, b, b, c_]], 0.9),  # {a,b,c}, {a,b}, {a,b,c}: union 3 == 3 -> 1
+    ]
+    for chains, stay in designs:
+        C, S, K, M = len(chains), 40, 4, 4
+        raw = np.empty((C, S, K, M), np.int8)
+        for ci, main in enumerate(chains):
+            for s_ in range(S):
+                g = np.array(main)
+                if rng.random() > stay:  # an excursion: one haplotype replaced by a random one
+                    g[rng.integers(K)] = rng.integers(0, 2, size=M)
+                raw[ci, s_] = g[rng.permutation(K)]
+        trace = GenotypeMultiTrace(raw, rng.normal(size=(C, S)))
+        burn = 4
+        post = trace.burn(burn).posterior()
+        sup = post.mode_genotype_support()
+        mg, mp = sup.mode_genotype()
+        haps, fr, oc = post.allele_frequencies()
+        inc = {str(t): int(trace.burn(burn).replicate_incongruence(t)) for t in (0.99, 0.8, 0.6, 0.3)}
+        cases.append(
+            dict(
+                raw=raw.tolist(), burn=burn, sorted=trace.genotypes.tolist(),
+                post_genotypes=post.genotypes.tolist(), post_probs=post.probabilities.tolist(),
+                support_genotypes=sup.genotypes.tolist(), support_probs=sup.probabilities.tolist(),
+                mode_genotype=mg.tolist(), mode_prob=float(mp), support_alleles=sup.alleles().tolist(),
+                af_haps=haps.tolist(), af_freqs=fr.tolist(), af_occur=oc.tolist(), incongruence=inc,
+                mode=[post.mode()[0].tolist(), float(post.mode()[1])],
+            )
+        )
     jdump("trace_posterior.json", {"cases": cases})
 
 

@@ -1,0 +1,129 @@
+"""GPU parity at the FULL sizes of BASELINE.json's configs that the other GPU tests only touch at reduced shapes.
+
+configs[3] (call-exact): hexaploid, 16 known haplotypes over 10 SNVs, 500 reads -> G = C(21, 6) = 54 264 genotypes per
+unit (14 enumeration blocks per unit, multi-block arg-max / log-sum-exp merge), Dirichlet-multinomial prior with
+inbreeding 0.1 and Dirichlet(1) allele frequencies.  Reference: calling/exact.py:156-329.
+configs[4] (LDS-pressure sampler): octoploid, 20 SNVs, 1000 reads, 4 chains; and its secondary variant of SURVEY.md 8d,
+one chain under the temperature ladder (0.001, 0.01, 0.1, 1.0).  Reference: assemble/mcmc.py:268-426.
+
+Checker: the CPU oracle (oracle/mchap_oracle.c) on the same inputs / Philox streams.  Tolerances as in DESIGN.md:
+integers bit-exact, fp64 1e-9 relative (llk traces 1e-10), float32 likelihoods 2.5e-7 relative, posteriors formed with
+float32 arithmetic 3e-5 relative."""
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _config4_inputs(U, seed=4):
+    from mchap_amd.synth import synth_units
+
+    K, H, M, R = 6, 16, 10, 500
+    rng = np.random.default_rng(seed)
+    reads, _, truth = synth_units(U, ploidy=K, n_pos=M, n_reads=R, window=(5, 10), first_unit=400)
+    # odd units: very low base qualities, so that the posterior is spread over many genotypes (the even units' 500
+    # good reads concentrate it on one)
+    noisy, _, _ = synth_units(U, ploidy=K, n_pos=M, n_reads=R, window=(5, 10), first_unit=400, qual=(1, 4))
+    reads[1::2] = noisy[1::2]
+    haps = np.zeros((U, H, M), np.int8)
+    for u in range(U):
+        # the unit's true haplotypes plus random ones, 16 distinct in a random order
+        pool = np.unique(np.concatenate([truth[u], rng.integers(0, 2, size=(8 * H, M)).astype(np.int8)]), axis=0)
+        rng.shuffle(pool)
+        keep = [p for p in pool if not any(np.array_equal(p, t) for t in truth[u])][: H - len(np.unique(truth[u], axis=0))]
+        hs = np.concatenate([np.unique(truth[u], axis=0), np.array(keep, np.int8)])
+        rng.shuffle(hs)
+        assert len(hs) == H
+        haps[u] = hs
+    F = np.full(U, 0.1)
+    freqs = rng.dirichlet(np.ones(H), size=U)
+    return K, H, M, R, reads, haps, F, freqs
+
+
+def test_config4_posterior_mode_full_size():
+    """posterior_mode_batch at configs[3]: every returned statistic against the oracle, two units."""
+    from mchap_amd import calling
+
+    U = 2
+    K, H, M, R, reads, haps, F, freqs = _config4_inputs(U)
+    assert calling.count_unique_genotypes(H, K) == 54264
+    out = calling.posterior_mode_batch(reads, K, haps, None, (F, freqs), True, True, True)
+    for u in range(U):
+        a, ml, mp, sp, fq, oc = orc.posterior_mode(reads[u], K, haps[u], None, (float(F[u]), freqs[u]))
+        assert out[0][u].tolist() == a.tolist()
+        np.testing.assert_allclose([out[1][u], out[2][u], out[3][u]], [ml, mp, sp], rtol=1e-9)
+        np.testing.assert_allclose(out[4][u], fq, rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(out[5][u], oc, rtol=1e-9, atol=1e-300)
+        assert abs(out[4][u].sum() - 1.0) < 1e-9
+    # the single-unit operator form gives the same answer as the batch
+    one = calling.posterior_mode(reads[1], K, haps[1], None, (float(F[1]), freqs[1]), True, True, True)
+    assert one[0].tolist() == out[0][1].tolist()
+    np.testing.assert_allclose(one[1:4], [out[1][1], out[2][1], out[3][1]], rtol=1e-12)
+
+
+def test_config4_likelihood_and_posterior_arrays_full_size():
+    """genotype_likelihoods (float32 store) and genotype_posteriors (float32 arithmetic) at configs[3], plus the array
+    summaries the reference's --report GL/GP path derives from them (call_exact.py:126-159)."""
+    from mchap_amd import calling
+
+    U = 2
+    K, H, M, R, reads, haps, F, freqs = _config4_inputs(U)
+    for u in range(U):
+        prior = (float(F[u]), freqs[u])
+        l32 = calling.genotype_likelihoods(reads[u], K, haps[u])
+        assert l32.dtype == np.float32 and l32.shape == (54264,)
+        e32, e64 = orc.genotype_likelihoods(reads[u], K, haps[u], None)
+        np.testing.assert_allclose(l32, e32, rtol=2.5e-7)
+        post = calling.genotype_posteriors(e32, K, H, prior)
+        ref = orc.genotype_posteriors(e32, K, H, prior)
+        np.testing.assert_allclose(post, ref, rtol=3e-5, atol=1e-12)
+        post64 = calling.genotype_posteriors(e64, K, H, prior)
+        ref64 = orc.genotype_posteriors(e64, K, H, prior)
+        np.testing.assert_allclose(post64, ref64, rtol=1e-9, atol=1e-300)
+        assert abs(post64.sum() - 1.0) < 1e-9
+        f, c, o = calling.posterior_allele_frequencies(ref64, K, H)
+        rf, rc, ro = orc.posterior_allele_frequencies(ref64, K, H)
+        np.testing.assert_allclose(np.stack([f, c, o]), np.stack([rf, rc, ro]), rtol=1e-9, atol=1e-300)
+        # mode of the array == streaming mode (same genotype; GP of it within the float64 tolerance)
+        idx = int(np.argmax(post64))
+        mode = calling.posterior_mode(reads[u], K, haps[u], None, prior, True)
+        assert calling.index_as_genotype_alleles(idx, K).tolist() == mode[0].tolist()
+        np.testing.assert_allclose(post64[idx], mode[2], rtol=1e-6)
+        ag, ap = calling.alternate_dosage_posteriors(mode[0], post64)
+        np.testing.assert_allclose(ap.sum(), mode[3], rtol=1e-6)
+
+
+@pytest.mark.parametrize("variant", ["four_chains", "tempered"])
+def test_config5_full_shape(variant, monkeypatch):
+    """configs[4]: K = 8, 20 SNVs, 1000 reads; 4 parallel chains, and the one-chain four-temperature variant.  25 steps
+    of every chain step for step against the oracle (the speculative kernel with three sub-steps per lane, and the
+    lanes-over-chains kernel)."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.classes import sort_haplotypes
+    from mchap_amd.synth import synth_units
+    from tests.helpers import beta_break_table
+
+    reads, _, _ = synth_units(2, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20), first_unit=77)
+    if variant == "four_chains":
+        kw = dict(chains=4, temperatures=(1.0,))
+    else:
+        kw = dict(chains=1, temperatures=(0.001, 0.01, 0.1, 1.0))
+    ref = None
+    for kernel in (3, 2):
+        monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
+        model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=25, random_seed=11, **kw)
+        traces = model.fit_batch(list(reads))
+        if ref is None:
+            ref = []
+            for u in range(len(reads)):
+                cfg = orc.make_cfg(8, 25, kw["chains"], None, kw["temperatures"], llk_cache_threshold=-1, rng_kind=orc.RNG_PHILOX,
+                                   seed=11, stream_id=u, break_table=beta_break_table(20, 1.0, 3.0))
+                g, l, code = orc.denovo_fit(cfg, reads[u], [2] * 20)
+                assert code == 0
+                ref.append((sort_haplotypes(g), l))
+        for u, tr in enumerate(traces):
+            assert tr.genotypes.shape == (kw["chains"], 25, 8, 20)
+            assert np.array_equal(tr.genotypes, ref[u][0]), "kernel %d unit %d" % (kernel, u)
+            np.testing.assert_allclose(tr.llks, ref[u][1], rtol=1e-10)

@@ -1,9 +1,103 @@
-"""GPU parity: on-device posterior summary vs the host classes (which mirror the reference's
-GenotypeMultiTrace / PosteriorGenotypeDistribution and are themselves pinned by tests/test_classes.py)."""
+"""GPU parity of the on-device posterior summary (trace_posterior_kernel / trace_incongruence_kernel):
+directly against vectors captured from the reference's GenotypeMultiTrace / PosteriorGenotypeDistribution
+(tests/golden/trace_posterior.json, assemble/classes.py:265-376), and against the host classes on real sampler traces."""
+import ctypes as C
+import json
+import os
+
 import numpy as np
 import pytest
 
+from tests.helpers import assert_same_posterior
+
 pytestmark = pytest.mark.gpu
+
+
+def _pack(genotypes, bits=1):
+    """int8 [..., K, M] -> uint64 words [..., K]: position 0 most significant (the sampler's trace format)."""
+    g = np.asarray(genotypes).astype(np.uint64)
+    M = g.shape[-1]
+    w = np.zeros(g.shape[:-1], dtype=np.uint64)
+    for j in range(M):
+        w |= g[..., j] << np.uint64(bits * (M - 1 - j))
+    return w
+
+
+def _unpack(words, M, bits=1):
+    w = np.asarray(words, dtype=np.uint64)
+    out = np.zeros(w.shape + (M,), dtype=np.int8)
+    for j in range(M):
+        out[..., j] = ((w >> np.uint64(bits * (M - 1 - j))) & np.uint64((1 << bits) - 1)).astype(np.int8)
+    return out
+
+
+def test_device_posterior_against_reference_goldens(golden_dir):
+    """The reference's own outputs for raw traces (sorted states, posterior order and probabilities, mode support,
+    SPM / GPM, mode genotype, incongruence codes at four thresholds) from the device kernels: the canonical sort is what
+    the sampler writes, so the golden's `sorted` trace is packed and handed to mchap_trace_posterior_batch_device /
+    mchap_trace_incongruence_batch_device as they would receive it."""
+    import torch
+    from mchap_amd import _lib
+
+    with open(os.path.join(golden_dir, "trace_posterior.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 5
+    L = _lib.lib()
+    seen_codes = set()
+    for c in cases:
+        srt = np.array(c["sorted"], dtype=np.int8)  # [C, S, K, M], haplotypes in canonical order
+        Cn, S, K, M = srt.shape
+        burn = int(c["burn"])
+        words = _pack(srt)
+        # the packed order of a canonically sorted genotype is ascending: the invariant the kernels rely on
+        assert (np.diff(words.astype(np.int64), axis=-1) >= 0).all()
+        units = np.zeros(1, dtype=_lib.UNIT_DTYPE)
+        units[0]["ploidy"], units[0]["trace_off"] = K, 0
+        d_units = torch.from_numpy(units.view(np.uint8).reshape(-1)).cuda()
+        d_trace = torch.from_numpy(words.view(np.int64).reshape(-1)).cuda()
+        ms = 64
+        d_words = torch.empty(ms * K, dtype=torch.int64, device="cuda")
+        d_counts = torch.empty(ms, dtype=torch.int32, device="cuda")
+        d_n = torch.empty(1, dtype=torch.int32, device="cuda")
+        d_stats = torch.empty(2, dtype=torch.float64, device="cuda")
+        d_mode = torch.empty(1, dtype=torch.int32, device="cuda")
+        d_mw = torch.empty(K, dtype=torch.int64, device="cuda")
+        d_mc = torch.empty(1, dtype=torch.int32, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        _lib.check(L.mchap_trace_posterior_batch_device(1, p(d_units), S, Cn, burn, p(d_trace), ms, K, p(d_words), p(d_counts),
+                                                        p(d_n), p(d_stats), p(d_mode), p(d_mw), p(d_mc), None))
+        torch.cuda.synchronize()
+        n = int(d_n.item())
+        exp_g = np.array(c["post_genotypes"], dtype=np.int8)
+        assert n == len(exp_g)
+        got_g = _unpack(d_words.cpu().numpy().view(np.uint64).reshape(ms, K)[:n], M)
+        total = Cn * (S - burn)
+        # states AND their order: probability descending, ties in the reference's (defined) order
+        assert_same_posterior(got_g, d_counts.cpu().numpy()[:n] / total, exp_g, c["post_probs"])
+        assert d_stats[0].item() == pytest.approx(float(np.sum(c["support_probs"])), rel=1e-14)  # SPM
+        assert d_stats[1].item() == c["mode_prob"]                                                 # GPM
+        assert np.array_equal(_unpack(d_mw.cpu().numpy().view(np.uint64), M), np.array(c["mode_genotype"], dtype=np.int8))
+        assert np.array_equal(got_g[int(d_mode.item())], np.array(c["mode_genotype"], dtype=np.int8))
+        assert int(d_mc.item()) / total == c["mode_prob"]
+        # incongruence: chains whose two best supports tie have no defined mode support in the reference (unstable
+        # argsort, see tests/test_classes.py) and are skipped there as here
+        from mchap_amd.classes import GenotypeMultiTrace
+
+        burned = GenotypeMultiTrace._from_sorted(srt, np.zeros((Cn, S))).burn(burn)
+        tie = False
+        for ch in burned.split():
+            top = np.sort(ch.posterior()._support_sums())[::-1]
+            tie = tie or (len(top) > 1 and top[0] == top[1])
+        if tie:
+            continue
+        d_mci = torch.empty(1, dtype=torch.int32, device="cuda")
+        for thr, expect in c["incongruence"].items():
+            _lib.check(L.mchap_trace_incongruence_batch_device(1, p(d_units), S, Cn, burn, p(d_trace), K, C.c_double(float(thr)),
+                                                               p(d_mci), None))
+            torch.cuda.synchronize()
+            assert int(d_mci.item()) == expect, (thr, expect)
+            seen_codes.add(expect)
+    assert {0, 1, 2} <= seen_codes
 
 
 def test_device_posterior_matches_host_classes():
@@ -43,7 +137,6 @@ def test_device_posterior_matches_host_classes():
 def test_device_incongruence_matches_host_classes():
     """MCI on the device vs GenotypeMultiTrace.replicate_incongruence (reference assemble/classes.py:341-376), on real
     traces (shallow reads: chains disagree now and then) and on constructed ones covering the codes 0, 1 and 2."""
-    import ctypes as C
     import torch
     from mchap_amd import DenovoMCMC, GenotypeMultiTrace, _lib
     from mchap_amd.device import DenovoDeviceBatch
@@ -66,7 +159,11 @@ def test_device_incongruence_matches_host_classes():
     L = _lib.lib()
     K, S, Cn = 4, 10, 2
     a, b, c, d, e = 1, 2, 4, 7, 9
-    cases = [([a, a, b, b], [a, a, b, b], 0), ([a, a, b, b], [a, b, b, b], 0), ([a, a, b, b], [a, a, a, c], 1), ([a, a, b, b], [c, c, d, e], 2)]
+    # the reference's rule for code 2 (assemble/classes.py:371-375): the union of the qualifying chains' supports holds
+    # more haplotypes than the FIRST such chain's support -- {a, b} vs {a, c}: union 3 > 2 -> 2; {a, b, c} vs {a, b}:
+    # union 3 == 3 -> 1, although both are tetraploid
+    cases = [([a, a, b, b], [a, a, b, b], 0), ([a, a, b, b], [a, b, b, b], 0), ([a, a, b, b], [a, a, a, c], 2),
+             ([a, a, b, c], [a, a, b, b], 1), ([a, a, b, b], [c, c, d, e], 2)]
     units = np.zeros(len(cases), dtype=_lib.UNIT_DTYPE)
     trace = np.zeros((len(cases), Cn, S, K), dtype=np.uint64)
     for i, (g0, g1, _) in enumerate(cases):
@@ -80,4 +177,4 @@ def test_device_incongruence_matches_host_classes():
         C.c_void_p(d_mci.data_ptr()), None))
     torch.cuda.synchronize()
     assert d_mci.cpu().tolist() == [x[2] for x in cases]
-    assert 0 in seen
+    assert 0 in seen and (1 in seen or 2 in seen)
