@@ -1,14 +1,14 @@
-"""Trace and posterior containers with the reference's API.
+"""Trace and posterior containers behind the reference's API.
 
-Mirrors mchap/assemble/classes.py of the reference (Assembler 16-52,
-PosteriorGenotypeDistribution 55-166, GenotypeSupportDistribution 169-244,
-GenotypeMultiTrace 247-376) -- same names, arguments and results -- implemented with
-vectorised numpy over packed haplotype keys instead of per-step Python loops.  Traces
-produced by the HIP sampler arrive already in canonical haplotype order, so no per-step
-sort runs on the host.
+Same class names, method names, arguments and results as mchap/assemble/classes.py of the reference (Assembler 16-52,
+PosteriorGenotypeDistribution 55-166, GenotypeSupportDistribution 169-244, GenotypeMultiTrace 247-376), written from
+their documented semantics on a different representation: every haplotype row is mapped to
+a small integer id (ids in order of first appearance), and the summaries are integer-table operations on those ids
+instead of dictionaries keyed on `tobytes()`.  Traces produced by the HIP sampler arrive already in canonical haplotype
+order (`GenotypeMultiTrace._from_sorted`), so no per-step sort runs on the host; the batched application takes these
+summaries from the device kernels (mchap_amd/device.py) and uses these classes for single units and as a checker.
 """
 from dataclasses import dataclass
-from functools import reduce
 
 import numpy as np
 
@@ -20,20 +20,21 @@ __all__ = [
 ]
 
 
+# ---------------------------------------------------------------------------------------------------------
+# id tables
+# ---------------------------------------------------------------------------------------------------------
 def _row_keys(array):
-    """One bytes key per element of the outer dimension (the reference keys on tobytes())."""
+    """One fixed-width opaque key per element of the outer dimension."""
     a = np.ascontiguousarray(array)
     n = len(a)
-    if n == 0:
-        return np.zeros(0, dtype="V1")
     width = a.dtype.itemsize * int(np.prod(a.shape[1:], dtype=np.int64))
-    if width == 0:
+    if n == 0 or width == 0:
         return np.zeros(n, dtype="V1")
     return a.reshape(n, -1).view("V%d" % width).reshape(n)
 
 
 def _first_occurrence_unique(array):
-    """(index of first occurrence of each distinct element, in order of appearance; inverse)."""
+    """(index of the first occurrence of each distinct element, in order of appearance; id of every element)."""
     keys = _row_keys(array)
     _, first, inverse = np.unique(keys, return_index=True, return_inverse=True)
     order = np.argsort(first, kind="stable")
@@ -43,26 +44,55 @@ def _first_occurrence_unique(array):
 
 
 def unique_rows(array):
-    """Distinct elements of the outer dimension in order of first appearance (reference mset.unique)."""
+    """Distinct elements of the outer dimension in order of first appearance (what the reference's mset.unique gives)."""
     idx, _ = _first_occurrence_unique(array)
     return array[idx]
 
 
 def unique_counts(array):
-    """Distinct elements in order of first appearance and their counts (reference mset.unique_counts)."""
+    """Distinct elements in order of first appearance and their counts (what mset.unique_counts gives)."""
     idx, inv = _first_occurrence_unique(array)
     return array[idx], np.bincount(inv, minlength=len(idx))
 
 
+def _haplotype_ids(genotypes):
+    """genotypes [n, K, M] -> (ids [n, K], table [n_haplotypes, M]): haplotype ids in order of first appearance over
+    the flattened genotype list."""
+    g = np.asarray(genotypes)
+    n, K = g.shape[:2]
+    first, ids = _first_occurrence_unique(g.reshape((n * K,) + g.shape[2:]))
+    return ids.reshape(n, K), g.reshape((n * K,) + g.shape[2:])[first]
+
+
+def _row_first_and_dose(ids):
+    """For id rows [n, K]: mask of the first copy of each id within its row, and the number of copies of the row's id
+    at every slot."""
+    same = ids[:, :, None] == ids[:, None, :]          # [n, K, K]
+    dose = same.sum(axis=2)
+    earlier = np.tril(np.ones(ids.shape[1:] * 2, dtype=bool), -1)[None]
+    first = ~(same & earlier).any(axis=2)
+    return first, dose
+
+
+def _support_keys(ids):
+    """The ordered list of distinct ids of every row (first copies, in row order), padded with -1: two genotypes have
+    the same support key iff they list the same distinct haplotypes in the same order."""
+    first, _ = _row_first_and_dose(ids)
+    order = np.argsort(~first, axis=1, kind="stable")  # first copies to the front, row order kept
+    keys = np.take_along_axis(ids, order, axis=1)
+    keys[~np.take_along_axis(first, order, axis=1)] = -1
+    return keys
+
+
 def sort_haplotypes(genotypes):
-    """Canonical haplotype order of every genotype [..., K, M]: lexicographic, position 0 most significant
-    (reference encoding/integer/sequence.py:78-110 applied per step in classes.py:275-278)."""
+    """Canonical haplotype order of every genotype [..., K, M]: lexicographic, position 0 most significant (the order
+    the reference establishes per step when a trace is constructed)."""
     g = np.asarray(genotypes)
     K, M = g.shape[-2:]
     flat = g.reshape(-1, K, M)
     if M == 0 or len(flat) == 0:
         return g.copy()
-    # stable sorts from the least to the most significant position == np.lexsort per genotype
+    # stable sorts from the least to the most significant position == a lexicographic sort per genotype
     order = np.tile(np.arange(K), (len(flat), 1))
     rows = np.arange(len(flat))[:, None]
     for j in range(M - 1, -1, -1):
@@ -72,9 +102,14 @@ def sort_haplotypes(genotypes):
     return flat[rows, order].reshape(g.shape)
 
 
+def _first_max(values):
+    """Index of the first maximum."""
+    return int(np.argmax(np.asarray(values)))
+
+
 @dataclass
 class Assembler(object):
-    """Abstract base class for haplotype assemblers (reference classes.py:16-52)."""
+    """Abstract base class for haplotype assemblers."""
 
     @classmethod
     def parameterize(cls, *args, **kwargs):
@@ -94,67 +129,53 @@ class PosteriorGenotypeDistribution(object):
     probabilities: np.ndarray
 
     def mode(self):
-        idx = np.argmax(self.probabilities)
-        return self.genotypes[idx], self.probabilities[idx]
+        """(genotype, probability) of the most probable genotype."""
+        i = _first_max(self.probabilities)
+        return self.genotypes[i], self.probabilities[i]
 
     def _support_labels(self):
-        """label[i] = index of the first genotype with the same set of unique haplotypes."""
-        n = len(self.genotypes)
-        sig = []
-        for gen in self.genotypes:
-            sig.append(unique_rows(gen).tobytes())
-        labels = np.zeros(n, dtype=int)
-        seen = {}
-        for i, s in enumerate(sig):
-            labels[i] = seen.setdefault(s, i)
-        return labels
+        """label[i] = index of the first genotype that lists the same distinct haplotypes."""
+        ids, _ = _haplotype_ids(self.genotypes)
+        first, inv = _first_occurrence_unique(_support_keys(ids))
+        return first[inv]
 
     def _support_sums(self):
+        """Summed probability of every support, supports in order of first appearance; each sum accumulated in
+        genotype order."""
         labels = self._support_labels()
-        firsts = np.unique(labels)  # ascending == order of first appearance
-        # sequential accumulation in order of appearance, as the reference's dict does
-        return np.array([_seq_sum(self.probabilities[labels == f]) for f in firsts])
+        firsts, inv = np.unique(labels, return_inverse=True)  # ascending label == order of first appearance
+        sums = np.zeros(len(firsts))
+        np.add.at(sums, inv, np.asarray(self.probabilities, dtype=float))  # unbuffered, in index order
+        return sums
 
     def mode_genotype_support(self):
-        """Genotypes congruent with the posterior mode support (reference classes.py:87-128)."""
+        """The genotypes that consist of exactly the haplotypes of the most probable support (any dosage), with
+        their probabilities."""
         labels = self._support_labels()
         firsts = np.unique(labels)
-        sums = self._support_sums()
-        mode = firsts[np.argmax(sums)]
-        idx = labels == mode
-        return GenotypeSupportDistribution(self.genotypes[idx], self.probabilities[idx])
+        keep = labels == firsts[_first_max(self._support_sums())]
+        return GenotypeSupportDistribution(self.genotypes[keep], self.probabilities[keep])
 
     def allele_frequencies(self, dosage=False):
-        """Posterior frequency / occurrence of haplotype alleles (reference classes.py:130-166)."""
-        n_gen, ploidy, n_base = self.genotypes.shape
-        haps = self.genotypes.reshape(n_gen * ploidy, n_base)
-        first, inv = _first_occurrence_unique(haps)
-        uhaps = haps[first]
-        inv = inv.reshape(n_gen, ploidy)
-        ufreqs = np.zeros(len(uhaps), float)
-        uoccur = np.zeros(len(uhaps), float)
-        for g in range(n_gen):
-            prob = self.probabilities[g]
-            labs, dose = np.unique(inv[g], return_counts=True)
-            ufreqs[labs] += prob * dose
-            uoccur[labs] += prob
+        """(haplotypes, posterior frequency -- or expected dosage --, posterior probability of occurrence) of every
+        haplotype of the distribution, haplotypes in order of first appearance."""
+        n_gen, ploidy, _ = self.genotypes.shape
+        ids, table = _haplotype_ids(self.genotypes)
+        first, dose = _row_first_and_dose(ids)
+        probs = np.broadcast_to(np.asarray(self.probabilities, dtype=float)[:, None], ids.shape)
+        weight = np.zeros(len(table))
+        occur = np.zeros(len(table))
+        # one term per (genotype, distinct haplotype), added genotype by genotype
+        np.add.at(weight, ids[first], probs[first] * dose[first])
+        np.add.at(occur, ids[first], probs[first])
         if dosage is False:
-            ufreqs /= ploidy
-        return uhaps, ufreqs, uoccur
-
-
-def _seq_sum(values):
-    acc = 0.0
-    first = True
-    for v in values:
-        acc = float(v) if first else acc + float(v)
-        first = False
-    return acc
+            weight /= ploidy
+        return table, weight, occur
 
 
 @dataclass
 class GenotypeSupportDistribution(object):
-    """Genotypes with identical alleles differing only by dosage (reference classes.py:169-244)."""
+    """Genotypes over one set of haplotypes that differ only by dosage."""
 
     genotypes: np.ndarray
     probabilities: np.ndarray
@@ -163,65 +184,38 @@ class GenotypeSupportDistribution(object):
         return unique_rows(self.genotypes[0])
 
     def mode_genotype(self):
-        idx = np.argmax(self.probabilities)
-        return self.genotypes[idx], self.probabilities[idx]
+        i = _first_max(self.probabilities)
+        return self.genotypes[i], self.probabilities[i]
 
     def call_genotype_support(self, threshold=0.95):
-        if np.max(self.probabilities) >= threshold:
-            idx = np.argmax(self.probabilities)
-            return self.genotypes[idx], self.probabilities[idx]
+        """The mode genotype if it reaches `threshold`; otherwise the haplotype copies shared by the most probable
+        genotypes that together reach it (multiset intersection), padded with rows of -1 up to the ploidy."""
+        probs = np.asarray(self.probabilities, dtype=float)
+        best = _first_max(probs)
+        if probs[best] >= threshold:
+            return self.genotypes[best], self.probabilities[best]
         _, ploidy, n_pos = self.genotypes.shape
-        result = np.zeros((ploidy, n_pos), dtype=self.genotypes.dtype) - 1
-        selected = list()
-        p = 0.0
-        genotypes = list(self.genotypes)
-        probabilities = list(self.probabilities)
-        while p < threshold:
-            if len(probabilities) == 0:
-                break
-            idx = np.argmax(probabilities)
-            p += probabilities.pop(idx)
-            selected.append(genotypes.pop(idx))
-        alleles = reduce(_multiset_intercept, selected)
-        for i, hap in enumerate(alleles):
-            result[i] = hap
-        return result, p
-
-
-def _multiset_op(x, y, union):
-    """Multiset intersection (min multiplicity) or union (max multiplicity) of the rows of two arrays; the
-    result lists each distinct row `multiplicity` times, distinct rows in order of first appearance in x
-    then y (the reference's Counter-based mset.intercept / mset.union)."""
-    from collections import Counter
-
-    rows = {}
-    for r in x:
-        rows.setdefault(r.tobytes(), r)
-    cx = Counter(r.tobytes() for r in x)
-    if union:
-        for r in y:
-            rows.setdefault(r.tobytes(), r)
-    cy = Counter(r.tobytes() for r in y)
-    counts = (cx | cy) if union else (cx & cy)
-    out = []
-    for k, v in counts.items():
-        out.extend([rows[k]] * v)
-    if not out:
-        return np.zeros((0,) + x.shape[1:], dtype=x.dtype)
-    return np.array(out, dtype=x.dtype)
-
-
-def _multiset_intercept(x, y):
-    return _multiset_op(x, y, union=False)
-
-
-def _multiset_union(x, y):
-    return _multiset_op(x, y, union=True)
+        # most probable first, equal probabilities in their listed order; running total in that order
+        ranked = np.argsort(-probs, kind="stable")
+        total = np.cumsum(probs[ranked])
+        reached = np.flatnonzero(total >= threshold)
+        n_sel = int(reached[0]) + 1 if len(reached) else len(ranked)
+        chosen = self.genotypes[ranked[:n_sel]]
+        out = np.full((ploidy, n_pos), -1, dtype=self.genotypes.dtype)
+        if n_sel == 1:
+            shared = chosen[0]
+        else:
+            ids, table = _haplotype_ids(chosen)
+            copies = np.stack([np.bincount(row, minlength=len(table)) for row in ids]).min(axis=0)
+            lead = ids[0][_row_first_and_dose(ids[:1])[0][0]]  # distinct haplotypes of the first genotype, in its order
+            shared = np.repeat(table[lead], copies[lead], axis=0)
+        out[: len(shared)] = shared
+        return out, float(total[n_sel - 1])
 
 
 @dataclass
 class GenotypeMultiTrace(object):
-    """Multi-chain MCMC haplotype assembler trace (reference classes.py:247-376).
+    """Multi-chain MCMC haplotype assembler trace.
 
     genotypes : int [n_chains, n_steps, ploidy, n_positions]; llks : float [n_chains, n_steps]."""
 
@@ -239,48 +233,40 @@ class GenotypeMultiTrace(object):
 
     @classmethod
     def _from_sorted(cls, genotypes, llks):
-        """Wrap a trace whose haplotypes are already in canonical order (what the HIP sampler writes)."""
+        """Wrap a trace whose haplotypes are already in canonical order (what the HIP sampler writes): no sort."""
         new = cls(None, None)
         new.genotypes = genotypes
         new.llks = llks
         return new
 
     def burn(self, n):
-        new = type(self)(None, None)
-        new.genotypes = self.genotypes[:, n:]
-        new.llks = self.llks[:, n:]
-        return new
+        """The trace without the first n steps of every chain."""
+        return self._from_sorted(self.genotypes[:, n:], self.llks[:, n:])
 
     def posterior(self):
-        """Posterior over phased genotypes: distinct states, probability descending (reference classes.py:316-325,
-        np.flip(np.argsort(probs))).  The reference leaves the order of TIED probabilities to numpy's default,
-        unstable argsort (it varies with the SIMD sort numpy dispatches to); here ties come out in descending order
-        of first appearance, which is what a stable sort gives and what the device kernel implements."""
+        """Posterior over phased genotypes: the distinct states of all chains, probability descending.  Tied
+        probabilities come out in descending order of first appearance (the reference leaves their order to numpy's
+        unstable default argsort; DESIGN.md "Known reference quirks"), on the host and in the device kernel alike."""
         n_chain, n_step, ploidy, n_base = self.genotypes.shape
-        genotypes = self.genotypes.reshape(n_chain * n_step, ploidy, n_base)
-        states, counts = unique_counts(genotypes)
+        states, counts = unique_counts(self.genotypes.reshape(n_chain * n_step, ploidy, n_base))
         probs = counts / np.sum(counts)
         idx = np.flip(np.argsort(probs, kind="stable"))
         return PosteriorGenotypeDistribution(states[idx], probs[idx])
 
     def split(self):
-        for genotypes, llks in zip(self.genotypes, self.llks):
-            new = type(self)(None, None)
-            new.genotypes = genotypes[None, ...]
-            new.llks = llks[None, ...]
-            yield new
+        """One single-chain trace per chain."""
+        for c in range(len(self.genotypes)):
+            yield self._from_sorted(self.genotypes[c: c + 1], self.llks[c: c + 1])
 
     def replicate_incongruence(self, threshold=0.6):
-        """0 / 1 / 2: none, incongruence, incongruence with > ploidy alleles (reference classes.py:341-376)."""
-        out = 0
-        posteriors = [trace.posterior() for trace in self.split()]
-        chain_modes = [dist.mode_genotype_support() for dist in posteriors]
-        alleles = [mode.alleles() for mode in chain_modes if mode.probabilities.sum() >= threshold]
-        mode_count = len({array.tobytes() for array in alleles})
-        if mode_count > 1:
-            out = 1
-            ploidy = len(alleles[0])
-            allele_count = len(reduce(_multiset_union, alleles))
-            if allele_count > ploidy:
-                out = 2
-        return out
+        """0: the chains whose mode support reaches `threshold` agree on it; 1: they do not; 2: they do not, and
+        together they hold more haplotypes than the first of them (putative copy-number variation)."""
+        supports = []
+        for chain in self.split():
+            support = chain.posterior().mode_genotype_support()
+            if support.probabilities.sum() >= threshold:
+                supports.append([h.tobytes() for h in support.alleles()])
+        if len({tuple(s) for s in supports}) <= 1:
+            return 0
+        pooled = set().union(*supports)
+        return 2 if len(pooled) > len(supports[0]) else 1

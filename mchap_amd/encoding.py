@@ -12,25 +12,24 @@ __all__ = ["as_probabilistic", "prob_of_qual", "encode_read_distributions", "uni
 
 
 def as_probabilistic(array, n_alleles=4, p=1.0, error_factor=3, dtype=float):
-    """Integer encoded alleles -> probabilistic row vectors.
+    """Integer encoded alleles -> probabilistic row vectors (same name and arguments as the reference's encoder).
 
-    The called allele gets `p`, every other allele `(1 - p) / error_factor` (error_factor stays 3 whatever
-    n_alleles is), alleles >= n_alleles[j] are zeroed, and a gap (call < 0) makes the whole position NaN
-    *before* that zero mask -- so a gap at a biallelic position of a 3-allele tensor is [nan, nan, 0]."""
-    array = np.asarray(array)
-    n_alleles = np.asarray(n_alleles)
-    error_factor = np.asarray(error_factor)
-    p = np.asarray(p)
-    if array.shape[-1] == 0:
-        return np.empty(array.shape + (0,), dtype=dtype)
-    alleles = np.arange(np.max(n_alleles))
-    onehot = array[..., None] == alleles
-    new = ((1 - p) / error_factor)[..., None] * ~onehot
-    calls = p[..., None] * onehot
-    new[onehot] = calls[onehot]
-    new[array < 0] = np.nan
-    new[..., n_alleles[..., None] <= alleles] = 0
-    return new.astype(dtype, copy=False)
+    Rules: the called allele gets `p`; every other allele gets `(1 - p) / error_factor`
+    (error_factor stays 3 whatever n_alleles is); a gap (call < 0) makes the whole position NaN; alleles the position
+    does not have (a >= n_alleles[j]) are zero -- applied last, so a gap at a biallelic position of a 3-allele tensor
+    reads [nan, nan, 0]."""
+    calls = np.asarray(array)
+    if calls.shape[-1] == 0:
+        return np.empty(calls.shape + (0,), dtype=dtype)
+    n_alleles = np.broadcast_to(np.asarray(n_alleles), calls.shape)
+    p = np.broadcast_to(np.asarray(p, dtype=float), calls.shape)
+    share = np.broadcast_to((1.0 - p) / np.asarray(error_factor, dtype=float), calls.shape)
+    allele = np.arange(int(np.max(n_alleles)))
+    called = calls[..., None] == allele
+    out = np.where(called, p[..., None], share[..., None])
+    out = np.where((calls < 0)[..., None], np.nan, out)
+    out = np.where(allele >= n_alleles[..., None], 0.0, out)
+    return out.astype(dtype, copy=False)
 
 
 def prob_of_qual(qual):

@@ -62,4 +62,5 @@ def test_lds_and_workspace_sizing():
     assert 32768 < n < 40000
     assert L.mchap_denovo_lds_bytes(200, 8, 2, 12, 2, 1) < 0
     cfg = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, random_seed=1, kernel=1)._cfg(8)
-    assert L.mchap_denovo_workspace_bytes(C.byref(cfg), 10, None) == 10 * 2 * 1024 * 16
+    # the call's break table ((8 + 1) x 8 doubles, rounded to 256 B) + 1024 cache entries of 16 B per chain
+    assert L.mchap_denovo_workspace_bytes(C.byref(cfg), 10, None) == 768 + 10 * 2 * 1024 * 16
