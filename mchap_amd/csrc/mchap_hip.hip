@@ -14,6 +14,7 @@
 #include "denovo_kernel.hpp"
 #include "denovo_simt_kernel.hpp"
 #include "denovo_spec_kernel.hpp"
+#include "denovo_lane_kernel.hpp"
 #include "exact_kernel.hpp"
 #include "posterior_kernel.hpp"
 
@@ -36,6 +37,18 @@ extern "C" int mchap_spec_init_6_64(const double *, const double *);
 extern "C" int mchap_spec_launch_6_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 extern "C" int mchap_spec_init_8_64(const double *, const double *);
 extern "C" int mchap_spec_launch_8_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+
+#define MCHAP_LANE_DECL(k)                                              \
+  extern "C" int mchap_lane_init_##k(const double *, const double *); \
+  extern "C" int mchap_lane_launch_##k(const mchap::SimtParams *, int, unsigned, size_t, hipStream_t);
+MCHAP_LANE_DECL(1)
+MCHAP_LANE_DECL(2)
+MCHAP_LANE_DECL(3)
+MCHAP_LANE_DECL(4)
+MCHAP_LANE_DECL(5)
+MCHAP_LANE_DECL(6)
+MCHAP_LANE_DECL(7)
+MCHAP_LANE_DECL(8)
 
 extern "C" int mchap_simt_init_0(const double *, const double *);
 extern "C" int mchap_simt_launch_0(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
@@ -148,7 +161,9 @@ int ensure_init() {
   {
     int (*inits[])(const double *, const double *) = {mchap_simt_init_0, mchap_simt_init_2, mchap_simt_init_4, mchap_simt_init_6,
                                                       mchap_simt_init_8, mchap_v1_init_1,   mchap_v1_init_2,   mchap_v1_init_4,
-                                                      mchap_v1_init_8,   mchap_v1_init_16};
+                                                      mchap_v1_init_8,   mchap_v1_init_16,  mchap_lane_init_1, mchap_lane_init_2,
+                                                      mchap_lane_init_3, mchap_lane_init_4, mchap_lane_init_5, mchap_lane_init_6,
+                                                      mchap_lane_init_7, mchap_lane_init_8};
     for (auto f : inits)
       if (f(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of a sampler object");
   }
@@ -299,6 +314,46 @@ int launch_spec(int K, int G, const mchap::SimtParams &P, int n_units, int chain
   return MCHAP_OK;
 }
 
+// The steady-state sampler (kernel 4, denovo_lane_kernel.hpp): any ploidy 1..8 with a single temperature; its serving
+// code is the speculative kernel's with the whole wavefront per chain, whose mutation step holds 2 (octoploids: 3)
+// sub-steps per lane.
+bool lane_supported(int K, int max_pos, int n_temps) {
+  if (n_temps != 1 || K < 1 || K > 8) return false;
+  const int slots = (K == 8) ? 3 : 2;
+  return K * max_pos <= slots * 64 && K * (K - 1) <= 64;
+}
+
+// lanes per chain in its fast path: few enough that the launch still fills the SIMDs twice over
+int lane_shift(long long n_chains, int K, int max_pos, int max_allele) {
+  if (const char *e = std::getenv("MCHAP_HIP_LANES")) {
+    const int l = std::atoi(e);
+    for (int s = 0; s <= 6; s++)
+      if ((1 << s) == l) return s;
+  }
+  int s = 0;
+  while (s < 4 && n_chains * (1ll << s) / 64 < 2048) s++;
+  // LDS per wave must leave room for two waves per SIMD (8 per CU of 160 KiB)
+  while (s < 6 && mchap::lane_lds_bytes(K, max_pos, max_allele, 1 << s) > 20 * 1024) s++;
+  return s;
+}
+
+int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipStream_t stream) {
+  int (*launch)(const mchap::SimtParams *, int, unsigned, size_t, hipStream_t) =
+      K == 1 ? mchap_lane_launch_1 : K == 2 ? mchap_lane_launch_2 : K == 3 ? mchap_lane_launch_3 : K == 4 ? mchap_lane_launch_4 :
+      K == 5 ? mchap_lane_launch_5 : K == 6 ? mchap_lane_launch_6 : K == 7 ? mchap_lane_launch_7 : mchap_lane_launch_8;
+  const long long n_chains = (long long)n_units * chains;
+  const int lsh = lane_shift(n_chains, K, P.max_pos, P.max_allele);
+  const size_t lds = mchap::lane_lds_bytes(K, P.max_pos, P.max_allele, 1 << lsh);
+  if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "steady-state sampler needs %zu bytes of LDS", lds);
+  const int per_wave = 64 >> lsh;
+  char name[96];
+  snprintf(name, sizeof(name), "denovo_lane_kernel<%d> L=%d", K, 1 << lsh);
+  SamplerTimer timer(stream, name);
+  const int e = launch(&P, lsh, (unsigned)((n_chains + per_wave - 1) / per_wave), lds, stream);
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
+  return MCHAP_OK;
+}
+
 // lanes per chain for the speculative sampler: every option of an interval step (<= K(K-1)) and half the
 // sub-steps of a mutation step (K * n_pos) must fit; 0 if the shape is not supported by it
 int spec_group(int K, int max_pos) {
@@ -337,11 +392,13 @@ size_t prep_lds_copy_limit() {
 }
 
 int spec_group(int K, int max_pos);
+bool lane_supported(int K, int max_pos, int n_temps);
 
 // Read chunks (of 64) per unit for the prepare pass and the sampler behind it.  The speculative sampler takes any
 // count up to 8 (then 12, 16); the lanes-over-chains kernel is instantiated for powers of two.
 int simt_rpl(const mchap_denovo_cfg *cfg, int uniform_ploidy, int max_pos, int max_reads) {
-  const bool spec = cfg->kernel != 1 && cfg->kernel != 2 && uniform_ploidy > 0 && spec_group(uniform_ploidy, max_pos) != 0;
+  const bool lane = cfg->kernel == 4 && uniform_ploidy > 0 && lane_supported(uniform_ploidy, max_pos, cfg->n_temps);
+  const bool spec = lane || (cfg->kernel != 1 && cfg->kernel != 2 && uniform_ploidy > 0 && spec_group(uniform_ploidy, max_pos) != 0);
   if (!spec) return rpl_for(max_reads);
   const int need = (max_reads + 63) / 64;
   if (need <= 8) return need < 1 ? 1 : need;
@@ -581,6 +638,8 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
       default: rc = launch_prepare<16>(SP, n_units, lds_prep, stream); break;
     }
     if (rc) return rc;
+    if (cfg->kernel == 4 && B.uniform_ploidy > 0 && lane_supported(B.uniform_ploidy, B.max_pos, cfg->n_temps))
+      return launch_lane(B.uniform_ploidy, SP, n_units, cfg->chains, stream);
     // default: the speculative sampler when every unit shares a supported ploidy, else lanes over chains
     if (cfg->kernel != 2) {
       const int K = B.uniform_ploidy;
