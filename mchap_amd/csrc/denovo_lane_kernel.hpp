@@ -400,8 +400,171 @@ __device__ __forceinline__ ServeResult<KT> serve_structural(Grp<KT> &cu, const S
   return R;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Chain state handed between the two kernels of the pipeline (one record per chain in the workspace)
+// ---------------------------------------------------------------------------------------------------------
+struct LaneState {
+  uint64_t g[MCHAP_MAX_PLOIDY];  // haplotype words
+  double llk;
+  uint64_t ctr;                  // next draw: the first draw of compound step `phase` of step `step`
+  uint64_t lo, hi;               // mutation bounds (valid iff flags & LS_MVALID)
+  int32_t step;                  // next step to run; == steps when the chain is finished (or dead)
+  int32_t phase;                 // compound step to resume at: 0 mutation, 1..3 the structural steps
+  int32_t flags;
+  int32_t pad;
+};
+static_assert(sizeof(LaneState) == 112, "LaneState layout");
+enum { LS_MVALID = 1, LS_SETTLED = 2 };  // SETTLED: every threshold of the genotype is known, the steady kernel may run it
+enum { LANE_MODE_RESUME = 1, LANE_MODE_PARK = 2 };
+
+// profiling builds (make stats / make phases): wave clock per region and event counts, summed over the launch
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+#define LPH(i)                                                   \
+  do {                                                           \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    lph[i] += t_ - lpt0;                                         \
+    lpt0 = t_;                                                   \
+  } while (0)
+#define LCNT(i, n) lph[i] += (unsigned long long)(n)
+#else
+#define LPH(i)
+#define LCNT(i, n)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------
+// The integer fast path, shared by both kernels
+// ---------------------------------------------------------------------------------------------------------
+// Mutation compound step of a chain whose bounds are valid: this lane's share of the Philox blocks behind draw `base`
+// (the step's first uniform): uniforms 0 .. n-1 are tested in registers, the E draws behind them go to the chain's window.
+// Returns false if one of this lane's uniforms falls outside [lo, hi).
+__device__ __forceinline__ bool fast_mutation(const Stream &st, uint64_t base, int n, int E, uint64_t lo, uint64_t hi, LDSP(uint64_t) win,
+                                              int sl, int L) {
+  bool ok = true;
+  const uint64_t b0 = base >> 1;
+  const int nblk = (int)(((base + (uint64_t)(n + E) + 1) >> 1) - b0);
+  for (int b = sl; b < nblk; b += L) {
+    uint32_t o[4];
+    const uint64_t blk = b0 + (uint64_t)b;
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), st.c2, st.c3, st.k0, st.k1, o);
+    const int i0 = (int)((long long)(blk << 1) - (long long)base);  // index of the block's first draw: >= -1
+    const uint64_t w0 = (uint64_t)o[0] | ((uint64_t)o[1] << 32), w1 = (uint64_t)o[2] | ((uint64_t)o[3] << 32);
+    const uint64_t x0 = u53_of(w0), x1 = u53_of(w1);
+    const bool in0 = x0 >= lo && x0 < hi, in1 = x1 >= lo && x1 < hi;
+    if (i0 >= 0 && i0 < n) ok = ok && in0;
+    if (i0 + 1 < n) ok = ok && in1;
+    if (i0 >= n && i0 < n + E) win[i0 - n] = w0;
+    if (i0 + 1 >= n && i0 + 1 < n + E) win[i0 + 1 - n] = w1;
+  }
+  return ok;
+}
+
+// One structural compound step on thresholds alone.  The chain's window holds draws from its current one on (entry
+// `doff`, `dcount` valid entries).  Outcome: done (nothing moves: doff_end = window offset behind the step), or exact
+// (the thresholds cannot decide: zeros / n_int / doff1 describe the drawn intervals), or bad (structural.py:49-50), or
+// short_ (the window ran out: nothing may be concluded; refill and call again).
+struct SFast {
+  bool done, exact, bad, short_;
+  uint64_t zeros;
+  int n_int, doff1, doff_end;
+};
+__device__ __forceinline__ SFast fast_structural(int kind, uint64_t pthr, int n_intervals_fixed, int Mh, LDSP(uint64_t) win, int doff0, int dcount,
+                                                 LDSP(uint64_t) bc, LDSP(uint32_t) memo /* of the step's type */, bool memo_iv) {
+  SFast R;
+  R.done = R.exact = R.bad = R.short_ = false;
+  R.zeros = 0;
+  R.n_int = 0;
+  int doff = doff0;
+  auto fetch = [&](int i) -> uint64_t {
+    if (i < dcount) return win[i];
+    R.short_ = true;
+    return 0ull;
+  };
+  bool doit = u53_of(fetch(doff)) < pthr;  // rand() <= p
+  doff++;
+  if (doit && kind < 2) {
+    int nb;
+    if (n_intervals_fixed > 0) {
+      doff++;  // break_dist = [0, ..., 0, 1]: the draw is consumed (assemble/mcmc.py:214-217)
+      nb = n_intervals_fixed - 1;
+    } else {
+      const uint64_t x = u53_of(fetch(doff));
+      doff++;
+      nb = Mh;
+      for (int j = 0; j < Mh; j++)
+        if (x < bc[j]) {
+          nb = j;
+          break;
+        }
+    }
+    if (nb >= Mh) {
+      R.bad = true;
+      doit = false;
+    } else {
+      uint64_t ind = 0;
+      for (int i = 1; i < Mh; i++) ind |= 1ull << i;
+      for (int b = 0; b < nb; b++) {
+        const int no = __popcll(ind);
+        if (no == 0) break;
+        int k = 0;
+        if (no > 1) {
+          k = (int)__umulhi((uint32_t)fetch(doff), (uint32_t)no);
+          doff++;
+        }
+        uint64_t t = ind;
+        while (k-- > 0) t &= t - 1;
+        ind &= ~(t & (~t + 1));
+      }
+      R.zeros = ~ind & ((1ull << (Mh + 1)) - 1ull);
+      R.n_int = nb + 1;
+    }
+  } else if (doit) {
+    R.zeros = 1ull | (1ull << Mh);
+    R.n_int = 1;
+  }
+  R.doff1 = doff;
+  if (!doit) {
+    R.done = !R.bad;
+  } else {
+    // order-free check: every interval known, and every consumed uniform beyond the largest threshold
+    bool unknown = !memo_iv;
+    int n_cons = 0;
+    uint32_t mx = 0;
+    uint64_t z = R.zeros;
+    for (int qq = 0; qq < R.n_int; qq++) {
+      const int start = __ffsll((long long)z) - 1;
+      z &= z - 1;
+      const int stop = __ffsll((long long)z) - 1;
+      const uint32_t t = memo[spec_memo_index(start, stop)];
+      if (t == MEMO_UNKNOWN) unknown = true;
+      else if (t != MEMO_NOOPT) {
+        n_cons++;
+        mx = t > mx ? t : mx;
+      }
+    }
+    if (!unknown) {
+      bool low = false;
+      for (int k = 0; k < n_cons; k++) low = low || (((uint32_t)fetch(doff + (R.n_int - 1) + k)) >> 5) < mx;
+      if (!low) {
+        doff += R.n_int - 1 + n_cons;
+        R.done = true;
+      }
+    }
+    R.exact = !R.done;
+  }
+  R.doff_end = doff;
+  if (R.short_) R.done = R.exact = R.bad = false;
+  return R;
+}
+__device__ __forceinline__ uint64_t decision_threshold(double pstep) {  // rand() <= p  <=>  u53 < threshold
+  return pstep < 0.0 ? 0ull : (pstep >= 1.0 ? (1ull << 53) : (uint64_t)floor(pstep * 9007199254740992.0) + 1ull);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Settling kernel: runs chains with the serving code at hand until their thresholds are complete (then parks them
+// for the steady kernel), or to the end.
+// ---------------------------------------------------------------------------------------------------------
 template <int KT>
-__global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, const int lsh) {
+__global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P, const int lsh, const int mode) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DenovoParams &D = P.d;
   const int L = 1 << lsh;
@@ -411,6 +574,19 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
   const int Cn = D.chains, Sn = D.steps;
   const int mmax = P.max_pos, nmax = KT * P.max_pos;
   const int rpad = D.rpad;
+  const bool resume = (mode & LANE_MODE_RESUME) != 0, may_park = (mode & LANE_MODE_PARK) != 0;
+  const long long q = (long long)blockIdx.x * NC + ci;  // chain index
+  const long long n_chains = (long long)P.n_units * Cn;
+  LaneState *state = reinterpret_cast<LaneState *>(P.lane_state);
+  if (resume) {
+    // nothing to do for this wave?  (finished chains, and settled ones the steady kernel will pick up)
+    bool want = false;
+    if (q < n_chains) {
+      const int st_step = state[q].step, st_flags = state[q].flags;
+      want = st_step < Sn && !((st_flags & LS_SETTLED) && may_park);
+    }
+    if (!wave_any(want)) return;
+  }
   LaneLds LL;
   {
     const int nopt = P.max_allele > 1 ? P.max_allele - 1 : 1;
@@ -458,8 +634,6 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
     const int start = i - stop * (stop - 1) / 2;
     LL.itab[i] = (uint16_t)(start | (stop << 8));
   }
-  const long long q = (long long)blockIdx.x * NC + ci;  // chain index
-  const long long n_chains = (long long)P.n_units * Cn;
   LChain<KT> c;
   c.alive = q < n_chains;
   const int u = c.alive ? (int)(q / Cn) : 0;
@@ -472,7 +646,9 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
   c.Mh = c.alive ? mi[META_I_MH] : 1;
   c.bits = allele_bits(A);
   const int Mh = c.Mh;
+  const int tri_h = spec_memo_entries(Mh);
   const bool cache_on = D.cache_slots > 0;
+  uint32_t *gmemo = reinterpret_cast<uint32_t *>(P.lane_memo) + (size_t)(c.alive ? q : 0) * 2 * LL.tri;
   if (sl == 0) {
     LL.gval[ci * GV_N + GV_INB] = U.inbreeding;
     LL.gval[ci * GV_N + GV_MLO] = 0.0;
@@ -507,7 +683,10 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
         LL.bcum[ci * mmax + j] = ceil53(cacc);
       }
     }
-    for (int i = sl; i < 2 * LL.tri; i += L) LL.memo[(size_t)ci * 2 * LL.tri + i] = MEMO_UNKNOWN;
+    if (resume)
+      for (int i = sl; i < 2 * LL.tri; i += L) LL.memo[(size_t)ci * 2 * LL.tri + i] = gmemo[i];
+    else
+      for (int i = sl; i < 2 * LL.tri; i += L) LL.memo[(size_t)ci * 2 * LL.tri + i] = MEMO_UNKNOWN;
   }
   lds_sync();
   const int amax = [&] {
@@ -516,14 +695,42 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
     for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, WAVE));
     return v;
   }();
-  // ---- initial genotype (assemble/mcmc.py:202-208) ----
   {
     GWords<KT> z;
 #pragma unroll
     for (int h = 0; h < KT; h++) z.w[h] = 0;
     c.g = z;
   }
-  if (c.alive) {
+  c.ctr = 0;
+  c.doff = 0;
+  c.dcount = 0;
+  c.llk = 0.0;
+  c.lo = 0;
+  c.hi = 0;
+  c.mvalid = false;
+  c.stable = false;
+  c.n_unknown = c.alive ? 2 * tri_h : 0;
+  c.cursor = 0;
+  int my_step = 0;   // the chain's next step
+  int skip = 0;      // first compound step to run in the chain's first step here (resume in mid-step)
+  bool running = c.alive;
+  if (resume) {
+    if (c.alive) {
+      const LaneState st = state[q];
+      my_step = st.step;
+      skip = st.phase;
+      running = st.step < Sn && !((st.flags & LS_SETTLED) && may_park);
+#pragma unroll
+      for (int h = 0; h < KT; h++) set_word<KT>(c.g, h, st.g[h]);
+      c.llk = st.llk;
+      c.ctr = st.ctr;
+      c.lo = st.lo;
+      c.hi = st.hi;
+      c.mvalid = (st.flags & LS_MVALID) != 0;
+      c.stable = true;
+    }
+  } else if (c.alive) {
+    // ---- initial genotype (assemble/mcmc.py:202-208) ----
     LDSP(uint8_t) shift = LL.shift + ci * mmax;
     if (U.initial_off >= 0) {
       const int8_t *ini = D.initial + U.initial_off + (size_t)chain * KT * Mh;
@@ -564,19 +771,21 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
       }
     }
   }
-  c.ctr = 0;
-  c.doff = 0;
-  c.dcount = 0;
-  c.llk = 0.0;
-  c.lo = 0;
-  c.hi = 0;
-  c.mvalid = false;
-  c.stable = false;
-  c.n_unknown = c.alive ? 2 * spec_memo_entries(Mh) : 0;
-  c.cursor = 0;
   const bool memo_mut = !(P.flags & 1), memo_iv = !(P.flags & 2);
   int cur_dict_unit = -1;  // unit whose dictionary sits in LL.dict (wave-uniform)
   int status = MCHAP_UNIT_OK;
+  // exact count of the chain's unknown thresholds (wave-level: every lane must call)
+  auto recount = [&]() {
+    int n = 0;
+    if (c.alive)
+      for (int i = sl; i < 2 * tri_h; i += L) {
+        const int ty = i >= tri_h ? 1 : 0;
+        n += LL.memo[(size_t)ci * 2 * LL.tri + (size_t)ty * LL.tri + (i - ty * tri_h)] == MEMO_UNKNOWN ? 1 : 0;
+      }
+    for (int o = 1; o < L; o <<= 1) n += __shfl_xor(n, o, WAVE);
+    return n;
+  };
+  if (resume) c.n_unknown = recount();
 
   // Wave-uniform view of chain `cs` for the serving code (speculative-kernel context, group 0 == the chain).
   auto open_chain = [&](int cs, Grp<KT> &cu, SpecLds &S) {
@@ -607,9 +816,12 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
       lds_sync();
     }
   };
+  auto wipe_memo = [&](int cs) {
+    for (int i = lane; i < 2 * LL.tri; i += WAVE) LL.memo[(size_t)cs * 2 * LL.tri + i] = MEMO_UNKNOWN;
+  };
 
   // ---- initial likelihood (assemble/mcmc.py:303): one evaluation per chain, the wave serving chain after chain ----
-  {
+  if (!resume) {
     unsigned long long todo = __ballot(c.alive && sl == 0);
     while (todo) {
       const int owner = __ffsll((long long)todo) - 1;
@@ -632,62 +844,45 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
     }
   }
 
-  for (int step = 0; step < Sn; step++) {
-    if (c.alive && isnan(c.llk)) {  // assemble/mcmc.py:330-331
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+  unsigned long long lph[24];
+  for (int i_ = 0; i_ < 24; i_++) lph[i_] = 0;
+  unsigned long long lpt0 = __builtin_amdgcn_s_memtime();
+#endif
+  int nbuf = 0;  // trace records of the chain waiting in LDS: steps my_step - nbuf .. my_step - 1
+  const uint64_t pthr0 = decision_threshold(D.p_recomb), pthr1 = decision_threshold(D.p_partial), pthr2 = decision_threshold(D.p_dosage);
+  while (wave_any(running)) {
+    LPH(0);
+    if (running && isnan(c.llk)) {  // assemble/mcmc.py:330-331
       status = MCHAP_UNIT_NAN_LLK;
       c.alive = false;
+      running = false;
     }
     bool changed = false;  // genotype changed during this step
     // =============================== mutation compound step ===============================
     {
+      const bool act = running && skip == 0;
       const int n = KT * Mh;
       const uint64_t ctr0 = c.ctr;
-      const uint64_t base = ctr0 + (uint64_t)(n - 1);  // first uniform
       const int E = lane_extra(Mh);
       LDSP(uint64_t) win = LL.win + (size_t)ci * LL.win_n;
-      bool ok = c.alive && c.mvalid;
-      if (ok) {
-        // the n uniforms (tested in registers) and the E draws behind them (the structural steps' window), Philox blocks
-        // dealt round-robin to the chain's lanes
-        const Stream st = ld_stream_l(LL.gstream, ci);
-        const uint64_t b0 = base >> 1;
-        const int nblk = (int)(((base + (uint64_t)(n + E) + 1) >> 1) - b0);
-        for (int b = sl; b < nblk; b += L) {
-          uint32_t o[4];
-          const uint64_t blk = b0 + (uint64_t)b;
-          philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), st.c2, st.c3, st.k0, st.k1, o);
-          const long long i0 = (long long)(blk << 1) - (long long)base;
-          const uint64_t w0 = (uint64_t)o[0] | ((uint64_t)o[1] << 32), w1 = (uint64_t)o[2] | ((uint64_t)o[3] << 32);
-          if (i0 >= 0) {
-            if (i0 < n) {
-              const uint64_t x = u53_of(w0);
-              ok = ok && x >= c.lo && x < c.hi;
-            } else if (i0 < n + E) {
-              win[i0 - n] = w0;
-            }
-          }
-          if (i0 + 1 < n) {
-            const uint64_t x = u53_of(w1);
-            ok = ok && x >= c.lo && x < c.hi;
-          } else if (i0 + 1 < n + E) {
-            win[i0 + 1 - n] = w1;
-          }
-        }
-      }
+      bool ok = act && c.mvalid;
+      if (ok) ok = fast_mutation(ld_stream_l(LL.gstream, ci), ctr0 + (uint64_t)(n - 1), n, E, c.lo, c.hi, win, sl, L);
       lds_sync();  // the window entries were written by the chain's other lanes
-      // all lanes of the chain must agree
       {
-        const unsigned long long badm = __ballot(c.alive && !ok);
+        const unsigned long long badm = __ballot(act && !ok);
         const unsigned long long mine = L == 64 ? ~0ull : (((1ull << L) - 1ull) << (ci * L));
-        ok = c.alive && !(badm & mine);
+        ok = act && !(badm & mine);
       }
-      if (c.alive && ok) {
+      if (ok) {
         c.ctr = ctr0 + (uint64_t)(2 * n - 1);
         c.doff = 0;
         c.dcount = E;
       }
+      LPH(1);
       // chains that could not decide: the whole wave runs the step for them, one chain at a time
-      unsigned long long todo = __ballot(c.alive && !ok && sl == 0);
+      unsigned long long todo = __ballot(act && !ok && sl == 0);
+      LCNT(10, __popcll(todo));
       while (todo) {
         const int owner = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -713,137 +908,55 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
           c.hi = ceil53(mhi);
           if (diff) {
             changed = true;
-            c.n_unknown = 2 * spec_memo_entries(Mh);
+            c.n_unknown = 2 * tri_h;
           }
         }
-        if (diff)  // the interval-step thresholds described the previous genotype
-          for (int i = lane; i < 2 * LL.tri; i += WAVE) LL.memo[(size_t)cs * 2 * LL.tri + i] = MEMO_UNKNOWN;
+        if (diff) wipe_memo(cs);  // the interval-step thresholds described the previous genotype
         lds_sync();
       }
     }
+    LPH(2);
     // =============================== structural compound steps ===============================
 #pragma unroll 1
     for (int kind = 0; kind < 3; kind++) {
       const int step_type = kind == 0 ? 0 : 1;
       LDSP(uint64_t) win = LL.win + (size_t)ci * LL.win_n;
       LDSP(uint32_t) memo = LL.memo + (size_t)ci * 2 * LL.tri + (size_t)step_type * LL.tri;
-      // decision threshold: rand() <= p  <=>  u53 < pt
-      const double pstep = kind == 0 ? D.p_recomb : (kind == 1 ? D.p_partial : D.p_dosage);
-      const uint64_t pthr = pstep < 0.0 ? 0ull : (pstep >= 1.0 ? (1ull << 53) : (uint64_t)floor(pstep * 9007199254740992.0) + 1ull);
-      bool pending = c.alive;   // chain has not finished this compound step
-      bool exact = false;       // fast path could not decide: visiting order + walk
+      const uint64_t pthr = kind == 0 ? pthr0 : (kind == 1 ? pthr1 : pthr2);
+      bool pending = running && skip <= kind + 1;  // chain has not finished this compound step
+      bool exact = false;                          // thresholds could not decide: visiting order + walk
       uint64_t zeros = 0;
       int n_int = 0;
-      int doff1 = 0;            // window offset after decision / breaks (start of the permutation draws)
+      int doff1 = 0;  // window offset after decision / breaks (start of the permutation draws)
       // ---- fast path; re-run after a refill for the chains whose window ran out ----
       while (wave_any(pending && !exact)) {
-        bool short_ = false;
+        LCNT(11, 1);
         const bool act = pending && !exact;
-        int doff = c.doff;
-        auto fetch = [&](int i) -> uint64_t {
-          if (i < c.dcount) return win[i];
-          short_ = true;
-          return 0ull;
-        };
-        bool doit = false, bad_breaks = false;
-        uint64_t zeros_ = 0;
-        int n_int_ = 0;
-        if (act) {
-          doit = u53_of(fetch(doff)) < pthr;
-          doff++;
-          if (doit && kind < 2) {
-            int nb;
-            if (D.n_intervals > 0) {
-              doff++;  // break_dist = [0, ..., 0, 1]: the draw is consumed (assemble/mcmc.py:214-217)
-              nb = D.n_intervals - 1;
-            } else {
-              const uint64_t x = u53_of(fetch(doff));
-              doff++;
-              LDSP(uint64_t) bc = LL.bcum + (size_t)ci * mmax;
-              nb = Mh;
-              for (int j = 0; j < Mh; j++)
-                if (x < bc[j]) {
-                  nb = j;
-                  break;
-                }
-            }
-            if (nb >= Mh) {
-              bad_breaks = true;
-              doit = false;
-            } else {
-              uint64_t ind = 0;
-              for (int i = 1; i < Mh; i++) ind |= 1ull << i;
-              for (int b = 0; b < nb; b++) {
-                const int no = __popcll(ind);
-                if (no == 0) break;
-                int k = 0;
-                if (no > 1) {
-                  k = (int)__umulhi((uint32_t)fetch(doff), (uint32_t)no);
-                  doff++;
-                }
-                uint64_t t = ind;
-                while (k-- > 0) t &= t - 1;
-                ind &= ~(t & (~t + 1));
-              }
-              zeros_ = ~ind & ((1ull << (Mh + 1)) - 1ull);
-              n_int_ = nb + 1;
-            }
-          } else if (doit) {
-            zeros_ = 1ull | (1ull << Mh);
-            n_int_ = 1;
-          }
-        }
-        const int doff1_ = doff;
-        bool done = act && !doit;
-        if (act && doit) {
-          // order-free check: every interval known, and every consumed uniform beyond the largest threshold
-          bool unknown = !memo_iv;
-          int n_cons = 0;
-          uint32_t mx = 0;
-          uint64_t z = zeros_;
-          for (int qq = 0; qq < n_int_; qq++) {
-            const int start = __ffsll((long long)z) - 1;
-            z &= z - 1;
-            const int stop = __ffsll((long long)z) - 1;
-            const uint32_t t = memo[spec_memo_index(start, stop)];
-            if (t == MEMO_UNKNOWN) unknown = true;
-            else if (t != MEMO_NOOPT) {
-              n_cons++;
-              mx = t > mx ? t : mx;
-            }
-          }
-          if (!unknown) {
-            bool low = false;
-            for (int k = 0; k < n_cons; k++) low = low || (((uint32_t)fetch(doff + (n_int_ - 1) + k)) >> 5) < mx;
-            if (!low) {
-              doff += n_int_ - 1 + n_cons;
-              done = true;
-            }
-          }
-        }
-        if (act && !short_) {
-          if (bad_breaks) {
+        SFast F;
+        F.short_ = false;
+        if (act) F = fast_structural(kind, pthr, D.n_intervals, Mh, win, c.doff, c.dcount, LL.bcum + (size_t)ci * mmax, memo, memo_iv);
+        if (act && !F.short_) {
+          if (F.bad) {
             status = MCHAP_UNIT_BREAKS;
             c.alive = false;
+            running = false;
             pending = false;
-          } else if (done) {
-            c.ctr += (uint64_t)(doff - c.doff);
-            c.doff = doff;
+          } else if (F.done) {
+            c.ctr += (uint64_t)(F.doff_end - c.doff);
+            c.doff = F.doff_end;
             pending = false;
           } else {
-            exact = true;  // keeps c.ctr / c.doff at the start of the step; doff1 marks the permutation draws
-            zeros = zeros_;
-            n_int = n_int_;
-            doff1 = doff1_;
+            exact = true;  // c.ctr / c.doff stay at the start of the step; doff1 marks the permutation draws
+            zeros = F.zeros;
+            n_int = F.n_int;
+            doff1 = F.doff1;
           }
         }
         // refill the windows that ran out (from the chain's current draw) and go again
-        if (wave_any(act && short_)) {
-          const bool mine = act && short_;
-          if (mine) {
-            const Stream st = ld_stream_l(LL.gstream, ci);
-            stage_draws_l(st, c.ctr, LL.win_n, win, sl, L);
-          }
+        if (wave_any(act && F.short_)) {
+          LCNT(12, 1);
+          const bool mine = act && F.short_;
+          if (mine) stage_draws_l(ld_stream_l(LL.gstream, ci), c.ctr, LL.win_n, win, sl, L);
           lds_sync();
           if (mine) {
             c.doff = 0;
@@ -851,16 +964,15 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
           }
         }
       }
+      LPH(3);
       // ---- exact path: visiting order (np.random.permutation), then the intervals one after the other ----
       if (wave_any(exact)) {
+        LCNT(13, 1);
         LDSP(uint8_t) ord = LL.ord + (size_t)ci * (mmax + 1);
         // the window must hold the rest of the step: n_int - 1 shuffle draws + up to n_int uniforms
         if (wave_any(exact && c.dcount - doff1 < 2 * n_int)) {
           const bool mine = exact && c.dcount - doff1 < 2 * n_int;
-          if (mine) {
-            const Stream st = ld_stream_l(LL.gstream, ci);
-            stage_draws_l(st, c.ctr, LL.win_n, win, sl, L);
-          }
+          if (mine) stage_draws_l(ld_stream_l(LL.gstream, ci), c.ctr, LL.win_n, win, sl, L);
           lds_sync();
           if (mine) {
             doff1 -= c.doff;
@@ -917,6 +1029,7 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
           }
           // serve the blocked chains, one at a time
           unsigned long long todo = __ballot(exact && sl == 0);
+          LCNT(14, __popcll(todo));
           while (todo) {
             const int owner = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -936,25 +1049,29 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
                 c.llk = cu.llk;
                 c.mvalid = false;
                 changed = true;
-                c.n_unknown = 2 * spec_memo_entries(Mh);
+                c.n_unknown = 2 * tri_h;
               } else {
                 c.n_unknown -= R.filled;
                 c.cursor += WAVE - 1;
-                if (c.cursor >= 2 * spec_memo_entries(Mh)) c.cursor %= 2 * spec_memo_entries(Mh);
+                if (c.cursor >= 2 * tri_h) c.cursor %= 2 * tri_h;
               }
               qi++;
             }
             if (R.moved) {  // the thresholds described the previous genotype
-              for (int i = lane; i < 2 * LL.tri; i += WAVE) LL.memo[(size_t)cs * 2 * LL.tri + i] = MEMO_UNKNOWN;
+              wipe_memo(cs);
               lds_sync();
             }
           }
         }
       }
+      LPH(7);
     }
+    LPH(4);
     // =============================== thresholds of settled chains ===============================
-    if (memo_iv && wave_any(c.alive && c.n_unknown > 0 && !changed && c.stable)) {
-      unsigned long long todo = __ballot(c.alive && c.n_unknown > 0 && !changed && c.stable && sl == 0);
+    // a chain whose genotype survived the previous and this step gets all its unknown thresholds now
+    if (memo_iv && wave_any(running && c.n_unknown > 0 && !changed && c.stable)) {
+      unsigned long long todo = __ballot(running && c.n_unknown > 0 && !changed && c.stable && sl == 0);
+      LCNT(15, __popcll(todo));
       while (todo) {
         const int owner = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -962,46 +1079,275 @@ __global__ __launch_bounds__(64, 2) void denovo_lane_kernel(const SimtParams P, 
         Grp<KT> cu;
         SpecLds S;
         open_chain(cs, cu, S);
-        const int cur = __builtin_amdgcn_readlane(c.cursor, owner);
-        const ServeResult<KT> R = serve_structural<KT>(cu, S, LL, cs, false, 0, 0, 0ull, cur, mmax, rpad, lane);
+        int cur = __builtin_amdgcn_readlane(c.cursor, owner);
+        const int total = 2 * spec_memo_entries(cu.Mh);
+        int left = total;  // upper bound of the rounds: every round resolves at least one candidate it finds
+        for (int pass = 0; pass < total && left > 0; pass++) {
+          const ServeResult<KT> R = serve_structural<KT>(cu, S, LL, cs, false, 0, 0, 0ull, cur, mmax, rpad, lane);
+          cur += WAVE;
+          if (cur >= total) cur %= total;
+          // done when a whole sweep over the table found nothing (counted exactly below)
+          int n = 0;
+          for (int i = lane; i < total; i += WAVE) {
+            const int ty = i >= total / 2 ? 1 : 0;
+            n += LL.memo[(size_t)cs * 2 * LL.tri + (size_t)ty * LL.tri + (i - ty * (total / 2))] == MEMO_UNKNOWN ? 1 : 0;
+          }
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, WAVE);
+          left = n;
+          (void)R;
+        }
         if (ci == cs) {
-          c.n_unknown -= R.filled;
-          c.cursor += WAVE;
-          if (c.cursor >= 2 * spec_memo_entries(Mh)) c.cursor %= 2 * spec_memo_entries(Mh);
+          c.n_unknown = left;
+          c.cursor = cur;
         }
       }
     }
-    c.stable = !changed;
+    LPH(5);
     // =============================== record ===============================
     {
       LDSP(uint64_t) tb = LL.tbuf + (size_t)ci * LANE_TB * (KT + 1);
-      const int slot = step % LANE_TB;
-      if (c.alive) {
+      if (running) {
         const GWords<KT> gr = c.g;
         for (int w = sl; w < KT; w += L) {
           const uint64_t x = sel_word<KT>(gr, w);
           int rank = 0;
 #pragma unroll
           for (int h = 0; h < KT; h++) rank += (gr.w[h] < x || (gr.w[h] == x && h < w)) ? 1 : 0;
-          tb[slot * KT + rank] = x;
+          tb[nbuf * KT + rank] = x;
         }
-        if (sl == 0) tb[LANE_TB * KT + slot] = (uint64_t)__double_as_longlong(c.llk);
+        if (sl == 0) tb[LANE_TB * KT + nbuf] = (uint64_t)__double_as_longlong(c.llk);
+        nbuf++;
+        my_step++;
+        skip = 0;
       }
-      if (slot == LANE_TB - 1 || step == Sn - 1) {
+      c.stable = !changed;
+      // finished, or settled: every threshold known, bounds valid, genotype stable -> the steady kernel takes over
+      bool stop = false, park = false;
+      if (running && my_step >= Sn) stop = true;
+      if (running && !stop && may_park && memo_iv && memo_mut && c.mvalid && c.n_unknown == 0 && c.stable) {
+        stop = true;
+        park = true;
+      }
+      const bool flush = running && (nbuf == LANE_TB || stop);
+      if (wave_any(flush)) {
         lds_sync();
-        if (c.alive) {
-          const int first = step - slot;
-          const int nw = (slot + 1) * KT;
+        if (flush) {
+          const int first = my_step - nbuf;
+          const int nw = nbuf * KT;
           uint64_t *tp = reinterpret_cast<uint64_t *>((uintptr_t)LL.gptr[ci * GP_N + GP_TRACE]) + (size_t)first * KT;
           for (int i = sl; i < nw; i += L) tp[i] = tb[i];
           uint64_t *lp = reinterpret_cast<uint64_t *>((uintptr_t)LL.gptr[ci * GP_N + GP_LLK]) + first;
-          for (int i = sl; i <= slot; i += L) lp[i] = tb[LANE_TB * KT + i];
+          for (int i = sl; i < nbuf; i += L) lp[i] = tb[LANE_TB * KT + i];
+          nbuf = 0;
         }
         lds_sync();
       }
+      LCNT(16, __popcll(__ballot(park && sl == 0)));
+      LCNT(17, wave_sum_i((park && sl == 0) ? my_step : 0));
+      LCNT(19, __popcll(__ballot(stop && !park && sl == 0)));
+      if (stop) {
+        running = false;
+        if (park) {
+          // hand the chain over: state record + its threshold table
+          for (int i = sl; i < 2 * LL.tri; i += L) gmemo[i] = LL.memo[(size_t)ci * 2 * LL.tri + i];
+          if (sl == 0) {
+            LaneState st;
+            const GWords<KT> gr = c.g;
+#pragma unroll
+            for (int h = 0; h < MCHAP_MAX_PLOIDY; h++) st.g[h] = h < KT ? gr.w[h < KT ? h : 0] : 0ull;
+            st.llk = c.llk;
+            st.ctr = c.ctr;
+            st.lo = c.lo;
+            st.hi = c.hi;
+            st.step = my_step;
+            st.phase = 0;
+            st.flags = LS_MVALID | LS_SETTLED;
+            st.pad = 0;
+            state[q] = st;
+          }
+        } else if (sl == 0) {
+          state[q].step = Sn;
+        }
+      }
     }
   }
+  // dead chains (errors) and lanes beyond the batch: nothing left to run
+  if (q < n_chains && !c.alive && sl == 0) state[q].step = Sn;
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+  LPH(6);
+  if (threadIdx.x == 0)
+    for (int i_ = 0; i_ < 24; i_++) atomicAdd(&g_stats[i_], lph[i_]);
+#endif
   if (status != MCHAP_UNIT_OK && sl == 0) atomicMax(&D.status[u], status);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Steady kernel: settled chains on thresholds alone.  No likelihood code, few registers, little LDS: many waves per
+// SIMD.  A chain runs until a compound step cannot be decided (it is handed back at the start of that compound step)
+// or to the end; its genotype cannot change here, so its trace rows are written in one sweep when it stops.
+// ---------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t steady_lds_bytes(int Mmax, int L) {
+  const int NC = 64 / L;
+  size_t b = 0;
+  b += (size_t)8 * NC * lane_window(Mmax);
+  b += (size_t)8 * NC * Mmax;
+  b += (size_t)4 * NC * 2 * spec_memo_entries(Mmax);
+  return (b + 63) & ~(size_t)63;
+}
+
+template <int KT>
+__global__ __launch_bounds__(64, 4) void denovo_steady_kernel(const SimtParams P, const int lsh) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const DenovoParams &D = P.d;
+  const int L = 1 << lsh;
+  const int NC = WAVE >> lsh;
+  const int lane = threadIdx.x;
+  const int ci = lane >> lsh, sl = lane & (L - 1);
+  const int Cn = D.chains, Sn = D.steps;
+  const int mmax = P.max_pos;
+  const int win_n = lane_window(mmax), tri = spec_memo_entries(mmax);
+  const long long q = (long long)blockIdx.x * NC + ci;
+  const long long n_chains = (long long)P.n_units * Cn;
+  LaneState *state = reinterpret_cast<LaneState *>(P.lane_state);
+  bool running = false;
+  int my_step = 0;
+  if (q < n_chains) {
+    my_step = state[q].step;
+    running = my_step < Sn && (state[q].flags & LS_SETTLED);
+  }
+  if (!wave_any(running)) return;
+  const bool ran = running;
+  LDSP(uint64_t) win = lds_cast<uint64_t>(smem) + (size_t)ci * win_n;
+  LDSP(uint64_t) bc = lds_cast<uint64_t>(smem + (size_t)8 * NC * win_n) + (size_t)ci * mmax;
+  LDSP(uint32_t) memo = lds_cast<uint32_t>(smem + (size_t)8 * NC * win_n + (size_t)8 * NC * mmax) + (size_t)ci * 2 * tri;
+  const int u = running ? (int)(q / Cn) : 0;
+  const int chain = running ? (int)(q % Cn) : 0;
+  const mchap_unit U = D.units[u];
+  const int32_t *mi = P.meta_i + (size_t)u * meta_i_stride(P.max_pos);
+  const int Mh = running ? mi[META_I_MH] : 1;
+  uint64_t ctr = 0, lo = 0, hi = 0;
+  Stream st;
+  st.k0 = (uint32_t)D.seed;
+  st.k1 = (uint32_t)(D.seed >> 32) ^ (uint32_t)(U.stream_id >> 32);
+  st.c2 = ((uint32_t)chain << 16) | 0u;
+  st.c3 = (uint32_t)U.stream_id;
+  if (running) {
+    ctr = state[q].ctr;
+    lo = state[q].lo;
+    hi = state[q].hi;
+    const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.lane_memo) + (size_t)q * 2 * tri;
+    for (int i = sl; i < 2 * tri; i += L) memo[i] = gm[i];
+    if (D.n_intervals == 0 && sl == 0) {
+      double cacc = 0.0;
+      for (int j = 0; j < Mh; j++) {
+        cacc += D.break_table[(size_t)Mh * D.max_pos + j];
+        bc[j] = ceil53(cacc);
+      }
+    }
+  }
+  lds_sync();
+  const int s_begin = my_step;
+  int phase = 0;  // compound step the chain stopped at (when it stops before the end)
+  int doff = 0, dcount = 0;
+  const int n = KT * Mh, E = lane_extra(Mh);
+  const uint64_t pthr0 = decision_threshold(D.p_recomb), pthr1 = decision_threshold(D.p_partial), pthr2 = decision_threshold(D.p_dosage);
+  const unsigned long long mine_mask = L == 64 ? ~0ull : (((1ull << L) - 1ull) << (ci * L));
+  while (wave_any(running)) {
+    // ---- mutation compound step ----
+    bool ok = running;
+    if (ok) ok = fast_mutation(st, ctr + (uint64_t)(n - 1), n, E, lo, hi, win, sl, L);
+    lds_sync();
+    ok = running && !(__ballot(running && !ok) & mine_mask);
+    if (running && !ok) {
+      running = false;
+      phase = 0;
+    }
+    if (running) {
+      ctr += (uint64_t)(2 * n - 1);
+      doff = 0;
+      dcount = E;
+    }
+    // ---- structural compound steps ----
+#pragma unroll 1
+    for (int kind = 0; kind < 3; kind++) {
+      const uint64_t pthr = kind == 0 ? pthr0 : (kind == 1 ? pthr1 : pthr2);
+      LDSP(uint32_t) mt = memo + (size_t)(kind == 0 ? 0 : 1) * tri;
+      bool pending = running;
+      while (wave_any(pending)) {
+        SFast F;
+        F.short_ = false;
+        if (pending) F = fast_structural(kind, pthr, D.n_intervals, Mh, win, doff, dcount, bc, mt, true);
+        if (pending && !F.short_) {
+          if (F.done) {
+            ctr += (uint64_t)(F.doff_end - doff);
+            doff = F.doff_end;
+          } else {  // cannot be decided here (or the reference's "breaks" error): back to the settling kernel
+            running = false;
+            phase = kind + 1;
+          }
+          pending = false;
+        }
+        if (wave_any(pending && F.short_)) {
+          if (pending) stage_draws_l(st, ctr, win_n, win, sl, L);
+          lds_sync();
+          if (pending) {
+            doff = 0;
+            dcount = win_n;
+          }
+        }
+      }
+    }
+    if (running) {
+      my_step++;
+      if (my_step >= Sn) running = false;
+    }
+  }
+  // ---- the chain's rows of the trace: one record, my_step - s_begin times ----
+  if (ran && my_step > s_begin) {
+    const LaneState &stt = state[q];
+    uint64_t gw[KT];
+#pragma unroll
+    for (int h = 0; h < KT; h++) gw[h] = stt.g[h];
+    // canonical (ascending) order
+#pragma unroll
+    for (int a = 1; a < KT; a++) {
+#pragma unroll
+      for (int b = 0; b < KT - 1; b++) {
+        if (b < KT - a) {
+          const uint64_t x = gw[b], y = gw[b + 1];
+          gw[b] = x < y ? x : y;
+          gw[b + 1] = x < y ? y : x;
+        }
+      }
+    }
+    const unsigned long long llk_bits = (unsigned long long)__double_as_longlong(stt.llk);
+    uint64_t *tp = D.trace + U.trace_off + ((size_t)chain * D.steps + s_begin) * KT;
+    const int nw = (my_step - s_begin) * KT;
+    for (int i = sl; i < nw; i += L) {
+      const int h = i % KT;
+      uint64_t x = gw[0];
+#pragma unroll
+      for (int k = 1; k < KT; k++) x = (h == k) ? gw[k] : x;
+      tp[i] = x;
+    }
+    uint64_t *lp = reinterpret_cast<uint64_t *>(D.llks + U.llk_off + (size_t)chain * D.steps + s_begin);
+    for (int i = sl; i < my_step - s_begin; i += L) lp[i] = llk_bits;
+  }
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+  if (ran && sl == 0) {
+    atomicAdd(&g_stats[18], (unsigned long long)(my_step - s_begin));
+    atomicAdd(&g_stats[20], 1ull);
+    if (my_step < Sn) atomicAdd(&g_stats[21], 1ull);
+  }
+#endif
+  if (ran && sl == 0) {
+    LaneState &stt = state[q];
+    stt.ctr = ctr;
+    stt.step = my_step;
+    stt.phase = phase;
+    if (my_step < Sn) stt.flags &= ~LS_SETTLED;  // stopped before the end: the settling kernel resumes it
+  }
 }
 
 }  // namespace mchap

@@ -52,6 +52,9 @@ struct SimtParams {
   int prep_rows_off; // byte offset of the prepare pass's per-position row staging in its LDS
   int cstride;       // bytes per lane and row of the coded table: rpad / 64 rounded up to 1, 2 or a multiple of 4
   int flags;         // debugging: bit 0 no mutation memo, bit 1 no interval memo (MCHAP_HIP_FLAGS); bit 30 below
+  // steady-state pipeline (denovo_lane_kernel.hpp): per-chain hand-over records and threshold tables
+  void *lane_state;  // [U * chains] LaneState
+  void *lane_memo;   // [U * chains][2][tri(max_pos)] uint32
 };
 constexpr int SIMT_FLAG_PREP_GLOBAL = 1 << 30;  // table too large for the prepare pass's LDS copy
 

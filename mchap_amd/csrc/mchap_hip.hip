@@ -40,7 +40,7 @@ extern "C" int mchap_spec_launch_8_64(const mchap::SimtParams *, unsigned, size_
 
 #define MCHAP_LANE_DECL(k)                                              \
   extern "C" int mchap_lane_init_##k(const double *, const double *); \
-  extern "C" int mchap_lane_launch_##k(const mchap::SimtParams *, int, unsigned, size_t, hipStream_t);
+  extern "C" int mchap_lane_launch_##k(const mchap::SimtParams *, int, int, unsigned, size_t, hipStream_t);
 MCHAP_LANE_DECL(1)
 MCHAP_LANE_DECL(2)
 MCHAP_LANE_DECL(3)
@@ -81,6 +81,7 @@ extern "C" int mchap_spec_stats_4_64(unsigned long long *, int);
 extern "C" int mchap_spec_stats_6_32(unsigned long long *, int);
 extern "C" int mchap_spec_stats_6_64(unsigned long long *, int);
 extern "C" int mchap_spec_stats_8_64(unsigned long long *, int);
+extern "C" int mchap_lane_stats_4(unsigned long long *, int);
 #endif
 namespace {
 
@@ -254,7 +255,7 @@ int batch_dims(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units
 }
 
 struct SimtCarve {
-  size_t cache = 0, rt = 0, cntw = 0, codes = 0, dict = 0, meta_i = 0, meta_f = 0, total = 0;
+  size_t cache = 0, rt = 0, cntw = 0, codes = 0, dict = 0, meta_i = 0, meta_f = 0, lane_state = 0, lane_memo = 0, total = 0;
 };
 
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -269,6 +270,10 @@ SimtCarve simt_carve(const mchap_denovo_cfg *cfg, int n_units, const BatchDims &
   c.dict = o; o += up256((size_t)n_units * mchap::DICT_MAX * 8);
   c.meta_i = o; o += up256((size_t)n_units * mchap::meta_i_stride(B.max_pos) * 4);
   c.meta_f = o; o += up256((size_t)n_units * mchap::meta_f_stride(B.max_ploidy, B.max_pos, B.max_allele) * 8);
+  if (cfg->kernel == 4) {  // hand-over records of the steady-state pipeline
+    c.lane_state = o; o += up256((size_t)n_units * cfg->chains * sizeof(mchap::LaneState));
+    c.lane_memo = o; o += up256((size_t)n_units * cfg->chains * 2 * mchap::spec_memo_entries(B.max_pos) * 4);
+  }
   c.total = o;
   return c;
 }
@@ -338,7 +343,7 @@ int lane_shift(long long n_chains, int K, int max_pos, int max_allele) {
 }
 
 int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipStream_t stream) {
-  int (*launch)(const mchap::SimtParams *, int, unsigned, size_t, hipStream_t) =
+  int (*launch)(const mchap::SimtParams *, int, int, unsigned, size_t, hipStream_t) =
       K == 1 ? mchap_lane_launch_1 : K == 2 ? mchap_lane_launch_2 : K == 3 ? mchap_lane_launch_3 : K == 4 ? mchap_lane_launch_4 :
       K == 5 ? mchap_lane_launch_5 : K == 6 ? mchap_lane_launch_6 : K == 7 ? mchap_lane_launch_7 : mchap_lane_launch_8;
   const long long n_chains = (long long)n_units * chains;
@@ -346,10 +351,29 @@ int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipS
   const size_t lds = mchap::lane_lds_bytes(K, P.max_pos, P.max_allele, 1 << lsh);
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "steady-state sampler needs %zu bytes of LDS", lds);
   const int per_wave = 64 >> lsh;
+  // the steady kernel's own geometry: it is lean, so more lanes per chain (more waves) only help the SIMDs' issue rate
+  int fsh = 0;
+  if (const char *e = std::getenv("MCHAP_HIP_STEADY_LANES")) {
+    const int l = std::atoi(e);
+    for (int s = 0; s <= 6; s++)
+      if ((1 << s) == l) fsh = s;
+  } else {
+    while (fsh < 4 && n_chains * (1ll << fsh) / 64 < 4096) fsh++;
+  }
+  const size_t lds_f = mchap::steady_lds_bytes(P.max_pos, 1 << fsh);
+  const int per_wave_f = 64 >> fsh;
+  int rounds = 2;
+  if (const char *e = std::getenv("MCHAP_HIP_ROUNDS")) rounds = std::atoi(e);
   char name[96];
-  snprintf(name, sizeof(name), "denovo_lane_kernel<%d> L=%d", K, 1 << lsh);
+  snprintf(name, sizeof(name), "denovo_settle_kernel<%d> L=%d + denovo_steady_kernel<%d> L=%d", K, 1 << lsh, K, 1 << fsh);
   SamplerTimer timer(stream, name);
-  const int e = launch(&P, lsh, (unsigned)((n_chains + per_wave - 1) / per_wave), lds, stream);
+  const unsigned grid_w = (unsigned)((n_chains + per_wave - 1) / per_wave), grid_f = (unsigned)((n_chains + per_wave_f - 1) / per_wave_f);
+  // settle (park the chains whose thresholds are complete) -> steady -> settle the ones handed back -> ... -> finish
+  int e = launch(&P, lsh, rounds > 0 ? mchap::LANE_MODE_PARK : 0, grid_w, lds, stream);
+  for (int r = 0; r < rounds && e == 0; r++) {
+    e = launch(&P, fsh, -1, grid_f, lds_f, stream);
+    if (e == 0) e = launch(&P, lsh, mchap::LANE_MODE_RESUME | (r + 1 < rounds ? mchap::LANE_MODE_PARK : 0), grid_w, lds, stream);
+  }
   if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
 }
@@ -445,6 +469,12 @@ int mchap_debug_stats(unsigned long long *out, int reset) {
     if (f(t, reset) != 0) return fail(MCHAP_ERR_HIP, "reading the counters of a sampler object");
     for (int i = 0; i < 24; i++) out[i] += t[i];
   }
+  return MCHAP_OK;
+}
+/* counters of the steady-state sampler's K = 4 object (its own layout: denovo_lane_kernel.hpp LPH / LCNT) */
+int mchap_debug_lane_stats(unsigned long long *out, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  if (mchap_lane_stats_4(out, reset) != 0) return fail(MCHAP_ERR_HIP, "reading the counters of the lane sampler");
   return MCHAP_OK;
 }
 #endif
@@ -601,6 +631,8 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.dict = reinterpret_cast<double *>(ws + cv.dict);
     SP.meta_i = reinterpret_cast<int32_t *>(ws + cv.meta_i);
     SP.meta_f = reinterpret_cast<double *>(ws + cv.meta_f);
+    SP.lane_state = ws + cv.lane_state;
+    SP.lane_memo = ws + cv.lane_memo;
     SP.n_units = n_units;
     SP.max_pos = B.max_pos;
     SP.max_allele = B.max_allele;
