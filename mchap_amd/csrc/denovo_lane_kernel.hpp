@@ -59,6 +59,10 @@ struct LaneLds {
   LDSP(uint8_t) ord;       // [NC][Mmax + 1]
   LDSP(uint16_t) nreads;   // [NC]
   LDSP(uint16_t) ndict;    // [NC]
+  LDSP(uint8_t) tct;       // [NC][tab_bytes] the unit's coded table (copied once: the evaluations then never leave the CU)
+  LDSP(double) tcw;        // [NC][rpad]      ... and its read weights
+  LDSP(double) dict;       // [NC][DICT_MAX]  ... and its dictionary
+  int tab_bytes;
   // per wave: the serving context
   LDSP(uint64_t) pw;       // [K][64]
   LDSP(double) ptab;       // [64]
@@ -69,14 +73,13 @@ struct LaneLds {
   LDSP(uint16_t) permtab;  // [nmax]
   LDSP(uint8_t) ktab;      // [nmax]
   LDSP(uint64_t) draws;    // [ndraws]
-  LDSP(double) dict;       // [DICT_MAX]
   LDSP(uint64_t) bw;       // [K]
   LDSP(int) cum;           // [64]
   LDSP(uint16_t) itab;     // [tri] start | stop << 8 of triangular index
   int win_n, tri, ndraws;
 };
 
-__host__ __device__ inline size_t lane_lds_bytes(int K, int Mmax, int Amax, int L) {
+__host__ __device__ inline size_t lane_lds_bytes(int K, int Mmax, int Amax, int L, int tab_bytes, int rpad) {
   const int NC = 64 / L;
   const int tri = spec_memo_entries(Mmax);
   const int nmax = K * Mmax;
@@ -101,7 +104,7 @@ __host__ __device__ inline size_t lane_lds_bytes(int K, int Mmax, int Amax, int 
   b += (size_t)8 * nopt * 64 * 2;       // optp, optl
   b += (size_t)8 * SPEC_LN * 2;
   b += (size_t)8 * spec_draws(K, Mmax); // draws
-  b += (size_t)8 * DICT_MAX;
+  b += (size_t)NC * ((size_t)tab_bytes + (size_t)8 * rpad + (size_t)8 * DICT_MAX);  // unit tables
   b += (size_t)8 * K;                   // bw
   b += (size_t)4 * 64;                  // cum
   b += (size_t)2 * nmax;                // permtab
@@ -177,7 +180,7 @@ __device__ __forceinline__ void lane_context(const LaneLds &LL, int cs, int mmax
   S.ktab = LL.ktab;
   S.draws = LL.draws;
   S.ndraws = LL.ndraws;
-  S.dict = LL.dict;
+  S.dict = LL.dict + (size_t)cs * DICT_MAX;
   S.bw = LL.bw;
   S.prior = LL.prior + cs * (2 * KT + 5);
   S.cols = LL.cols + cs * mmax;
@@ -190,6 +193,11 @@ __device__ __forceinline__ void lane_context(const LaneLds &LL, int cs, int mmax
   S.gstream = LL.gstream + cs * 4;
   S.memo_stride = 0;
   S.memo_tot = nullptr;
+}
+template <int KT>
+__device__ __forceinline__ void lane_context_tabs(const LaneLds &LL, int cs, int rpad, SpecLds &S) {
+  S.lds_ct = (LDSP(const uint8_t))(LL.tct + (size_t)cs * LL.tab_bytes);
+  S.lds_cw = (LDSP(const double))(LL.tcw + (size_t)cs * rpad);
 }
 
 template <int KT>
@@ -210,11 +218,6 @@ __device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
 }
 __device__ __forceinline__ double bcast_f64(double v, int src) {
   return __longlong_as_double((long long)bcast_u64((uint64_t)__double_as_longlong(v), src));
-}
-
-// The unit's dictionary into the wave's LDS slot (the co-operative evaluation gathers its factors from it).
-__device__ __forceinline__ void load_dict(const LaneLds &LL, const double *du, int nd, int lane) {
-  for (int i = lane; i < nd; i += WAVE) LL.dict[i] = du[i];
 }
 
 // One serving round for chain `cs` (wave-uniform): the interval step the chain waits for (has_req: type, start, stop, its
@@ -358,7 +361,7 @@ __device__ __forceinline__ ServeResult<KT> serve_structural(Grp<KT> &cu, const S
 #pragma unroll
     for (int h = 0; h < KT; h++) pw.w[h] = (cg.w[h] & ~t_msk) | (sel_word<KT>(cg, (int)nib(oin, h)) & t_msk);
   }
-  const double llk_i = spec_eval<KT, 64>(prop, pw, cu, S, mmax, rpad, lane);
+  const double llk_i = spec_eval<KT, 64, true>(prop, pw, cu, S, mmax, rpad, lane);
   if (prop) {
     double lprior_ratio = 0.0;
     if (!isnan(C_INB(S, 0)))
@@ -418,7 +421,7 @@ enum { LS_MVALID = 1, LS_SETTLED = 2 };  // SETTLED: every threshold of the geno
 enum { LANE_MODE_RESUME = 1, LANE_MODE_PARK = 2 };
 
 // profiling builds (make stats / make phases): wave clock per region and event counts, summed over the launch
-#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+#if defined(MCHAP_PHASES)
 #define LPH(i)                                                   \
   do {                                                           \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
@@ -555,6 +558,139 @@ __device__ __forceinline__ SFast fast_structural(int kind, uint64_t pthr, int n_
   if (R.short_) R.done = R.exact = R.bad = false;
   return R;
 }
+// The same step with few dependent LDS round trips (the common shapes: at most 3 breaks, at least 5 positions, at most
+// FS_PRE draws): the first draws of the window and the first break thresholds are read at static offsets in one batch,
+// the drawn intervals' thresholds in a second one, everything else is register arithmetic.  Falls back to
+// fast_structural() otherwise; identical outcomes.
+constexpr int FS_PRE = 12;
+__device__ __forceinline__ SFast fast_structural_ll(int kind, uint64_t pthr, int n_intervals_fixed, int Mh, LDSP(uint64_t) win, int doff0,
+                                                    int dcount, LDSP(uint64_t) bc, LDSP(uint32_t) memo, bool memo_iv) {
+  const int avail = dcount - doff0;
+  if (!memo_iv || n_intervals_fixed > 0 || Mh < 5) return fast_structural(kind, pthr, n_intervals_fixed, Mh, win, doff0, dcount, bc, memo, memo_iv);
+  SFast R;
+  R.done = R.exact = R.bad = R.short_ = false;
+  R.zeros = 0;
+  R.n_int = 0;
+  R.doff1 = doff0;
+  R.doff_end = doff0;
+  LDSP(uint64_t) wb = win + doff0;
+  if (kind == 2) {
+    // whole-haplotype dosage step: decision, then one interval [0, Mh)
+    if (avail < 2) {
+      R.short_ = true;
+      return R;
+    }
+    const uint64_t w0 = wb[0];
+    const uint32_t a1 = (uint32_t)wb[1];
+    const uint32_t t = memo[spec_memo_index(0, Mh)];
+    const bool doit = u53_of(w0) < pthr;
+    R.doff1 = doff0 + 1;
+    if (!doit) {
+      R.done = true;
+      R.doff_end = doff0 + 1;
+      return R;
+    }
+    R.zeros = 1ull | (1ull << Mh);
+    R.n_int = 1;
+    if (t == MEMO_NOOPT) {
+      R.done = true;
+      R.doff_end = doff0 + 1;
+    } else if (t != MEMO_UNKNOWN && (a1 >> 5) >= t) {
+      R.done = true;
+      R.doff_end = doff0 + 2;
+    } else {
+      R.exact = true;
+      R.doff_end = doff0 + 1;
+    }
+    return R;
+  }
+  // ---- batch 1: draws 0, 1 in full, the first words of draws 2 .. FS_PRE-1, break thresholds 0 .. 3 ----
+  const int nv = avail < FS_PRE ? avail : FS_PRE;
+  if (nv < 2) {
+    R.short_ = true;
+    return R;
+  }
+  const uint64_t w0 = wb[0], w1 = wb[1];
+  uint32_t a[FS_PRE];
+#pragma unroll
+  for (int i = 2; i < FS_PRE; i++) a[i] = i < nv ? (uint32_t)wb[i] : 0u;
+  const uint64_t b0 = bc[0], b1 = bc[1], b2 = bc[2], b3 = bc[3];  // Mh >= 5
+  const bool doit = u53_of(w0) < pthr;
+  if (!doit) {
+    R.done = true;
+    R.doff1 = R.doff_end = doff0 + 1;
+    return R;
+  }
+  const uint64_t x = u53_of(w1);
+  const int nb = x < b0 ? 0 : (x < b1 ? 1 : (x < b2 ? 2 : (x < b3 ? 3 : 4)));
+  if (nb > 3) return fast_structural(kind, pthr, n_intervals_fixed, Mh, win, doff0, dcount, bc, memo, memo_iv);
+  // break points: b-th draw picks among the Mh - 1 - b remaining interior points (all > 1 here: Mh >= 5, b <= 2)
+  uint64_t ind = ((1ull << Mh) - 1ull) & ~1ull;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    if (b < nb) {
+      int k = (int)__umulhi(a[2 + b], (uint32_t)(Mh - 1 - b));
+      uint64_t t = ind;
+      while (k-- > 0) t &= t - 1;
+      ind &= ~(t & (~t + 1));
+    }
+  }
+  const int used = 2 + nb;  // decision, break count, nb break points
+  R.doff1 = doff0 + used;
+  R.zeros = ~ind & ((1ull << (Mh + 1)) - 1ull);
+  R.n_int = nb + 1;
+  // ---- batch 2: thresholds of the (up to 4) intervals ----
+  uint32_t th[4];
+  {
+    uint64_t z = R.zeros;
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) {
+      th[qq] = MEMO_NOOPT;
+      if (qq <= nb) {
+        const int start = __ffsll((long long)z) - 1;
+        z &= z - 1;
+        const int stop = __ffsll((long long)z) - 1;
+        th[qq] = memo[spec_memo_index(start, stop)];
+      }
+    }
+  }
+  bool unknown = false;
+  int n_cons = 0;
+  uint32_t mx = 0;
+#pragma unroll
+  for (int qq = 0; qq < 4; qq++) {
+    if (th[qq] == MEMO_UNKNOWN) unknown = true;
+    else if (th[qq] != MEMO_NOOPT) {
+      n_cons++;
+      mx = th[qq] > mx ? th[qq] : mx;
+    }
+  }
+  const int s = used + nb;  // first uniform: behind the nb shuffle draws
+  const int last = s + n_cons;  // one past the last draw the step consumes when nothing moves
+  if (last > nv) {  // beyond the batch: the window's end (refill) or just this routine's reach
+    if (last > avail || used > avail) {
+      R.short_ = true;
+      R.zeros = 0;
+      R.n_int = 0;
+      return R;
+    }
+    return fast_structural(kind, pthr, n_intervals_fixed, Mh, win, doff0, dcount, bc, memo, memo_iv);
+  }
+  if (!unknown) {
+    bool low = false;
+#pragma unroll
+    for (int i = 2; i < FS_PRE; i++) low = low || (i >= s && i < last && (a[i] >> 5) < mx);
+    if (!low) {
+      R.done = true;
+      R.doff_end = doff0 + last;
+      return R;
+    }
+  }
+  R.exact = true;
+  R.doff_end = R.doff1;
+  return R;
+}
+
 __device__ __forceinline__ uint64_t decision_threshold(double pstep) {  // rand() <= p  <=>  u53 < threshold
   return pstep < 0.0 ? 0ull : (pstep >= 1.0 ? (1ull << 53) : (uint64_t)floor(pstep * 9007199254740992.0) + 1ull);
 }
@@ -617,7 +753,10 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
     LL.ln = lds_cast<double>(p); p += (size_t)8 * SPEC_LN;
     LL.lninv = lds_cast<double>(p); p += (size_t)8 * SPEC_LN;
     LL.draws = lds_cast<uint64_t>(p); p += (size_t)8 * LL.ndraws;
-    LL.dict = lds_cast<double>(p); p += (size_t)8 * DICT_MAX;
+    LL.tab_bytes = P.max_ma * WAVE * P.cstride;
+    LL.tcw = lds_cast<double>(p); p += (size_t)8 * NC * rpad;
+    LL.dict = lds_cast<double>(p); p += (size_t)8 * NC * DICT_MAX;
+    LL.tct = lds_cast<uint8_t>(p); p += (size_t)NC * LL.tab_bytes;
     LL.bw = lds_cast<uint64_t>(p); p += (size_t)8 * KT;
     LL.cum = lds_cast<int>(p); p += (size_t)4 * 64;
     LL.permtab = lds_cast<uint16_t>(p); p += (size_t)2 * nmax;
@@ -687,6 +826,23 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
       for (int i = sl; i < 2 * LL.tri; i += L) LL.memo[(size_t)ci * 2 * LL.tri + i] = gmemo[i];
     else
       for (int i = sl; i < 2 * LL.tri; i += L) LL.memo[(size_t)ci * 2 * LL.tri + i] = MEMO_UNKNOWN;
+  }
+  // the unit tables of the wave's chains: coded table, read weights, dictionary (a chain that will not run here -- a
+  // settled one on resume -- still gets its slot filled: cheap, and keeps the code uniform)
+  for (int cs = 0; cs < NC; cs++) {
+    const int owner = cs << lsh;
+    const bool live = __builtin_amdgcn_readlane((int)c.alive, owner) != 0;
+    if (!live) continue;
+    const int unit = __builtin_amdgcn_readlane(u, owner);
+    const int nd = __builtin_amdgcn_readfirstlane((int)((P.flags & 4) ? 0 : P.meta_i[(size_t)unit * meta_i_stride(P.max_pos) + META_I_NDICT]));
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(P.codes + (size_t)unit * LL.tab_bytes);
+    LDSP(uint32_t) dst = (LDSP(uint32_t))(LL.tct + (size_t)cs * LL.tab_bytes);
+    if (nd > 0)
+      for (int i = lane; i < LL.tab_bytes / 4; i += WAVE) dst[i] = src[i];
+    const double *cws = P.cntw + (size_t)unit * rpad;
+    for (int i = lane; i < rpad; i += WAVE) LL.tcw[(size_t)cs * rpad + i] = cws[i];
+    const double *du = P.dict + (size_t)unit * DICT_MAX;
+    for (int i = lane; i < nd; i += WAVE) LL.dict[(size_t)cs * DICT_MAX + i] = du[i];
   }
   lds_sync();
   const int amax = [&] {
@@ -772,7 +928,6 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
     }
   }
   const bool memo_mut = !(P.flags & 1), memo_iv = !(P.flags & 2);
-  int cur_dict_unit = -1;  // unit whose dictionary sits in LL.dict (wave-uniform)
   int status = MCHAP_UNIT_OK;
   // exact count of the chain's unknown thresholds (wave-level: every lane must call)
   auto recount = [&]() {
@@ -807,14 +962,11 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
     cu.mvalid = false;
     cu.gen = 1;
     cu.memo_gen = 1;
-    // the unit's dictionary
-    const int unit = __builtin_amdgcn_readlane(u, owner);
-    if (unit != cur_dict_unit) {
-      lds_sync();
-      load_dict(LL, P.dict + (size_t)unit * DICT_MAX, (int)LL.ndict[cs], lane);
-      cur_dict_unit = unit;
-      lds_sync();
-    }
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+    for (int i_ = 0; i_ < 12; i_++) cu.ph[i_] = 0;
+    cu.pt0 = __builtin_amdgcn_s_memtime();
+#endif
+    lane_context_tabs<KT>(LL, cs, rpad, S);
   };
   auto wipe_memo = [&](int cs) {
     for (int i = lane; i < 2 * LL.tri; i += WAVE) LL.memo[(size_t)cs * 2 * LL.tri + i] = MEMO_UNKNOWN;
@@ -836,15 +988,15 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
         for (int h = 0; h < KT; h++) S.pw[h * WAVE] = g0.w[h];
       }
       lds_sync();
-      const double v = spec_coop_all<KT, 64>(1ull, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, false, S.crow, mmax, cu.Mh,
-                                             (1u << cu.bits) - 1u, rpad, lane);
+      const double v = spec_coop_all<KT, 64, true>(1ull, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, false, S.crow, mmax, cu.Mh,
+                                                   (1u << cu.bits) - 1u, rpad, lane, S.lds_ct, S.lds_cw);
       lds_sync();
       const double l0 = __shfl(v, 0, WAVE);
       if (ci == cs) c.llk = l0;
     }
   }
 
-#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+#if defined(MCHAP_PHASES)
   unsigned long long lph[24];
   for (int i_ = 0; i_ < 24; i_++) lph[i_] = 0;
   unsigned long long lpt0 = __builtin_amdgcn_s_memtime();
@@ -891,7 +1043,10 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
         SpecLds S;
         open_chain(cs, cu, S);
         const GWords<KT> before = cu.g;
-        spec_mutation<KT, 64>(cu, S, 1.0, amax, mmax, nmax, rpad, lane, 0, lane);
+        spec_mutation<KT, 64, true>(cu, S, 1.0, amax, mmax, nmax, rpad, lane, 0, lane);
+        LCNT(20, cu.ph[9]);
+        LCNT(21, cu.ph[10]);
+        LCNT(22, cu.ph[11]);
         bool diff = false;
 #pragma unroll
         for (int h = 0; h < KT; h++) diff = diff || before.w[h] != cu.g.w[h];
@@ -934,7 +1089,7 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
         const bool act = pending && !exact;
         SFast F;
         F.short_ = false;
-        if (act) F = fast_structural(kind, pthr, D.n_intervals, Mh, win, c.doff, c.dcount, LL.bcum + (size_t)ci * mmax, memo, memo_iv);
+        if (act) F = fast_structural_ll(kind, pthr, D.n_intervals, Mh, win, c.doff, c.dcount, LL.bcum + (size_t)ci * mmax, memo, memo_iv);
         if (act && !F.short_) {
           if (F.bad) {
             status = MCHAP_UNIT_BREAKS;
@@ -1042,6 +1197,9 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
             const uint64_t uw = LL.win[(size_t)cs * LL.win_n + r_doff];
             const int cur = __builtin_amdgcn_readlane(c.cursor, owner);
             const ServeResult<KT> R = serve_structural<KT>(cu, S, LL, cs, true, step_type, r_idx, uw, cur, mmax, rpad, lane);
+            LCNT(8, cu.ph[9]);
+            LCNT(9, cu.ph[10]);
+            LCNT(23, cu.ph[11]);
             if (ci == cs) {
               if (R.n_opt_req > 0) doff++;  // the step's uniform (structural.py:504-506: none without options)
               if (R.moved) {
@@ -1174,7 +1332,7 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
   }
   // dead chains (errors) and lanes beyond the batch: nothing left to run
   if (q < n_chains && !c.alive && sl == 0) state[q].step = Sn;
-#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+#if defined(MCHAP_PHASES)
   LPH(6);
   if (threadIdx.x == 0)
     for (int i_ = 0; i_ < 24; i_++) atomicAdd(&g_stats[i_], lph[i_]);
@@ -1256,7 +1414,7 @@ __global__ __launch_bounds__(64, 4) void denovo_steady_kernel(const SimtParams P
   while (wave_any(running)) {
     // ---- mutation compound step ----
     bool ok = running;
-    if (ok) ok = fast_mutation(st, ctr + (uint64_t)(n - 1), n, E, lo, hi, win, sl, L);
+    if (ok && !(P.flags & 16)) ok = fast_mutation(st, ctr + (uint64_t)(n - 1), n, E, lo, hi, win, sl, L);  // (flag: timing experiments)
     lds_sync();
     ok = running && !(__ballot(running && !ok) & mine_mask);
     if (running && !ok) {
@@ -1273,11 +1431,11 @@ __global__ __launch_bounds__(64, 4) void denovo_steady_kernel(const SimtParams P
     for (int kind = 0; kind < 3; kind++) {
       const uint64_t pthr = kind == 0 ? pthr0 : (kind == 1 ? pthr1 : pthr2);
       LDSP(uint32_t) mt = memo + (size_t)(kind == 0 ? 0 : 1) * tri;
-      bool pending = running;
+      bool pending = running && !(P.flags & 32);
       while (wave_any(pending)) {
         SFast F;
         F.short_ = false;
-        if (pending) F = fast_structural(kind, pthr, D.n_intervals, Mh, win, doff, dcount, bc, mt, true);
+        if (pending) F = fast_structural_ll(kind, pthr, D.n_intervals, Mh, win, doff, dcount, bc, mt, true);
         if (pending && !F.short_) {
           if (F.done) {
             ctr += (uint64_t)(F.doff_end - doff);
@@ -1334,7 +1492,7 @@ __global__ __launch_bounds__(64, 4) void denovo_steady_kernel(const SimtParams P
     uint64_t *lp = reinterpret_cast<uint64_t *>(D.llks + U.llk_off + (size_t)chain * D.steps + s_begin);
     for (int i = sl; i < my_step - s_begin; i += L) lp[i] = llk_bits;
   }
-#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+#if defined(MCHAP_PHASES)
   if (ran && sl == 0) {
     atomicAdd(&g_stats[18], (unsigned long long)(my_step - s_begin));
     atomicAdd(&g_stats[20], 1ull);

@@ -70,6 +70,25 @@ __device__ __forceinline__ LDSP(T) lds_cast(void *p) {
   return (LDSP(T))p;
 }
 
+// The unit's coded table and read weights: in HBM / L2 (LT = false, the speculative kernel) or copied into the wave's LDS
+// (LT = true, the settling kernel of denovo_lane_kernel.hpp, whose evaluations are then free of memory latency).
+template <bool LT>
+struct TabPtr;
+template <>
+struct TabPtr<false> {
+  typedef GLBP(const uint8_t) u8;
+  typedef GLBP(const double) f64;
+  template <class CT>
+  static __device__ __forceinline__ CT ld(u8 p) { return *reinterpret_cast<GLBP(const CT)>(p); }
+};
+template <>
+struct TabPtr<true> {
+  typedef LDSP(const uint8_t) u8;
+  typedef LDSP(const double) f64;
+  template <class CT>
+  static __device__ __forceinline__ CT ld(u8 p) { return *reinterpret_cast<LDSP(const CT)>(p); }
+};
+
 enum { GP_RT = 0, GP_CW, GP_CT, GP_CACHE, GP_TRACE, GP_LLK, GP_N };
 enum { GV_INB = 0, GV_MLO, GV_MHI, GV_N };
 struct SpecLds {
@@ -104,6 +123,8 @@ struct SpecLds {
   uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
   bool cache_on;
   bool reuse_on;          // haplotype products of the chain's current genotype are reused by its proposals
+  LDSP(const uint8_t) lds_ct;  // the unit's coded table / read weights copied into LDS (settling kernel), else null
+  LDSP(const double) lds_cw;
   int crow;               // bytes per row of the coded table (64 lanes x SimtParams::cstride)
   LDSP(uint64_t) draws;   // [NG][SPEC_DRAWS] the two 32-bit words (lo, hi) of draws base .. base + SPEC_DRAWS - 1
   LDSP(double) memo_tot;     // [NG][2][(Mmax+1)^2] total move probability of an interval step for the current
@@ -457,9 +478,9 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
 // The same evaluation from the coded table: one load per (haplotype, position) pair fetches the codes of the
 // lane's RPL reads (RPL bytes, lane-major layout), the float64 factors come from the unit's dictionary in LDS.
 // Same factors in the same order, hence the same value as spec_coop_body.
-template <int KT, int RPL, class CT>
+template <int KT, int RPL, class CT, bool LT = false>
 __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
-                                                  GLBP(const uint8_t) ct, GLBP(const double) cw, int crow, int lane) {
+                                                  typename TabPtr<LT>::u8 ct, typename TabPtr<LT>::f64 cw, int crow, int lane) {
   // ct points at the lane's first code of the block of RPL chunks; cw at the lane's first read of the block;
   // crow = bytes per row of the coded table
   constexpr int UNR = MCHAP_CODED_UNR;
@@ -491,7 +512,7 @@ __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int
       for (int u = 0; u < UNR; u++) {
         const int q = q0 + u;
         const int row = __builtin_amdgcn_readlane(myrow, q < lim ? q : 0);
-        cd[u] = *reinterpret_cast<GLBP(const CT)>(ct + (size_t)row * crow);
+        cd[u] = TabPtr<LT>::template ld<CT>(ct + (size_t)row * crow);
       }
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
@@ -540,8 +561,8 @@ __device__ __forceinline__ void spec_pair_rows(LDSP(const uint64_t) words, int w
 }
 // prod[i] = product over the Mh positions of haplotype h (pairs h*Mh .. h*Mh+Mh-1, rows in row0/row1), reads of
 // chunk i, in position order: the factors and their order are those of spec_coop_coded
-template <int RPL, class CT>
-__device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int row1, int p0, int Mh, GLBP(const uint8_t) ct,
+template <int RPL, class CT, bool LT = false>
+__device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int row1, int p0, int Mh, typename TabPtr<LT>::u8 ct,
                                               int crow, double (&prod)[RPL]) {
   constexpr int UNR = 8;
 #pragma unroll
@@ -552,7 +573,7 @@ __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int r
     for (int u = 0; u < UNR; u++) {
       const int p = __builtin_amdgcn_readfirstlane(p0 + min(j0 + u, Mh - 1));
       const int row = p < WAVE ? __builtin_amdgcn_readlane(row0, p & (WAVE - 1)) : __builtin_amdgcn_readlane(row1, p & (WAVE - 1));
-      cd[u] = *reinterpret_cast<GLBP(const CT)>(ct + (size_t)row * crow);
+      cd[u] = TabPtr<LT>::template ld<CT>(ct + (size_t)row * crow);
     }
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
@@ -564,9 +585,9 @@ __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int r
   }
 }
 // One request with reuse: haplotypes whose word equals the base word take the base product bp[h].
-template <int KT, int RPL, class CT>
+template <int KT, int RPL, class CT, bool LT = false>
 __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
-                                                  GLBP(const uint8_t) ct, GLBP(const double) cw, int crow, int lane,
+                                                  typename TabPtr<LT>::u8 ct, typename TabPtr<LT>::f64 cw, int crow, int lane,
                                                   const double (&bp)[KT][4], bool use_base) {
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   const double invK = 1.0 / (double)KT;
@@ -584,7 +605,7 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
 #pragma unroll
       for (int i = 0; i < RPL; i++) ph[i] = bp[h][i];
     } else {
-      spec_hap_prod<RPL, CT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
+      spec_hap_prod<RPL, CT, LT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
     }
 #pragma unroll
     for (int i = 0; i < RPL; i++) acc[i] += ph[i] * invK;
@@ -594,29 +615,38 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
   for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
   return s;
 }
-template <int KT, int RPL, class CT>
+template <int KT, int RPL, class CT, bool LT = false>
 __device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int mmax, int Mh, uint32_t amask,
-                                                   GLBP(const uint8_t) ct, int crow, int lane, double (&bp)[KT][4]) {
+                                                   typename TabPtr<LT>::u8 ct, int crow, int lane, double (&bp)[KT][4]) {
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   int row0, row1;
   spec_pair_rows<KT>(S.bw + (size_t)sg * KT, 1, 0, S, sg, mmax, Mh, amask, lane, row0, row1);
 #pragma unroll
   for (int h = 0; h < KT; h++) {
     double ph[RPL];
-    spec_hap_prod<RPL, CT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
+    spec_hap_prod<RPL, CT, LT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
 #pragma unroll
     for (int i = 0; i < RPL; i++) bp[h][i] = ph[i];
   }
 }
 
+// lanes of `reqs` whose request words equal those of lane `src` (src included)
+template <int KT>
+__device__ __forceinline__ unsigned long long spec_same_request(LDSP(uint64_t) pwbuf, unsigned long long reqs, int src, int lane) {
+  bool eq = ((reqs >> lane) & 1ull) != 0ull;
+#pragma unroll
+  for (int h = 0; h < KT; h++) eq = eq && pwbuf[(size_t)h * WAVE + lane] == pwbuf[(size_t)h * WAVE + src];
+  return __ballot(eq);
+}
+
 // Serves every request of the wave (bit mask `todo`), chain by chain, with all 64 lanes.  Inlined on purpose: see the
 // note on device function calls in DESIGN.md section 4.1.
-template <int KT, int G>
+template <int KT, int G, bool LT = false>
 __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
                                                 LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab, LDSP(uint16_t) ndict_tab,
                                                 LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, LDSP(uint64_t) bw_tab,
                                                 bool reuse, int crow, int mmax, int Mh_lane, uint32_t amask_lane, int rpad,
-                                                int lane) {
+                                                int lane, LDSP(const uint8_t) lds_ct = nullptr, LDSP(const double) lds_cw = nullptr) {
   SpecLds S;
   S.pw = pwbuf;
   S.shift = shift_tab;
@@ -639,14 +669,18 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
     const uint32_t amask = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)amask_lane, first, WAVE));
     LDSP(uint64_t) gp = gptr_tab + sg * GP_N;  // the requesting chain's pointers (wave-uniform)
     GLBP(const double) rt = (GLBP(const double))(uintptr_t)gp[GP_RT] + lane;
-    GLBP(const double) cw = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;
+    typename TabPtr<LT>::f64 cw;
+    if constexpr (LT) cw = lds_cw + lane;
+    else cw = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;
     const int nrd = (int)nreads_tab[sg];
     const int cstride = crow / WAVE;  // code bytes per lane and row
     if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && KT * Mh <= 2 * WAVE) {
       // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped.
       // The base products cover the first block of (up to) 4 chunks; deeper reads add their other blocks in full.
       const int nb0 = nch < 4 ? nch : 4;
-      GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
+      typename TabPtr<LT>::u8 ct;
+      if constexpr (LT) ct = lds_ct + (size_t)lane * cstride;
+      else ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
       const bool use_base = reuse && __popcll(reqs) >= 2;
       double bp[KT][4];
 #pragma unroll
@@ -654,57 +688,64 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
 #pragma unroll
         for (int i = 0; i < 4; i++) bp[h][i] = 0.0;
       if (use_base) {
-        if (nb0 == 1) spec_base_products<KT, 1, uint8_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
-        else if (nb0 == 2) spec_base_products<KT, 2, uint16_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
-        else if (nb0 == 3) spec_base_products<KT, 3, uint32_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
-        else spec_base_products<KT, 4, uint32_t>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        if (nb0 == 1) spec_base_products<KT, 1, uint8_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        else if (nb0 == 2) spec_base_products<KT, 2, uint16_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        else if (nb0 == 3) spec_base_products<KT, 3, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        else spec_base_products<KT, 4, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
       }
       while (reqs) {
         const int src = __ffsll((long long)reqs) - 1;
-        reqs &= reqs - 1;
+        // requests for the same genotype (options of different intervals often coincide) are evaluated once
+        const unsigned long long dups = spec_same_request<KT>(pwbuf, reqs, src, lane);
+        reqs &= ~dups;
         double s = 0.0;
-        if (nb0 == 1) s += spec_coop_reuse<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
-        else if (nb0 == 2) s += spec_coop_reuse<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
-        else if (nb0 == 3) s += spec_coop_reuse<KT, 3, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
-        else s += spec_coop_reuse<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        if (nb0 == 1) s += spec_coop_reuse<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        else if (nb0 == 2) s += spec_coop_reuse<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        else if (nb0 == 3) s += spec_coop_reuse<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        else s += spec_coop_reuse<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
         for (int cb = 4; cb < nch; cb += 4) {
           const int rem = nch - cb;
-          GLBP(const double) cwb = cw + cb * WAVE;
-          if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-          else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-          else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-          else s += spec_coop_coded<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          typename TabPtr<LT>::f64 cwb = cw + cb * WAVE;
+          if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          else s += spec_coop_coded<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
         }
         s = wave_sum(s);
-        if (lane == src) val = s;
+        if ((dups >> lane) & 1ull) val = s;
       }
     } else {
       while (reqs) {
         const int src = __ffsll((long long)reqs) - 1;
-        reqs &= reqs - 1;
+        const unsigned long long dups = spec_same_request<KT>(pwbuf, reqs, src, lane);
+        reqs &= ~dups;
         // the lane's reads in blocks of at most 4 chunks of 64 (keeps the loads in flight, and the registers,
         // bounded whatever the read depth); the last block may hold 1-3 chunks
         double s = 0.0;
         const bool coded = ndict_tab[sg] != 0;
-        GLBP(const uint8_t) ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
+        typename TabPtr<LT>::u8 ct;
+        if constexpr (LT) ct = lds_ct + (size_t)lane * cstride;
+        else ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
+        GLBP(const double) cwg = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;  // the float64 rows go with the global weights
         for (int cb = 0; cb < nch; cb += 4) {
           const int rem = nch - cb;
-          GLBP(const double) cwb = cw + cb * WAVE;
+          typename TabPtr<LT>::f64 cwb = cw + cb * WAVE;
           if (coded) {
-            if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-            else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-            else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-            else s += spec_coop_coded<KT, 1, uint8_t>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            else s += spec_coop_coded<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
           } else {
             GLBP(const double) rtb = rt + cb * WAVE;
-            if (rem >= 4) s += spec_coop_body<KT, 4>(S, src, sg, mmax, Mh, amask, rtb, cwb, rpad, lane, nrd - cb * WAVE);
-            else if (rem == 3) s += spec_coop_body<KT, 3>(S, src, sg, mmax, Mh, amask, rtb, cwb, rpad, lane, nrd - cb * WAVE);
-            else if (rem == 2) s += spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rtb, cwb, rpad, lane, nrd - cb * WAVE);
-            else s += spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rtb, cwb, rpad, lane, nrd - cb * WAVE);
+            GLBP(const double) cwgb = cwg + cb * WAVE;
+            if (rem >= 4) s += spec_coop_body<KT, 4>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE);
+            else if (rem == 3) s += spec_coop_body<KT, 3>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE);
+            else if (rem == 2) s += spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE);
+            else s += spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE);
           }
         }
         s = wave_sum(s);
-        if (lane == src) val = s;
+        if ((dups >> lane) & 1ull) val = s;
       }
     }
   }
@@ -713,7 +754,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
 
 // Likelihood of the lane's proposal `pw` (where need): 4-way cache probe, then co-operative evaluation of the
 // misses by the whole wavefront (request words staged through LDS).  Every lane of the wave must call.
-template <int KT, int G>
+template <int KT, int G, bool LT = false>
 __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, const Grp<KT> &c, const SpecLds &S, int mmax,
                                             int rpad, int lane) {
   double val = 0.0;
@@ -770,7 +811,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
       for (int h = 0; h < KT; h++) S.bw[(size_t)(lane / G) * KT + h] = cg.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane);
+    const double v = spec_coop_all<KT, G, LT>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw);
     if (miss) {
       val = v;
       if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
@@ -786,7 +827,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
 #define MCHAP_SPEC_WPE 2
 #endif
 
-template <int KT, int G>
+template <int KT, int G, bool LT = false>
 __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, int mmax, int nmax, int rpad,
                                               int lane, int gi, int gl) {
   const int Mh = c.Mh;
@@ -925,7 +966,7 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
         GWords<KT> pw = c.g;
         const uint64_t nw = (wh & ~((uint64_t)C_AMASK(c) << sh)) | ((uint64_t)i << sh);
         set_word<KT>(pw, h, nw);
-        const double llk_i = spec_eval<KT, G>(prop, pw, c, S, mmax, rpad, lane);
+        const double llk_i = spec_eval<KT, G, LT>(prop, pw, c, S, mmax, rpad, lane);
         if (prop) {
           double lprior_ratio = 0.0;
           if (!isnan(C_INB(S, gi))) lprior_ratio = prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(pw)) - lprior;
@@ -1453,6 +1494,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.gstream[gi * 4 + 3] = (uint32_t)U.stream_id;
   }
   S.reuse_on = !(P.flags & 8);
+  S.lds_ct = nullptr;
+  S.lds_cw = nullptr;
   S.crow = WAVE * P.cstride;
   S.cache_on = D.cache_slots > 0;
   S.cache_mask = S.cache_on ? (uint32_t)(D.cache_slots / 8) - 1u : 0u;  // sets of 8 ways

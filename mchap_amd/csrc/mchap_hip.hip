@@ -329,16 +329,17 @@ bool lane_supported(int K, int max_pos, int n_temps) {
 }
 
 // lanes per chain in its fast path: few enough that the launch still fills the SIMDs twice over
-int lane_shift(long long n_chains, int K, int max_pos, int max_allele) {
+// Lanes per chain of the settling kernel (it runs one wave per SIMD -- its serving code needs the registers -- so a
+// wave may use a quarter of a CU's LDS: the unit tables of its chains live there).  -1: does not fit.
+int lane_shift(long long n_chains, int K, int max_pos, int max_allele, int tab_bytes, int rpad) {
+  int s = 4;
   if (const char *e = std::getenv("MCHAP_HIP_LANES")) {
     const int l = std::atoi(e);
-    for (int s = 0; s <= 6; s++)
-      if ((1 << s) == l) return s;
+    for (int q = 0; q <= 6; q++)
+      if ((1 << q) == l) s = q;
   }
-  int s = 0;
-  while (s < 4 && n_chains * (1ll << s) / 64 < 2048) s++;
-  // LDS per wave must leave room for two waves per SIMD (8 per CU of 160 KiB)
-  while (s < 6 && mchap::lane_lds_bytes(K, max_pos, max_allele, 1 << s) > 20 * 1024) s++;
+  while (s < 6 && mchap::lane_lds_bytes(K, max_pos, max_allele, 1 << s, tab_bytes, rpad) > 40 * 1024) s++;
+  if (mchap::lane_lds_bytes(K, max_pos, max_allele, 1 << s, tab_bytes, rpad) > 160 * 1024) return -1;
   return s;
 }
 
@@ -347,9 +348,10 @@ int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipS
       K == 1 ? mchap_lane_launch_1 : K == 2 ? mchap_lane_launch_2 : K == 3 ? mchap_lane_launch_3 : K == 4 ? mchap_lane_launch_4 :
       K == 5 ? mchap_lane_launch_5 : K == 6 ? mchap_lane_launch_6 : K == 7 ? mchap_lane_launch_7 : mchap_lane_launch_8;
   const long long n_chains = (long long)n_units * chains;
-  const int lsh = lane_shift(n_chains, K, P.max_pos, P.max_allele);
-  const size_t lds = mchap::lane_lds_bytes(K, P.max_pos, P.max_allele, 1 << lsh);
-  if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "steady-state sampler needs %zu bytes of LDS", lds);
+  const int tab_bytes = P.max_ma * 64 * P.cstride;
+  const int lsh = lane_shift(n_chains, K, P.max_pos, P.max_allele, tab_bytes, P.d.rpad);
+  if (lsh < 0) return fail(MCHAP_ERR_LIMIT, "steady-state sampler: the unit tables do not fit the LDS");
+  const size_t lds = mchap::lane_lds_bytes(K, P.max_pos, P.max_allele, 1 << lsh, tab_bytes, P.d.rpad);
   const int per_wave = 64 >> lsh;
   // the steady kernel's own geometry: it is lean, so more lanes per chain (more waves) only help the SIMDs' issue rate
   int fsh = 0;

@@ -33,3 +33,7 @@ print("per chain-step: mutation serves %.4f, fast-loop iterations/wave %d, refil
     out[10] / cs, out[11], out[12], out[13], out[14] / cs, out[15] / cs))
 print("settle kernel: chains parked %d (mean step %.1f), chains finished in it %d; steady kernel: chain runs %d, steps %d (%.1f per run), handed back %d" % (
     out[16], out[17] / max(out[16], 1), out[19], out[20], out[18], out[18] / max(out[20], 1), out[21]))
+print("mutation serves: probe %.0f ticks, probe + evaluations %.0f ticks, %.1f evaluations per serve -> %.0f ticks per evaluation" % (
+    out[20] / max(out[10], 1), out[21] / max(out[10], 1), out[22] / max(out[10], 1), (out[21] - out[20]) / max(out[22], 1)))
+print("structural serves: probe %.0f ticks, probe + evaluations %.0f ticks, %.1f evaluations per serve -> %.0f ticks per evaluation" % (
+    out[8] / max(out[14], 1), out[9] / max(out[14], 1), out[23] / max(out[14], 1), (out[9] - out[8]) / max(out[23], 1)))
