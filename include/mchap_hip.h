@@ -184,8 +184,49 @@ int mchap_trace_incongruence_batch_device(int n_units, const mchap_unit *units_d
                                           const uint64_t *trace_words, int ploidy_max, double threshold, int32_t *mci,
                                           void *stream);
 
+/* Exact caller for a batch of units that share (n_reads, n_pos, max_allele, n_haps, ploidy), everything resident on the
+ * device: what application/call_exact.py:126-179 asks of calling/exact.py per sample, for all samples of a chunk of
+ * loci at once.  Every output is optional (NULL = not wanted):
+ *   streaming form, float64, no per-genotype array is formed (calling.exact.posterior_mode, exact.py:156-249: a pass
+ *   over the genotypes for the normaliser and the mode, a second one for the frequencies):
+ *     mode_alleles int64 [U][K], mode_llk / mode_prob / support_prob float64 [U], freqs / occur float64 [U][H]
+ *   array form (genotype_likelihoods 266-292: float32 store; genotype_posteriors 295-329 on that float32 array, hence
+ *   float32 arithmetic, float64 result) with G = C(H + K - 1, K) genotypes in VCF order:
+ *     llks float32 [U][G], llks64 float64 [U][G] (the unrounded values), posteriors float64 [U][G]
+ *   and what the caller derives from the posterior array (call_exact.py:142-159; exact.py:332-407): its first maximum
+ *   (arr_mode_alleles / arr_mode_prob), the summed probability of the genotypes over the mode's alleles
+ *   (arr_support_prob = alternate_dosage_posteriors(...).sum()), posterior_allele_frequencies (arr_freqs, arr_counts,
+ *   arr_occur [U][H]).
+ * prior: has_prior == 0 -> None; else inbreeding [U] and frequencies [U][H] or NULL.  `workspace` (device,
+ * mchap_exact_workspace_bytes) is only needed for the streaming outputs.  Enqueues on `stream`, no synchronisation. */
+typedef struct mchap_exact_out {
+  int64_t *mode_alleles;
+  double *mode_llk, *mode_prob, *support_prob, *freqs, *occur;
+  float *llks;
+  double *llks64;
+  double *posteriors;
+  int64_t *arr_mode_alleles;
+  double *arr_mode_prob, *arr_support_prob, *arr_freqs, *arr_counts, *arr_occur;
+} mchap_exact_out;
+int64_t mchap_exact_workspace_bytes(int n_units, int n_haps, int ploidy);
+int mchap_exact_call_batch_device(int n_units, const double *reads, int n_reads, int n_pos, int max_allele,
+                                  const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy, int has_prior,
+                                  const double *inbreeding, const double *frequencies, const mchap_exact_out *out,
+                                  void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Summaries of given posterior arrays [U][G] (calling.exact.posterior_allele_frequencies 332-369, the sum of
+ * alternate_dosage_posteriors 372-407 for the array's mode): device pointers, any output may be NULL. */
+int mchap_exact_posterior_summaries_batch_device(int n_units, const double *posteriors, int64_t n_genotypes, int ploidy,
+                                                 int n_alleles, int64_t *mode_alleles, double *mode_prob, double *support_prob,
+                                                 double *freqs, double *counts, double *occur, void *stream);
+/* ... and for one array in host memory */
+int mchap_exact_posterior_summaries(const double *posteriors, int64_t n_genotypes, int ploidy, int n_alleles,
+                                    int64_t *mode_alleles, double *mode_prob, double *support_prob, double *freqs,
+                                    double *counts, double *occur);
+
 /* Exact caller, streaming form: replaces calling.exact.posterior_mode (calling/exact.py:156-249) for a batch
- * of units that share (n_reads, n_pos, max_allele, n_haps, ploidy).  Host pointers. */
+ * of units that share (n_reads, n_pos, max_allele, n_haps, ploidy).  Host pointers (one device allocation, copies,
+ * mchap_exact_call_batch_device, copies back). */
 int mchap_exact_posterior_mode_batch(int n_units, const double *reads, int n_reads, int n_pos, int max_allele,
                                      const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy,
                                      int has_prior, const double *inbreeding, const double *frequencies,

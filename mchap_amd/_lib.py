@@ -77,6 +77,14 @@ UNIT_DTYPE = np.dtype(
 assert UNIT_DTYPE.itemsize == 96
 
 
+class ExactOut(C.Structure):
+    """mchap_exact_out: optional device outputs of mchap_exact_call_batch_device."""
+
+    _fields_ = [(n, C.c_void_p) for n in (
+        "mode_alleles", "mode_llk", "mode_prob", "support_prob", "freqs", "occur", "llks", "llks64", "posteriors",
+        "arr_mode_alleles", "arr_mode_prob", "arr_support_prob", "arr_freqs", "arr_counts", "arr_occur")]
+
+
 class MchapLibraryError(RuntimeError):
     pass
 
@@ -113,6 +121,7 @@ def lib():
         L.mchap_last_error.restype = C.c_char_p
         L.mchap_denovo_lds_bytes.restype = C.c_int64
         L.mchap_denovo_workspace_bytes.restype = C.c_int64
+        L.mchap_exact_workspace_bytes.restype = C.c_int64
         L.mchap_last_sampler_ms.restype = C.c_double
         L.mchap_last_sampler_name.restype = C.c_char_p
         _lib = L
@@ -129,6 +138,10 @@ EXPORTS = [
     "mchap_exact_genotype_likelihoods",
     "mchap_exact_genotype_posteriors",
     "mchap_exact_posterior_mode_batch",
+    "mchap_exact_workspace_bytes",
+    "mchap_exact_call_batch_device",
+    "mchap_exact_posterior_summaries_batch_device",
+    "mchap_exact_posterior_summaries",
     "mchap_version",
     "mchap_last_error",
     "mchap_device_count",

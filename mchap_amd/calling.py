@@ -19,6 +19,8 @@ __all__ = [
     "posterior_allele_frequencies",
     "alternate_dosage_posteriors",
     "count_unique_genotypes",
+    "genotypes_in_vcf_order",
+    "call_arrays_batch",
     "genotype_alleles_as_index",
     "index_as_genotype_alleles",
 ]
@@ -101,39 +103,29 @@ def genotype_posteriors(log_likelihoods, ploidy, n_alleles, prior=None):
 
 
 def posterior_allele_frequencies(posteriors, ploidy, n_alleles):
-    """(mean allele frequencies, allele counts, occurrence probabilities) of a posterior over VCF ordered genotypes.
-
-    Host side, vectorised: a weighted histogram over the enumerated genotypes (the reference loops in numba)."""
-    posteriors = np.asarray(posteriors, dtype=np.float64)
-    G = len(posteriors)
-    alleles = _enumerate_genotypes(G, ploidy)
-    counts = np.zeros(n_alleles)
-    occur = np.zeros(n_alleles)
-    for j in range(ploidy):
-        np.add.at(counts, alleles[:, j], posteriors)
-        first = np.ones(G, bool) if j == 0 else alleles[:, j] != alleles[:, j - 1]
-        np.add.at(occur, alleles[first, j], posteriors[first])
-    return counts / ploidy, counts, occur
+    """(mean allele frequencies, allele counts, occurrence probabilities) of a posterior over VCF ordered genotypes
+    (one pass of the device kernel over the array)."""
+    post = np.ascontiguousarray(posteriors, dtype=np.float64)
+    freqs, counts, occur = np.zeros(n_alleles), np.zeros(n_alleles), np.zeros(n_alleles)
+    _lib.check(_lib.lib().mchap_exact_posterior_summaries(
+        _lib.ptr(post), C.c_int64(len(post)), int(ploidy), int(n_alleles), None, None, None, _lib.ptr(freqs), _lib.ptr(counts),
+        _lib.ptr(occur)))
+    return freqs, counts, occur
 
 
-def _enumerate_genotypes(n, ploidy):
-    """First n genotypes in VCF order, shape [n, ploidy] (ascending alleles per row)."""
+def genotypes_in_vcf_order(n, ploidy):
+    """Alleles [n, ploidy] of the first n genotypes in VCF order: the combinatorial number system read from the
+    highest position down (what index_as_genotype_alleles does one index at a time), vectorised over the indices."""
+    rem = np.arange(n, dtype=np.int64)
     out = np.zeros((n, ploidy), dtype=np.int64)
-    g = np.zeros(ploidy, dtype=np.int64)
-    for i in range(n):
-        out[i] = g
-        # increment_genotype (reference jitutils.py:114-146)
-        if ploidy == 1:
-            g[0] += 1
-            continue
-        for k in range(1, ploidy):
-            if g[k] != g[0]:
-                g[k - 1] += 1
-                g[: k - 1] = 0
-                break
-        else:
-            g[-1] += 1
-            g[:-1] = 0
+    top = 1
+    while _cwr(top, ploidy) <= max(n - 1, 0):
+        top += 1
+    for p in range(ploidy, 0, -1):
+        table = np.array([_cwr(a, p) for a in range(top + 2)], dtype=np.int64)  # genotypes of p alleles below allele a
+        a = np.searchsorted(table, rem, side="right") - 1
+        out[:, p - 1] = a
+        rem = rem - table[a]
     return out
 
 
@@ -214,3 +206,20 @@ def posterior_mode(reads, ploidy, haplotypes, read_counts=None, prior=None, retu
     if return_posterior_occurrence:
         res.append(out[k][0])
     return tuple(res)
+
+
+def call_arrays_batch(reads, ploidy, haplotypes, read_counts=None, prior=None, return_arrays=True):
+    """The array form of the exact caller for a batch (what `mchap call-exact --report GL GP` computes per sample,
+    reference application/call_exact.py:126-159): genotype_likelihoods (float32) -> genotype_posteriors -> the
+    posterior array's mode, the probability of the mode's support, posterior_allele_frequencies -- one device call,
+    no host loop over genotypes or units.
+
+    reads [U, R, M, A], haplotypes [U, H, M] or [H, M], read_counts [U, R] or None,
+    prior = None | (inbreeding scalar or [U], frequencies None | [H] | [U, H]).
+    Returns a dict: alleles [U, K], prob [U], support_prob [U], freqs / counts / occur [U, H] and, with
+    return_arrays, llks float32 [U, G] and posteriors float64 [U, G]."""
+    from .device import ExactDeviceBatch
+
+    batch = ExactDeviceBatch(reads, ploidy, haplotypes, read_counts, prior)
+    batch.run(arrays=True, streaming=False)
+    return batch.array_results(return_arrays)

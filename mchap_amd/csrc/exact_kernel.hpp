@@ -33,6 +33,10 @@ struct ExactParams {
   long long *part_idx;      // [U][nblk] index of the block maximum (first occurrence)
   double *part_llk;         // [U][nblk] llk at the block maximum
   double *part_lse;         // [U][nblk] log-sum-exp of the block's ljoint
+  // second pass of the streaming form (exact_pass2_kernel): inputs written by exact_mode_kernel, per-block partial sums out
+  const double *unit_total;     // [U] log normaliser
+  const int64_t *unit_mode;     // [U][K] mode alleles
+  double *part_freq;            // [U][nblk][2H + 1]: allele counts, allele occurrence, mode-support probability
 };
 
 // C(n + k - 1, k), the number of genotypes of ploidy k over n alleles (jitutils.py:228-250; 0 for n == 0)
@@ -130,18 +134,25 @@ __device__ inline double calling_log_prior(const PriorTab &t, const int *g, int 
   return t.left + prod;
 }
 
-__global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactParams P) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int unit = blockIdx.y;
+// LDS of the enumeration passes: product table, read weights, prior tables, then the caller's scratch
+struct ExactLds {
+  double *ptab;   // [R][H]
+  double *cnt;    // [R]
+  double *lgd;    // [H][K+1]
+  double *lgf;    // [K+1]
+  double *lfreq;  // [H]
+  double *red;    // reduction scratch (the rest of the allocation)
+};
+// Builds P[r][h], the read weights and the prior tables of `unit` (whole workgroup; ends with a barrier).
+__device__ __forceinline__ void exact_setup(const ExactParams &P, int unit, unsigned char *smem, ExactLds &E, PriorTab &pt) {
   const int R = P.R, M = P.M, A = P.A, H = P.H, K = P.K;
-  double *ptab = reinterpret_cast<double *>(smem);            // [R][H]
-  double *cnt = ptab + (size_t)R * H;                         // [R]
-  double *lgd = cnt + R;                                      // [H][K+1]
-  double *lgf = lgd + (size_t)H * (K + 1);                    // [K+1]
-  double *lfreq = lgf + (K + 1);                              // [H]
-  double *red = lfreq + H;                                    // [5][EXACT_THREADS] reduction scratch
+  E.ptab = reinterpret_cast<double *>(smem);
+  E.cnt = E.ptab + (size_t)R * H;
+  E.lgd = E.cnt + R;
+  E.lgf = E.lgd + (size_t)H * (K + 1);
+  E.lfreq = E.lgf + (K + 1);
+  E.red = E.lfreq + H;
   __shared__ double s_left;
-
   const double *reads = P.reads + (size_t)unit * R * M * A;
   const int8_t *haps = P.haps + (size_t)unit * H * M;
   for (int q = threadIdx.x; q < R * H; q += blockDim.x) {
@@ -151,9 +162,9 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
       const double v = reads[((size_t)r * M + j) * A + haps[h * M + j]];
       if (!isnan(v)) prod *= v;  // assemble/likelihood.py:54-59
     }
-    ptab[q] = prod;
+    E.ptab[q] = prod;
   }
-  for (int r = threadIdx.x; r < R; r += blockDim.x) cnt[r] = P.counts ? (double)P.counts[(size_t)unit * R + r] : 1.0;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) E.cnt[r] = P.counts ? (double)P.counts[(size_t)unit * R + r] : 1.0;
   double F = 0.0;
   const bool has_prior = P.has_prior != 0;
   const bool has_freqs = has_prior && P.freqs != nullptr;
@@ -163,10 +174,10 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
     for (int q = threadIdx.x; q < H * (K + 1); q += blockDim.x) {
       const int h = q / (K + 1), d = q % (K + 1);
       const double alpha = has_freqs ? P.freqs[(size_t)unit * H + h] * scale : (1.0 / (double)H) * scale;
-      lgd[q] = (F == 0.0 || d == 0) ? 0.0 : lgamma((double)d + alpha) - (lgamma((double)d + 1.0) + lgamma(alpha));
+      E.lgd[q] = (F == 0.0 || d == 0) ? 0.0 : lgamma((double)d + alpha) - (lgamma((double)d + 1.0) + lgamma(alpha));
     }
-    for (int d = threadIdx.x; d <= K; d += blockDim.x) lgf[d] = lgamma((double)d + 1.0);
-    for (int h = threadIdx.x; h < H; h += blockDim.x) lfreq[h] = has_freqs ? P.freqs[(size_t)unit * H + h] : 0.0;
+    for (int d = threadIdx.x; d <= K; d += blockDim.x) E.lgf[d] = lgamma((double)d + 1.0);
+    for (int h = threadIdx.x; h < H; h += blockDim.x) E.lfreq[h] = has_freqs ? P.freqs[(size_t)unit * H + h] : 0.0;
     if (threadIdx.x == 0) {
       double sum_alpha;
       if (has_freqs) {
@@ -179,14 +190,38 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
     }
   }
   __syncthreads();
-  PriorTab pt;
-  pt.lgd = lgd;
-  pt.lgf = lgf;
-  pt.lfreq = lfreq;
+  pt.lgd = E.lgd;
+  pt.lgf = E.lgf;
+  pt.lfreq = E.lfreq;
   pt.left = has_prior ? s_left : 0.0;
   pt.lnH = log((double)H);
   pt.F = F;
   pt.has_freqs = has_freqs ? 1 : 0;
+}
+
+// log likelihood of the genotype with ascending alleles g (calling/exact.py:252-263 via assemble/likelihood.py:17-70)
+__device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[MCHAP_MAX_PLOIDY], int R, int H, int K, double invK) {
+  double llk = 0.0;
+  for (int r = 0; r < R; r++) {
+    const double *row = E.ptab + (size_t)r * H;
+    double rp = 0.0;
+#pragma unroll
+    for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+      if (k < K) rp += row[g[k]] * invK;
+    llk += log(rp) * E.cnt[r];
+  }
+  return llk;
+}
+
+__global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int unit = blockIdx.y;
+  const int R = P.R, H = P.H, K = P.K;
+  const bool has_prior = P.has_prior != 0;
+  ExactLds E;
+  PriorTab pt;
+  exact_setup(P, unit, smem, E, pt);
+  double *red = E.red;  // [5][EXACT_THREADS] reduction scratch
 
   const long long G = P.G;
   const long long lo = (long long)blockIdx.x * EXACT_GENOS_PER_BLOCK;
@@ -199,22 +234,14 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
   for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     int g[MCHAP_MAX_PLOIDY];
     unrank_genotype(i, K, g);
-    double llk = 0.0;
-    for (int r = 0; r < R; r++) {
-      const double *row = ptab + (size_t)r * H;
-      double rp = 0.0;
-#pragma unroll
-      for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
-        if (k < K) rp += row[g[k]] * invK;
-      llk += log(rp) * cnt[r];
-    }
+    const double llk = exact_llk(E, g, R, H, K, invK);
     const size_t o = (size_t)unit * G + i;
     if (P.llk32) P.llk32[o] = (float)llk;  // calling/exact.py:254 float32 store
     if (P.llk64) P.llk64[o] = llk;
-    if (P.ljoint) {
+    if (P.ljoint || P.part_max) {
       const double lpr = has_prior ? calling_log_prior(pt, g, K) : 0.0;
       const double lj = llk + lpr;
-      P.ljoint[o] = lj;
+      if (P.ljoint) P.ljoint[o] = lj;
       if (lj > best) {  // calling/exact.py:51: strict, first maximum wins
         best = lj;
         best_idx = i;
@@ -228,7 +255,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
       }
     }
   }
-  if (!P.ljoint) return;
+  if (!P.part_max) return;
   // block reduction
   double *rb = red, *ri = red + EXACT_THREADS, *rl = red + 2 * EXACT_THREADS, *rm = red + 3 * EXACT_THREADS, *rs = red + 4 * EXACT_THREADS;
   rb[threadIdx.x] = best;
@@ -262,199 +289,294 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
   }
 }
 
-struct ExactFinalParams {
+// ---- streaming form without any per-genotype array (calling/exact.py:156-249: two passes over the genotypes) ----
+// After pass 1: normaliser and mode of every unit from the per-block partials.
+struct ExactModeParams {
   ExactParams e;
-  int64_t *mode_alleles;  // [U][K]
-  double *mode_llk, *mode_prob, *support_prob;  // [U]
-  double *freqs_out, *occur_out;                // [U][H] or null
+  int64_t *mode_alleles;                  // [U][K] (output, and input of the second pass)
+  double *mode_llk, *mode_prob, *total;   // [U]
 };
-
-// calling/exact.py:156-249 after the enumeration: normaliser, mode, support probability (64-105), and the
-// posterior allele frequency / occurrence pass (108-153) over the stored joint values.
-__global__ __launch_bounds__(256) void exact_finalize_kernel(const ExactFinalParams P) {
-  extern __shared__ __align__(16) unsigned char smem[];
+__global__ __launch_bounds__(64) void exact_mode_kernel(const ExactModeParams P) {
   const ExactParams &E = P.e;
   const int unit = blockIdx.x;
-  const int K = E.K, H = E.H;
-  const long long G = E.G;
-  __shared__ double s_total;
-  double *acc = reinterpret_cast<double *>(smem);  // [2][H][blockDim]
-  if (threadIdx.x == 0) {
-    double b = -INFINITY, bl = -INFINITY, total = -INFINITY;
-    long long bi = 0;
-    for (int q = 0; q < E.nblk; q++) {
-      const size_t o = (size_t)unit * E.nblk + q;
-      if (E.part_max[o] > b) {  // blocks are in index order: strict > keeps the first maximum
-        b = E.part_max[o];
-        bi = E.part_idx[o];
-        bl = E.part_llk[o];
-      }
-      total = add_log_prob(total, E.part_lse[o]);
+  if (threadIdx.x != 0) return;
+  double b = -INFINITY, bl = -INFINITY, total = -INFINITY;
+  long long bi = 0;
+  for (int q = 0; q < E.nblk; q++) {
+    const size_t o = (size_t)unit * E.nblk + q;
+    if (E.part_max[o] > b) {  // blocks are in index order: strict > keeps the first maximum (calling/exact.py:51)
+      b = E.part_max[o];
+      bi = E.part_idx[o];
+      bl = E.part_llk[o];
     }
-    s_total = total;
-    int g[MCHAP_MAX_PLOIDY];
-    unrank_genotype(bi, K, g);
-    for (int k = 0; k < K; k++) P.mode_alleles[(size_t)unit * K + k] = g[k];
-    P.mode_llk[unit] = bl;
-    P.mode_prob[unit] = exp(b - total);
-    if (P.support_prob) {
-      // calling/exact.py:64-105: every dosage variant of the mode's support, itertools order
-      int support[MCHAP_MAX_PLOIDY], ns = 0;
-      for (int k = 0; k < K; k++)
-        if (k == 0 || g[k] != g[k - 1]) support[ns++] = g[k];
-      const int rem = K - ns;
-      int idx[MCHAP_MAX_PLOIDY];
-      for (int k = 0; k < rem; k++) idx[k] = 0;
-      double slj = -INFINITY;
-      bool more = true;
-      while (more) {
-        int tmp[MCHAP_MAX_PLOIDY];
-        for (int k = 0; k < ns; k++) tmp[k] = support[k];
-        for (int k = 0; k < rem; k++) tmp[ns + k] = support[idx[k]];
-        for (int a = 1; a < K; a++) {  // insertion sort
-          const int v = tmp[a];
-          int b2 = a - 1;
-          while (b2 >= 0 && tmp[b2] > v) {
-            tmp[b2 + 1] = tmp[b2];
-            b2--;
-          }
-          tmp[b2 + 1] = v;
-        }
-        slj = add_log_prob(slj, E.ljoint[(size_t)unit * G + rank_genotype(tmp, K)]);
-        more = false;
-        if (rem > 0) {
-          int q = rem - 1;
-          while (q >= 0 && idx[q] == ns - 1) q--;
-          if (q >= 0) {
-            const int v = idx[q] + 1;
-            for (int z = q; z < rem; z++) idx[z] = v;
-            more = true;
-          }
-        }
-      }
-      P.support_prob[unit] = exp(slj - total);
-    }
+    total = add_log_prob(total, E.part_lse[o]);
   }
-  __syncthreads();
-  if (!P.freqs_out && !P.occur_out) return;
-  const double total = s_total;
+  int g[MCHAP_MAX_PLOIDY];
+  unrank_genotype(bi, E.K, g);
+  for (int k = 0; k < E.K; k++) P.mode_alleles[(size_t)unit * E.K + k] = g[k];
+  if (P.mode_llk) P.mode_llk[unit] = bl;
+  if (P.mode_prob) P.mode_prob[unit] = exp(b - total);
+  P.total[unit] = total;
+}
+
+// Second pass: every genotype's joint value again, its probability under the known normaliser added to the allele
+// count / occurrence sums (calling/exact.py:108-153) and, when it consists of exactly the mode's alleles, to the
+// support probability (64-105).  Per-thread LDS columns, summed in thread order, then in block order by
+// exact_freq_kernel: deterministic.
+inline size_t exact_pass2_lds(int R, int H, int K, int threads) {
+  return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)(2 * H + 1) * threads) * 8;
+}
+__global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int unit = blockIdx.y;
+  const int R = P.R, H = P.H, K = P.K;
+  const bool has_prior = P.has_prior != 0;
+  ExactLds E;
+  PriorTab pt;
+  exact_setup(P, unit, smem, E, pt);
+  double *acc = E.red;  // [2H + 1][nt]
   const int nt = blockDim.x;
-  for (int h = 0; h < H; h++) {
-    acc[(size_t)h * nt + threadIdx.x] = 0.0;
-    acc[(size_t)(H + h) * nt + threadIdx.x] = 0.0;
+  for (int h = 0; h < 2 * H + 1; h++) acc[(size_t)h * nt + threadIdx.x] = 0.0;
+  const double total = P.unit_total[unit];
+  int ms[MCHAP_MAX_PLOIDY], ns = 0;  // distinct alleles of the mode, ascending
+  for (int k = 0; k < K; k++) {
+    const int a = (int)P.unit_mode[(size_t)unit * K + k];
+    if (k == 0 || a != ms[ns - 1]) ms[ns++] = a;
   }
-  for (long long i = threadIdx.x; i < G; i += nt) {
+  const long long G = P.G;
+  const long long lo = (long long)blockIdx.x * EXACT_GENOS_PER_BLOCK;
+  long long hi = lo + EXACT_GENOS_PER_BLOCK;
+  if (hi > G) hi = G;
+  const double invK = 1.0 / (double)K;
+  for (long long i = lo + threadIdx.x; i < hi; i += nt) {
     int g[MCHAP_MAX_PLOIDY];
     unrank_genotype(i, K, g);
-    const double prob = exp(E.ljoint[(size_t)unit * G + i] - total);
+    const double llk = exact_llk(E, g, R, H, K, invK);
+    const double lpr = has_prior ? calling_log_prior(pt, g, K) : 0.0;
+    const double prob = exp((llk + lpr) - total);
+    int nd = 0;
+    bool same = true;
     for (int k = 0; k < K; k++) {
       acc[(size_t)g[k] * nt + threadIdx.x] += prob;
-      if (k == 0 || g[k] != g[k - 1]) acc[(size_t)(H + g[k]) * nt + threadIdx.x] += prob;
+      if (k == 0 || g[k] != g[k - 1]) {
+        acc[(size_t)(H + g[k]) * nt + threadIdx.x] += prob;
+        same = same && nd < ns && ms[nd] == g[k];
+        nd++;
+      }
     }
+    if (same && nd == ns) acc[(size_t)(2 * H) * nt + threadIdx.x] += prob;
   }
   __syncthreads();
-  for (int h = threadIdx.x; h < 2 * H; h += nt) {
-    double s = 0.0;
-    for (int t = 0; t < nt; t++) s += acc[(size_t)h * nt + t];
-    if (h < H) {
-      if (P.freqs_out) P.freqs_out[(size_t)unit * H + h] = s / (double)K;
-    } else if (P.occur_out) {
-      P.occur_out[(size_t)unit * H + (h - H)] = s;
+  for (int h = threadIdx.x; h < 2 * H + 1; h += nt) {
+    double sum = 0.0;
+    for (int t = 0; t < nt; t++) sum += acc[(size_t)h * nt + t];
+    P.part_freq[((size_t)unit * P.nblk + blockIdx.x) * (2 * H + 1) + h] = sum;
+  }
+}
+struct ExactFreqParams {
+  const double *part_freq;  // [U][nblk][2H + 1]
+  int nblk, H, K;
+  double *support_prob;     // [U] or null
+  double *freqs_out, *occur_out;  // [U][H] or null
+};
+__global__ __launch_bounds__(64) void exact_freq_kernel(const ExactFreqParams P) {
+  const int unit = blockIdx.x;
+  for (int h = threadIdx.x; h < 2 * P.H + 1; h += blockDim.x) {
+    double sum = 0.0;
+    for (int q = 0; q < P.nblk; q++) sum += P.part_freq[((size_t)unit * P.nblk + q) * (2 * P.H + 1) + h];
+    if (h < P.H) {
+      if (P.freqs_out) P.freqs_out[(size_t)unit * P.H + h] = sum / (double)P.K;
+    } else if (h < 2 * P.H) {
+      if (P.occur_out) P.occur_out[(size_t)unit * P.H + (h - P.H)] = sum;
+    } else if (P.support_prob) {
+      P.support_prob[unit] = sum;
     }
   }
 }
 
-// calling/exact.py:295-329 on a stored likelihood array: priors, joint values stored in the array's dtype
-// (float32 when is_f32), the float32-typed log-sum-exp of jitutils.py:7-74, float64 result array.
-struct ExactPostParams {
-  const float *llk32;
-  const double *llk64;
-  double *out;
+// ---- array form for a batch: genotype_posteriors on stored likelihoods (calling/exact.py:295-329), one workgroup per unit,
+// the joint values parked in the output array itself, and what call_exact.py:126-159 / exact.py:332-407 derive from the
+// posterior array: its first maximum, the probability of the mode's support, allele frequencies / counts / occurrence ----
+struct ExactArrayParams {
+  const float *llk32;       // [U][G] or null
+  const double *llk64;      // [U][G] or null (used when llk32 is null)
+  double *post;             // [U][G] out (may be null when only... never: the summaries read it)
+  const double *post_in;    // [U][G] summaries of a given posterior array instead (llk32 == llk64 == null)
   long long G;
-  int K, H, has_prior, is_f32;
-  double F;
-  const double *freqs;
-  double *scratch;  // [G] joint values
+  int K, H, has_prior;
+  const double *inbreeding; // [U]
+  const double *freqs;      // [U][H] or null
+  int64_t *mode_alleles;    // [U][K] or null
+  double *mode_prob, *support_prob;       // [U] or null
+  double *afreq, *acount, *aoccur;        // [U][H] or null
+  int nacc;                 // threads that accumulate the allele sums (an LDS column each)
 };
-
-__global__ __launch_bounds__(1024) void exact_posteriors_kernel(const ExactPostParams P) {
+constexpr int EXACT_ARRAY_THREADS = 1024;
+inline size_t exact_array_lds(int H, int K, int nacc) {
+  return ((size_t)H * (K + 1) + (K + 1) + H + 2 * (size_t)EXACT_ARRAY_THREADS + (size_t)(2 * H + 1) * nacc) * 8;
+}
+__global__ __launch_bounds__(EXACT_ARRAY_THREADS) void exact_array_kernel(const ExactArrayParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
+  const int unit = blockIdx.x;
   const int K = P.K, H = P.H;
+  const long long G = P.G;
   double *lgd = reinterpret_cast<double *>(smem);
   double *lgf = lgd + (size_t)H * (K + 1);
   double *lfreq = lgf + (K + 1);
-  double *red = lfreq + H;  // [2][1024]
+  double *red = lfreq + H;                    // [2][threads]
+  double *acc = red + 2 * EXACT_ARRAY_THREADS;  // [2H + 1][nacc]
   __shared__ double s_left, s_total;
-  const bool has_freqs = P.has_prior && P.freqs;
-  const double F = P.F;
-  if (P.has_prior) {
-    const double scale = (1.0 - F) / F;
-    for (int q = threadIdx.x; q < H * (K + 1); q += blockDim.x) {
-      const int h = q / (K + 1), d = q % (K + 1);
-      const double alpha = has_freqs ? P.freqs[h] * scale : (1.0 / (double)H) * scale;
-      lgd[q] = (F == 0.0 || d == 0) ? 0.0 : lgamma((double)d + alpha) - (lgamma((double)d + 1.0) + lgamma(alpha));
-    }
-    for (int d = threadIdx.x; d <= K; d += blockDim.x) lgf[d] = lgamma((double)d + 1.0);
-    for (int h = threadIdx.x; h < H; h += blockDim.x) lfreq[h] = has_freqs ? P.freqs[h] : 0.0;
-    if (threadIdx.x == 0) {
-      double sum_alpha = 0.0;
-      if (has_freqs) {
-        for (int h = 0; h < H; h++) sum_alpha += P.freqs[h] * scale;
-      } else {
-        sum_alpha = ((1.0 / (double)H) * scale) * (double)H;
+  __shared__ long long s_mode;
+  const int nt = blockDim.x;
+  const double *post;
+  if (P.post_in) {
+    post = P.post_in + (size_t)unit * G;
+  } else {
+    // ---- genotype_posteriors ----
+    const bool is_f32 = P.llk32 != nullptr;
+    const bool has_freqs = P.has_prior && P.freqs;
+    const double F = P.has_prior ? P.inbreeding[unit] : 0.0;
+    if (P.has_prior) {
+      const double scale = (1.0 - F) / F;
+      for (int q = threadIdx.x; q < H * (K + 1); q += nt) {
+        const int h = q / (K + 1), d = q % (K + 1);
+        const double alpha = has_freqs ? P.freqs[(size_t)unit * H + h] * scale : (1.0 / (double)H) * scale;
+        lgd[q] = (F == 0.0 || d == 0) ? 0.0 : lgamma((double)d + alpha) - (lgamma((double)d + 1.0) + lgamma(alpha));
       }
-      s_left = (F == 0.0) ? 0.0 : (lgamma((double)K + 1.0) + lgamma(sum_alpha)) - lgamma((double)K + sum_alpha);
-    }
-  }
-  __syncthreads();
-  PriorTab pt;
-  pt.lgd = lgd;
-  pt.lgf = lgf;
-  pt.lfreq = lfreq;
-  pt.left = P.has_prior ? s_left : 0.0;
-  pt.lnH = log((double)H);
-  pt.F = F;
-  pt.has_freqs = has_freqs ? 1 : 0;
-  double m = -INFINITY, s = 0.0;
-  for (long long i = threadIdx.x; i < P.G; i += blockDim.x) {
-    int g[MCHAP_MAX_PLOIDY];
-    unrank_genotype(i, K, g);
-    const double lpr = P.has_prior ? calling_log_prior(pt, g, K) : 0.0;
-    double j;
-    if (P.is_f32) j = (double)(float)((double)P.llk32[i] + lpr);
-    else j = P.llk64[i] + lpr;
-    P.scratch[i] = j;
-    if (j > m) {
-      s = s * exp(m - j) + 1.0;
-      m = j;
-    } else if (j > -INFINITY) {
-      s += exp(j - m);
-    }
-  }
-  red[threadIdx.x] = m;
-  red[1024 + threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double mm = -INFINITY, ss = 0.0;
-    for (int t = 0; t < (int)blockDim.x; t++) {
-      if (red[t] > -INFINITY) {
-        if (red[t] > mm) {
-          ss = ss * exp(mm - red[t]) + red[1024 + t];
-          mm = red[t];
+      for (int d = threadIdx.x; d <= K; d += nt) lgf[d] = lgamma((double)d + 1.0);
+      for (int h = threadIdx.x; h < H; h += nt) lfreq[h] = has_freqs ? P.freqs[(size_t)unit * H + h] : 0.0;
+      if (threadIdx.x == 0) {
+        double sum_alpha = 0.0;
+        if (has_freqs) {
+          for (int h = 0; h < H; h++) sum_alpha += P.freqs[(size_t)unit * H + h] * scale;
         } else {
-          ss += red[1024 + t] * exp(red[t] - mm);
+          sum_alpha = ((1.0 / (double)H) * scale) * (double)H;
+        }
+        s_left = (F == 0.0) ? 0.0 : (lgamma((double)K + 1.0) + lgamma(sum_alpha)) - lgamma((double)K + sum_alpha);
+      }
+    }
+    __syncthreads();
+    PriorTab pt;
+    pt.lgd = lgd;
+    pt.lgf = lgf;
+    pt.lfreq = lfreq;
+    pt.left = P.has_prior ? s_left : 0.0;
+    pt.lnH = log((double)H);
+    pt.F = F;
+    pt.has_freqs = has_freqs ? 1 : 0;
+    double *out = P.post + (size_t)unit * G;
+    double m = -INFINITY, sacc = 0.0;
+    for (long long i = threadIdx.x; i < G; i += nt) {
+      int g[MCHAP_MAX_PLOIDY];
+      unrank_genotype(i, K, g);
+      const double lpr = P.has_prior ? calling_log_prior(pt, g, K) : 0.0;
+      double j;
+      if (is_f32) j = (double)(float)((double)P.llk32[(size_t)unit * G + i] + lpr);  // stored in the array's dtype (exact.py:317)
+      else j = P.llk64[(size_t)unit * G + i] + lpr;
+      out[i] = j;
+      if (j > m) {
+        sacc = sacc * exp(m - j) + 1.0;
+        m = j;
+      } else if (j > -INFINITY) {
+        sacc += exp(j - m);
+      }
+    }
+    red[threadIdx.x] = m;
+    red[EXACT_ARRAY_THREADS + threadIdx.x] = sacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double mm = -INFINITY, ss = 0.0;
+      for (int t = 0; t < nt; t++) {
+        if (red[t] > -INFINITY) {
+          if (red[t] > mm) {
+            ss = ss * exp(mm - red[t]) + red[EXACT_ARRAY_THREADS + t];
+            mm = red[t];
+          } else {
+            ss += red[EXACT_ARRAY_THREADS + t] * exp(red[t] - mm);
+          }
         }
       }
+      double total = mm + log(ss);
+      if (is_f32) total = (double)(float)total;  // the reference's accumulator is float32 here (jitutils.py:7-74)
+      s_total = total;
     }
-    double total = mm + log(ss);
-    if (P.is_f32) total = (double)(float)total;  // the reference's accumulator is float32 here
-    s_total = total;
+    __syncthreads();
+    const double total = s_total;
+    for (long long i = threadIdx.x; i < G; i += nt) {
+      if (is_f32) out[i] = (double)expf((float)out[i] - (float)total);
+      else out[i] = exp(out[i] - total);
+    }
+    __syncthreads();
+    post = out;
+  }
+  const bool want_mode = P.mode_alleles || P.mode_prob || P.support_prob;
+  const bool want_freq = P.afreq || P.acount || P.aoccur;
+  if (!want_mode && !want_freq) return;
+  // ---- first maximum of the posterior array (np.argmax) ----
+  {
+    double b = -INFINITY;
+    long long bi = 0x7fffffffffffffffll;
+    for (long long i = threadIdx.x; i < G; i += nt) {
+      const double v = post[i];
+      if (v > b) {
+        b = v;
+        bi = i;
+      }
+    }
+    red[threadIdx.x] = b;
+    red[EXACT_ARRAY_THREADS + threadIdx.x] = (double)bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double bb = -INFINITY, bidx = 9.0e18;
+      for (int t = 0; t < nt; t++)
+        if (red[t] > bb || (red[t] == bb && red[EXACT_ARRAY_THREADS + t] < bidx)) {
+          bb = red[t];
+          bidx = red[EXACT_ARRAY_THREADS + t];
+        }
+      s_mode = bidx < 9.0e18 ? (long long)bidx : 0;
+      if (P.mode_prob) P.mode_prob[unit] = bb;
+    }
+    __syncthreads();
+  }
+  int mg[MCHAP_MAX_PLOIDY];
+  unrank_genotype(s_mode, K, mg);
+  if (P.mode_alleles && threadIdx.x < K) P.mode_alleles[(size_t)unit * K + threadIdx.x] = mg[threadIdx.x];
+  int ms[MCHAP_MAX_PLOIDY], ns = 0;
+  for (int k = 0; k < K; k++)
+    if (k == 0 || mg[k] != mg[k - 1]) ms[ns++] = mg[k];
+  // ---- sums over the genotypes: P.nacc accumulating threads (an LDS column each), summed in thread order ----
+  const int na = P.nacc;
+  if ((int)threadIdx.x < na) {
+    for (int h = 0; h < 2 * H + 1; h++) acc[(size_t)h * na + threadIdx.x] = 0.0;
+    for (long long i = threadIdx.x; i < G; i += na) {
+      int g[MCHAP_MAX_PLOIDY];
+      unrank_genotype(i, K, g);
+      const double prob = post[i];
+      int nd = 0;
+      bool same = true;
+      for (int k = 0; k < K; k++) {
+        acc[(size_t)g[k] * na + threadIdx.x] += prob;
+        if (k == 0 || g[k] != g[k - 1]) {
+          acc[(size_t)(H + g[k]) * na + threadIdx.x] += prob;
+          same = same && nd < ns && ms[nd] == g[k];
+          nd++;
+        }
+      }
+      if (same && nd == ns) acc[(size_t)(2 * H) * na + threadIdx.x] += prob;
+    }
   }
   __syncthreads();
-  const double total = s_total;
-  for (long long i = threadIdx.x; i < P.G; i += blockDim.x) {
-    if (P.is_f32) P.out[i] = (double)expf((float)P.scratch[i] - (float)total);
-    else P.out[i] = exp(P.scratch[i] - total);
+  for (int h = threadIdx.x; h < 2 * H + 1; h += nt) {
+    double sum = 0.0;
+    for (int t = 0; t < na; t++) sum += acc[(size_t)h * na + t];
+    if (h < H) {
+      if (P.afreq) P.afreq[(size_t)unit * H + h] = sum / (double)K;
+      if (P.acount) P.acount[(size_t)unit * H + h] = sum;
+    } else if (h < 2 * H) {
+      if (P.aoccur) P.aoccur[(size_t)unit * H + (h - H)] = sum;
+    } else if (P.support_prob) {
+      P.support_prob[unit] = sum;
+    }
   }
 }
 

@@ -181,6 +181,25 @@ struct DevBuf {
   T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+size_t up256(size_t x);
+// one device allocation for a host-pointer call: pieces handed out 256-byte aligned
+struct DevArena {
+  DevBuf buf;
+  size_t cap = 0, off = 0;
+  int reserve(size_t bytes) {
+    cap = bytes + 4096;
+    if (hipMalloc(&buf.p, cap) != hipSuccess) return fail(MCHAP_ERR_HIP, "hipMalloc of %zu bytes", cap);
+    return MCHAP_OK;
+  }
+  template <class T>
+  T *take(size_t n) {
+    T *p = reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(buf.p) + off);
+    off += up256(n * sizeof(T));
+    return off <= cap ? p : nullptr;
+  }
+};
+
+
 // bytes per lane and row of the coded table: 1, 2, or a multiple of 4 (the sampler loads 1 / 2 / 4 bytes at a time)
 int code_stride(int rpl) { return rpl <= 2 ? rpl : (rpl + 3) & ~3; }
 

@@ -181,3 +181,100 @@ class DenovoDeviceBatch:
             mode_words=P["mode_words"].cpu().numpy().view(np.uint64).reshape(U, self.K),
             mode_count=P["mode_count"].cpu().numpy(),
         )
+
+
+class ExactDeviceBatch:
+    """A batch of exact-caller units that share a shape, resident on one GPU: inputs are uploaded once, every output of
+    mchap_exact_call_batch_device stays in HBM until asked for.
+
+    reads float64 [U, R, M, A]; haplotypes int8 [U, H, M] (or [H, M] for all units); read_counts int64 [U, R] or None;
+    prior None | (inbreeding scalar or [U], frequencies None | [H] | [U, H])."""
+
+    def __init__(self, reads, ploidy, haplotypes, read_counts=None, prior=None, device=None):
+        torch = _torch()
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        dev = self.device
+        reads = np.ascontiguousarray(reads, dtype=np.float64)
+        U, R, M, A = reads.shape
+        haps = np.asarray(haplotypes, dtype=np.int8)
+        if haps.ndim == 2:
+            haps = np.broadcast_to(haps, (U,) + haps.shape)
+        haps = np.array(haps)
+        H = haps.shape[1]
+        self.shape = (U, R, M, A, H, int(ploidy))
+        from math import comb
+
+        self.G = comb(H + int(ploidy) - 1, int(ploidy))
+        self.d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+        self.d_haps = torch.from_numpy(haps.reshape(-1)).to(dev)
+        self.d_counts = None if read_counts is None else torch.from_numpy(
+            np.ascontiguousarray(read_counts, dtype=np.int64).reshape(-1)).to(dev)
+        self.has_prior = 0 if prior is None else 1
+        self.d_F = self.d_fr = None
+        if prior is not None:
+            F = np.array(np.broadcast_to(np.asarray(prior[0], dtype=np.float64), (U,)))
+            self.d_F = torch.from_numpy(F).to(dev)
+            if prior[1] is not None:
+                fr = np.array(np.broadcast_to(np.asarray(prior[1], dtype=np.float64), (U, H)))
+                self.d_fr = torch.from_numpy(fr.reshape(-1)).to(dev)
+        self.ws_bytes = int(_lib.lib().mchap_exact_workspace_bytes(U, H, int(ploidy)))
+        self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
+        self.out = {}
+
+    def _p(self, t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _buf(self, name, n, dtype):
+        t = self.out.get(name)
+        if t is None:
+            t = self.torch.empty(n, dtype=dtype, device=self.device)
+            self.out[name] = t
+        return t
+
+    def run(self, streaming=True, arrays=False, llks64=False):
+        """Enqueue the exact caller on torch's current stream: the streaming outputs (posterior_mode), and / or the
+        array outputs (likelihoods, posteriors and their summaries)."""
+        torch = self.torch
+        U, R, M, A, H, K = self.shape
+        o = _lib.ExactOut()
+        if streaming:
+            o.mode_alleles = self._buf("mode_alleles", U * K, torch.int64).data_ptr()
+            for nm in ("mode_llk", "mode_prob", "support_prob"):
+                setattr(o, nm, self._buf(nm, U, torch.float64).data_ptr())
+            for nm in ("freqs", "occur"):
+                setattr(o, nm, self._buf(nm, U * H, torch.float64).data_ptr())
+        if arrays:
+            o.llks = self._buf("llks", U * self.G, torch.float32).data_ptr()
+            if llks64:
+                o.llks64 = self._buf("llks64", U * self.G, torch.float64).data_ptr()
+            o.posteriors = self._buf("posteriors", U * self.G, torch.float64).data_ptr()
+            o.arr_mode_alleles = self._buf("arr_mode_alleles", U * K, torch.int64).data_ptr()
+            for nm in ("arr_mode_prob", "arr_support_prob"):
+                setattr(o, nm, self._buf(nm, U, torch.float64).data_ptr())
+            for nm in ("arr_freqs", "arr_counts", "arr_occur"):
+                setattr(o, nm, self._buf(nm, U * H, torch.float64).data_ptr())
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _lib.lib().mchap_exact_call_batch_device(
+            U, self._p(self.d_reads), R, M, A, self._p(self.d_counts), self._p(self.d_haps), H, K, self.has_prior,
+            self._p(self.d_F), self._p(self.d_fr), C.byref(o), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream))
+        _lib.check(rc)
+
+    def _host(self, name, shape):
+        return self.out[name].cpu().numpy().reshape(shape)
+
+    def mode_results(self):
+        """(alleles [U, K], llk [U], prob [U], support_prob [U], freqs [U, H], occur [U, H]) of the streaming form."""
+        U, R, M, A, H, K = self.shape
+        return (self._host("mode_alleles", (U, K)), self._host("mode_llk", (U,)), self._host("mode_prob", (U,)),
+                self._host("support_prob", (U,)), self._host("freqs", (U, H)), self._host("occur", (U, H)))
+
+    def array_results(self, with_arrays=True):
+        U, R, M, A, H, K = self.shape
+        res = dict(alleles=self._host("arr_mode_alleles", (U, K)), prob=self._host("arr_mode_prob", (U,)),
+                   support_prob=self._host("arr_support_prob", (U,)), freqs=self._host("arr_freqs", (U, H)),
+                   counts=self._host("arr_counts", (U, H)), occur=self._host("arr_occur", (U, H)))
+        if with_arrays:
+            res["llks"] = self._host("llks", (U, self.G))
+            res["posteriors"] = self._host("posteriors", (U, self.G))
+        return res

@@ -30,3 +30,18 @@ def test_encode_read_distributions_and_dedup():
     d2 = encoding.encode_read_distributions([2, 2, 2], calls, q)
     assert d2[0, 0, 0] == (1 - 10 ** (30 / -10)) * (1 - 0.0024)
     assert encoding.encode_read_distributions([2, 2], np.zeros((0, 2), np.int8)).shape == (0, 2, 2)
+
+
+def test_genotypes_in_vcf_order_matches_the_indexing_functions():
+    """The vectorised enumeration (no per-genotype Python loop) against index_as_genotype_alleles / genotype_alleles_as_index,
+    themselves pinned to the reference's tables in tests/test_oracle_golden.py."""
+    from mchap_amd import calling
+
+    for n_alleles, ploidy in [(2, 2), (3, 4), (5, 3), (7, 6), (16, 2), (1, 4)]:
+        G = calling.count_unique_genotypes(n_alleles, ploidy)
+        g = calling.genotypes_in_vcf_order(G, ploidy)
+        assert g.shape == (G, ploidy)
+        assert (np.diff(g, axis=1) >= 0).all() and g.max() == n_alleles - 1
+        for i in range(0, G, max(1, G // 50)):
+            assert g[i].tolist() == calling.index_as_genotype_alleles(i, ploidy).tolist()
+            assert calling.genotype_alleles_as_index(g[i]) == i

@@ -132,3 +132,40 @@ def test_config5_full_shape(variant, monkeypatch):
             assert tr.genotypes.shape == (kw["chains"], 25, 8, 20)
             assert np.array_equal(tr.genotypes, ref[u][0]), "kernel %d unit %d" % (kernel, u)
             np.testing.assert_allclose(tr.llks, ref[u][1], rtol=1e-10)
+
+
+def test_config4_call_exact_arrays_batched_on_the_device():
+    """`mchap call-exact --report GL GP` at configs[3] for a chunk of 24 (locus x sample) units in one device call: no
+    host loop over units or genotypes (the reference's per-sample sequence genotype_likelihoods -> genotype_posteriors ->
+    argmax -> alternate_dosage_posteriors -> posterior_allele_frequencies, call_exact.py:126-159).  Two units against
+    the oracle, every unit against the streaming form and the invariants of a distribution."""
+    from mchap_amd import calling
+    from mchap_amd.device import ExactDeviceBatch
+
+    U = 24
+    K, H, M, R, reads, haps, F, freqs = _config4_inputs(U)
+    batch = ExactDeviceBatch(reads, K, haps, None, (F, freqs))
+    batch.run(streaming=True, arrays=True)
+    mode = batch.mode_results()
+    arr = batch.array_results()
+    assert arr["posteriors"].shape == (U, 54264) and arr["llks"].dtype == np.float32
+    np.testing.assert_allclose(arr["posteriors"].sum(axis=1), 1.0, rtol=2e-3)   # float32 arithmetic at |llk| ~ 4500
+    np.testing.assert_allclose(arr["freqs"].sum(axis=1), arr["posteriors"].sum(axis=1), rtol=1e-9)
+    np.testing.assert_allclose(mode[4].sum(axis=1), 1.0, rtol=1e-9)
+    for u in range(U):
+        # array mode == streaming mode whenever the mode is not a near tie (float32 vs float64 arithmetic)
+        if mode[2][u] > 0.6:
+            assert arr["alleles"][u].tolist() == mode[0][u].tolist()
+            np.testing.assert_allclose(arr["prob"][u], mode[2][u], rtol=2e-3)
+            np.testing.assert_allclose(arr["support_prob"][u], mode[3][u], rtol=2e-3)
+    for u in (0, 1):
+        prior = (float(F[u]), freqs[u])
+        e32, _ = orc.genotype_likelihoods(reads[u], K, haps[u], None)
+        np.testing.assert_allclose(arr["llks"][u], e32, rtol=2.5e-7)
+        ref = orc.genotype_posteriors(e32, K, H, prior)
+        ulp = float(np.spacing(np.float32(np.abs(e32).max())))
+        np.testing.assert_allclose(arr["posteriors"][u], ref, rtol=max(3e-5, 4 * ulp), atol=1e-12)
+        a, ml, mp, sp, fq, oc = orc.posterior_mode(reads[u], K, haps[u], None, prior)
+        assert mode[0][u].tolist() == a.tolist()
+        np.testing.assert_allclose([mode[1][u], mode[2][u], mode[3][u]], [ml, mp, sp], rtol=1e-9)
+        np.testing.assert_allclose(mode[4][u], fq, rtol=1e-9, atol=1e-300)

@@ -95,3 +95,54 @@ def test_zero_frequency_allele_and_zero_reads():
     assert np.all(llks == 0)
     post = calling.genotype_posteriors(llks.astype(np.float64), 4, H, None)
     np.testing.assert_allclose(post, 1.0 / len(post), rtol=1e-12)
+
+
+@pytest.mark.parametrize("K,H,M,R,U", [(4, 6, 6, 60, 5), (6, 7, 5, 33, 3), (2, 12, 6, 64, 4)])
+def test_device_batch_arrays_and_streaming_against_oracle(K, H, M, R, U):
+    """mchap_exact_call_batch_device: every output of the streaming form and of the array form (likelihoods, posteriors
+    and the summaries call_exact.py:126-159 derives from the posterior array) for a batch, against the oracle unit by
+    unit; the streaming form forms no per-genotype array (two passes), the array form needs no workspace."""
+    from mchap_amd import calling
+    from mchap_amd.device import ExactDeviceBatch
+    from mchap_amd.synth import synth_units
+
+    rng = np.random.default_rng(K * 1000 + H)
+    reads, _, truth = synth_units(U, ploidy=K, n_pos=M, n_reads=R, first_unit=3 * H, window=(2, M), qual=(2, 12))
+    haps = np.zeros((U, H, M), np.int8)
+    for u in range(U):
+        pool = np.unique(rng.integers(0, 2, size=(6 * H, M)).astype(np.int8), axis=0)
+        rng.shuffle(pool)
+        haps[u] = pool[:H]
+    counts = rng.integers(1, 4, size=(U, R)).astype(np.int64)
+    F = rng.choice([0.0, 0.1, 0.3], size=U)
+    fr = rng.dirichlet(np.ones(H), size=U)
+    for prior in (None, (F, None), (F, fr)):
+        batch = ExactDeviceBatch(reads, K, haps, counts, prior)
+        batch.run(streaming=True, arrays=True, llks64=True)
+        mode = batch.mode_results()
+        arr = batch.array_results()
+        for u in range(U):
+            pr = None if prior is None else (float(F[u]), None if prior[1] is None else fr[u])
+            a, ml, mp, sp, fq, oc = orc.posterior_mode(reads[u], K, haps[u], counts[u], pr)
+            assert mode[0][u].tolist() == a.tolist()
+            np.testing.assert_allclose([mode[1][u], mode[2][u], mode[3][u]], [ml, mp, sp], rtol=1e-9)
+            np.testing.assert_allclose(mode[4][u], fq, rtol=1e-9, atol=1e-300)
+            np.testing.assert_allclose(mode[5][u], oc, rtol=1e-9, atol=1e-300)
+            e32, e64 = orc.genotype_likelihoods(reads[u], K, haps[u], counts[u])
+            np.testing.assert_allclose(arr["llks"][u], e32, rtol=2.5e-7)
+            np.testing.assert_allclose(batch._host("llks64", (U, batch.G))[u], e64, rtol=1e-10)
+            ref = orc.genotype_posteriors(e32, K, H, pr)
+            ulp = float(np.spacing(np.float32(np.abs(e32).max())))
+            np.testing.assert_allclose(arr["posteriors"][u], ref, rtol=max(3e-5, 4 * ulp), atol=1e-12)
+            # summaries of the (device's own) posterior array: exact sums over the array
+            post = arr["posteriors"][u]
+            idx = int(np.argmax(post))
+            assert arr["alleles"][u].tolist() == calling.index_as_genotype_alleles(idx, K).tolist()
+            assert arr["prob"][u] == post[idx]
+            rf, rc_, ro = orc.posterior_allele_frequencies(post, K, H)
+            np.testing.assert_allclose(np.stack([arr["freqs"][u], arr["counts"][u], arr["occur"][u]]), np.stack([rf, rc_, ro]), rtol=1e-9, atol=1e-300)
+            ag, ap = calling.alternate_dosage_posteriors(arr["alleles"][u], post)
+            np.testing.assert_allclose(arr["support_prob"][u], ap.sum(), rtol=1e-12)
+    # the convenience wrapper
+    res = calling.call_arrays_batch(reads, K, haps, counts, (F, fr))
+    np.testing.assert_allclose(res["posteriors"], arr["posteriors"], rtol=0, atol=0)
