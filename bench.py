@@ -4,8 +4,16 @@
 A "step" is one pass of the hot path (DenovoMCMC.fit for every unit of the batch, burn-in, posterior
 summary) over one batch of synthetic loci already resident in HBM.  Workload at N=1 = BASELINE.json
 configs[1]: 10k synthetic tetraploid loci, 8 SNVs, 200 reads, 1000 MCMC steps (2 chains, burn 500).
-With --gpus N every rank runs the same number of loci (weak scaling; loci are independent, so there is
-no data-path collective: only the timing barrier / max-over-ranks).
+With --gpus N every rank runs the same number of loci (weak scaling; --total-loci T shards T loci over the ranks
+instead: strong scaling, BASELINE.json configs[2] with T = 100000).  Loci are independent, so the compute needs no
+collective; the one exchange of the design -- the gather of the fixed-size posterior records of every rank (RCCL
+all_gather over xGMI) -- is inside the timed region and reported as gather_ms.
+
+Besides the headline line the JSON carries `value_incl_h2d` (the same pass fed from host memory with the compact int8 /
+int16 input and the posterior records copied back: what a caller gets end to end) and, under `extra`, the other
+single-GPU configurations of BASELINE.json: config4 (call-exact, hexaploid, 16 haplotypes, 500 reads) and config5
+(octoploid, 20 SNVs, 1000 reads, 4 chains x 2000 steps), each with its kernel time, a roofline figure that means
+something for it, and the oracle's CPU rate.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how roofline / cpu_baseline are defined.
 """
@@ -38,6 +46,10 @@ def parse():
     ap.add_argument("--no-cache", action="store_true", help="disable the per-chain llk cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="units for the CPU baseline (0 = auto)")
+    ap.add_argument("--total-loci", type=int, default=0, help="strong scaling: this many loci sharded over the ranks")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_incl_h2d and the config4 / config5 lines")
+    ap.add_argument("--config5-loci", type=int, default=64)
+    ap.add_argument("--config4-units", type=int, default=256)
     return ap.parse_args()
 
 
@@ -137,6 +149,135 @@ def pmc_traffic(args):
     return None
 
 
+def incl_h2d(args, model):
+    """The same pass as the caller sees it from host memory: compact input (int8 allele calls + int16 base qualities,
+    4.8 KB per locus at the default shape) uploaded, prepare + sampler + posterior summary, the posterior records
+    (<= 4 KB per locus) copied back.  Returns loci/s including both PCIe legs (pageable host memory, as numpy gives)."""
+    import torch
+    from mchap_amd.device import DenovoDeviceBatch
+    from mchap_amd.synth import synth_units
+
+    U = args.loci
+    _, calls, _ = synth_units(U, ploidy=args.ploidy, n_pos=args.snvs, n_reads=args.reads, first_unit=0)
+    rng = np.random.default_rng(5)
+    quals = rng.integers(20, 41, size=calls.shape).astype(np.int16)
+
+    def once():
+        b = DenovoDeviceBatch(model, None, calls=calls, quals=quals)
+        b.run()
+        b.posterior(args.burn)
+        return b.posterior_host()
+
+    once()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n
+    return {"value": U / dt, "unit": "loci/s", "ms_per_pass": dt * 1e3, "h2d_bytes_per_locus": int(calls[0].size * 3),
+            "d2h_bytes_per_locus": int(32 * args.ploidy * 8 + 32 * 4 + 40),
+            "note": "device buffers allocated, compact input uploaded, posterior records downloaded inside the timed region"}
+
+
+def bench_config4(args):
+    """BASELINE.json configs[3]: call-exact, hexaploid, 16 known haplotypes over 10 SNVs, 500 reads (G = 54 264 genotypes),
+    Dirichlet-multinomial prior; inputs resident in HBM; streaming form (mode, support, frequencies) and array form (GL + GP)."""
+    import torch
+    from mchap_amd.device import ExactDeviceBatch
+    from mchap_amd.synth import synth_units
+
+    U, K, H, M, R = args.config4_units, 6, 16, 10, 500
+    rng = np.random.default_rng(4)
+    reads, _, _ = synth_units(U, ploidy=K, n_pos=M, n_reads=R, window=(5, 10), first_unit=400)
+    haps = np.unique(rng.integers(0, 2, size=(64, M)).astype(np.int8), axis=0)[:H]
+    prior = (0.1, rng.dirichlet(np.ones(H)))
+    batch = ExactDeviceBatch(reads, K, haps, None, prior)
+    res = {}
+    for name, kw in (("streaming", dict(streaming=True, arrays=False)), ("arrays", dict(streaming=False, arrays=True))):
+        batch.run(**kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 3
+        for _ in range(n):
+            batch.run(**kw)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / n
+    G = batch.G
+    terms = 2.0 * U * G * R  # (genotype, read) terms of the two passes of the streaming form
+    flop_per_term = 2 * K + 40  # K multiply-adds + one float64 log (about 20 fused multiply-adds in the device library)
+    ms = res["streaming"]
+    out = {
+        "workload": "%d units: hexaploid, %d haplotypes x %d SNVs, %d reads, G = %d genotypes, prior (0.1, Dirichlet(1)); HBM resident" % (U, H, M, R, G),
+        "value": U / (ms * 1e-3), "unit": "units/s", "kernel": "exact_pass1_kernel + exact_pass2_kernel", "kernel_ms": ms,
+        "arrays_value": U / (res["arrays"] * 1e-3), "arrays_kernel_ms": res["arrays"],
+        "roofline": {"bound": "valu_fp64", "achieved": terms * flop_per_term / (ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                     "frac": terms * flop_per_term / (ms * 1e-3) / 1e12 / 78.6, "terms_per_s": terms / (ms * 1e-3),
+                     "assumed_flop_per_term": flop_per_term,
+                     "note": "log-throughput bound: one float64 log per (genotype, read) term; 80 KB in, < 1 KB out per unit"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import binding as orc
+
+        mode = batch.mode_results()
+        t = time.perf_counter()
+        n_cpu = 3
+        for u in range(n_cpu):
+            a, ml, mp, sp, fq, oc = orc.posterior_mode(reads[u], K, haps, None, prior)
+            assert a.tolist() == mode[0][u].tolist() and abs(mp - mode[2][u]) < 1e-9
+        dc = (time.perf_counter() - t) / n_cpu
+        out["cpu_baseline"] = {"value": 1.0 / dc, "unit": "units/s", "cores": 1, "kind": "port",
+                               "sample": "%d units through oracle/mchap_oracle.c posterior_mode, one thread; mode and GPM equal the GPU's" % n_cpu}
+    return out
+
+
+def bench_config5(args):
+    """BASELINE.json configs[4] on one GPU: octoploid, 20 SNVs, 1000 reads, 4 chains x 2000 steps (the LDS-pressure shape)."""
+    import torch
+    from mchap_amd import DenovoMCMC, _lib
+    from mchap_amd.device import DenovoDeviceBatch
+    from mchap_amd.synth import synth_units
+
+    U, K, M, R, C_, S = args.config5_loci, 8, 20, 1000, 4, 2000
+    reads, _, _ = synth_units(U, ploidy=K, n_pos=M, n_reads=R, window=(8, 20), first_unit=77)
+    model = DenovoMCMC(ploidy=K, n_alleles=[2] * M, steps=S, chains=C_, random_seed=42)
+    batch = DenovoDeviceBatch(model, reads)
+    L = _lib.lib()
+    L.mchap_set_profiling(1)
+    t = time.perf_counter()
+    batch.run()
+    batch.posterior(S // 2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    kms = L.mchap_last_sampler_ms()
+    status = batch.d_status.cpu().numpy()
+    n = K * M
+    substeps = float(U) * C_ * S * (n + 3)  # mutation sub-steps + the three structural compound steps, per chain step
+    out = {
+        "workload": "%d loci: octoploid, %d SNVs, %d reads, %d chains x %d steps, burn %d; HBM resident; one pass" % (U, M, R, C_, S, S // 2),
+        "value": U / dt, "unit": "loci/s", "kernel": L.mchap_last_sampler_name().decode(), "kernel_ms": kms, "pass_ms": dt * 1e3,
+        "ok": bool((status <= 1).all()),
+        "roofline": {"bound": "issue", "achieved": substeps / (kms * 1e-3), "unit": "sub-steps/s",
+                     "note": "serial sub-step latency bound like configs[1]; 160 mutation sub-steps per chain step"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import binding as orc
+        from mchap_amd.assemble import break_table
+
+        cfg = orc.make_cfg(K, S, C_, None, (1.0,), llk_cache_threshold=100, seed=42, rng_kind=orc.RNG_PHILOX, break_table=break_table(M, 1.0, 3.0))
+        cores, _ = usable_cores()
+        n_cpu = max(1, min(U, cores))
+        t = time.perf_counter()
+        orc.denovo_fit_batch(cfg, reads[:n_cpu], [2] * M, n_threads=cores, keep_traces=False)
+        dc = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": min(cores, n_cpu), "kind": "port",
+                               "sample": "%d loci of the same workload, oracle with llk cache, one locus per thread, %.1f s wall" % (n_cpu, dc)}
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -159,8 +300,16 @@ def main():
     from mchap_amd.device import DenovoDeviceBatch
     from mchap_amd.synth import synth_units
 
-    U = args.loci
-    first = rank * U  # rank r owns loci [r*U, (r+1)*U): contiguous shard, RNG keyed by global locus id
+    from mchap_amd.shard import gather_records, shard_range
+
+    if args.total_loci:
+        first, stop = shard_range(args.total_loci, rank, world)  # strong scaling: contiguous, balanced shards
+        U = stop - first
+        n_total = args.total_loci
+    else:
+        U = args.loci
+        first = rank * U  # rank r owns loci [r*U, (r+1)*U): contiguous shard, RNG keyed by global locus id
+        n_total = U * world
     reads, _, _ = synth_units(U, ploidy=args.ploidy, n_pos=args.snvs, n_reads=args.reads, first_unit=first)
     model = DenovoMCMC(ploidy=args.ploidy, n_alleles=[2] * args.snvs, steps=args.mcmc_steps, chains=args.chains,
                        random_seed=42, llk_cache_threshold=-1 if args.no_cache else 100)
@@ -172,6 +321,16 @@ def main():
     L = _lib.lib()
     L.mchap_set_profiling(1)  # HIP events on the launch stream right around the sampler kernel
     kernel_ms = []
+    gather_ev = []
+    K = args.ploidy
+    gathered = [None]
+
+    def records():
+        """The unit's posterior record as one int64 row: mode genotype words, (SPM, GPM) bit patterns, distinct states,
+        count of the mode genotype -- what the application formats a VCF sample column from."""
+        P = batch.post
+        return torch.cat([P["mode_words"].view(U, K), P["stats"].view(U, 2).view(torch.int64), P["n"].to(torch.int64).view(U, 1),
+                          P["mode_count"].to(torch.int64).view(U, 1)], dim=1)
 
     def one_pass(events=None):
         if events is not None:
@@ -182,8 +341,24 @@ def main():
             e1.record()
             events.append((e0, e1))
         batch.posterior(args.burn)
+        if dist is not None:
+            # the design's only exchange: every rank's records to every rank (padded all_gather; RCCL on GPUs)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            rec = records()
+            if dist.get_backend() != "nccl":
+                rec = rec.cpu()
+            gathered[0] = gather_records(rec, n_total, dist) if args.total_loci else _gather_equal(rec, dist)
+            g1.record()
+            if events is not None:
+                gather_ev.append((g0, g1))
         if events is not None:
             kernel_ms.append(L.mchap_last_sampler_ms())  # waits for that launch only
+
+    def _gather_equal(rec, dist_):
+        parts = [torch.empty_like(rec) for _ in range(world)]
+        dist_.all_gather(parts, rec)
+        return torch.cat(parts, dim=0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -214,9 +389,26 @@ def main():
     status = batch.d_status.cpu().numpy()
     if (status > 1).any() or (status < 0).any():
         raise SystemExit("sampler reported errors: %s" % np.unique(status))
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ev])) if gather_ev else None
+    gather_checked = None
+    if dist is not None and rank == 0:
+        # the gathered records of ANOTHER rank's units must be what a single-rank run of those units gives
+        other = world - 1
+        o_first = shard_range(n_total, other, world)[0] if args.total_loci else other * U
+        n_chk = 8
+        rd, _, _ = synth_units(n_chk, ploidy=args.ploidy, n_pos=args.snvs, n_reads=args.reads, first_unit=o_first)
+        chk = DenovoDeviceBatch(model, rd, first_stream=o_first)
+        chk.run()
+        chk.posterior(args.burn)
+        torch.cuda.synchronize()
+        mine = chk.post["mode_words"].view(n_chk, K).cpu()
+        got = gathered[0][o_first: o_first + n_chk, :K].cpu()
+        if not torch.equal(mine, got):
+            raise SystemExit("gathered posterior records differ from a single-rank run of the same units")
+        gather_checked = n_chk
 
     if rank == 0:
-        total_units = U * world * args.steps
+        total_units = n_total * args.steps
         value = total_units / dt
         # algorithmic HBM bytes per locus: float64 read tensor in, packed trace + llk out
         bytes_in = args.reads * args.snvs * 2 * 8
@@ -232,7 +424,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_loci else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -241,7 +433,8 @@ def main():
                             "posterior summary (BASELINE.json configs[1])" % (U, args.snvs, args.reads, args.mcmc_steps, args.chains, args.burn),
                 "loci_per_gpu": U, "ploidy": args.ploidy, "snvs": args.snvs, "reads": args.reads,
                 "mcmc_steps": args.mcmc_steps, "chains": args.chains, "burn": args.burn,
-                "llk_cache": not args.no_cache, "parallelism": "loci sharded contiguously, %d rank(s), no data-path collective" % world,
+                "llk_cache": not args.no_cache,
+                "parallelism": "loci sharded contiguously over %d rank(s); posterior records all-gathered every pass" % world,
             },
             "roofline": {
                 "bound": "hbm", "kernel": kern_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -251,6 +444,13 @@ def main():
                         "fraction is reported because the contract asks for it",
             },
         }
+        if dist is not None:
+            out["gather_ms"] = gather_ms
+            out["gather_bytes_per_rank"] = int(U * (K + 4) * 8)
+            out["gather_checked_units"] = gather_checked
+        if world == 1 and not args.no_extras:
+            out["value_incl_h2d"] = incl_h2d(args, model)
+            out["extra"] = {"config4": bench_config4(args), "config5": bench_config5(args)}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline leg runs at N = 1 only
             cores, quota = usable_cores()
             out["cpu_baseline"] = cpu_baseline(args, cores, quota)

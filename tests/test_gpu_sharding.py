@@ -55,3 +55,20 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["kernel"].startswith("denovo_")
+    # the posterior records of both ranks were all-gathered inside the timed region and rank 0 verified the other
+    # rank's records against its own run of those units
+    assert d["gather_ms"] is not None and d["gather_ms"] >= 0 and d["gather_checked_units"] == 8
+
+
+def test_bench_strong_scaling_uneven_shards():
+    """--total-loci: BASELINE.json configs[2]'s mode (a fixed number of loci sharded over the ranks), uneven split."""
+    env = dict(os.environ, MCHAP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--total-loci", "777", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2
+    assert abs(d["value"] - 777 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["gather_checked_units"] == 8
