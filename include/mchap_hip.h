@@ -233,6 +233,29 @@ int mchap_exact_posterior_mode_batch(int n_units, const double *reads, int n_rea
                                      int64_t *mode_alleles, double *mode_llk, double *mode_prob, double *support_prob,
                                      double *freqs, double *occur);
 
+/* `mchap call`: Gibbs / Metropolis-Hastings sampler over the genotypes of known haplotypes for a batch of units that share
+ * a shape: replaces CallingMCMC.fit (calling/classes.py:62-124) -> mcmc_sampler / compound_step / gibbs_options /
+ * mh_options / greedy_caller (calling/mcmc.py:15-453) with the Gibbs-step priors of calling/prior.py:30-113.
+ *   step_type 0 = "Gibbs", 1 = "Metropolis-Hastings"; initial int64 [U][K] or NULL (greedy_caller);
+ *   stream_ids [U]: the unit's Philox stream (results do not depend on batch composition);
+ *   genotypes int64 [U][chains][steps][K] (sorted alleles per step), llks float64 [U][chains][steps];
+ *   status int32 [U]: 0, or MCHAP_ERR_LIMIT if a chain's table of remembered likelihoods filled up (cannot happen with a
+ *   workspace of mchap_call_mcmc_workspace_bytes).
+ * The workspace holds, per chain, the counterpart of the reference's llk dict (calling/likelihood.py:36-78), which never
+ * forgets an entry.  Device pointers; enqueues on `stream`. */
+int64_t mchap_call_mcmc_workspace_bytes(int n_units, int n_haps, int ploidy, int steps, int chains);
+int mchap_call_mcmc_batch_device(int n_units, const double *reads, int n_reads, int n_pos, int max_allele,
+                                 const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy, int has_prior,
+                                 const double *inbreeding, const double *frequencies, const int64_t *initial,
+                                 const uint64_t *stream_ids, int steps, int chains, int step_type, uint64_t seed,
+                                 int64_t *genotypes, double *llks, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                 void *stream);
+/* the same with host pointers (one device allocation, copies, the device entry point, copies back) */
+int mchap_call_mcmc_batch(int n_units, const double *reads, int n_reads, int n_pos, int max_allele, const int64_t *read_counts,
+                          const int8_t *haplotypes, int n_haps, int ploidy, int has_prior, const double *inbreeding,
+                          const double *frequencies, const int64_t *initial, const uint64_t *stream_ids, int steps, int chains,
+                          int step_type, uint64_t seed, int64_t *genotypes, double *llks, int32_t *status);
+
 /* Measurement hooks (bench.py): when enabled, mchap_denovo_fit_batch_device records HIP events on the launch
  * stream right around its sampler kernel (not the prepare pass or the memsets); mchap_last_sampler_ms waits for
  * that launch and returns its duration in milliseconds (< 0 if nothing was recorded). */

@@ -1,0 +1,467 @@
+// `mchap call`: Gibbs / Metropolis-Hastings sampler over the genotypes of KNOWN haplotypes, for MI355X (gfx950).
+// Reference: calling/mcmc.py:15-453 (mh_options, gibbs_options, compound_step, mcmc_sampler, greedy_caller),
+// calling/classes.py:14-124 (CallingMCMC.fit), calling/prior.py:30-179, calling/likelihood.py:8-78, calling/utils.py:36-58.
+//
+// One wavefront per (unit, chain).  The per-(read, haplotype) products P[r][h] of the exact caller (exact_kernel.hpp) sit in
+// LDS, so a likelihood is R * K table reads; a sub-step's options (one per known haplotype) are spread over the lanes:
+// each lane forms its proposal's key (VCF index of the sorted alleles) and probes the chain's table of remembered
+// likelihoods -- the reference's dict (calling/likelihood.py:36-78: keyed on the SORTED genotype, so the first
+// evaluated allele order's value is what every later request gets; the table here never evicts, to keep that) -- and the
+// misses are evaluated one after the other by the whole wavefront, lanes over reads.  The categorical draw follows the
+// reference's sequential arithmetic (normalise_log_probs / cumsum in allele order) on one lane.
+// Philox streams as in philox.hpp: key (seed, unit stream), counter word 2 = chain << 16, draws in the reference's order: K - 1 shuffle draws, then one uniform per sub-step.
+#pragma once
+#include "exact_kernel.hpp"
+
+namespace mchap {
+
+constexpr uint32_t SLOT_CALL = 0u;  // the chain's stream (the de novo sampler's temperature-0 slot: another operator, another call)
+
+// stateless Philox draws of a stream (the contract of philox.hpp)
+struct CallStream {
+  uint32_t k0, k1, c2, c3;
+};
+__device__ __forceinline__ void call_words(const CallStream &s, uint64_t n, uint32_t &a, uint32_t &b) {
+  uint32_t o[4];
+  const uint64_t blk = n >> 1;
+  philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), s.c2, s.c3, s.k0, s.k1, o);
+  a = (n & 1) ? o[2] : o[0];
+  b = (n & 1) ? o[3] : o[1];
+}
+__device__ __forceinline__ double call_double(const CallStream &s, uint64_t n) {
+  uint32_t a, b;
+  call_words(s, n, a, b);
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ uint32_t call_interval(const CallStream &s, uint64_t n, uint32_t max) {
+  uint32_t a, b;
+  call_words(s, n, a, b);
+  return __umulhi(a, max + 1u);
+}
+constexpr int CALL_MAX_HAPS = 256;
+
+struct CallParams {
+  const double *reads;       // [U][R][M][A]
+  const int64_t *counts;     // [U][R] or null
+  const int8_t *haps;        // [U][H][M]
+  const double *inbreeding;  // [U] or null (no prior)
+  const double *freqs;       // [U][H] or null
+  const int64_t *initial;    // [U][K] or null (greedy_caller)
+  const uint64_t *stream_ids;  // [U]
+  int R, M, A, H, K;
+  int has_prior, step_type, steps, chains;
+  uint64_t seed;
+  // per-chain table of remembered likelihoods: [U * chains][cache_slots] of {key + 1, llk bits}; never evicts
+  ulonglong2 *cache;
+  long long cache_slots;     // power of two
+  int64_t *genotypes;        // [U][chains][steps][K] sorted alleles
+  double *llks;              // [U][chains][steps]
+  int32_t *status;           // [U]: 0 ok, MCHAP_ERR_LIMIT if a table filled up
+};
+
+inline size_t call_lds_bytes(int R, int H, int K) {
+  // ptab, cnt, lgd, lgf, lfreq (exact_setup) + rtab [H][K] + 3 arrays [H] + request words
+  return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)H * K + 4 * (size_t)CALL_MAX_HAPS + 64) * 8;
+}
+
+// calling/prior.py:116-179 on the alleles in ARRAY order (allelic dosage at first occurrence, calling/utils.py:7-35)
+__device__ inline double calling_log_prior_unsorted(const PriorTab &t, const int *g, int K) {
+  if (t.F == 0.0) {
+    double den = 0.0;
+    for (int i = 0; i < K; i++) {
+      bool first = true;
+      int dose = 0;
+      for (int j = 0; j < K; j++) {
+        if (g[j] == g[i]) {
+          dose++;
+          if (j < i) first = false;
+        }
+      }
+      den += first ? t.lgf[dose] : 0.0;  // lgamma(0 + 1) = 0 at the later copies
+    }
+    const double ln_perms = t.lgf[K] - den;
+    if (!t.has_freqs) return ln_perms - (double)K * t.lnH;
+    double prod = 1.0;
+    for (int q = 0; q < K; q++) prod *= t.lfreq[g[q]];
+    return ln_perms + log(prod);
+  }
+  double prod = 0.0;
+  for (int i = 0; i < K; i++) {
+    bool first = true;
+    int dose = 0;
+    for (int j = 0; j < K; j++) {
+      if (g[j] == g[i]) {
+        dose++;
+        if (j < i) first = false;
+      }
+    }
+    if (first) prod += t.lgd[g[i] * (K + 1) + dose];
+  }
+  return t.left + prod;
+}
+
+__device__ __forceinline__ long long call_key(const int *g, int K) {
+  int s[MCHAP_MAX_PLOIDY];
+  for (int i = 0; i < K; i++) s[i] = g[i];
+  for (int a = 1; a < K; a++) {  // insertion sort
+    const int v = s[a];
+    int b = a - 1;
+    while (b >= 0 && s[b] > v) {
+      s[b + 1] = s[b];
+      b--;
+    }
+    s[b + 1] = v;
+  }
+  return rank_genotype(s, K);
+}
+
+__global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int unit = blockIdx.y, chain = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int R = P.R, H = P.H, K = P.K;
+  ExactParams EP;
+  EP.reads = P.reads;
+  EP.counts = P.counts;
+  EP.haps = P.haps;
+  EP.inbreeding = P.inbreeding;
+  EP.freqs = P.freqs;
+  EP.R = R; EP.M = P.M; EP.A = P.A; EP.H = H; EP.K = K;
+  EP.has_prior = P.has_prior;
+  ExactLds E;
+  PriorTab pt;
+  exact_setup(EP, unit, smem, E, pt);
+  double *rtab = E.red;                     // [H][K]: lgamma(1 + alpha_a + ibs) - lgamma(alpha_a + ibs)
+  double *o_llk = rtab + (size_t)H * K;     // [CALL_MAX_HAPS]
+  double *o_lpr = o_llk + CALL_MAX_HAPS;
+  double *o_prob = o_lpr + CALL_MAX_HAPS;
+  double *o_aux = o_prob + CALL_MAX_HAPS;   // proposal ratios (Metropolis-Hastings)
+  __shared__ int s_g[MCHAP_MAX_PLOIDY];     // the chain's genotype (array order)
+  __shared__ int s_req[MCHAP_MAX_PLOIDY];   // alleles of the request being evaluated
+  __shared__ double s_left;                 // Gibbs prior: lgamma(sum_alpha) - lgamma(1 + sum_alpha)
+  __shared__ int s_choice;
+  __shared__ int s_full;
+  const bool has_prior = P.has_prior != 0;
+  const bool has_freqs = has_prior && P.freqs != nullptr;
+  const double F = pt.F;
+  if (lane == 0) s_full = 0;
+  if (has_prior && F != 0.0) {
+    const double scale = (1.0 - F) / F;
+    for (int q = lane; q < H * K; q += WAVE) {
+      const int a = q / K, ibs = q % K;
+      const double alpha = has_freqs ? P.freqs[(size_t)unit * H + a] * scale : (1.0 / (double)H) * scale;
+      const double va = alpha + (double)ibs;
+      rtab[q] = lgamma(1.0 + va) - lgamma(va);
+    }
+    if (lane == 0) {
+      double sum_alpha;
+      if (has_freqs) {
+        double s = 0.0;
+        for (int h = 0; h < H; h++) s += P.freqs[(size_t)unit * H + h] * scale;
+        sum_alpha = (double)(K - 1) + s;
+      } else {
+        sum_alpha = (double)(K - 1) + ((1.0 / (double)H) * scale) * (double)H;
+      }
+      s_left = lgamma(sum_alpha) - lgamma(1.0 + sum_alpha);
+    }
+  }
+  __syncthreads();
+  const double invK_full = 1.0 / (double)K;
+  ulonglong2 *cache = P.cache + ((size_t)unit * P.chains + chain) * (size_t)P.cache_slots;
+  const unsigned long long cmask = (unsigned long long)P.cache_slots - 1ull;
+
+  // likelihood of the request in s_req (ploidy kk <= K), whole wave: lanes over reads, sums in read order per lane,
+  // then the wave butterfly (assemble/likelihood.py:17-70 up to the order of the sum over reads)
+  auto coop_llk = [&](int kk) -> double {
+    const double invk = 1.0 / (double)kk;
+    double s = 0.0;
+    for (int r = lane; r < R; r += WAVE) {
+      const double *row = E.ptab + (size_t)r * H;
+      double rp = 0.0;
+      for (int i = 0; i < kk; i++) rp += row[s_req[i]] * invk;
+      s += log(rp) * E.cnt[r];
+    }
+    return wave_sum(s);
+  };
+  (void)invK_full;
+
+  // ---- initial genotype: the caller's, or greedy_caller (calling/mcmc.py:393-453) ----
+  if (P.initial) {
+    if (lane < K) s_g[lane] = (int)P.initial[(size_t)unit * K + lane];
+    __syncthreads();
+  } else {
+    for (int i = 0; i < K; i++) {
+      double best = -INFINITY;
+      int best_a = -1;
+      for (int a = 0; a < H; a++) {
+        if (lane == 0) {
+          for (int q = 0; q < i; q++) s_req[q] = s_g[q];
+          s_req[i] = a;
+        }
+        __syncthreads();
+        const double llk = coop_llk(i + 1);
+        double lprior = 0.0;
+        if (has_prior) {
+          // the prior of a genotype of ploidy i + 1: its tables depend on the ploidy (left term, lgamma(ploidy + 1))
+          int g[MCHAP_MAX_PLOIDY];
+          for (int q = 0; q <= i; q++) g[q] = s_req[q];
+          const int kk = i + 1;
+          if (F == 0.0) {
+            PriorTab t2 = pt;
+            double den = 0.0;
+            for (int x = 0; x < kk; x++) {
+              bool first = true;
+              int dose = 0;
+              for (int y = 0; y < kk; y++)
+                if (g[y] == g[x]) {
+                  dose++;
+                  if (y < x) first = false;
+                }
+              den += first ? lgamma((double)dose + 1.0) : 0.0;
+            }
+            const double ln_perms = lgamma((double)kk + 1.0) - den;
+            if (!t2.has_freqs) lprior = ln_perms - (double)kk * t2.lnH;
+            else {
+              double prod = 1.0;
+              for (int q = 0; q < kk; q++) prod *= t2.lfreq[g[q]];
+              lprior = ln_perms + log(prod);
+            }
+          } else {
+            const double scale = (1.0 - F) / F;
+            double sum_alphas;
+            if (has_freqs) {
+              sum_alphas = 0.0;
+              for (int h = 0; h < H; h++) sum_alphas += P.freqs[(size_t)unit * H + h] * scale;
+            } else {
+              sum_alphas = ((1.0 / (double)H) * scale) * (double)H;
+            }
+            const double left = (lgamma((double)kk + 1.0) + lgamma(sum_alphas)) - lgamma((double)kk + sum_alphas);
+            double prod = 0.0;
+            for (int x = 0; x < kk; x++) {
+              bool first = true;
+              int dose = 0;
+              for (int y = 0; y < kk; y++)
+                if (g[y] == g[x]) {
+                  dose++;
+                  if (y < x) first = false;
+                }
+              if (first) {
+                const double alpha = has_freqs ? P.freqs[(size_t)unit * H + g[x]] * scale : (1.0 / (double)H) * scale;
+                prod += lgamma((double)dose + alpha) - (lgamma((double)dose + 1.0) + lgamma(alpha));
+              }
+            }
+            lprior = left + prod;
+          }
+        }
+        const double lprob = llk + lprior;
+        if (lprob > best) {
+          best = lprob;
+          best_a = a;
+        }
+        __syncthreads();
+      }
+      if (lane == 0) s_g[i] = best_a;
+      __syncthreads();
+    }
+    // genotype.sort()
+    if (lane == 0) {
+      for (int a = 1; a < K; a++) {
+        const int v = s_g[a];
+        int b = a - 1;
+        while (b >= 0 && s_g[b] > v) {
+          s_g[b + 1] = s_g[b];
+          b--;
+        }
+        s_g[b + 1] = v;
+      }
+    }
+    __syncthreads();
+  }
+
+  CallStream st;
+  st.k0 = (uint32_t)P.seed;
+  st.k1 = (uint32_t)(P.seed >> 32) ^ (uint32_t)(P.stream_ids[unit] >> 32);
+  st.c2 = ((uint32_t)chain << 16) | SLOT_CALL;
+  st.c3 = (uint32_t)P.stream_ids[unit];
+  uint64_t ctr = 0;
+  int64_t *gout = P.genotypes + (((size_t)unit * P.chains + chain) * P.steps) * K;
+  double *lout = P.llks + ((size_t)unit * P.chains + chain) * P.steps;
+
+  // probe the chain's table for `key`: returns true and the value, or false and the slot to fill
+  auto probe = [&](long long key, double &val, ulonglong2 *&slot) -> bool {
+    unsigned long long h = (unsigned long long)key * 0x9E3779B97F4A7C15ull;
+    unsigned long long i = (h >> 20) & cmask;
+    for (long long tries = 0; tries < P.cache_slots; tries++) {
+      ulonglong2 e = cache[i];
+      if (e.x == (unsigned long long)key + 1ull) {
+        val = __longlong_as_double((long long)e.y);
+        return true;
+      }
+      if (e.x == 0ull) {
+        slot = cache + i;
+        return false;
+      }
+      i = (i + 1) & cmask;
+    }
+    slot = nullptr;  // full
+    return false;
+  };
+
+  // llks of the options `a` in [a0, a0 + 64) of a sub-step at position k, into o_llk: cache probe per lane, misses one by one
+  auto option_llks = [&](int k, int a0) {
+    const int a = a0 + lane;
+    const bool act = a < H;
+    int g[MCHAP_MAX_PLOIDY];
+    for (int i = 0; i < K; i++) g[i] = s_g[i];
+    g[k] = act ? a : g[k];
+    double val = 0.0;
+    ulonglong2 *slot = nullptr;
+    bool miss = false;
+    long long key = 0;
+    if (act) {
+      key = call_key(g, K);
+      miss = !probe(key, val, slot);
+      if (miss && !slot) s_full = 1;
+    }
+    unsigned long long todo = __ballot(miss);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      if (lane == src)
+        for (int i = 0; i < K; i++) s_req[i] = g[i];
+      __syncthreads();
+      const double v = coop_llk(K);
+      if (lane == src) {
+        val = v;
+        if (slot) *slot = make_ulonglong2((unsigned long long)key + 1ull, (unsigned long long)__double_as_longlong(v));
+      }
+      __syncthreads();
+    }
+    if (act) o_llk[a] = val;
+  };
+
+  for (int step = 0; step < P.steps; step++) {
+    // np.random.shuffle(arange(ploidy)) -- every lane the same
+    int order[MCHAP_MAX_PLOIDY];
+    for (int i = 0; i < K; i++) order[i] = i;
+    for (int i = K - 1; i >= 1; i--) {
+      const int j = (int)call_interval(st, ctr++, (uint32_t)i);
+      const int t = order[i];
+      order[i] = order[j];
+      order[j] = t;
+    }
+    int choice = 0;
+    for (int jj = 0; jj < K; jj++) {
+      const int k = order[jj];
+      const int current = s_g[k];
+      double cur_llk = 0.0, cur_lprior = 0.0;
+      int cur_copies = 1;
+      if (P.step_type == 1) {
+        // mh_options (calling/mcmc.py:15-140): likelihood and prior of the current genotype first
+        int g[MCHAP_MAX_PLOIDY];
+        for (int i = 0; i < K; i++) g[i] = s_g[i];
+        cur_copies = 0;
+        for (int i = 0; i < K; i++) cur_copies += g[i] == current ? 1 : 0;
+        if (has_prior) cur_lprior = calling_log_prior_unsorted(pt, g, K);
+        double val = 0.0;
+        ulonglong2 *slot = nullptr;
+        const long long key = call_key(g, K);
+        bool hit = false;
+        if (lane == 0) {
+          hit = probe(key, val, slot);
+          if (!hit && !slot) s_full = 1;
+        }
+        hit = __shfl((int)hit, 0, WAVE) != 0;
+        if (!hit) {
+          if (lane == 0)
+            for (int i = 0; i < K; i++) s_req[i] = g[i];
+          __syncthreads();
+          val = coop_llk(K);
+          if (lane == 0 && slot) *slot = make_ulonglong2((unsigned long long)key + 1ull, (unsigned long long)__double_as_longlong(val));
+          __syncthreads();
+        }
+        cur_llk = __shfl(val, 0, WAVE);
+      }
+      for (int a0 = 0; a0 < H; a0 += WAVE) option_llks(k, a0);
+      // priors (and proposal ratios) of the options
+      for (int a = lane; a < H; a += WAVE) {
+        int g[MCHAP_MAX_PLOIDY];
+        for (int i = 0; i < K; i++) g[i] = s_g[i];
+        g[k] = a;
+        int copies = 0;
+        for (int i = 0; i < K; i++) copies += g[i] == a ? 1 : 0;
+        if (P.step_type == 0) {
+          double lp;
+          if (!has_prior) lp = log((double)copies);  // log_genotype_allele_flat_prior (prior.py:30-52)
+          else if (F == 0.0) lp = has_freqs ? log(pt.lfreq[a]) : log(1.0 / (double)H);
+          else lp = s_left + rtab[a * K + (copies - 1)];
+          o_lpr[a] = lp;
+        } else {
+          if (a == current) {
+            o_lpr[a] = cur_lprior;
+            o_llk[a] = cur_llk;
+            o_aux[a] = 0.0;
+          } else {
+            o_lpr[a] = has_prior ? calling_log_prior_unsorted(pt, g, K) : 0.0;
+            o_aux[a] = log((double)copies / (double)cur_copies);
+          }
+        }
+      }
+      __syncthreads();
+      if (lane == 0) {
+        if (P.step_type == 0) {
+          // normalise_log_probs(llks + lpriors): sequential add_log_prob in allele order (jitutils.py:30-74)
+          double acc = o_llk[0] + o_lpr[0];
+          for (int a = 1; a < H; a++) acc = add_log_prob(acc, o_llk[a] + o_lpr[a]);
+          for (int a = 0; a < H; a++) o_prob[a] = exp((o_llk[a] + o_lpr[a]) - acc);
+        } else {
+          double sum = 0.0;
+          for (int a = 0; a < H; a++) {
+            const double r = ((o_llk[a] - cur_llk) + (o_lpr[a] - cur_lprior)) + o_aux[a];
+            o_prob[a] = exp(fmin(0.0, r));
+          }
+          o_prob[current] = 0.0;
+          for (int a = 0; a < H; a++) o_prob[a] /= (double)(H - 1);
+          for (int a = 0; a < H; a++) sum += o_prob[a];
+          o_prob[current] = 1.0 - sum;
+        }
+        // random_choice: searchsorted(cumsum(p), u, side="right")
+        const double u = call_double(st, ctr);
+        double cacc = 0.0;
+        int ch = H;
+        for (int a = 0; a < H; a++) {
+          cacc += o_prob[a];
+          if (cacc > u) {
+            ch = a;
+            break;
+          }
+        }
+        if (ch >= H) ch = H - 1;  // u beyond the last cumulative value (probability ~1e-16)
+        s_choice = ch;
+        s_g[k] = ch;
+      }
+      ctr++;
+      __syncthreads();
+      choice = s_choice;
+    }
+    // genotype_alleles.sort(); the step's llk is that of the last choice
+    if (lane == 0) {
+      for (int a = 1; a < K; a++) {
+        const int v = s_g[a];
+        int b = a - 1;
+        while (b >= 0 && s_g[b] > v) {
+          s_g[b + 1] = s_g[b];
+          b--;
+        }
+        s_g[b + 1] = v;
+      }
+      lout[step] = o_llk[choice];
+    }
+    __syncthreads();
+    if (lane < K) gout[(size_t)step * K + lane] = s_g[lane];
+    __syncthreads();
+  }
+  if (lane == 0 && s_full) atomicMin(&P.status[unit], MCHAP_ERR_LIMIT);
+}
+
+}  // namespace mchap

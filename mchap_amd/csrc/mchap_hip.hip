@@ -16,6 +16,7 @@
 #include "denovo_spec_kernel.hpp"
 #include "denovo_lane_kernel.hpp"
 #include "exact_kernel.hpp"
+#include "call_mcmc_kernel.hpp"
 #include "posterior_kernel.hpp"
 
 // entry points of the speculative sampler's object files (spec_inst.hip), internal to the library

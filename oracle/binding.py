@@ -76,6 +76,7 @@ def lib():
         _lib.orc_philox_double.restype = C.c_double
         _lib.orc_philox_interval.restype = C.c_uint32
         _lib.orc_version.restype = C.c_char_p
+        _lib.orc_log_genotype_allele_prior.restype = C.c_double
     return _lib
 
 
@@ -394,3 +395,67 @@ def mt_doubles(seed, n):
     out = np.zeros(n)
     lib().orc_mt_doubles(C.c_uint32(seed), n, _p(out, f64p))
     return out
+
+
+# ---- `mchap call` sampler over known haplotypes (calling/mcmc.py) ----
+def _prior_args(prior):
+    has = 0 if prior is None else 1
+    F = 0.0 if prior is None else float(prior[0])
+    fr = None if (prior is None or prior[1] is None) else _f64(prior[1])
+    return has, F, fr
+
+
+def log_genotype_allele_prior(genotype, variable_allele, unique_haplotypes, prior=None):
+    """calling/prior.py:30-113; prior None -> log_genotype_allele_flat_prior."""
+    g = _i64(genotype)
+    has, F, fr = _prior_args(prior)
+    return lib().orc_log_genotype_allele_prior(_p(g, i64p), len(g), int(variable_allele), C.c_int64(unique_haplotypes), has,
+                                               C.c_double(F), _p(fr, f64p))
+
+
+def call_step_options(reads, haplotypes, genotype, variable_allele, step_type, read_counts=None, prior=None):
+    """(llks, lpriors, probabilities) of gibbs_options (step_type 0) / mh_options (1), calling/mcmc.py:15-229."""
+    reads = _f64(reads)
+    haps = _i8(haplotypes)
+    rc = _i64(read_counts)
+    g = _i64(genotype)
+    R, M, A = reads.shape
+    H = len(haps)
+    has, F, fr = _prior_args(prior)
+    llks, lpriors, probs = np.zeros(H), np.zeros(H), np.zeros(H)
+    code = lib().orc_call_step_options(_p(reads, f64p), R, M, A, _p(rc, i64p), _p(haps, i8p), H, _p(g, i64p), len(g),
+                                       int(variable_allele), int(step_type), has, C.c_double(F), _p(fr, f64p),
+                                       _p(llks, f64p), _p(lpriors, f64p), _p(probs, f64p))
+    assert code == 0
+    return llks, lpriors, probs
+
+
+def greedy_caller(reads, haplotypes, ploidy, read_counts=None, prior=None):
+    reads = _f64(reads)
+    haps = _i8(haplotypes)
+    rc = _i64(read_counts)
+    R, M, A = reads.shape
+    has, F, fr = _prior_args(prior)
+    out = np.zeros(ploidy, np.int64)
+    code = lib().orc_greedy_caller(_p(reads, f64p), R, M, A, _p(rc, i64p), _p(haps, i8p), len(haps), int(ploidy), has,
+                                   C.c_double(F), _p(fr, f64p), _p(out, i64p))
+    assert code == 0
+    return out
+
+
+def call_mcmc(reads, haplotypes, ploidy, steps=1000, chains=2, step_type=0, read_counts=None, prior=None, initial=None,
+              rng_kind=RNG_PHILOX, seed=0, stream_id=0):
+    """CallingMCMC.fit (calling/classes.py:62-124): (genotypes int64 [chains, steps, ploidy], llks [chains, steps])."""
+    reads = _f64(reads)
+    haps = _i8(haplotypes)
+    rc = _i64(read_counts)
+    ini = _i64(initial)
+    R, M, A = reads.shape
+    has, F, fr = _prior_args(prior)
+    g = np.zeros((chains, steps, ploidy), np.int64)
+    l = np.zeros((chains, steps))
+    code = lib().orc_call_mcmc(_p(reads, f64p), R, M, A, _p(rc, i64p), _p(haps, i8p), len(haps), int(ploidy), has,
+                               C.c_double(F), _p(fr, f64p), int(steps), int(chains), int(step_type), _p(ini, i64p),
+                               int(rng_kind), C.c_uint64(seed), C.c_uint64(stream_id), _p(g, i64p), _p(l, f64p))
+    assert code == 0, code
+    return g, l

@@ -1477,3 +1477,262 @@ int orc_posterior_mode(const double *reads, int n_reads, int n_pos, int max_alle
   }
   return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* `mchap call`: sampler over known haplotypes (calling/mcmc.py)              */
+/* ------------------------------------------------------------------------- */
+
+/* calling/utils.py:36-58 */
+static int count_allele(const int64_t *g, int ploidy, int64_t allele) {
+  int n = 0;
+  for (int i = 0; i < ploidy; i++) n += g[i] == allele;
+  return n;
+}
+
+/* calling/prior.py:30-52 (flat) and 55-113 */
+double orc_log_genotype_allele_prior(const int64_t *genotype, int ploidy, int variable_allele, int64_t unique_haplotypes,
+                                     int has_prior, double inbreeding, const double *frequencies) {
+  if (!has_prior) return log((double)count_allele(genotype, ploidy, genotype[variable_allele]));
+  if (inbreeding == 0.0) {
+    if (!frequencies) return log(1.0 / (double)unique_haplotypes);
+    return log(frequencies[genotype[variable_allele]]);
+  }
+  const double constant_sum = (double)(ploidy - 1);
+  const double constant_ibs = (double)(count_allele(genotype, ploidy, genotype[variable_allele]) - 1);
+  const double scale = (1.0 - inbreeding) / inbreeding;
+  double sum_alpha, variable_alpha;
+  if (!frequencies) {
+    const double alpha = (1.0 / (double)unique_haplotypes) * scale;
+    sum_alpha = constant_sum + alpha * (double)unique_haplotypes;
+    variable_alpha = alpha + constant_ibs;
+  } else {
+    double s = 0.0; /* alphas.sum(): sequential (numba) */
+    for (int64_t i = 0; i < unique_haplotypes; i++) s += frequencies[i] * scale;
+    sum_alpha = constant_sum + s;
+    variable_alpha = frequencies[genotype[variable_allele]] * scale + constant_ibs;
+  }
+  const double left = lgamma(sum_alpha) - lgamma(1.0 + sum_alpha);
+  const double right = lgamma(1.0 + variable_alpha) - lgamma(variable_alpha);
+  return left + right;
+}
+
+/* dict of calling/likelihood.py:36-78: genotype index of the SORTED alleles -> llk */
+typedef struct {
+  int64_t *keys;
+  double *vals;
+  int cap, n;
+} call_cache;
+static void call_cache_init(call_cache *c) {
+  c->cap = 256;
+  c->n = 0;
+  c->keys = (int64_t *)malloc(sizeof(int64_t) * (size_t)c->cap);
+  c->vals = (double *)malloc(sizeof(double) * (size_t)c->cap);
+  for (int i = 0; i < c->cap; i++) c->keys[i] = -1;
+}
+static void call_cache_free(call_cache *c) {
+  free(c->keys);
+  free(c->vals);
+}
+static int call_cache_slot(const call_cache *c, int64_t key) {
+  uint64_t h = (uint64_t)key * 0x9E3779B97F4A7C15ull;
+  int i = (int)(h >> 40) & (c->cap - 1);
+  while (c->keys[i] != -1 && c->keys[i] != key) i = (i + 1) & (c->cap - 1);
+  return i;
+}
+static void call_cache_put(call_cache *c, int64_t key, double v) {
+  if (2 * (c->n + 1) > c->cap) {
+    call_cache old = *c;
+    c->cap *= 2;
+    c->keys = (int64_t *)malloc(sizeof(int64_t) * (size_t)c->cap);
+    c->vals = (double *)malloc(sizeof(double) * (size_t)c->cap);
+    for (int i = 0; i < c->cap; i++) c->keys[i] = -1;
+    for (int i = 0; i < old.cap; i++)
+      if (old.keys[i] != -1) {
+        int s = call_cache_slot(c, old.keys[i]);
+        c->keys[s] = old.keys[i];
+        c->vals[s] = old.vals[i];
+      }
+    free(old.keys);
+    free(old.vals);
+  }
+  int s = call_cache_slot(c, key);
+  if (c->keys[s] == -1) c->n++;
+  c->keys[s] = key;
+  c->vals[s] = v;
+}
+
+typedef struct {
+  const double *reads;
+  int n_reads, n_pos, max_allele;
+  const int64_t *read_counts;
+  const int8_t *haplotypes;
+  int n_haps, ploidy;
+  int has_prior;
+  double inbreeding;
+  const double *frequencies;
+  call_cache *cache; /* nullable */
+} call_ctx;
+
+/* calling/likelihood.py:36-78 */
+static double call_llk(const call_ctx *c, const int64_t *g) {
+  if (!c->cache) return llk_of_alleles(c->reads, c->n_reads, c->n_pos, c->max_allele, c->ploidy, c->haplotypes, g, c->read_counts);
+  int64_t sorted[ORC_MAX_PLOIDY];
+  memcpy(sorted, g, sizeof(int64_t) * (size_t)c->ploidy);
+  qsort(sorted, (size_t)c->ploidy, sizeof(int64_t), cmp_i64);
+  const int64_t key = orc_genotype_alleles_as_index(sorted, c->ploidy);
+  const int s = call_cache_slot(c->cache, key);
+  if (c->cache->keys[s] == key) return c->cache->vals[s];
+  const double v = llk_of_alleles(c->reads, c->n_reads, c->n_pos, c->max_allele, c->ploidy, c->haplotypes, g, c->read_counts);
+  call_cache_put(c->cache, key, v);
+  return v;
+}
+
+static double call_genotype_prior(const call_ctx *c, const int64_t *g) {
+  if (!c->has_prior) return 0.0;
+  return orc_calling_log_genotype_prior(g, c->ploidy, c->n_haps, c->inbreeding, c->frequencies);
+}
+
+/* calling/mcmc.py:143-229 */
+static void gibbs_options(const call_ctx *c, int64_t *g, int k, double *llks, double *lpriors, double *probs) {
+  const int64_t current = g[k];
+  const int H = c->n_haps;
+  double joint[256];
+  for (int a = 0; a < H; a++) {
+    g[k] = a;
+    lpriors[a] = orc_log_genotype_allele_prior(g, c->ploidy, k, H, c->has_prior, c->inbreeding, c->frequencies);
+    llks[a] = call_llk(c, g);
+    joint[a] = llks[a] + lpriors[a];
+  }
+  normalise_log_probs(joint, H, probs);
+  g[k] = current;
+}
+
+/* calling/mcmc.py:15-140 */
+static void mh_options(const call_ctx *c, int64_t *g, int k, double *llks, double *lpriors, double *probs) {
+  const int64_t current = g[k];
+  const int H = c->n_haps;
+  const int copies = count_allele(g, c->ploidy, g[k]);
+  const double lprior = call_genotype_prior(c, g);
+  const double llk = call_llk(c, g);
+  double lprop[256];
+  for (int a = 0; a < H; a++) {
+    if (g[k] == a) { /* g[k] is reset to `current` only at the end: the comparison is against the running value */
+      lprop[a] = 0.0;
+      lpriors[a] = lprior;
+      llks[a] = llk;
+    } else {
+      g[k] = a;
+      lpriors[a] = call_genotype_prior(c, g);
+      llks[a] = call_llk(c, g);
+      lprop[a] = log((double)count_allele(g, c->ploidy, g[k]) / (double)copies);
+    }
+  }
+  double sum = 0.0;
+  for (int a = 0; a < H; a++) {
+    const double r = (llks[a] - llk) + (lpriors[a] - lprior) + lprop[a];
+    probs[a] = exp(r < 0.0 ? r : 0.0);
+  }
+  probs[current] = 0.0;
+  for (int a = 0; a < H; a++) probs[a] /= (double)(H - 1);
+  for (int a = 0; a < H; a++) sum += probs[a]; /* probabilities_array.sum() */
+  probs[current] = 1.0 - sum;
+  g[k] = current;
+}
+
+int orc_call_step_options(const double *reads, int n_reads, int n_pos, int max_allele, const int64_t *read_counts,
+                          const int8_t *haplotypes, int n_haps, const int64_t *genotype, int ploidy, int variable_allele,
+                          int step_type, int has_prior, double inbreeding, const double *frequencies, double *llks,
+                          double *lpriors, double *probs) {
+  if (ploidy > ORC_MAX_PLOIDY || n_pos > ORC_MAX_POS || n_haps > 256) return ORC_ERR_LIMIT;
+  call_ctx c = {reads, n_reads, n_pos, max_allele, read_counts, haplotypes, n_haps, ploidy, has_prior, inbreeding, frequencies, NULL};
+  int64_t g[ORC_MAX_PLOIDY];
+  memcpy(g, genotype, sizeof(int64_t) * (size_t)ploidy);
+  if (step_type == 0) gibbs_options(&c, g, variable_allele, llks, lpriors, probs);
+  else mh_options(&c, g, variable_allele, llks, lpriors, probs);
+  return ORC_OK;
+}
+
+/* calling/mcmc.py:393-453 */
+int orc_greedy_caller(const double *reads, int n_reads, int n_pos, int max_allele, const int64_t *read_counts,
+                      const int8_t *haplotypes, int n_haps, int ploidy, int has_prior, double inbreeding,
+                      const double *frequencies, int64_t *genotype_out) {
+  if (ploidy > ORC_MAX_PLOIDY || n_pos > ORC_MAX_POS) return ORC_ERR_LIMIT;
+  int64_t g[ORC_MAX_PLOIDY];
+  for (int i = 0; i < ploidy; i++) {
+    const int k = i + 1;
+    double best = -INFINITY;
+    int64_t best_allele = -1;
+    for (int a = 0; a < n_haps; a++) {
+      g[i] = a;
+      const double llk = llk_of_alleles(reads, n_reads, n_pos, max_allele, k, haplotypes, g, read_counts);
+      const double lprior = has_prior ? orc_calling_log_genotype_prior(g, k, n_haps, inbreeding, frequencies) : 0.0;
+      const double lprob = llk + lprior;
+      if (lprob > best) {
+        best = lprob;
+        best_allele = a;
+      }
+    }
+    g[i] = best_allele;
+  }
+  qsort(g, (size_t)ploidy, sizeof(int64_t), cmp_i64);
+  memcpy(genotype_out, g, sizeof(int64_t) * (size_t)ploidy);
+  return ORC_OK;
+}
+
+/* calling/mcmc.py:232-327 */
+static double call_compound_step(const call_ctx *c, orc_rng *rng, int64_t *g, int step_type) {
+  const int K = c->ploidy, H = c->n_haps;
+  double llks[256], lpriors[256], probs[256];
+  int order[ORC_MAX_PLOIDY];
+  for (int i = 0; i < K; i++) order[i] = i;
+  for (int i = K - 1; i >= 1; i--) { /* np.random.shuffle(order) */
+    const int j = (int)rng_interval(rng, 0, (uint32_t)i);
+    const int t = order[i];
+    order[i] = order[j];
+    order[j] = t;
+  }
+  int choice = 0;
+  for (int j = 0; j < K; j++) {
+    const int k = order[j];
+    if (step_type == 0) gibbs_options(c, g, k, llks, lpriors, probs);
+    else mh_options(c, g, k, llks, lpriors, probs);
+    choice = choose_from(probs, H, rng_double(rng, 0));
+    g[k] = choice;
+  }
+  qsort(g, (size_t)K, sizeof(int64_t), cmp_i64);
+  return llks[choice < H ? choice : H - 1];
+}
+
+int orc_call_mcmc(const double *reads, int n_reads, int n_pos, int max_allele, const int64_t *read_counts,
+                  const int8_t *haplotypes, int n_haps, int ploidy, int has_prior, double inbreeding,
+                  const double *frequencies, int steps, int chains, int step_type, const int64_t *initial, int rng_kind,
+                  uint64_t seed, uint64_t stream_id, int64_t *genotypes_out, double *llks_out) {
+  if (ploidy > ORC_MAX_PLOIDY || n_pos > ORC_MAX_POS || n_haps > 256) return ORC_ERR_LIMIT;
+  if (step_type != 0 && step_type != 1) return ORC_ERR_BAD_ARG;
+  int64_t init[ORC_MAX_PLOIDY];
+  if (initial) memcpy(init, initial, sizeof(int64_t) * (size_t)ploidy);
+  else orc_greedy_caller(reads, n_reads, n_pos, max_allele, read_counts, haplotypes, n_haps, ploidy, has_prior, inbreeding, frequencies, init);
+  mt_state mt;
+  if (rng_kind == ORC_RNG_NUMPY_MT19937) mt_seed(&mt, (uint32_t)seed);
+  for (int ch = 0; ch < chains; ch++) {
+    orc_rng rng;
+    memset(&rng, 0, sizeof(rng));
+    rng.kind = rng_kind;
+    rng.seed = seed;
+    rng.stream_id = stream_id;
+    rng.chain = (uint32_t)ch;
+    rng.mt = &mt;
+    call_cache cache;
+    call_cache_init(&cache);
+    call_ctx c = {reads, n_reads, n_pos, max_allele, read_counts, haplotypes, n_haps, ploidy, has_prior, inbreeding, frequencies, &cache};
+    int64_t g[ORC_MAX_PLOIDY];
+    memcpy(g, init, sizeof(int64_t) * (size_t)ploidy);
+    for (int s = 0; s < steps; s++) {
+      const double llk = call_compound_step(&c, &rng, g, step_type);
+      llks_out[(size_t)ch * steps + s] = llk;
+      memcpy(genotypes_out + ((size_t)ch * steps + s) * ploidy, g, sizeof(int64_t) * (size_t)ploidy);
+    }
+    call_cache_free(&cache);
+  }
+  return ORC_OK;
+}

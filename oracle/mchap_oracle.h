@@ -146,6 +146,28 @@ int orc_posterior_mode(const double *reads, int n_reads, int n_pos, int max_alle
 void orc_posterior_allele_frequencies_f64(const double *posteriors, int64_t n_genotypes, int ploidy, int n_alleles,
                                           double *freqs, double *counts, double *occur);
 
+/* ---- `mchap call`: Gibbs / Metropolis-Hastings sampler over known haplotypes (calling/mcmc.py, calling/classes.py:14-124,
+ * calling/prior.py:30-113, calling/likelihood.py:8-78) ---- */
+/* calling/prior.py:30-113: Gibbs-step prior of the variable allele (has_prior == 0: the flat prior of 30-52) */
+double orc_log_genotype_allele_prior(const int64_t *genotype, int ploidy, int variable_allele, int64_t unique_haplotypes,
+                                     int has_prior, double inbreeding, const double *frequencies /*nullable*/);
+/* calling/mcmc.py:15-229: transition vectors of one sub-step (step_type 0 Gibbs, 1 Metropolis-Hastings), no cache */
+int orc_call_step_options(const double *reads, int n_reads, int n_pos, int max_allele, const int64_t *read_counts,
+                          const int8_t *haplotypes, int n_haps, const int64_t *genotype, int ploidy, int variable_allele,
+                          int step_type, int has_prior, double inbreeding, const double *frequencies,
+                          double *llks /*[H]*/, double *lpriors /*[H]*/, double *probs /*[H]*/);
+/* calling/mcmc.py:393-453 */
+int orc_greedy_caller(const double *reads, int n_reads, int n_pos, int max_allele, const int64_t *read_counts,
+                      const int8_t *haplotypes, int n_haps, int ploidy, int has_prior, double inbreeding,
+                      const double *frequencies, int64_t *genotype_out);
+/* CallingMCMC.fit (calling/classes.py:62-124) with mcmc_sampler (calling/mcmc.py:330-390, cache=True: a likelihood is
+ * remembered per SORTED genotype, i.e. a later request for the same alleles in another order gets the first value) */
+int orc_call_mcmc(const double *reads, int n_reads, int n_pos, int max_allele, const int64_t *read_counts,
+                  const int8_t *haplotypes, int n_haps, int ploidy, int has_prior, double inbreeding,
+                  const double *frequencies, int steps, int chains, int step_type, const int64_t *initial /*nullable*/,
+                  int rng_kind, uint64_t seed, uint64_t stream_id,
+                  int64_t *genotypes_out /*[chains][steps][ploidy]*/, double *llks_out /*[chains][steps]*/);
+
 /* ---- RNG test hooks ---- */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double orc_philox_double(uint64_t seed, uint64_t stream_id, uint32_t substream, uint64_t n);

@@ -564,11 +564,105 @@ def gen_encoding():
     zdump("encoding.npz", **out)
 
 
+# --------------------------------------------------------------------------- G11
+def gen_call_mcmc():
+    """`mchap call`: calling/mcmc.py (gibbs_options, mh_options, greedy_caller), calling/prior.py:30-113 and whole seeded
+    CallingMCMC.fit traces (numpy legacy MT19937 under the shim), calling/classes.py posterior summaries."""
+    from mchap.calling import mcmc as ref_cm
+    from mchap.calling import prior as ref_cp
+    from mchap.calling.classes import CallingMCMC
+
+    # math.lgamma(0) raises in CPython where numba returns +inf (SURVEY 8c): give the reference module numba's behaviour
+    import math
+
+    def lgamma_inf(x):
+        return math.inf if x == 0 else math.lgamma(x)
+
+    ref_cp.lgamma = lgamma_inf
+    rng = np.random.default_rng(1111)
+    out = {}
+    n = 0
+    for (K, H, M, R, prior_kind) in [(4, 5, 4, 12, None), (2, 6, 5, 20, "F"), (4, 4, 3, 15, "Ff"), (6, 5, 4, 30, "Ff"),
+                                     (3, 7, 5, 25, "F0"), (4, 9, 6, 40, "Ff")]:
+        haps = np.unique(rng.integers(0, 2, size=(8 * H, M)).astype(np.int8), axis=0)
+        rng.shuffle(haps)
+        haps = haps[:H]
+        H = len(haps)
+        truth = haps[rng.integers(0, H, size=K)]
+        reads = simulate_reads(truth, n_reads=R, errors=False, qual=(10, 30), uniform_sample=True)
+        # knock out some calls -> NaN gaps
+        gap = rng.random(reads.shape[:2]) < 0.15
+        reads[gap] = np.nan
+        counts = rng.integers(1, 4, size=R).astype(np.int64) if K != 2 else None
+        fr = rng.dirichlet(np.ones(H))
+        prior = {None: None, "F": (0.2, None), "Ff": (0.15, fr), "F0": (0.0, fr)}[prior_kind]
+        pre = "c%d_" % n
+        out[pre + "haps"] = haps
+        out[pre + "reads"] = reads
+        out[pre + "counts"] = np.zeros(0, np.int64) if counts is None else counts
+        out[pre + "meta"] = np.array([K, -1.0 if prior is None else prior[0], 0 if (prior is None or prior[1] is None) else 1])
+        out[pre + "freqs"] = fr
+        # transition vectors of both step types at random states
+        states, vecs = [], []
+        for t in range(4):
+            g = rng.integers(0, H, size=K).astype(np.int64)
+            k = int(rng.integers(0, K))
+            row = []
+            for fn in (ref_cm.gibbs_options, ref_cm.mh_options):
+                llks, lpri, probs = np.zeros(H), np.zeros(H), np.zeros(H)
+                fn(g.copy(), k, haps, reads, counts, llks, lpri, probs, prior, None)
+                row.append(np.stack([llks, lpri, probs]))
+            states.append(np.append(g, k))
+            vecs.append(np.stack(row))
+        out[pre + "states"] = np.array(states)
+        out[pre + "vectors"] = np.array(vecs)  # [4][2 (gibbs, mh)][3 (llk, lprior, prob)][H]
+        out[pre + "greedy"] = ref_cm.greedy_caller(haps, K, reads, counts, prior).astype(np.int64)
+        # seeded fits
+        for st, name in ((0, "Gibbs"), (1, "Metropolis-Hastings")):
+            model = CallingMCMC(ploidy=K, haplotypes=haps, prior=prior, steps=60, chains=2, random_seed=100 + n, step_type=name)
+            tr = model.fit(reads, read_counts=counts)
+            out[pre + "trace%d_g" % st] = tr.genotypes.astype(np.int64)
+            out[pre + "trace%d_l" % st] = tr.llks
+            if st == 0:
+                post = tr.burn(10).posterior()
+                out[pre + "post_g"] = post.genotypes.astype(np.int64)
+                out[pre + "post_p"] = post.probabilities
+                m = post.mode(genotype_support=True)
+                out[pre + "mode_support"] = np.append(m[0].astype(float), [m[1], m[2]])
+                fq = tr.burn(10).posterior_frequencies()
+                out[pre + "post_freqs"] = np.stack(fq)
+                out[pre + "incongruence"] = np.array([tr.burn(10).replicate_incongruence(t) for t in (0.9, 0.6, 0.3)])
+                out[pre + "as_array"] = post.as_array(H)
+        # a fit from a user initial genotype
+        ini = rng.integers(0, H, size=K).astype(np.int64)
+        ini.sort()
+        model = CallingMCMC(ploidy=K, haplotypes=haps, prior=prior, steps=25, chains=1, random_seed=7 + n)
+        tr = model.fit(reads, read_counts=counts, initial=ini)
+        out[pre + "initial"] = ini
+        out[pre + "trace_ini_g"] = tr.genotypes.astype(np.int64)
+        out[pre + "trace_ini_l"] = tr.llks
+        n += 1
+    # allele-prior grid
+    grid = []
+    for K, H in [(2, 3), (4, 5), (6, 4)]:
+        fr = rng.dirichlet(np.ones(H))
+        for F, f in [(0.0, None), (0.0, fr), (0.1, None), (0.35, fr)]:
+            for t in range(3):
+                g = rng.integers(0, H, size=K).astype(np.int64)
+                k = int(rng.integers(0, K))
+                grid.append(dict(g=g.tolist(), k=k, H=H, F=F, freqs=None if f is None else f.tolist(),
+                                 value=float(ref_cp.log_genotype_allele_prior(g, k, H, F, f)),
+                                 flat=float(ref_cp.log_genotype_allele_flat_prior(g, k))))
+    out["n_cases"] = np.array(n)
+    zdump("call_mcmc.npz", **out)
+    jdump("call_mcmc_prior.json", {"grid": grid})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["likelihood", "tables", "priors", "structural", "presampling", "exact", "transitions",
-                             "trace_posterior", "mcmc", "encoding"]
+                             "trace_posterior", "mcmc", "encoding", "call_mcmc"]
     fns = dict(likelihood=gen_likelihood, tables=reference_test_tables, priors=gen_priors, structural=gen_structural,
                presampling=gen_presampling, exact=gen_exact, transitions=gen_transitions,
-               trace_posterior=gen_trace_posterior, mcmc=gen_mcmc_traces, encoding=gen_encoding)
+               trace_posterior=gen_trace_posterior, mcmc=gen_mcmc_traces, encoding=gen_encoding, call_mcmc=gen_call_mcmc)
     for w in which:
         fns[w]()

@@ -1,0 +1,85 @@
+"""GPU parity of `mchap call`'s sampler (call_mcmc_kernel behind CallingMCMC) against the CPU oracle on the same Philox
+streams -- alleles bit-exact step for step, llks to 1e-10 -- and, independently of any generator, its stationary
+distribution against the exact caller's enumeration (the reference's own criterion,
+tests/test_calling/test_calling_mcmc.py: Gibbs == Metropolis-Hastings == exact to two decimals)."""
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(U, K, H, M, R, seed, qual=(5, 25)):
+    from mchap_amd.synth import synth_units
+
+    rng = np.random.default_rng(seed)
+    reads, _, truth = synth_units(U, ploidy=K, n_pos=M, n_reads=R, first_unit=seed, window=(2, M), qual=qual)
+    haps = np.zeros((U, H, M), np.int8)
+    for u in range(U):
+        pool = np.unique(np.concatenate([truth[u], rng.integers(0, 2, size=(6 * H, M)).astype(np.int8)]), axis=0)
+        rng.shuffle(pool)
+        haps[u] = pool[:H]
+    counts = rng.integers(1, 4, size=(U, R)).astype(np.int64)
+    return reads, haps, counts, rng
+
+
+@pytest.mark.parametrize("step_type", ["Gibbs", "Metropolis-Hastings"])
+@pytest.mark.parametrize("K,H,M,R", [(4, 6, 6, 40), (2, 9, 5, 20), (6, 5, 4, 70), (3, 12, 6, 130)])
+def test_traces_match_oracle_step_for_step(step_type, K, H, M, R):
+    from mchap_amd.calling_mcmc import CallingMCMC
+
+    U = 3
+    reads, haps, counts, rng = _inputs(U, K, H, M, R, seed=K * 100 + H)
+    F = np.array([0.0, 0.12, 0.3])
+    fr = rng.dirichlet(np.ones(H), size=U)
+    st = 0 if step_type == "Gibbs" else 1
+    for prior, rc in ((None, None), ((F, None), counts), ((F, fr), counts)):
+        model = CallingMCMC(ploidy=K, haplotypes=haps[0], prior=None, steps=80, chains=2, random_seed=17, step_type=step_type)
+        traces = model.fit_batch(reads, rc, haplotypes=haps, prior=prior)
+        for u in range(U):
+            pr = None if prior is None else (float(F[u]), None if prior[1] is None else fr[u])
+            g, l = orc.call_mcmc(reads[u], haps[u], K, steps=80, chains=2, step_type=st, read_counts=None if rc is None else rc[u],
+                                 prior=pr, rng_kind=orc.RNG_PHILOX, seed=17, stream_id=u)
+            assert np.array_equal(traces[u].genotypes, g), (u, prior is None)
+            np.testing.assert_allclose(traces[u].llks, l, rtol=1e-10, atol=1e-9)
+            assert traces[u].n_allele == H
+
+
+def test_initial_genotype_zero_reads_and_errors():
+    from mchap_amd.calling_mcmc import CallingMCMC
+
+    reads, haps, counts, rng = _inputs(2, 4, 5, 5, 30, seed=5)
+    ini = np.sort(rng.integers(0, 5, size=(2, 4)), axis=1)
+    model = CallingMCMC(ploidy=4, haplotypes=haps[0], steps=40, chains=3, random_seed=3)
+    traces = model.fit_batch(reads, None, initial=ini, haplotypes=haps)
+    for u in range(2):
+        g, l = orc.call_mcmc(reads[u], haps[u], 4, steps=40, chains=3, initial=ini[u], rng_kind=orc.RNG_PHILOX, seed=3, stream_id=u)
+        assert np.array_equal(traces[u].genotypes, g)
+    # the one-unit operator form == unit 0 of the batch
+    one = CallingMCMC(ploidy=4, haplotypes=haps[0], steps=40, chains=3, random_seed=3).fit(reads[0], initial=ini[0])
+    assert np.array_equal(one.genotypes, traces[0].genotypes)
+    # no reads: every genotype equally likely under the flat prior; llk 0
+    empty = CallingMCMC(ploidy=4, haplotypes=haps[0], steps=30, chains=2, random_seed=1).fit(np.empty((0, 5, 2)))
+    assert np.all(empty.llks == 0.0)
+    with pytest.raises(ValueError):
+        CallingMCMC(ploidy=4, haplotypes=haps[0], step_type="Other").fit(reads[0])
+    # no variants: the constant trace (calling/classes.py:77-83)
+    none = CallingMCMC(ploidy=4, haplotypes=np.zeros((1, 0), np.int8), steps=10, chains=2).fit(np.empty((5, 0, 0)))
+    assert none.genotypes.shape == (2, 10, 4) and np.isnan(none.llks).all()
+
+
+@pytest.mark.parametrize("prior", [None, (0.2, None)])
+def test_gibbs_and_mh_agree_with_the_exact_posterior(prior):
+    """25 000 steps x 2 chains of either step type against genotype_posteriors over all genotypes (2 decimals)."""
+    from mchap_amd import calling
+    from mchap_amd.calling_mcmc import CallingMCMC
+
+    K, H = 4, 4
+    reads, haps, counts, rng = _inputs(1, K, H, 4, 14, seed=31, qual=(3, 10))
+    llks = calling.genotype_likelihoods(reads[0], K, haps[0]).astype(np.float64)
+    exact = calling.genotype_posteriors(llks, K, H, prior)
+    for step_type in ("Gibbs", "Metropolis-Hastings"):
+        model = CallingMCMC(ploidy=K, haplotypes=haps[0], prior=prior, steps=25000, chains=2, random_seed=11, step_type=step_type)
+        post = model.fit(reads[0]).burn(1000).posterior().as_array(H)
+        assert np.abs(post - exact).max() < 0.015, step_type
