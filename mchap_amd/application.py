@@ -36,22 +36,113 @@ def _mec(calls, genotype):
     return int(diff.sum(axis=-1).min(axis=-1).sum())
 
 
-def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024, use_phred=False, prior_tag=None,
-                      inbreeding=None, calling=None):
-    """One record of the input VCF -> (FILTER, INFO string, FORMAT string, {sample: column}) as `mchap call-exact`
-    writes them.  `calling`: mchap_amd.calling (default, GPU) or an object with the same functions."""
-    if calling is None:
-        from . import calling
+def _exact_units(records, bams, samples, ploidy, report, error_rate, use_phred, prior_tag, inbreeding):
+    """Everything `call-exact` needs from the input side, record by record: the locus, per sample the encoded reads,
+    and which (record, sample) units need the kernel (a record with a single haplotype, or no variable position, has
+    one genotype with probability 1; an invalid record is not called at all)."""
+    out = []
+    for rec in records:
+        locus = Locus(rec, prior_tag)
+        H, M = locus.haplotypes.shape
+        invalid = None
+        if locus.mask_reference_allele and H == 1:
+            invalid = "NOA"
+        elif np.any(np.isnan(locus.frequencies)):
+            invalid = "AF0"
+        per = {s: sample_reads(locus, bams[s], s, error_rate, use_phred) for s in samples}
+        out.append(dict(rec=rec, locus=locus, invalid=invalid, reads=per, needs_kernel=(invalid is None and M > 0 and H > 1)))
+    return out
 
-    locus = Locus(rec, prior_tag)
+
+def _run_exact_groups(units, ploidy_of, inbreeding_of, full, backend=None):
+    """The exact caller for all units that need it, grouped by shape (positions, alleles, haplotypes, ploidy): one device
+    call per group, reads padded to the group's deepest sample with weight-0 gap rows.  `backend`: an object with the
+    reference's module-level functions (the oracle replay of the CPU tests); None = the device batch.
+    Returns {(record index, sample): dict(alleles, gprob, sprob, freqs, occur[, GL, GP])}."""
+    from .device import ExactDeviceBatch
+
+    groups = {}
+    for ri, unit in enumerate(units):
+        if not unit["needs_kernel"]:
+            continue
+        locus = unit["locus"]
+        H, M = locus.haplotypes.shape
+        for s, sr in unit["reads"].items():
+            A = sr["dists"].shape[2] if sr["dists"].ndim == 3 and sr["dists"].shape[0] else int(max(locus.n_alleles))
+            groups.setdefault((M, A, H, int(ploidy_of(s))), []).append((ri, s))
+    results = {}
+    for (M, A, H, K), members in groups.items():
+        if backend is not None:
+            for ri, s in members:
+                unit = units[ri]
+                sr, locus = unit["reads"][s], unit["locus"]
+                F = inbreeding_of(s)
+                prior = None if F is None else (F, locus.frequencies)
+                results[(ri, s)] = _exact_one(backend, sr, locus.haplotypes, K, prior, full)
+            continue
+        Rmax = max(max(len(units[ri]["reads"][s]["dists"]), 1) for ri, s in members)
+        U = len(members)
+        reads = np.full((U, Rmax, M, A), np.nan)
+        counts = np.zeros((U, Rmax), dtype=np.int64)
+        haps = np.zeros((U, H, M), dtype=np.int8)
+        Fs = np.zeros(U)
+        frs = np.zeros((U, H))
+        has_prior = inbreeding_of(members[0][1]) is not None
+        for i, (ri, s) in enumerate(members):
+            sr, locus = units[ri]["reads"][s], units[ri]["locus"]
+            n = len(sr["dists"])
+            if n:
+                reads[i, :n] = sr["dists"]
+                counts[i, :n] = sr["counts"]
+            haps[i] = locus.haplotypes
+            if has_prior:
+                Fs[i] = inbreeding_of(s)
+                frs[i] = locus.frequencies
+        batch = ExactDeviceBatch(reads, K, haps, counts, (Fs, frs) if has_prior else None)
+        batch.run(streaming=not full, arrays=full)
+        if full:
+            arr = batch.array_results(True)
+            for i, key in enumerate(members):
+                results[key] = dict(alleles=arr["alleles"][i], gprob=arr["prob"][i], sprob=arr["support_prob"][i], freqs=arr["freqs"][i],
+                                    occur=arr["occur"][i], GL=arr["llks"][i].astype(np.float64) / np.log(10), GP=arr["posteriors"][i])
+        else:
+            al, _, gp, sp, fq, oc = batch.mode_results()
+            for i, key in enumerate(members):
+                results[key] = dict(alleles=al[i], gprob=gp[i], sprob=sp[i], freqs=fq[i], occur=oc[i])
+    return results
+
+
+def _exact_one(calling, sr, haps, ploidy, prior, full):
+    """One unit through the reference's own sequence of calls (application/call_exact.py:126-179) on `calling`."""
+    H = len(haps)
+    if full:
+        llks = calling.genotype_likelihoods(sr["dists"], ploidy, haps, read_counts=sr["counts"])
+        probs = calling.genotype_posteriors(llks, ploidy, H, prior=prior)
+        idx = int(np.argmax(probs))
+        alleles = calling.index_as_genotype_alleles(idx, ploidy)
+        sprob = calling.alternate_dosage_posteriors(alleles, probs)[1].sum()
+        freqs, _, occur = calling.posterior_allele_frequencies(probs, ploidy, H)
+        return dict(alleles=alleles, gprob=probs[idx], sprob=sprob, freqs=freqs, occur=occur,
+                    GL=llks.astype(np.float64) / np.log(10), GP=probs)
+    alleles, _, gprob, sprob, freqs, occur = calling.posterior_mode(
+        sr["dists"], ploidy, haps, read_counts=sr["counts"], prior=prior, return_support_prob=True,
+        return_posterior_frequencies=True, return_posterior_occurrence=True)
+    return dict(alleles=alleles, gprob=gprob, sprob=sprob, freqs=freqs, occur=occur)
+
+
+def _per_sample(value, samples):
+    """A scalar, or a {sample: value} mapping (the reference's per-sample ploidy / inbreeding files), as a function."""
+    if isinstance(value, dict):
+        return lambda s: value[s]
+    return lambda s: value
+
+
+def _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_tag):
+    """(FILTER, INFO, FORMAT, {sample: column}) of one record from the units' results (application/baseclass.py:220-302,
+    call_exact.py:84-199)."""
+    rec, locus, invalid = unit["rec"], unit["locus"], unit["invalid"]
     haps = locus.haplotypes
     H, M = haps.shape
-    full = ("GL" in report) or ("GP" in report)
-    invalid = None
-    if locus.mask_reference_allele and H == 1:
-        invalid = "NOA"
-    elif np.any(np.isnan(locus.frequencies)):
-        invalid = "AF0"
     cols, gts = {}, {}
     acp_sum = np.zeros(H)
     aop_not = np.ones(H)
@@ -59,8 +150,11 @@ def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024
     snvdp_sum = np.zeros(M)
     dps, rcounts = [], []
     nan_arrays = False
+    ploidy_total = 0
     for sample in samples:
-        sr = sample_reads(locus, bams[sample], sample, error_rate, use_phred)
+        ploidy = int(ploidy_of(sample))
+        ploidy_total += ploidy
+        sr = unit["reads"][sample]
         calls, depth = sr["calls"], sr["depth"]
         rcount = len(calls)
         dp = np.round(np.mean(depth)) if len(depth) else np.nan
@@ -76,28 +170,15 @@ def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024
             cols[sample] = ":".join(fields)
             nan_arrays = True
             continue
-        prior = None if inbreeding is None else (inbreeding, locus.frequencies)
-        extra = {}
         if M == 0 or H == 1:
             # a single haplotype: one genotype with probability 1 (the reference's arithmetic gives exactly that)
-            alleles, gprob, sprob = np.zeros(ploidy, int), 1.0, 1.0
-            freqs, occur = np.ones(1), np.ones(1)
-            extra = dict(GL=np.zeros(1), GP=np.ones(1))
-        elif full:
-            llks = calling.genotype_likelihoods(sr["dists"], ploidy, haps, read_counts=sr["counts"])
-            probs = calling.genotype_posteriors(llks, ploidy, H, prior=prior)
-            idx = int(np.argmax(probs))
-            alleles = calling.index_as_genotype_alleles(idx, ploidy)
-            gprob = probs[idx]
-            sprob = calling.alternate_dosage_posteriors(alleles, probs)[1].sum()
-            freqs, _, occur = calling.posterior_allele_frequencies(probs, ploidy, H)
-            extra = dict(GL=llks.astype(np.float64) / np.log(10), GP=probs)
+            res = dict(alleles=np.zeros(ploidy, int), gprob=1.0, sprob=1.0, freqs=np.ones(1), occur=np.ones(1), GL=np.zeros(1), GP=np.ones(1))
         else:
-            alleles, _, gprob, sprob, freqs, occur = calling.posterior_mode(
-                sr["dists"], ploidy, haps, read_counts=sr["counts"], prior=prior, return_support_prob=True,
-                return_posterior_frequencies=True, return_posterior_occurrence=True)
-        gts[sample] = np.asarray(alleles)
-        freqs, occur = np.asarray(freqs, float), np.asarray(occur, float)
+            res = results[(ri, sample)]
+        alleles = np.asarray(res["alleles"])
+        gprob, sprob = res["gprob"], res["sprob"]
+        gts[sample] = alleles
+        freqs, occur = np.asarray(res["freqs"], float), np.asarray(res["occur"], float)
         acp_sum += freqs * ploidy
         aop_sum += occur
         aop_not *= 1 - occur
@@ -116,9 +197,9 @@ def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024
             elif tag == "SNVDP":
                 fields.append(vcfstr(np.round(depth).astype(float)) if len(depth) else ".")
             elif tag in ("GL", "GP"):
-                fields.append(vcfstr(np.asarray(extra[tag], float)))
+                fields.append(vcfstr(np.asarray(res[tag], float)))
         cols[sample] = ":".join(fields)
-    # ---- record level (application/baseclass.py:220-302) ----
+    # ---- record level ----
     counts = np.zeros(H, int)
     for g in gts.values():
         for a in g:
@@ -137,7 +218,7 @@ def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024
         if tag == "ACP":
             info.append(("ACP", null_r if nan_arrays else acp_sum))
         elif tag == "AFP":
-            info.append(("AFP", null_r if nan_arrays else acp_sum / (ploidy * len(samples))))
+            info.append(("AFP", null_r if nan_arrays else acp_sum / ploidy_total))
         elif tag == "AOP":
             info.append(("AOP", null_r if nan_arrays else 1 - aop_not))
             info.append(("AOPSUM", null_r if nan_arrays else aop_sum))
@@ -154,16 +235,34 @@ def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024
     return invalid or "PASS", ";".join(parts), fmt, cols
 
 
+def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024, use_phred=False, prior_tag=None,
+                      inbreeding=None, calling=None):
+    """One record of the input VCF -> (FILTER, INFO string, FORMAT string, {sample: column}) as `mchap call-exact` writes
+    them.  `calling`: None = the device batch; or an object with the reference's functions (test replays)."""
+    units = _exact_units([rec], bams, samples, ploidy, report, error_rate, use_phred, prior_tag, inbreeding)
+    full = ("GL" in report) or ("GP" in report)
+    ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
+    results = _run_exact_groups(units, ploidy_of, inbreeding_of, full, calling)
+    return _format_exact_record(units[0], samples, results, 0, ploidy_of, report, prior_tag)
+
+
 def call_exact(vcf_path, sample_bams, ploidy=4, report=(), base_error_rate=0.0024, use_base_phred_scores=False,
                prior_frequencies_tag=None, inbreeding=None, calling=None):
     """`mchap call-exact` over a VCF of known haplotypes: yields one VCF record line per input record (no header).
-    sample_bams: ordered mapping sample name -> BAM path."""
+    sample_bams: ordered mapping sample name -> BAM path; ploidy / inbreeding: a value or {sample: value}.
+    All (record x sample) units of the file are encoded first, grouped by shape and evaluated in one device call per
+    shape; the records are then formatted from the results."""
     samples = list(sample_bams)
     bams = {s: read_bam(p) for s, p in sample_bams.items()}
     _, records = read_vcf(vcf_path)
-    for rec in records:
-        flt, info, fmt, cols = call_exact_record(rec, bams, samples, ploidy, tuple(report), base_error_rate, use_base_phred_scores,
-                                                 prior_frequencies_tag, inbreeding, calling)
+    report = tuple(report)
+    units = _exact_units(records, bams, samples, ploidy, report, base_error_rate, use_base_phred_scores, prior_frequencies_tag, inbreeding)
+    full = ("GL" in report) or ("GP" in report)
+    ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
+    results = _run_exact_groups(units, ploidy_of, inbreeding_of, full, calling)
+    for ri, unit in enumerate(units):
+        rec = unit["rec"]
+        flt, info, fmt, cols = _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_frequencies_tag)
         alt = ",".join(rec["alts"]) if rec["alts"] else "."
         yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
 
@@ -172,60 +271,40 @@ def call_exact(vcf_path, sample_bams, ploidy=4, report=(), base_error_rate=0.002
 # mchap assemble (application/assemble.py:95-252, assemble/haplotype_calling.py:4-64)
 # ---------------------------------------------------------------------------------------------------------
 def call_posterior_haplotypes(posteriors, threshold=0.01):
-    """Haplotype alleles of the VCF record from the samples' posteriors: every haplotype whose occurrence probability
-    reaches `threshold` in some sample, ordered by summed dosage weight (descending), reference first."""
-    arrays, values = {}, {}
-    for post in posteriors:
-        haps, weights, probs = post.allele_frequencies(dosage=True)
-        keep = probs >= threshold
-        for h, w in zip(haps[keep], weights[keep]):
-            b = h.tobytes()
-            if b not in arrays:
-                arrays[b] = h
-                values[b] = 0
-            values[b] += w
-    ref = [b for b, h in arrays.items() if np.all(h == 0)]
-    ref_observed = bool(ref)
-    for b in ref:
-        arrays.pop(b)
-        values.pop(b)
+    """The haplotype alleles of a VCF record from the samples' posteriors (same name and result as the reference's
+    assemble/haplotype_calling.py): a haplotype is listed when its posterior probability of occurrence reaches
+    `threshold` in at least one sample; listed haplotypes are ranked by their expected dosage summed over the samples
+    that list them, the all-reference haplotype always first.  Returns (haplotypes int8 [n, n_base], ref_observed)."""
+    from .classes import _first_occurrence_unique
+
     n_base = posteriors[0].genotypes.shape[-1]
-    haplotypes = np.full((len(arrays) + 1, n_base), -1, np.int8)
-    vals = np.full(len(arrays) + 1, -1, float)
-    for i, (b, h) in enumerate(arrays.items()):
-        haplotypes[i] = h
-        vals[i] = values[b]
-    haplotypes[-1][:] = 0
-    vals[-1] = vals.max() + 1
-    order = np.flip(np.argsort(vals))
-    return haplotypes[order], ref_observed
+    rows, weights = [], []
+    for post in posteriors:
+        haps, dosage, occurrence = post.allele_frequencies(dosage=True)
+        listed = occurrence >= threshold
+        rows.append(np.asarray(haps[listed], dtype=np.int8).reshape(int(np.sum(listed)), n_base))
+        weights.append(dosage[listed])
+    rows = np.concatenate(rows) if rows else np.zeros((0, n_base), np.int8)
+    weights = np.concatenate(weights) if weights else np.zeros(0)
+    if len(rows):
+        first, ids = _first_occurrence_unique(rows)      # distinct haplotypes in order of first listing
+        distinct = rows[first]
+        score = np.zeros(len(distinct))
+        np.add.at(score, ids, weights)                   # summed sample after sample
+    else:
+        distinct, score = rows, np.zeros(0)
+    is_ref = (distinct == 0).all(axis=1) if len(distinct) else np.zeros(0, bool)
+    ref_observed = bool(is_ref.any())
+    distinct, score = distinct[~is_ref], score[~is_ref]
+    haplotypes = np.concatenate([distinct, np.zeros((1, n_base), np.int8)]).astype(np.int8)
+    value = np.append(score, (score.max() if len(score) else -1.0) + 1.0)  # the reference allele outranks everything
+    return haplotypes[np.flip(np.argsort(value))], ref_observed
 
 
-def assemble_record(locus, bams, samples, ploidy=4, inbreeding=None, steps=1000, burn=500, chains=2, seed=None,
-                    error_rate=0.0024, use_phred=False, haplotype_posterior_threshold=0.20, incongruence_threshold=0.60,
-                    **mcmc_kw):
-    """One target locus (DenovoLocus) -> the VCF record line of `mchap assemble` (no --report extras)."""
-    from .assemble import DenovoMCMC
-
+def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold):
+    """The VCF record line of `mchap assemble` from the per-sample summaries (application/assemble.py:144-252,
+    baseclass.py:220-302).  per[sample]: genotype [K, M], gprob, sprob, mec, mecp, mci, rcount, rcalls, dp."""
     M = len(locus.positions)
-    per = {}
-    posteriors = []
-    for sample in samples:
-        sr = sample_reads(locus, bams[sample], sample, error_rate, use_phred)
-        model = DenovoMCMC(ploidy=ploidy, n_alleles=locus.n_alleles, inbreeding=inbreeding, steps=steps, chains=chains,
-                           random_seed=seed, **mcmc_kw)
-        trace = model.fit(sr["dists"], read_counts=sr["counts"]).burn(burn)
-        post = trace.posterior()
-        posteriors.append(post)
-        support = post.mode_genotype_support()
-        sprob = float(support.probabilities.sum())
-        genotype, gprob = support.mode_genotype()
-        calls, depth = sr["calls"], sr["depth"]
-        mec = _mec(calls, genotype)
-        denom = int((calls >= 0).sum())
-        per[sample] = dict(genotype=genotype, gprob=float(gprob), sprob=sprob, mec=mec, mecp=mec / denom if denom > 0 else np.nan,
-                           mci=int(trace.replicate_incongruence(threshold=incongruence_threshold)), rcount=len(calls),
-                           rcalls=denom, dp=np.round(np.mean(depth)) if len(depth) else np.nan)
     haplotypes, ref_called = call_posterior_haplotypes(posteriors, threshold=haplotype_posterior_threshold)
     labels = {h.tobytes(): i for i, h in enumerate(haplotypes)}
     flt = "PASS"
@@ -238,7 +317,7 @@ def assemble_record(locus, bams, samples, ploidy=4, inbreeding=None, steps=1000,
     cols = []
     for sample in samples:
         d = per[sample]
-        a = np.sort([labels.get(h.tobytes(), -1) for h in d["genotype"]])
+        a = np.sort([labels.get(np.asarray(h, dtype=np.int8).tobytes(), -1) for h in d["genotype"]])
         a = np.append(a[a >= 0], a[a < 0])
         for x in a:
             if x >= 0:
@@ -266,12 +345,66 @@ def assemble_record(locus, bams, samples, ploidy=4, inbreeding=None, steps=1000,
                       ";".join(parts), ":".join(SAMPLE_FIELDS)] + cols)
 
 
-def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, **kw):
+def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploidy=4, inbreeding=None, steps=1000, burn=500,
+             chains=2, seed=None, error_rate=0.0024, use_phred=False, haplotype_posterior_threshold=0.20,
+             incongruence_threshold=0.60, **mcmc_kw):
     """`mchap assemble` over the targets of a BED4 file: yields one VCF record line per target (no header).
-    reference_sequences: {contig: sequence string}; sample_bams: ordered mapping sample name -> BAM path."""
+    reference_sequences: {contig: sequence string}; sample_bams: ordered mapping sample name -> BAM path; ploidy /
+    inbreeding: a value or {sample: value}.
+
+    Batched: every (target x sample) unit of the file is encoded first, all units go through ONE sampler launch
+    (ragged: loci differ in SNVs, samples in depth), the posterior summary (distinct genotypes, SPM, GPM, mode) and the
+    replicate incongruence (MCI) are taken on the device, and the records are formatted from those few hundred bytes
+    per unit.  As in the reference every unit restarts from the same seed (application/baseclass.py:360-388,
+    assemble/mcmc.py:140-142), so the result does not depend on the order or the batching of the targets."""
+    from .assemble import DenovoMCMC
+    from .classes import PosteriorGenotypeDistribution
+    from .device import DenovoRaggedBatch
+
     samples = list(sample_bams)
     bams = {s: read_bam(p) for s, p in sample_bams.items()}
+    ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
     _, variants = read_vcf(variants_vcf_path)
-    for contig, start, stop, name in read_bed4(bed_path):
-        locus = DenovoLocus(contig, start, stop, name, variants, reference_sequences[contig][start:stop])
-        yield assemble_record(locus, bams, samples, **kw)
+    loci = [DenovoLocus(contig, start, stop, name, variants, reference_sequences[contig][start:stop])
+            for contig, start, stop, name in read_bed4(bed_path)]
+    encoded = {}
+    units, where = [], []
+    for li, locus in enumerate(loci):
+        M = len(locus.positions)
+        for sample in samples:
+            sr = sample_reads(locus, bams[sample], sample, error_rate, use_phred)
+            encoded[(li, sample)] = sr
+            if M == 0:
+                continue  # nothing to sample: the empty genotype with probability 1
+            dists, counts = sr["dists"], sr["counts"]
+            if len(dists) == 0:  # no reads: one all-gap read (assemble/mcmc.py:132-137)
+                dists, counts = np.full((1, M, int(max(locus.n_alleles))), np.nan), None
+            units.append(dict(reads=dists, counts=counts, n_alleles=locus.n_alleles, ploidy=int(ploidy_of(sample)),
+                              inbreeding=inbreeding_of(sample), stream_id=0))
+            where.append((li, sample))
+    summaries = {}
+    if units:
+        model = DenovoMCMC(ploidy=int(ploidy_of(samples[0])), n_alleles=[2], inbreeding=None, steps=steps, chains=chains, random_seed=seed, **mcmc_kw)
+        batch = DenovoRaggedBatch(model, units)
+        batch.run(burn, incongruence_threshold=incongruence_threshold)
+        for key, res in zip(where, batch.results()):
+            summaries[key] = res
+    for li, locus in enumerate(loci):
+        M = len(locus.positions)
+        per, posteriors = {}, []
+        for sample in samples:
+            sr = encoded[(li, sample)]
+            K = int(ploidy_of(sample))
+            if M == 0:
+                res = dict(genotypes=np.zeros((1, K, 0), np.int8), probabilities=np.ones(1), spm=1.0, gpm=1.0,
+                           mode_genotype=np.zeros((K, 0), np.int8), mci=0)
+            else:
+                res = summaries[(li, sample)]
+            posteriors.append(PosteriorGenotypeDistribution(res["genotypes"], res["probabilities"]))
+            calls, depth = sr["calls"], sr["depth"]
+            mec = _mec(calls, res["mode_genotype"])
+            denom = int((calls >= 0).sum())
+            per[sample] = dict(genotype=res["mode_genotype"], gprob=float(res["gpm"]), sprob=float(res["spm"]), mec=mec,
+                               mecp=mec / denom if denom > 0 else np.nan, mci=int(res["mci"]), rcount=len(calls), rcalls=denom,
+                               dp=np.round(np.mean(depth)) if len(depth) else np.nan)
+        yield _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold)

@@ -278,3 +278,159 @@ class ExactDeviceBatch:
             res["llks"] = self._host("llks", (U, self.G))
             res["posteriors"] = self._host("posteriors", (U, self.G))
         return res
+
+
+class DenovoRaggedBatch:
+    """Units of different shapes (loci with different numbers of SNVs and alleles, samples with different read depths,
+    per-sample ploidy / inbreeding) in ONE sampler launch, with the posterior summary and the replicate incongruence
+    taken on the device: what `mchap assemble` needs per (locus x sample) comes back as a few hundred bytes per unit.
+
+    units: list of dicts with reads float64 [R, M, A] (R >= 1, M >= 1), counts int64 [R] or None, n_alleles int [M],
+    ploidy int, inbreeding float or None, stream_id int.  Sampler settings from `model` (a DenovoMCMC; its ploidy /
+    n_alleles / inbreeding fields are not used)."""
+
+    n_runs = 0  # sampler launches issued by this class (the application tests assert O(1) per VCF)
+
+    def __init__(self, model: DenovoMCMC, units, device=None):
+        torch = _torch()
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        dev = self.device
+        self.model = model
+        U = len(units)
+        Cn, S = int(model.chains), int(model.steps)
+        self.Cn, self.S = Cn, S
+        desc = np.zeros(U, dtype=_lib.UNIT_DTYPE)
+        r_parts, c_parts, a_parts = [], [], []
+        r_off = c_off = a_off = t_off = l_off = f_off = 0
+        self.Kmax = max(int(u["ploidy"]) for u in units)
+        self.max_pos = max(u["reads"].shape[1] for u in units)
+        for i, u in enumerate(units):
+            rd = np.ascontiguousarray(u["reads"], dtype=np.float64)
+            R, M, A = rd.shape
+            assert R >= 1 and M >= 1 and len(u["n_alleles"]) == M
+            K = int(u["ploidy"])
+            D = desc[i]
+            D["reads_off"] = r_off
+            r_parts.append(rd.reshape(-1))
+            r_off += rd.size
+            if u.get("counts") is not None:
+                cn = np.ascontiguousarray(u["counts"], dtype=np.int64)
+                assert cn.shape == (R,)
+                D["counts_off"] = c_off
+                c_parts.append(cn)
+                c_off += R
+            else:
+                D["counts_off"] = -1
+            D["nalleles_off"] = a_off
+            a_parts.append(np.asarray(u["n_alleles"], dtype=np.int8))
+            a_off += M
+            D["initial_off"] = -1
+            D["trace_off"] = t_off
+            t_off += Cn * S * K
+            D["llk_off"] = l_off
+            l_off += Cn * S
+            D["fixed_off"] = f_off
+            f_off += M
+            D["n_reads"], D["n_pos"], D["max_allele"], D["ploidy"] = R, M, A, K
+            F = u.get("inbreeding")
+            D["inbreeding"] = np.nan if F is None else float(F)
+            D["stream_id"] = int(u.get("stream_id", 0))
+        self.units_host = desc
+        self.n_units = U
+        self.d_units = torch.from_numpy(desc.view(np.uint8).reshape(-1)).to(dev)
+        self.d_reads = torch.from_numpy(np.concatenate(r_parts)).to(dev)
+        self.d_counts = torch.from_numpy(np.concatenate(c_parts)).to(dev) if c_parts else None
+        self.d_nalleles = torch.from_numpy(np.concatenate(a_parts)).to(dev)
+        self.d_trace = torch.empty(t_off, dtype=torch.int64, device=dev)
+        self.d_llks = torch.empty(l_off, dtype=torch.float64, device=dev)
+        self.d_fixed = torch.empty(f_off, dtype=torch.int8, device=dev)
+        self.d_status = torch.empty(U, dtype=torch.int32, device=dev)
+        self.cfg = model._cfg(self.max_pos)
+        self.ws_bytes = int(_lib.lib().mchap_denovo_workspace_bytes(C.byref(self.cfg), U, _lib.ptr(desc)))
+        if self.ws_bytes < 0:
+            raise NotImplementedError("mchap_hip: unsupported unit shape")
+        self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
+
+    def _p(self, t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def run(self, burn, max_states=512, incongruence_threshold=0.6):
+        """Sampler, posterior summary and incongruence code, all enqueued on torch's current stream."""
+        torch = self.torch
+        dev = self.device
+        U, K = self.n_units, self.Kmax
+        stream = torch.cuda.current_stream().cuda_stream
+        L = _lib.lib()
+        type(self).n_runs += 1
+        _lib.check(L.mchap_denovo_fit_batch_device(
+            C.byref(self.cfg), U, self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_reads), self._p(self.d_counts),
+            self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks), self._p(self.d_fixed),
+            self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream)))
+        self.max_states = max_states
+        self.p_words = torch.empty(U * max_states * K, dtype=torch.int64, device=dev)
+        self.p_counts = torch.empty(U * max_states, dtype=torch.int32, device=dev)
+        self.p_n = torch.empty(U, dtype=torch.int32, device=dev)
+        self.p_stats = torch.empty(U * 2, dtype=torch.float64, device=dev)
+        self.p_mode = torch.empty(U, dtype=torch.int32, device=dev)
+        self.p_mode_words = torch.empty(U * K, dtype=torch.int64, device=dev)
+        self.p_mode_count = torch.empty(U, dtype=torch.int32, device=dev)
+        self.p_mci = torch.empty(U, dtype=torch.int32, device=dev)
+        _lib.check(L.mchap_trace_posterior_batch_device(
+            U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), int(max_states), K, self._p(self.p_words),
+            self._p(self.p_counts), self._p(self.p_n), self._p(self.p_stats), self._p(self.p_mode), self._p(self.p_mode_words),
+            self._p(self.p_mode_count), C.c_void_p(stream)))
+        _lib.check(L.mchap_trace_incongruence_batch_device(
+            U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), K, C.c_double(float(incongruence_threshold)),
+            self._p(self.p_mci), C.c_void_p(stream)))
+        self.burn = int(burn)
+
+    def results(self):
+        """Per unit: dict(genotypes int8 [n, K, M] distinct states (probability descending), probabilities [n], spm, gpm,
+        mode_genotype int8 [K, M], mci, status).  Units with more distinct states than the kernel keeps are summarised
+        from their downloaded trace by the host classes."""
+        from .classes import GenotypeMultiTrace
+
+        U, K, ms = self.n_units, self.Kmax, self.max_states
+        words = self.p_words.cpu().numpy().view(np.uint64).reshape(U, ms, K)
+        counts = self.p_counts.cpu().numpy().reshape(U, ms)
+        n = self.p_n.cpu().numpy()
+        stats = self.p_stats.cpu().numpy().reshape(U, 2)
+        mode_words = self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K)
+        mci = self.p_mci.cpu().numpy()
+        status = self.d_status.cpu().numpy()
+        fixed = self.d_fixed.cpu().numpy()
+        total = self.Cn * (self.S - self.burn)
+        out = []
+        trace = llks = None
+        for u in range(U):
+            D = self.units_host[u]
+            Ku, M, A = int(D["ploidy"]), int(D["n_pos"]), int(D["max_allele"])
+            fx = fixed[int(D["fixed_off"]): int(D["fixed_off"]) + M]
+            st = int(status[u])
+            if st == _lib.UNIT_NAN_LLK:
+                raise ValueError("Encountered log likelihood of nan")
+            if st == _lib.UNIT_BREAKS:
+                raise ValueError("breaks must be smaller then n")
+            if st < 0:
+                raise NotImplementedError("mchap_hip: unit %d exceeds the packed haplotype width" % u)
+            if n[u] < 0 or n[u] > ms or mci[u] < 0:
+                # more distinct states than the device summary keeps: the host classes on the trace
+                if trace is None:
+                    trace = self.d_trace.cpu().numpy().view(np.uint64)
+                    llks = self.d_llks.cpu().numpy()
+                w = trace[int(D["trace_off"]): int(D["trace_off"]) + self.Cn * self.S * Ku].reshape(self.Cn, self.S, Ku)
+                g = unpack_trace(w, fx, A)
+                lk = llks[int(D["llk_off"]): int(D["llk_off"]) + self.Cn * self.S].reshape(self.Cn, self.S)
+                tr = GenotypeMultiTrace._from_sorted(g, lk).burn(self.burn)
+                post = tr.posterior()
+                sup = post.mode_genotype_support()
+                mg, gp = sup.mode_genotype()
+                out.append(dict(genotypes=post.genotypes, probabilities=post.probabilities, spm=float(sup.probabilities.sum()),
+                                gpm=float(gp), mode_genotype=mg, mci=int(tr.replicate_incongruence(0.6)), status=st))
+                continue
+            k = int(n[u])
+            out.append(dict(genotypes=unpack_trace(words[u, :k, :Ku], fx, A), probabilities=counts[u, :k] / total,
+                            spm=float(stats[u, 0]), gpm=float(stats[u, 1]), mode_genotype=unpack_trace(mode_words[u, :Ku], fx, A),
+                            mci=int(mci[u]), status=st))
+        return out

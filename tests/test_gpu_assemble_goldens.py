@@ -71,3 +71,26 @@ def test_deep_assemble_golden_whole_records():
                                     inbreeding=0.0, steps=500, burn=100, chains=2, seed=11))
     want = [ln.rstrip("\n") for ln in open(os.path.join(HERE, "simple.output.deep.assemble.vcf")) if ln.strip() and not ln.startswith("#")]
     assert got == want
+
+
+def test_assemble_is_one_sampler_launch_per_vcf():
+    """The batched application: every (target x sample) unit of the file in ONE sampler launch, posterior summary and MCI
+    from the device kernels (reference application/assemble.py:95-252 loops over samples and loci)."""
+    from mchap_amd import application
+    from mchap_amd.device import DenovoRaggedBatch
+
+    bams = {s: os.path.join(HERE, f) for s, f in zip(["SAMPLE1", "SAMPLE2", "SAMPLE3"],
+                                                     ["simple.sample1.bam", "simple.sample2.bam", "simple.sample3.bam"])}
+    ref = {c: SEQ for c in ("CHR1", "CHR2", "CHR3")}
+    before = DenovoRaggedBatch.n_runs
+    lines = list(application.assemble(os.path.join(HERE, "simple.bed"), os.path.join(HERE, "simple.vcf"), ref, bams, ploidy=4,
+                                      inbreeding=0.0, steps=300, burn=100, chains=2, seed=11))
+    assert DenovoRaggedBatch.n_runs - before == 1
+    assert len(lines) == len(open(os.path.join(HERE, "simple.bed")).read().strip().splitlines())
+    # per-sample parameters (the reference's --sample-ploidy / --sample-inbreeding files): a mapping instead of a value
+    mixed = list(application.assemble(os.path.join(HERE, "simple.bed"), os.path.join(HERE, "simple.vcf"), ref, bams,
+                                      ploidy={"SAMPLE1": 4, "SAMPLE2": 2, "SAMPLE3": 4}, inbreeding={"SAMPLE1": 0.0, "SAMPLE2": 0.1, "SAMPLE3": 0.0},
+                                      steps=200, burn=50, chains=2, seed=11))
+    for ln in mixed:
+        cols = ln.split("\t")
+        assert len(cols[10].split(":")[0].split("/")) == 2 and len(cols[9].split(":")[0].split("/")) == 4
