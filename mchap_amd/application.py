@@ -166,7 +166,7 @@ def _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_ta
         if invalid:
             gts[sample] = np.full(ploidy, -1, int)
             fields = ["/".join(["."] * ploidy), ".", ".", vcfstr(float(dp)), str(rcount), str(rcalls), ".", ".", ".", ".", "."]
-            fields += ["."] * len(report)
+            fields += ["."] * len([t for t in report if t in ("AFP", "ACP", "AOP", "SNVDP", "GL", "GP")])
             cols[sample] = ":".join(fields)
             nan_arrays = True
             continue
@@ -408,3 +408,107 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
                                mecp=mec / denom if denom > 0 else np.nan, mci=int(res["mci"]), rcount=len(calls), rcalls=denom,
                                dp=np.round(np.mean(depth)) if len(depth) else np.nan)
         yield _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mchap call (application/call.py:52-199): Gibbs sampler over the known haplotypes of an input VCF
+# ---------------------------------------------------------------------------------------------------------
+def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use_base_phred_scores=False,
+         prior_frequencies_tag=None, inbreeding=None, steps=2000, burn=1000, chains=2, seed=None,
+         incongruence_threshold=0.60, step_type="Gibbs"):
+    """`mchap call`: yields one VCF record line per record of the input VCF (no header).  Units ((record x sample)) are
+    grouped by shape and each group is one launch of the sampler kernel (CallingMCMC.fit_batch); as in the reference every
+    unit restarts from the same seed."""
+    from .calling_mcmc import CallingMCMC, GenotypeAllelesMultiTrace
+    from . import calling
+
+    samples = list(sample_bams)
+    bams = {s: read_bam(p) for s, p in sample_bams.items()}
+    _, records = read_vcf(vcf_path)
+    report = tuple(report)
+    ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
+    units = _exact_units(records, bams, samples, ploidy, report, base_error_rate, use_base_phred_scores, prior_frequencies_tag, inbreeding)
+    # haplotypes with zero prior frequency (and a masked reference) are left out of the sampler (call.py:72-84)
+    groups = {}
+    for ri, unit in enumerate(units):
+        locus = unit["locus"]
+        H, M = locus.haplotypes.shape
+        keep = np.ones(H, bool)
+        if locus.mask_reference_allele:
+            keep[0] = False
+        keep &= ~(np.nan_to_num(locus.frequencies, nan=1.0) == 0)
+        unit["keep"] = keep
+        if unit["invalid"] is None and keep.sum() == 0:
+            unit["invalid"] = "NOA"
+        if unit["invalid"] is not None or M == 0:
+            continue
+        for s in samples:
+            groups.setdefault((M, int(max(locus.n_alleles)), int(keep.sum()), int(ploidy_of(s))), []).append((ri, s))
+    results = {}
+    for (M, A, H, K), members in groups.items():
+        Rmax = max(max(len(units[ri]["reads"][s]["dists"]), 1) for ri, s in members)
+        U = len(members)
+        reads = np.full((U, Rmax, M, A), np.nan)
+        counts = np.zeros((U, Rmax), dtype=np.int64)
+        haps = np.zeros((U, H, M), dtype=np.int8)
+        has_prior = inbreeding_of(members[0][1]) is not None
+        Fs, frs = np.zeros(U), np.zeros((U, H))
+        for i, (ri, s) in enumerate(members):
+            sr, locus = units[ri]["reads"][s], units[ri]["locus"]
+            n = len(sr["dists"])
+            if n:
+                reads[i, :n] = sr["dists"]
+                counts[i, :n] = sr["counts"]
+            haps[i] = locus.haplotypes[units[ri]["keep"]]
+            if has_prior:
+                Fs[i] = inbreeding_of(s)
+                frs[i] = locus.frequencies[units[ri]["keep"]]
+        model = CallingMCMC(ploidy=K, haplotypes=haps[0], steps=steps, chains=chains, random_seed=seed, step_type=step_type)
+        traces = model.fit_batch(reads, counts, haplotypes=haps, prior=(Fs, frs) if has_prior else None,
+                                 stream_ids=np.zeros(U, dtype=np.uint64))
+        for key, tr in zip(members, traces):
+            results[key] = tr
+    for ri, unit in enumerate(units):
+        rec, locus = unit["rec"], unit["locus"]
+        H, M = locus.haplotypes.shape
+        res = {}
+        if unit["invalid"] is None:
+            for s in samples:
+                K = int(ploidy_of(s))
+                if M == 0:
+                    trace = GenotypeAllelesMultiTrace(np.zeros((chains, steps, K), np.int8), np.full((chains, steps), np.nan), 1)
+                else:
+                    trace = results[(ri, s)]
+                trace = trace.burn(burn)
+                if not unit["keep"].all() and M > 0:
+                    trace = trace.relabel(np.flatnonzero(unit["keep"]))
+                post = trace.posterior()
+                alleles, gprob, sprob = post.mode(genotype_support=True)
+                f0, _, o0 = trace.posterior_frequencies()  # over the alleles the trace knows: pad to the record's
+                freqs, occur = np.zeros(H), np.zeros(H)
+                freqs[: len(f0)], occur[: len(o0)] = f0[:H], o0[:H]
+                r = dict(alleles=np.asarray(alleles), gprob=float(gprob), sprob=float(sprob), freqs=freqs, occur=occur,
+                         mci=int(trace.replicate_incongruence(threshold=incongruence_threshold)))
+                if "GP" in report:
+                    r["GP"] = post.as_array(H)
+                if "GL" in report:
+                    sr = unit["reads"][s]
+                    r["GL"] = calling.genotype_likelihoods(sr["dists"], K, locus.haplotypes, read_counts=sr["counts"]).astype(np.float64) / np.log(10)
+                res[(ri, s)] = r
+        flt, info, fmt, cols = _format_exact_record(dict(unit, invalid=unit["invalid"]), samples, _Forced(res), ri, ploidy_of, report, prior_frequencies_tag)
+        # MCI is a sampler statistic here: per sample in the FORMAT column, the number of incongruent samples in INFO
+        if unit["invalid"] is None:
+            n_inc = 0
+            for s in samples:
+                f = cols[s].split(":")
+                f[10] = str(res[(ri, s)]["mci"])
+                n_inc += int(res[(ri, s)]["mci"] > 0)
+                cols[s] = ":".join(f)
+            info = info.replace(";MCI=0;", ";MCI=%d;" % n_inc)
+        alt = ",".join(rec["alts"]) if rec["alts"] else "."
+        yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
+
+
+class _Forced(dict):
+    """results mapping for _format_exact_record that also serves records with a single haplotype or no position (the
+    sampler path has its own summaries for those)."""

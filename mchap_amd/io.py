@@ -230,3 +230,105 @@ class DenovoLocus:
 
 def read_bed4(path):
     return [(f[0], int(f[1]), int(f[2]), f[3]) for f in (line.split() for line in open(path)) if len(f) >= 4]
+
+
+# ---- inputs of the command line programs ----
+def read_fasta(path):
+    """{contig: sequence} of a (possibly gzip / bgzip compressed) FASTA file; the fetch of io/loci.py:86-92 is a slice of it."""
+    opener = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
+    seqs, name, parts = {}, None, []
+    with opener(path, "rt") as f:
+        for line in f:
+            line = line.strip()
+            if not line:
+                continue
+            if line.startswith(">"):
+                if name is not None:
+                    seqs[name] = "".join(parts)
+                name, parts = line[1:].split()[0], []
+            else:
+                parts.append(line.upper())
+    if name is not None:
+        seqs[name] = "".join(parts)
+    return seqs
+
+
+def bam_header(path):
+    """(reference names with lengths, {read group id: sample}) of a BAM file."""
+    data = gzip.open(path, "rb")
+    head = data.read(8)
+    assert head[:4] == b"BAM\1"
+    (l_text,) = struct.unpack("<i", head[4:8])
+    text = data.read(l_text).decode().rstrip("\0")
+    (n_ref,) = struct.unpack("<i", data.read(4))
+    refs = []
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack("<i", data.read(4))
+        nm = data.read(l_name)[:-1].decode()
+        (l_ref,) = struct.unpack("<i", data.read(4))
+        refs.append((nm, l_ref))
+    rg = {}
+    for line in text.splitlines():
+        if line.startswith("@RG"):
+            f = dict(x.split(":", 1) for x in line.split("\t")[1:])
+            rg[f["ID"]] = f.get("SM", f["ID"])
+    return refs, rg
+
+
+def sample_bam_table(bam_args):
+    """--bam: (1) BAM paths, (2) a text file with one path per line, (3) a text file of `sample<TAB>path` lines
+    (reference application/arguments.py:135-152, 890-955).  Returns an ordered {sample: path}: for (1) and (2) every
+    sample of every BAM's read groups."""
+    paths, table = [], {}
+    if len(bam_args) == 1 and not _is_bam(bam_args[0]):
+        for line in open(bam_args[0]):
+            f = line.rstrip("\n").split("\t")
+            if not f or not f[0].strip():
+                continue
+            if len(f) == 1:
+                paths.append(f[0].strip())
+            else:
+                if f[0] in table:
+                    raise IOError('Duplicate input sample name "%s"' % f[0])
+                table[f[0]] = f[1].strip()
+        if table:
+            for s, p in table.items():
+                if s not in bam_header(p)[1].values():
+                    raise IOError('Sample "%s" was not found in bam "%s"' % (s, p))
+            return table
+    else:
+        paths = list(bam_args)
+    for p in paths:
+        for s in dict.fromkeys(bam_header(p)[1].values()):
+            if s in table:
+                raise IOError('Duplicate input sample name "%s"' % s)
+            table[s] = p
+    return table
+
+
+def _is_bam(path):
+    try:
+        with gzip.open(path, "rb") as f:
+            return f.read(4) == b"BAM\1"
+    except OSError:
+        return False
+
+
+def sample_values(arg, samples, cast, default=None):
+    """--ploidy / inbreeding: one value for all samples, or a text file of `sample<TAB>value` lines naming every sample
+    (reference application/arguments.py:957-988, 1122-1166).  Returns a value or a {sample: value} mapping."""
+    import os
+
+    if arg is None:
+        return default
+    if os.path.isfile(str(arg)):
+        table = {}
+        for line in open(arg):
+            f = line.rstrip("\n").split("\t")
+            if len(f) >= 2:
+                table[f[0]] = cast(f[1])
+        missing = [s for s in samples if s not in table]
+        if missing:
+            raise IOError('Sample "%s" is not specified in "%s"' % (missing[0], arg))
+        return {s: table[s] for s in samples}
+    return cast(arg)

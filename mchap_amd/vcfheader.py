@@ -1,0 +1,106 @@
+"""VCF meta-information of the programs' output: the header block `mchap assemble / call / call-exact` write before
+their records (reference io/vcf/headermeta.py, infofields.py, formatfields.py, filters.py, application/baseclass.py:
+392-434).  The field identifiers, Number / Type and description strings are the output format itself (a consumer of
+the reference's VCFs must find the same declarations), so they are tabulated here once."""
+from datetime import date
+
+
+
+FILTERS = [
+    ("PASS", "All filters passed"),
+    ("NOA", "No observed alleles at locus"),
+    ("AF0", "All alleles have prior allele frequency of zero"),
+]
+
+# (id, Number, Type, Description); the order is the order of the header and of the INFO column
+INFO_FIELDS = [
+    ("AN", "1", "Integer", "Total number of alleles in called genotypes"),
+    ("UAN", "1", "Integer", "Total number of unique alleles in called genotypes"),
+    ("AC", "A", "Integer", "Allele count in genotypes, for each ALT allele, in the same order as listed"),
+    ("REFMASKED", "0", "Flag", "Reference allele is masked"),
+    ("NS", "1", "Integer", "Number of samples with data"),
+    ("MCI", "1", "Integer", "Number of samples with incongruent Markov chain replicates"),
+    ("DP", "1", "Integer", "Combined depth across samples"),
+    ("RCOUNT", "1", "Integer", "Total number of observed reads across all samples"),
+    ("END", "1", "Integer", "End position on CHROM"),
+    ("NVAR", "1", "Integer", "Number of input variants within assembly locus"),
+    ("SNVPOS", ".", "Integer", "Relative (1-based) positions of SNVs within haplotypes"),
+]
+OPTIONAL_INFO_FIELDS = {
+    "AFPRIOR": ("R", "Float", "Prior allele frequencies"),
+    "ACP": ("R", "Float", "Posterior allele counts"),
+    "AFP": ("R", "Float", "Posterior mean allele frequencies"),
+    "AOP": ("R", "Float", "Posterior probability of allele occurring across all samples"),
+    "AOPSUM": ("R", "Float", "Posterior estimate of the number of samples containing an allele"),
+    "SNVDP": (".", "Integer", "Read depth at each SNV position"),
+}
+FORMAT_FIELDS = [
+    ("GT", "1", "String", "Genotype"),
+    ("GQ", "1", "Integer", "Genotype quality"),
+    ("SQ", "1", "Integer", "Genotype support quality"),
+    ("DP", "1", "Integer", "Read depth"),
+    ("RCOUNT", "1", "Integer", "Total count of read pairs within haplotype interval"),
+    ("RCALLS", "1", "Integer", "Total count of read base calls matching a known variant"),
+    ("MEC", "1", "Integer", "Minimum error correction"),
+    ("MECP", "1", "Float", "Minimum error correction proportion"),
+    ("GPM", "1", "Float", "Genotype posterior mode probability"),
+    ("SPM", "1", "Float", "Genotype support posterior mode probability"),
+    ("MCI", "1", "Integer", "Replicate Markov-chain incongruence, 0 = none, 1 = incongruence, 2 = putative CNV"),
+]
+OPTIONAL_FORMAT_FIELDS = {
+    "ACP": ("R", "Float", "Posterior allele counts"),
+    "AFP": ("R", "Float", "Posterior mean allele frequencies"),
+    "AOP": ("R", "Float", "Posterior probability of allele occurring"),
+    "GP": ("G", "Float", "Genotype posterior probabilities"),
+    "GL": ("G", "Float", "Genotype likelihoods"),
+    "SNVDP": (".", "Integer", "Read depth at each SNV position"),
+}
+
+
+def report_fields(report):
+    """--report arguments -> (optional INFO ids, optional FORMAT ids) in their header order.  A bare name asks for both
+    variants of the field; an `INFO/` or `FORMAT/` prefix for one (reference application/arguments.py:405-426)."""
+    info, fmt = [], []
+    for name in report:
+        if name.startswith("INFO/"):
+            info.append(name[5:])
+        elif name.startswith("FORMAT/"):
+            fmt.append(name[7:])
+        else:
+            if name in OPTIONAL_INFO_FIELDS:
+                info.append(name)
+            if name in OPTIONAL_FORMAT_FIELDS:
+                fmt.append(name)
+    if "AOP" in info and "AOPSUM" not in info:
+        info.insert(info.index("AOP") + 1, "AOPSUM")
+    for x in info:
+        if x not in OPTIONAL_INFO_FIELDS:
+            raise ValueError("Unknown INFO field to report: %s" % x)
+    for x in fmt:
+        if x not in OPTIONAL_FORMAT_FIELDS:
+            raise ValueError("Unknown FORMAT field to report: %s" % x)
+    return info, fmt
+
+
+def header_lines(program, command, samples, contigs, report=(), random_seed=None, today=None, version=None):
+    """The header block as a list of lines.  contigs: [(name, length)]; command: the argv list or a string."""
+    from . import __version__
+
+    d = today or date.today()
+    cmd = command if isinstance(command, str) else '"%s"' % " ".join(command)
+    out = ["##fileformat=VCFv4.3", "##fileDate=%04d%02d%02d" % (d.year, d.month, d.day),
+           "##source=mchap_amd v%s (%s)" % (version or __version__, program), "##phasing=None", "##commandline=%s" % cmd,
+           "##randomseed=%s" % random_seed]
+    out += ["##contig=<ID=%s,length=%d>" % (n, l) for n, l in contigs]
+    out += ['##FILTER=<ID=%s,Description="%s">' % f for f in FILTERS]
+    info_opt, fmt_opt = report_fields(report)
+    for fid, num, typ, descr in INFO_FIELDS:
+        out.append('##INFO=<ID=%s,Number=%s,Type=%s,Description="%s">' % (fid, num, typ, descr))
+    for fid in info_opt:
+        out.append('##INFO=<ID=%s,Number=%s,Type=%s,Description="%s">' % ((fid,) + OPTIONAL_INFO_FIELDS[fid]))
+    for fid, num, typ, descr in FORMAT_FIELDS:
+        out.append('##FORMAT=<ID=%s,Number=%s,Type=%s,Description="%s">' % (fid, num, typ, descr))
+    for fid in fmt_opt:
+        out.append('##FORMAT=<ID=%s,Number=%s,Type=%s,Description="%s">' % ((fid,) + OPTIONAL_FORMAT_FIELDS[fid]))
+    out.append("#" + "\t".join(["CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"] + list(samples)))
+    return out

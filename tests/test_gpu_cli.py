@@ -1,0 +1,69 @@
+"""GPU: the programs end to end through the command-line shell (python -m mchap_amd ...): VCF header + records from BAM /
+VCF / BED / FASTA files, against the reference's golden VCFs (call-exact, deep assemble) and, for `mchap call` (whose
+goldens depend on numba's generator), against call-exact on the same data."""
+import io as _io
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_data")
+MIXED = ["simple.sample1.bam", "simple.sample2.deep.bam", "simple.sample3.bam"]
+DEEP = ["simple.sample1.deep.bam", "simple.sample2.deep.bam", "simple.sample3.deep.bam"]
+
+
+def _records(text):
+    return [ln for ln in text.splitlines() if ln and not ln.startswith("#")]
+
+
+def _golden(name):
+    return [ln.rstrip("\n") for ln in open(os.path.join(HERE, name)) if ln.strip() and not ln.startswith("#")]
+
+
+def test_call_exact_program_reproduces_the_golden_vcf():
+    from mchap_amd import cli
+
+    out = _io.StringIO()
+    argv = ["mchap_amd", "call-exact", "--bam"] + [os.path.join(HERE, f) for f in MIXED] + [
+        "--ploidy", "4", "--haplotypes", os.path.join(HERE, "mock.input.frequencies.vcf"), "--prior-frequencies", "AFP",
+        "--use-dirmul-prior", "0.0", "AFP", "--report", "AFPRIOR", "AFP"]
+    n = cli.run(argv, out)
+    text = out.getvalue()
+    assert _records(text) == _golden("simple.output.mixed_depth.call-exact.frequencies.prior.vcf") and n == len(_records(text))
+    head = [ln for ln in text.splitlines() if ln.startswith("#")]
+    assert head[0] == "##fileformat=VCFv4.3" and head[-1].split("\t")[9:] == ["SAMPLE1", "SAMPLE2", "SAMPLE3"]
+    assert any(ln.startswith("##commandline=") and "call-exact" in ln for ln in head)
+
+
+def test_assemble_program_reproduces_the_deep_golden_vcf(tmp_path):
+    from mchap_amd import cli
+
+    fa = tmp_path / "simple.fasta"
+    fa.write_text("".join(">%s\n%s\n" % (c, "A" * 60) for c in ("CHR1", "CHR2", "CHR3")))
+    ploidy = tmp_path / "ploidy.txt"
+    ploidy.write_text("SAMPLE1\t4\nSAMPLE2\t4\nSAMPLE3\t4\n")
+    out = _io.StringIO()
+    argv = ["mchap_amd", "assemble", "--bam"] + [os.path.join(HERE, f) for f in DEEP] + [
+        "--ploidy", str(ploidy), "--targets", os.path.join(HERE, "simple.bed"), "--variants", os.path.join(HERE, "simple.vcf"),
+        "--reference", str(fa), "--use-dirmul-prior", "0.0", "--mcmc-steps", "500", "--mcmc-burn", "100", "--mcmc-seed", "11"]
+    cli.run(argv, out)
+    assert _records(out.getvalue()) == _golden("simple.output.deep.assemble.vcf")
+
+
+def test_call_program_agrees_with_call_exact_on_deep_data():
+    from mchap_amd import cli
+
+    common = ["--bam"] + [os.path.join(HERE, f) for f in DEEP] + ["--ploidy", "4", "--haplotypes", os.path.join(HERE, "simple.output.deep.assemble.vcf")]
+    a, b = _io.StringIO(), _io.StringIO()
+    cli.run(["mchap_amd", "call-exact"] + common, a)
+    cli.run(["mchap_amd", "call"] + common + ["--mcmc-steps", "600", "--mcmc-burn", "100", "--mcmc-seed", "11", "--report", "AFP"], b)
+    ra, rb = _records(a.getvalue()), _records(b.getvalue())
+    assert len(ra) == len(rb) > 0
+    for x, y in zip(ra, rb):
+        fx, fy = x.split("\t"), y.split("\t")
+        assert fx[:7] == fy[:7]
+        for sx, sy in zip(fx[9:], fy[9:]):
+            gx, gy = sx.split(":"), sy.split(":")
+            assert gx[0] == gy[0]                      # GT
+            assert gy[10] in ("0", "1", "2")           # MCI from the sampler's replicate chains
+            assert abs(float(gx[8]) - float(gy[8])) < 0.05 if gx[8] != "." else True   # GPM
