@@ -26,6 +26,18 @@ extern "C" int mchap_spec_init_2_32(const double *, const double *);
 extern "C" int mchap_spec_launch_2_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 extern "C" int mchap_spec_init_2_64(const double *, const double *);
 extern "C" int mchap_spec_launch_2_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_3_16(const double *, const double *);
+extern "C" int mchap_spec_launch_3_16(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_3_32(const double *, const double *);
+extern "C" int mchap_spec_launch_3_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_3_64(const double *, const double *);
+extern "C" int mchap_spec_launch_3_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_5_32(const double *, const double *);
+extern "C" int mchap_spec_launch_5_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_5_64(const double *, const double *);
+extern "C" int mchap_spec_launch_5_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_spec_init_7_64(const double *, const double *);
+extern "C" int mchap_spec_launch_7_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 extern "C" int mchap_spec_init_4_16(const double *, const double *);
 extern "C" int mchap_spec_launch_4_16(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 extern "C" int mchap_spec_init_4_32(const double *, const double *);
@@ -76,6 +88,12 @@ extern "C" int mchap_v1_launch_16(const mchap::DenovoParams *, unsigned, unsigne
 extern "C" int mchap_spec_stats_2_16(unsigned long long *, int);
 extern "C" int mchap_spec_stats_2_32(unsigned long long *, int);
 extern "C" int mchap_spec_stats_2_64(unsigned long long *, int);
+extern "C" int mchap_spec_stats_3_16(unsigned long long *, int);
+extern "C" int mchap_spec_stats_3_32(unsigned long long *, int);
+extern "C" int mchap_spec_stats_3_64(unsigned long long *, int);
+extern "C" int mchap_spec_stats_5_32(unsigned long long *, int);
+extern "C" int mchap_spec_stats_5_64(unsigned long long *, int);
+extern "C" int mchap_spec_stats_7_64(unsigned long long *, int);
 extern "C" int mchap_spec_stats_4_16(unsigned long long *, int);
 extern "C" int mchap_spec_stats_4_32(unsigned long long *, int);
 extern "C" int mchap_spec_stats_4_64(unsigned long long *, int);
@@ -403,7 +421,7 @@ int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipS
 // lanes per chain for the speculative sampler: every option of an interval step (<= K(K-1)) and half the
 // sub-steps of a mutation step (K * n_pos) must fit; 0 if the shape is not supported by it
 int spec_group(int K, int max_pos) {
-  if (K != 2 && K != 4 && K != 6 && K != 8) return 0;
+  if (K < 2 || K > 8) return 0;
   const int n = K * max_pos;
   int g = 16;
   if (const char *e = std::getenv("MCHAP_HIP_GROUP")) g = std::atoi(e);
@@ -411,8 +429,8 @@ int spec_group(int K, int max_pos) {
   while (g < 64 && (g < K * (K - 1) || 2 * g < n)) g *= 2;
   const int slots = (K == 8) ? 3 : 2;  // sub-steps per lane the instantiation supports (denovo_spec_kernel.hpp)
   if (g < K * (K - 1) || slots * g < n) return 0;
-  if (K == 6 && g < 32) g = 32;
-  if (K == 8) g = 64;
+  if ((K == 5 || K == 6) && g < 32) g = 32;  // instantiated group sizes: 2..4: 16/32/64, 5..6: 32/64, 7..8: 64
+  if (K >= 7) g = 64;
   return g;
 }
 
@@ -421,6 +439,12 @@ const SpecInst *spec_insts(int *n) {
     {2, 16, mchap_spec_init_2_16, mchap_spec_launch_2_16},
     {2, 32, mchap_spec_init_2_32, mchap_spec_launch_2_32},
     {2, 64, mchap_spec_init_2_64, mchap_spec_launch_2_64},
+    {3, 16, mchap_spec_init_3_16, mchap_spec_launch_3_16},
+    {3, 32, mchap_spec_init_3_32, mchap_spec_launch_3_32},
+    {3, 64, mchap_spec_init_3_64, mchap_spec_launch_3_64},
+    {5, 32, mchap_spec_init_5_32, mchap_spec_launch_5_32},
+    {5, 64, mchap_spec_init_5_64, mchap_spec_launch_5_64},
+    {7, 64, mchap_spec_init_7_64, mchap_spec_launch_7_64},
     {4, 16, mchap_spec_init_4_16, mchap_spec_launch_4_16},
     {4, 32, mchap_spec_init_4_32, mchap_spec_launch_4_32},
     {4, 64, mchap_spec_init_4_64, mchap_spec_launch_4_64},
@@ -485,7 +509,7 @@ int mchap_debug_stats(unsigned long long *out, int reset) {
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_stats), sizeof(z)));
   if (reset) HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::g_stats), z, sizeof(z)));
   // plus the copies of the speculative sampler's object files
-  int (*fs[])(unsigned long long *, int) = {mchap_spec_stats_2_16, mchap_spec_stats_2_32, mchap_spec_stats_2_64, mchap_spec_stats_4_16, mchap_spec_stats_4_32, mchap_spec_stats_4_64, mchap_spec_stats_6_32, mchap_spec_stats_6_64, mchap_spec_stats_8_64};
+  int (*fs[])(unsigned long long *, int) = {mchap_spec_stats_2_16, mchap_spec_stats_2_32, mchap_spec_stats_2_64, mchap_spec_stats_3_16, mchap_spec_stats_3_32, mchap_spec_stats_3_64, mchap_spec_stats_5_32, mchap_spec_stats_5_64, mchap_spec_stats_7_64, mchap_spec_stats_4_16, mchap_spec_stats_4_32, mchap_spec_stats_4_64, mchap_spec_stats_6_32, mchap_spec_stats_6_64, mchap_spec_stats_8_64};
   for (auto f : fs) {
     unsigned long long t[24];
     if (f(t, reset) != 0) return fail(MCHAP_ERR_HIP, "reading the counters of a sampler object");
