@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
       const double *row = E.ptab + (size_t)r * H;
       double rp = 0.0;
       for (int i = 0; i < kk; i++) rp += row[s_req[i]] * invk;
-      s += log(rp) * E.cnt[r];
+      s += read_log(rp) * E.cnt[r];
     }
     return wave_sum(s);
   };

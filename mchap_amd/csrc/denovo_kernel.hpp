@@ -290,7 +290,7 @@ __device__ __forceinline__ double eval_llk(const Chain &c, const uint64_t *hw, c
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += log(acc[i]) * cnt[i];
+  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cnt[i];
   return wave_sum(s);
 }
 
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(64 * CHAINS_PER_BLOCK) void denovo_mcmc_kernel(cons
       for (int i = 0; i < RPL; i++) {
         double rp = 0.0;
         for (int h = 0; h < K; h++) rp += rl[(size_t)(j * A + nib(g, h)) * rpad + lane + WAVE * i] / (double)K;
-        s += log(rp) * cnt[i];
+        s += read_log(rp) * cnt[i];
       }
       const double llk = wave_sum(s);
       lp[q] = lprior + llk;
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(64 * CHAINS_PER_BLOCK) void denovo_mcmc_kernel(cons
         status = MCHAP_UNIT_NAN_LLK;
         break;
       }
-      rng_open(c.rng, P.seed, U.stream_id, (uint32_t)chain, (uint32_t)t, c.rngn[t]);
+      rng_open(c.rng, P.seed, U.stream_id, (uint32_t)chain, (uint32_t)t, (uint64_t)step * STEP_DRAWS);
       llk = mutation_compound_step<RPL>(c, wt, llk, temp, cnt);
       for (int kind = 0; kind < 2; kind++) {
         const double pstep = kind == 0 ? P.p_recomb : P.p_partial;

@@ -1015,6 +1015,7 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
     {
       const bool act = running && skip == 0;
       const int n = KT * Mh;
+      if (act) c.ctr = (uint64_t)my_step * STEP_DRAWS;  // the step's draws (philox.hpp)
       const uint64_t ctr0 = c.ctr;
       const int E = lane_extra(Mh);
       LDSP(uint64_t) win = LL.win + (size_t)ci * LL.win_n;
@@ -1414,6 +1415,7 @@ __global__ __launch_bounds__(64, 4) void denovo_steady_kernel(const SimtParams P
   while (wave_any(running)) {
     // ---- mutation compound step ----
     bool ok = running;
+    if (running) ctr = (uint64_t)my_step * STEP_DRAWS;  // the step's draws (philox.hpp)
     if (ok && !(P.flags & 16)) ok = fast_mutation(st, ctr + (uint64_t)(n - 1), n, E, lo, hi, win, sl, L);  // (flag: timing experiments)
     lds_sync();
     ok = running && !(__ballot(running && !ok) & mine_mask);

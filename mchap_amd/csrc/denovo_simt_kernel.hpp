@@ -55,7 +55,30 @@ struct SimtParams {
   // steady-state pipeline (denovo_lane_kernel.hpp): per-chain hand-over records and threshold tables
   void *lane_state;  // [U * chains] LaneState
   void *lane_memo;   // [U * chains][2][tri(max_pos)] uint32
+  // phased sampler (kernel 5: denovo_spec_kernel<K, G, true> in phases + denovo_coast_kernel): hand-over records
+  void *pipe_state;           // [U * chains] PipeState
+  double *pipe_memo;          // [U * chains][2][tri(max_pos)] total move probabilities of the interval steps
+  const int32_t *pipe_list;   // chains of this launch (nullptr: all of them, in order)
+  const int32_t *pipe_count;  // their number, on the device (nullptr: all)
+  int32_t *pipe_out;          // coasting kernel: the chains it hands back, appended in any order
+  int32_t *pipe_out_count;
+  int pipe_iters;             // compound steps per chain in this launch (<= 0: to the end)
+  int pipe_iters_max;         // ... which a wave extends to while one of its chains is not settled (PIPE_EXPORT)
+  int pipe_mode;              // PIPE_RESUME | PIPE_EXPORT
 };
+constexpr int PIPE_RESUME = 1;  // start from the chains' PipeState records
+constexpr int PIPE_EXPORT = 2;  // at the end: complete the interval memo of the current genotype, write the records
+// hand-over record of a chain between the launches of the phased sampler
+struct PipeState {
+  uint64_t g[8];     // haplotype words in the chain's own (unsorted) order
+  double llk;
+  uint64_t ctr;      // next draw of the chain's stream
+  double mlo, mhi;   // mutation step: no move while every uniform is in [mlo, mhi)
+  int32_t step;      // MCMC steps done (== steps: finished, or stopped by an error status)
+  int32_t mvalid;
+  uint64_t pad[3];
+};
+static_assert(sizeof(PipeState) == 128, "PipeState layout");
 constexpr int SIMT_FLAG_PREP_GLOBAL = 1 << 30;  // table too large for the prepare pass's LDS copy
 
 // ---------------------------------------------------------------------------------------------------------
@@ -206,7 +229,7 @@ __global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) 
       for (int i = 0; i < RPL; i++) {
         double rp = 0.0;
         for (int h = 0; h < K; h++) rp += rowp[(size_t)nib(g, h) * rpad + lane + WAVE * i] / (double)K;
-        s += log(rp) * cnt[i];
+        s += read_log(rp) * cnt[i];
       }
       const double llk = wave_sum(s);
       lp[q] = lprior + llk;
@@ -505,7 +528,7 @@ __device__ __forceinline__ double coop_body(const SimtLds &S, int src, int K, in
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
+  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
   return wave_sum(s);
 }
 
@@ -959,7 +982,7 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
         }
       }
       if (c.alive) {
-        rng_open(c.rng, D.seed, U.stream_id, (uint32_t)chain, (uint32_t)t, L_(S.rngn, t));
+        rng_open(c.rng, D.seed, U.stream_id, (uint32_t)chain, (uint32_t)t, (uint64_t)step * STEP_DRAWS);
         // mutation.compound_step: shuffle (mutation.py:219-229)
         // entry i = (h << 8) | j of sub-step h * Mh + j (no division when it is consumed)
         for (int h = 0, i = 0; h < K; h++)

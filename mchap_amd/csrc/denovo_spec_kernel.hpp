@@ -144,6 +144,12 @@ __host__ __device__ inline size_t spec_memo_bytes(int Mmax, int T, int G) {
   return per_group * (64 / G);
 }
 
+// dynamic LDS of denovo_coast_kernel (denovo_coast_kernel.hpp): a chain's two memo tables, its break distribution,
+// its sorted words
+__host__ __device__ inline size_t coast_lds_bytes(int Mmax) {
+  return (size_t)8 * (2 * spec_memo_entries(Mmax) + Mmax) + (size_t)8 * 12;
+}
+
 __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int T, int G) {
   const int NG = 64 / G;
   const int nmax = K * Mmax;
@@ -471,7 +477,7 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += log(acc[i]) * (MCHAP_PAD_LANE(lane + WAVE * i < nrd) ? cw[WAVE * i] : 0.0);
+  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * (MCHAP_PAD_LANE(lane + WAVE * i < nrd) ? cw[WAVE * i] : 0.0);
   return s;  // per-lane partial sum; the caller reduces across the wave
 }
 
@@ -533,7 +539,7 @@ __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
+  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
   return s;
 }
 
@@ -612,7 +618,7 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += log(acc[i]) * cw[WAVE * i];
+  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
   return s;
 }
 template <int KT, int RPL, class CT, bool LT = false>
@@ -1050,12 +1056,16 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
 
 // One structural compound step (structural.py:22-71, 433-673) of kind 0 recombination, 1 interval dosage,
 // 2 whole-haplotype dosage.  Returns false if the group hit the reference's "breaks" ValueError.
-template <int KT, int G>
+// With PIPE, kind 3 / 4 is not a step: it completes the interval memo of step type 0 / 1 for the current genotype --
+// every (start, stop) still unknown is evaluated by the same code (and so to the same totals) as a visit would, but
+// without draws or decisions (phased sampler: the coasting kernel then decides every interval step from the table).
+template <int KT, int G, bool PIPE = false>
 __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D, int kind, double temp,
                                                 const double *break_dist, int n_break_dist, int mmax, int rpad, int lane,
                                                 int gi, int gl) {
   const int Mh = c.Mh;
-  const int step_type = kind == 0 ? 0 : 1;
+  const bool fill = PIPE && kind >= 3;  // wave-uniform
+  const int step_type = (kind == 0 || kind == 3) ? 0 : 1;
   const int nivs = mmax + 1;
   LDSP(uint32_t) ivse = S.ivse + gi * nivs;
   LDSP(uint32_t) ivlin = S.ivlin + gi * nivs;
@@ -1071,7 +1081,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
   // of the wave at once, one Philox block per lane) when a group runs low, and single draws beyond it are computed
   // on the spot.
   LDSP(uint64_t) dtab = S.draws + gi * S.ndraws;
-  {
+  if (!fill) {
     const int low = min(3 * Mh + 2, MCHAP_SPEC_LOW);
     if (wave_any(c.alive && c.dcount - c.doff < low)) {
       const int W = min(S.ndraws, 2 * G - 1);
@@ -1093,7 +1103,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
     return (uint64_t)a | ((uint64_t)b << 32);
   };
   uint64_t zeros = 0;
-  if (c.alive) {
+  if (c.alive && !fill) {
     const double pstep = kind == 0 ? D.p_recomb : (kind == 1 ? D.p_partial : D.p_dosage);
     doit = draw_double(next_words()) <= pstep;
     if (doit && kind < 2) {
@@ -1270,6 +1280,35 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
   STAT_ADD(13 + 4 * (kind > 0), doit && gl == 0);
   STAT_ADD(14 + 4 * (kind > 0), !done && gl == 0);
   if (wave_any(!done)) STAT_WAVE(20 + (kind > 0), 1);
+  int fill_next = 0;  // fill mode: next entry of the table to look at
+  // (a chain that has moved since its last mutation step is not settled: the coasting kernel hands it straight back,
+  // so its table is not worth completing)
+  const bool filling = fill && memo && c.alive && c.mvalid;
+  do {
+  if (fill) {
+    // the next (up to Mmax + 1) entries that are still unknown become this pass's interval list
+    int cnt = 0;
+    if (filling && gl == 0) {
+      const int n_entries = spec_memo_entries(Mh);
+      int p = fill_next, stop = 1;
+      while (spec_memo_entries(stop) <= p) stop++;
+      int start = p - spec_memo_index(0, stop);
+      while (p < n_entries && cnt < nivs) {
+        if (isnan(mtot[p])) ivse[cnt++] = (uint32_t)start | ((uint32_t)stop << 8);
+        p++;
+        if (++start == stop) {
+          start = 0;
+          stop++;
+        }
+      }
+      fill_next = p;
+    }
+    n_int = __shfl(cnt, 0, G);
+    fill_next = __shfl(fill_next, 0, G);
+    ii0 = 0;
+    done = !(filling && n_int > 0);
+    lds_sync();
+  }
   while (wave_any(!done)) {
     STAT_WAVE(15 + 4 * (kind > 0), 1);
     // (a) labels and option counts of the next (up to G) intervals, one interval per lane
@@ -1360,7 +1399,21 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
     lds_sync();
     // (d) sequential validation walk over the intervals of this round
     int acc_gl = -1;
-    if (!done) {
+    if (!done && fill) {
+      // the totals of this round's intervals: the sum a visit without a move would have formed
+      int off = 0;
+      for (int ii = ii0; ii < ii1; ii++) {
+        const int no = (int)ivno[ii];
+        double cacc = 0.0;
+        for (int o = 0; o < no; o++) cacc += S.ptab[gi * G + off + o];
+        if (gl == 0) {
+          const uint32_t se = ivse[ii];
+          mtot[spec_memo_index((int)(se & 255u), (int)(se >> 8))] = no > 0 ? cacc : -1.0;
+        }
+        off += no;
+      }
+      ii0 = ii1;
+    } else if (!done) {
       int off = 0;
       int ii = ii0;
       for (; ii < ii1; ii++) {
@@ -1407,19 +1460,28 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
     if (!done && ii0 >= n_int) done = true;
     lds_sync();
   }
+  } while (fill && wave_any(filling && n_int > 0));
   GPHASE(c, 7);
   return ok;
 }
 
 
 
-template <int KT, int G>
+// PIPE: the phased form (kernel 5).  A launch runs the chains of P.pipe_list for P.pipe_iters compound steps each,
+// starting from scratch or (PIPE_RESUME) from their PipeState records, and (PIPE_EXPORT) leaves records + complete
+// interval memos behind for denovo_coast_kernel.  Single temperature only.
+template <int KT, int G, bool PIPE = false>
 __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const SimtParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NG = 64 / G;
   const DenovoParams &D = P.d;
   const int lane = threadIdx.x;
   const int gi = lane / G, gl = lane % G;
+  int n_list = 0;
+  if constexpr (PIPE) {
+    n_list = P.pipe_count ? *P.pipe_count : (int)((long long)P.n_units * D.chains);
+    if ((long long)blockIdx.x * NG >= n_list) return;  // the grid is sized for every chain
+  }
   const int T = D.n_temps, Cn = D.chains, Sn = D.steps;
   const int mmax = P.max_pos, nmax = KT * P.max_pos;
   const int rpad = D.rpad;
@@ -1471,10 +1533,19 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.ln[i] = c_ln[i];
     S.lninv[i] = c_ln_inv[i];
   }
-  const long long q = (long long)blockIdx.x * NG + gi;  // chain index of the group
+  long long q = (long long)blockIdx.x * NG + gi;  // chain index of the group
   const long long n_chains = (long long)P.n_units * Cn;
   Grp<KT> c;
   c.alive = q < n_chains;
+  bool listed = false;  // PIPE: the group holds a chain of the list (its record is written at the end)
+  if constexpr (PIPE) {
+    listed = q < n_list;
+    c.alive = listed;
+    if (listed && P.pipe_list) q = P.pipe_list[q];
+    if (!listed) q = 0;
+  }
+  const bool resume = PIPE && (P.pipe_mode & PIPE_RESUME);
+  int base = 0;  // first MCMC step of this launch (PIPE)
   const int u = c.alive ? (int)(q / Cn) : 0;
   const int chain = c.alive ? (int)(q % Cn) : 0;
   const mchap_unit U = D.units[u];
@@ -1555,7 +1626,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     for (int h = 0; h < KT; h++) z.w[h] = 0;
     c.g = z;
   }
-  if (c.alive) {
+  if (c.alive && !resume) {
     LDSP(uint8_t) shift = S.shift + gi * mmax;
     if (U.initial_off >= 0) {
       const int8_t *ini = D.initial + U.initial_off + (size_t)chain * KT * Mh;
@@ -1597,7 +1668,30 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       }
     }
   }
-  {
+  if constexpr (PIPE) {
+    if (resume) {
+      const PipeState *st = reinterpret_cast<const PipeState *>(P.pipe_state) + q;
+      if (c.alive) {
+        GWords<KT> gr;
+#pragma unroll
+        for (int h = 0; h < KT; h++) gr.w[h] = st->g[h];
+        c.g = gr;
+        c.llk = st->llk;
+        c.ctr = st->ctr;
+        c.mvalid = st->mvalid != 0;
+        base = st->step;
+        if (gl == 0) {
+          S.gval[gi * GV_N + GV_MLO] = st->mlo;
+          S.gval[gi * GV_N + GV_MHI] = st->mhi;
+        }
+        const double *pm = P.pipe_memo + (size_t)q * S.memo_stride;
+        for (int i = gl; i < S.memo_stride; i += G) S.memo_tot[gi * S.memo_stride + i] = pm[i];
+        if (base >= Sn) c.alive = false;  // finished (or stopped by an error) in an earlier launch
+      }
+      lds_sync();
+    }
+  }
+  if (!resume) {
     const bool req = c.alive && gl == 0;  // assemble/mcmc.py:303
     const GWords<KT> g0 = c.g;
     if (req) {
@@ -1626,7 +1720,32 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   for (int i_ = 0; i_ < 12; i_++) c.ph[i_] = 0;
   c.pt0 = __builtin_amdgcn_s_memtime();
 #endif
-  for (int step = 0; step < Sn; step++) {
+  int n_iter = Sn;
+  if constexpr (PIPE) {
+    int mine = c.alive ? Sn - base : 0;
+    if (P.pipe_iters > 0 && mine > P.pipe_iters) mine = P.pipe_iters;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mine = max(mine, __shfl_xor(mine, o, WAVE));
+    n_iter = mine;
+  }
+  // PIPE_EXPORT: a wave with a chain that is not settled yet (it moved after its last full mutation step) keeps
+  // stepping, up to n_cap iterations: the coasting kernel would hand that chain straight back
+  int n_cap = n_iter;
+  if constexpr (PIPE) {
+    if ((P.pipe_mode & PIPE_EXPORT) && P.pipe_iters > 0) {
+      int mine = c.alive ? Sn - base : 0;
+      if (mine > P.pipe_iters_max) mine = P.pipe_iters_max;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) mine = max(mine, __shfl_xor(mine, o, WAVE));
+      n_cap = max(n_iter, mine);
+    }
+  }
+  int n_done = 0;  // PIPE: compound steps this chain completed in this launch
+  for (int it = 0; it < n_iter; it++) {
+    const int step = base + it;
+    if constexpr (PIPE) {
+      if (step >= Sn) c.alive = false;  // this chain is complete; others of the wave go on
+    }
     for (int t = 0; t < T; t++) {
       GPHASE(c, 8);
       if (T > 1) {
@@ -1635,9 +1754,9 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
         for (int h = 0; h < KT; h++) gt.w[h] = S.wst[((size_t)gi * T + t) * KT + h];
         c.g = gt;
         c.llk = S.llk_t[(size_t)gi * T + t];
-        c.ctr = S.rngn[(size_t)gi * T + t];
-        c.dcount = 0;  // another stream: nothing staged
       }
+      c.ctr = (uint64_t)step * STEP_DRAWS;  // the step's draws (philox.hpp)
+      c.dcount = 0;  // nothing staged
       const double temp = D.temps[t];
       if (T > 1) {  // the temperature's stream
         lds_sync();
@@ -1651,7 +1770,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       spec_mutation<KT, G>(c, S, temp, amax, mmax, nmax, rpad, lane, gi, gl);
 #pragma unroll 1
       for (int kind = 0; kind < 3; kind++) {
-        if (!spec_structural<KT, G>(c, S, D, kind, temp, break_dist, n_break_dist, mmax, rpad, lane, gi, gl)) {
+        if (!spec_structural<KT, G, PIPE>(c, S, D, kind, temp, break_dist, n_break_dist, mmax, rpad, lane, gi, gl)) {
           status = MCHAP_UNIT_BREAKS;
           c.alive = false;
         }
@@ -1700,7 +1819,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     // are collected in LDS and written together, the words as one contiguous run (a full line for K = 4)
     {
       LDSP(uint64_t) tb = S.tbuf + (size_t)gi * SPEC_TB * (KT + 1);
-      const int slot = step % SPEC_TB;
+      const int slot = it % SPEC_TB;
+      if (c.alive) n_done = it + 1;
       if (c.alive) {
         if (gl < KT) {
           const GWords<KT> gr = c.g;
@@ -1712,9 +1832,18 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
         }
         if (gl == 0) tb[SPEC_TB * KT + slot] = (uint64_t)__double_as_longlong(c.llk);
       }
-      if (slot == SPEC_TB - 1 || step == Sn - 1) {
+      // (PIPE: the chains of a wave may be at different steps; one that completes flushes its block then)
+      bool last = it + 1 >= n_iter;
+      if constexpr (PIPE) {
+        if (last && it + 1 < n_cap && wave_any(c.alive && !c.mvalid && step + 1 < Sn)) {
+          n_iter = it + 2;
+          last = false;
+        }
+      }
+      const bool flush = slot == SPEC_TB - 1 || last || step == Sn - 1;
+      if (PIPE ? wave_any(flush && c.alive) : flush) {
         lds_sync();
-        if (c.alive) {
+        if (c.alive && flush) {
           const int first = step - slot;  // first step of the block
           const int nw = (slot + 1) * KT;
           uint64_t *tp = reinterpret_cast<uint64_t *>((uintptr_t)S.gptr[gi * GP_N + GP_TRACE]) + (size_t)first * KT;
@@ -1730,6 +1859,33 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   if (threadIdx.x == 0)
     for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_stats[3 + i_], c.ph[i_]);
 #endif
+  if constexpr (PIPE) {
+    if (P.pipe_mode & PIPE_EXPORT) {
+      // the interval memo of the current genotype, completed (both step types), then the hand-over record
+#pragma unroll 1
+      for (int kind = 3; kind < 5; kind++)
+        spec_structural<KT, G, true>(c, S, D, kind, D.temps[0], break_dist, n_break_dist, mmax, rpad, lane, gi, gl);
+      lds_sync();
+      if (listed) {
+        PipeState *st = reinterpret_cast<PipeState *>(P.pipe_state) + q;
+        const GWords<KT> ge = c.g;
+        if (gl == 0) {
+#pragma unroll
+          for (int h = 0; h < KT; h++) st->g[h] = ge.w[h];
+          st->llk = c.llk;
+          st->ctr = c.ctr;
+          st->mlo = S.gval[gi * GV_N + GV_MLO];
+          st->mhi = S.gval[gi * GV_N + GV_MHI];
+          st->mvalid = (c.alive && c.mvalid && c.memo_on) ? 1 : 0;
+          st->step = c.alive ? base + n_done : Sn;
+        }
+        if (c.alive) {
+          double *pm = P.pipe_memo + (size_t)q * S.memo_stride;
+          for (int i = gl; i < S.memo_stride; i += G) pm[i] = S.memo_tot[gi * S.memo_stride + i];
+        }
+      }
+    }
+  }
   if (status != MCHAP_UNIT_OK && gl == 0) atomicMax(&D.status[u], status);
 }
 

@@ -208,7 +208,7 @@ __device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[MC
 #pragma unroll
     for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
       if (k < K) rp += row[g[k]] * invK;
-    llk += log(rp) * E.cnt[r];
+    llk += read_log(rp) * E.cnt[r];
   }
   return llk;
 }

@@ -63,6 +63,18 @@ MCHAP_LANE_DECL(6)
 MCHAP_LANE_DECL(7)
 MCHAP_LANE_DECL(8)
 
+#define MCHAP_SPECP_DECL(k, g)                                                   \
+  extern "C" int mchap_specp_init_##k##_##g(const double *, const double *); \
+  extern "C" int mchap_specp_launch_##k##_##g(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+MCHAP_SPECP_DECL(2, 16)
+MCHAP_SPECP_DECL(3, 16)
+MCHAP_SPECP_DECL(4, 16)
+MCHAP_SPECP_DECL(5, 32)
+MCHAP_SPECP_DECL(6, 32)
+MCHAP_SPECP_DECL(7, 64)
+MCHAP_SPECP_DECL(8, 64)
+extern "C" int mchap_coast_launch(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+
 extern "C" int mchap_simt_init_0(const double *, const double *);
 extern "C" int mchap_simt_launch_0(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 extern "C" int mchap_simt_init_2(const double *, const double *);
@@ -183,7 +195,10 @@ int ensure_init() {
                                                       mchap_simt_init_8, mchap_v1_init_1,   mchap_v1_init_2,   mchap_v1_init_4,
                                                       mchap_v1_init_8,   mchap_v1_init_16,  mchap_lane_init_1, mchap_lane_init_2,
                                                       mchap_lane_init_3, mchap_lane_init_4, mchap_lane_init_5, mchap_lane_init_6,
-                                                      mchap_lane_init_7, mchap_lane_init_8};
+                                                      mchap_lane_init_7, mchap_lane_init_8,
+                                                      mchap_specp_init_2_16, mchap_specp_init_3_16, mchap_specp_init_4_16,
+                                                      mchap_specp_init_5_32, mchap_specp_init_6_32, mchap_specp_init_7_64,
+                                                      mchap_specp_init_8_64};
     for (auto f : inits)
       if (f(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of a sampler object");
   }
@@ -294,7 +309,10 @@ int batch_dims(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units
 
 struct SimtCarve {
   size_t cache = 0, rt = 0, cntw = 0, codes = 0, dict = 0, meta_i = 0, meta_f = 0, lane_state = 0, lane_memo = 0, total = 0;
+  size_t pipe_state = 0, pipe_memo = 0, pipe_lists = 0, pipe_counts = 0;
 };
+constexpr int PIPE_MAX_ROUNDS = 6;  // resume rounds of the phased sampler (counters in the workspace)
+bool pipe_supported(const mchap_denovo_cfg *cfg, int K, int max_pos);
 
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -311,6 +329,13 @@ SimtCarve simt_carve(const mchap_denovo_cfg *cfg, int n_units, const BatchDims &
   if (cfg->kernel == 4) {  // hand-over records of the steady-state pipeline
     c.lane_state = o; o += up256((size_t)n_units * cfg->chains * sizeof(mchap::LaneState));
     c.lane_memo = o; o += up256((size_t)n_units * cfg->chains * 2 * mchap::spec_memo_entries(B.max_pos) * 4);
+  }
+  if (pipe_supported(cfg, B.uniform_ploidy, B.max_pos)) {  // hand-over records of the phased sampler
+    const size_t nc = (size_t)n_units * cfg->chains;
+    c.pipe_state = o; o += up256(nc * sizeof(mchap::PipeState));
+    c.pipe_memo = o; o += up256(nc * 2 * mchap::spec_memo_entries(B.max_pos) * 8);
+    c.pipe_lists = o; o += up256(nc * 4) * 2;
+    c.pipe_counts = o; o += up256((PIPE_MAX_ROUNDS + 2) * 4);
   }
   c.total = o;
   return c;
@@ -413,6 +438,77 @@ int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipS
   for (int r = 0; r < rounds && e == 0; r++) {
     e = launch(&P, fsh, -1, grid_f, lds_f, stream);
     if (e == 0) e = launch(&P, lsh, mchap::LANE_MODE_RESUME | (r + 1 < rounds ? mchap::LANE_MODE_PARK : 0), grid_w, lds, stream);
+  }
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
+  return MCHAP_OK;
+}
+
+// The phased sampler (kernel 5): denovo_spec_kernel<K, G, true> for the first steps, denovo_coast_kernel for the
+// chains' long no-move stretches, denovo_spec_kernel again for the chains handed back.  Instantiated for each
+// ploidy's default group size; needs the interval memo (single temperature, table in LDS) and a mutation step whose
+// draws fit the staged window.
+int spec_group(int K, int max_pos);
+int pipe_group(int K) { return K < 2 || K > 8 ? 0 : (K <= 4 ? 16 : (K <= 6 ? 32 : 64)); }
+bool pipe_supported(const mchap_denovo_cfg *cfg, int K, int max_pos) {
+  if (cfg->kernel != 5 || cfg->n_temps != 1 || K < 2 || K > 8 || max_pos > 10) return false;
+  if (std::getenv("MCHAP_HIP_GROUP")) return false;
+  if (const char *e = std::getenv("MCHAP_HIP_FLAGS"))
+    if (std::atoi(e) & 3) return false;  // memos switched off
+  const int g = spec_group(K, max_pos);
+  if (g == 0 || g != pipe_group(K)) return false;
+  if (mchap::spec_memo_bytes(max_pos, 1, g) == 0) return false;
+  return K * max_pos <= mchap::spec_draws(K, max_pos);
+}
+
+int env_int(const char *name, int dflt, int lo, int hi) {
+  if (const char *e = std::getenv(name)) {
+    const int v = std::atoi(e);
+    if (v >= lo && v <= hi) return v;
+  }
+  return dflt;
+}
+
+int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *lists, int32_t *counts, hipStream_t stream) {
+  const int G = pipe_group(K);
+  int (*launch)(const mchap::SimtParams *, unsigned, size_t, hipStream_t) =
+      K == 2 ? mchap_specp_launch_2_16 : K == 3 ? mchap_specp_launch_3_16 : K == 4 ? mchap_specp_launch_4_16 :
+      K == 5 ? mchap_specp_launch_5_32 : K == 6 ? mchap_specp_launch_6_32 : K == 7 ? mchap_specp_launch_7_64 : mchap_specp_launch_8_64;
+  const size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, 1, G);
+  if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
+  const long long n_chains = (long long)n_units * chains;
+  const int s0 = env_int("MCHAP_HIP_PIPE_FIRST", 8, 1, 1 << 30);    // steps before the first hand-over
+  const int nr = env_int("MCHAP_HIP_PIPE_RESUME", 8, 1, 1 << 30);   // steps a handed-back chain runs before the next
+  const int rounds = env_int("MCHAP_HIP_ROUNDS", 2, 0, PIPE_MAX_ROUNDS);
+  P.pipe_iters_max = env_int("MCHAP_HIP_PIPE_MAX", 64, 1, 1 << 30);  // ... extended to while a chain of the wave is unsettled
+  const size_t lds_c = mchap::coast_lds_bytes(P.max_pos);
+  const unsigned grid_s = (unsigned)((n_chains + 64 / G - 1) / (64 / G)), grid_c = (unsigned)n_chains;
+  const size_t list_stride = up256((size_t)n_chains * 4) / 4;
+  HIP_TRY(hipMemsetAsync(counts, 0, (PIPE_MAX_ROUNDS + 2) * 4, stream));
+  char name[96];
+  snprintf(name, sizeof(name), "denovo_spec_kernel<%d, %d, phased> + denovo_coast_kernel", K, G);
+  SamplerTimer timer(stream, name);
+  // every chain: first steps from scratch, complete tables, records
+  P.pipe_list = nullptr;
+  P.pipe_count = nullptr;
+  P.pipe_iters = s0;
+  P.pipe_mode = mchap::PIPE_EXPORT;
+  int e = launch(&P, grid_s, lds, stream);
+  // coast; then rounds of (resume the chains handed back for a few steps, coast again); the rest runs to the end
+  P.pipe_out = lists;
+  P.pipe_out_count = counts;
+  if (e == 0) e = mchap_coast_launch(&P, grid_c, lds_c, stream);
+  const bool stop_early = std::getenv("MCHAP_HIP_PIPE_STOP") != nullptr;  // measurement aid: traces are incomplete
+  for (int r = 0; r <= rounds && e == 0 && !stop_early; r++) {
+    P.pipe_list = lists + (size_t)(r & 1) * list_stride;
+    P.pipe_count = counts + r;
+    const bool last = r == rounds;
+    P.pipe_iters = last ? 0 : nr;
+    P.pipe_mode = mchap::PIPE_RESUME | (last ? 0 : mchap::PIPE_EXPORT);
+    e = launch(&P, grid_s, lds, stream);
+    if (last || e != 0) break;
+    P.pipe_out = lists + (size_t)((r + 1) & 1) * list_stride;
+    P.pipe_out_count = counts + r + 1;
+    e = mchap_coast_launch(&P, grid_c, lds_c, stream);
   }
   if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
@@ -524,6 +620,23 @@ int mchap_debug_lane_stats(unsigned long long *out, int reset) {
   return MCHAP_OK;
 }
 #endif
+
+/* measurement aid (tools/pipe_records.py; not declared in mchap_hip.h): the phased sampler's hand-over records and
+ * round counters as the last fit on this workspace left them.  records: [n_units * chains] PipeState (128 bytes each),
+ * counts: [8] int32. */
+int mchap_debug_pipe_records(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host, const void *workspace,
+                             void *records, int32_t *counts) {
+  BatchDims B;
+  if (batch_dims(cfg, n_units, units_host, B)) return MCHAP_ERR_BAD_ARG;
+  const int rpl = simt_rpl(cfg, B.uniform_ploidy, B.max_pos, B.max_reads);
+  if (rpl < 0 || !pipe_supported(cfg, B.uniform_ploidy, B.max_pos)) return fail(MCHAP_ERR_BAD_ARG, "not a phased-sampler batch");
+  const SimtCarve cv = simt_carve(cfg, n_units, B, 64 * rpl, cfg->llk_cache ? CACHE_SLOTS : 0);
+  const unsigned char *ws = reinterpret_cast<const unsigned char *>(workspace) + break_table_bytes(cfg);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(records, ws + cv.pipe_state, (size_t)n_units * cfg->chains * sizeof(mchap::PipeState), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(counts, ws + cv.pipe_counts, (PIPE_MAX_ROUNDS + 2) * 4, hipMemcpyDeviceToHost));
+  return MCHAP_OK;
+}
 
 int mchap_device_count(void) {
   int n = 0;
@@ -679,6 +792,8 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.meta_f = reinterpret_cast<double *>(ws + cv.meta_f);
     SP.lane_state = ws + cv.lane_state;
     SP.lane_memo = ws + cv.lane_memo;
+    SP.pipe_state = ws + cv.pipe_state;
+    SP.pipe_memo = reinterpret_cast<double *>(ws + cv.pipe_memo);
     SP.n_units = n_units;
     SP.max_pos = B.max_pos;
     SP.max_allele = B.max_allele;
@@ -718,6 +833,9 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     if (rc) return rc;
     if (cfg->kernel == 4 && B.uniform_ploidy > 0 && lane_supported(B.uniform_ploidy, B.max_pos, cfg->n_temps))
       return launch_lane(B.uniform_ploidy, SP, n_units, cfg->chains, stream);
+    if (pipe_supported(cfg, B.uniform_ploidy, B.max_pos))
+      return launch_pipe(B.uniform_ploidy, SP, n_units, cfg->chains, reinterpret_cast<int32_t *>(ws + cv.pipe_lists),
+                         reinterpret_cast<int32_t *>(ws + cv.pipe_counts), stream);
     // default: the speculative sampler when every unit shares a supported ploidy, else lanes over chains
     if (cfg->kernel != 2) {
       const int K = B.uniform_ploidy;

@@ -11,10 +11,16 @@
 // other program can reproduce; the order in which draws are consumed is the reference's
 // (SURVEY.md Appendix A.8).
 #pragma once
+#include "read_log.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mchap {
+
+// Draw numbering: the draws of MCMC step i of a stream are i * STEP_DRAWS, i * STEP_DRAWS + 1, ... in the order the
+// reference consumes them (a step uses fewer than 2000), so a step's draws do not depend on what earlier steps
+// consumed.  The oracle's Philox mode numbers them the same way (ORC_STEP_DRAWS).
+constexpr uint64_t STEP_DRAWS = 65536;
 
 struct Rng {
   uint32_t k0, k1, c2, c3;

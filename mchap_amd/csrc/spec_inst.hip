@@ -9,6 +9,26 @@
 #define SPEC_CAT_(a, k, g) a##k##_##g
 #define SPEC_CAT(a, k, g) SPEC_CAT_(a, k, g)
 
+#ifdef SPEC_PIPE
+// the phased form (kernel 5) of this instantiation: its own object file, its own copy of the constant tables
+extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_specp_init_, SPEC_K, SPEC_G)(const double *ln,
+                                                                                                 const double *ln_inv) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln), ln, sizeof(double) * 260) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln_inv), ln_inv, sizeof(double) * 260) != hipSuccess) return 1;
+  return 0;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_specp_launch_, SPEC_K, SPEC_G)(
+    const mchap::SimtParams *P, unsigned grid, size_t lds, hipStream_t stream) {
+  auto ks = mchap::denovo_spec_kernel<SPEC_K, SPEC_G, true>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(ks, dim3(grid), dim3(64), lds, stream, *P);
+  return (int)hipGetLastError();
+}
+#else
 extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_init_, SPEC_K, SPEC_G)(const double *ln,
                                                                                                 const double *ln_inv) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln), ln, sizeof(double) * 260) != hipSuccess) return 1;
@@ -36,3 +56,4 @@ extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_stats_,
   return 0;
 }
 #endif
+#endif  // SPEC_PIPE

@@ -124,6 +124,7 @@ static uint32_t mt_next32(mt_state *s) {
 }
 
 #define ORC_SUB_INIT 0xFFFFu
+#define ORC_STEP_DRAWS 65536u /* draw numbers reserved per MCMC step and stream (Philox mode); a step uses < 2000 */
 
 typedef struct {
   int kind;
@@ -1088,6 +1089,9 @@ static int denovo_assembler(const orc_denovo_cfg *cfg, orc_ctx *c, const int8_t 
       int8_t *g = genotypes[t];
       double temp = cfg->temperatures[t];
       if (isnan(llk)) { rc = ORC_ERR_NAN_LLK; break; }
+      /* Philox mode: the draws of MCMC step i are numbered from i * ORC_STEP_DRAWS in each temperature's stream,
+         whatever earlier steps consumed (the HIP kernels evaluate the steps of a settled chain independently) */
+      c->rng->n[t] = (uint64_t)i * ORC_STEP_DRAWS;
       llk = mutation_compound_step(c, g, llk, temp, t);
       if (rng_double(c->rng, t) <= cfg->p_recomb) {
         int nb = choose_from(break_dist, n_break_dist, rng_double(c->rng, t));

@@ -50,7 +50,7 @@ def run(n_cases, seed, ploidies=(2, 3, 4, 5, 6, 8), read_depths=(1, 5, 30, 64, 7
             g, l = _oracle_trace(m0, reads[u], m0.n_alleles, None, u)
             ref.append((sort_haplotypes(g), l))
         res = []
-        for k in (1, 2, 3, 4):
+        for k in (1, 2, 3, 4, 5):
             try:
                 tr = DenovoMCMC(kernel=k, **kw).fit_batch(list(reads))
             except NotImplementedError:

@@ -11,7 +11,7 @@ from tests.helpers import beta_break_table
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[4, 3, 2, 1], ids=["steady-state", "speculative", "lanes-over-chains", "wave-per-chain"])
+@pytest.fixture(autouse=True, params=[5, 4, 3, 2, 1], ids=["phased", "steady-state", "speculative", "lanes-over-chains", "wave-per-chain"])
 def sampler_kernel(request, monkeypatch):
     """Every test runs against both sampler kernels; they must give identical traces."""
     monkeypatch.setenv("MCHAP_HIP_KERNEL", str(request.param))
