@@ -66,9 +66,12 @@ typedef struct mchap_denovo_cfg {
                                                increments over m het bases (assemble/mcmc.py:429-452) */
   int32_t max_pos;                          /* leading dimension of break_table */
   int32_t llk_cache;                        /* llk_cache_threshold >= 0: 1 = cache likelihoods per chain, 0 = recompute */
-  int32_t kernel;                           /* 0 = default (3 when the batch's shape allows, else 2), 1 = wavefront per chain
-                                               with LDS-staged reads, 2 = lanes over chains, 3 = speculative sub-steps with
-                                               a group of lanes per chain.  Identical results whichever runs. */
+  int32_t kernel;                           /* 0 = default (5 when the batch's shape allows, else 3, else 2), 1 = wavefront
+                                               per chain with LDS-staged reads, 2 = lanes over chains, 3 = speculative
+                                               sub-steps with a group of lanes per chain, 4 = settle/steady pipeline
+                                               (experimental), 5 = phased: kernel 3 for a chain's first steps, then its
+                                               settled stretches one lane per MCMC step (single temperature, one ploidy
+                                               per launch).  Identical results whichever runs. */
   int32_t reserved;
 } mchap_denovo_cfg;
 

@@ -960,6 +960,7 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
     cu.g = bcast_words<KT>(c.g, owner);
     cu.memo_on = memo_mut;
     cu.mvalid = false;
+    cu.mwin = 8;
     cu.gen = 1;
     cu.memo_gen = 1;
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)

@@ -41,6 +41,12 @@
 #ifndef MCHAP_SPEC_LOW
 #define MCHAP_SPEC_LOW 8   // staged draws a structural step wants to find before it refills the window
 #endif
+#ifndef MCHAP_SPEC_WIN0
+#define MCHAP_SPEC_WIN0 4     // mutation sub-steps a chain's first compound step speculates over per round
+#endif
+#ifndef MCHAP_SPEC_WIN_MIN
+#define MCHAP_SPEC_WIN_MIN 2  // ... and the least a converging chain falls back to
+#endif
 #ifndef MCHAP_REUSE_MAXK
 #define MCHAP_REUSE_MAXK 8  // largest ploidy whose kernels carry the product-reuse path (K x 4 products in registers)
 #endif
@@ -376,6 +382,7 @@ struct Grp {
   // memo of the current genotype (single temperature only): a mutation compound step moves nothing if every one
   // of its uniforms u satisfies mlo <= u < mhi; gen tags the interval-step memo entries
   bool memo_on, mvalid;  // bounds mlo / mhi: SpecLds::gval
+  int mwin;              // sub-steps the next mutation compound step speculates over per round (spec_mutation)
   uint32_t gen, memo_gen;  // memo_gen: the generation the interval memo table currently describes
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
   unsigned long long ph[12], pt0;
@@ -570,7 +577,8 @@ __device__ __forceinline__ void spec_pair_rows(LDSP(const uint64_t) words, int w
 template <int RPL, class CT, bool LT = false>
 __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int row1, int p0, int Mh, typename TabPtr<LT>::u8 ct,
                                               int crow, double (&prod)[RPL]) {
-  constexpr int UNR = 8;
+  constexpr int UNR = 8;  // code loads in flight
+  constexpr int GB = 4;   // positions whose dictionary gathers are in flight together
 #pragma unroll
   for (int i = 0; i < RPL; i++) prod[i] = 1.0;
   for (int j0 = 0; j0 < Mh; j0 += UNR) {
@@ -581,11 +589,23 @@ __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int r
       const int row = p < WAVE ? __builtin_amdgcn_readlane(row0, p & (WAVE - 1)) : __builtin_amdgcn_readlane(row1, p & (WAVE - 1));
       cd[u] = TabPtr<LT>::template ld<CT>(ct + (size_t)row * crow);
     }
+    // No branch between the positions: the gathers of GB positions are issued together (a branch per position made
+    // every gather a full LDS round trip: 2/3 of an evaluation's time) and a position beyond Mh multiplies by 1.0
+    // (exact), so the products are those of the plain loop, factor for factor.
 #pragma unroll
-    for (int u = 0; u < UNR; u++) {
-      if (j0 + u < Mh) {
+    for (int u0 = 0; u0 < UNR; u0 += GB) {
+      if (j0 + u0 < Mh) {
+        double f[GB][RPL];
 #pragma unroll
-        for (int i = 0; i < RPL; i++) prod[i] *= dict[((uint32_t)cd[u] >> (8 * i)) & 255u];
+        for (int u = 0; u < GB; u++)
+#pragma unroll
+          for (int i = 0; i < RPL; i++) f[u][i] = dict[((uint32_t)cd[u0 + u] >> (8 * i)) & 255u];
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+          const bool on = j0 + u0 + u < Mh;
+#pragma unroll
+          for (int i = 0; i < RPL; i++) prod[i] *= on ? f[u][i] : 1.0;
+        }
       }
     }
   }
@@ -936,18 +956,24 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
   //     sub-step is permtab[p] and its uniform is draw ctr0 + (n-1) + p.
   if (run) c.ctr = ctr0 + (uint64_t)(n - 1) + (uint64_t)n;
   const int nslots = (NS > 2 && wave_any(c.alive && n > 2 * G)) ? 3 : (two ? 2 : 1);
+  // Window.  A round evaluates the sub-steps [start, start + win) only: while a chain is still converging nearly
+  // every round ends at an accepted move and whatever was evaluated behind it is thrown away, so the window halves
+  // after a round with a move and doubles after one without (Grp::mwin carries it to the next compound step; a
+  // settled chain evaluates all n sub-steps in one round).  Results do not depend on it.
   int start = 0;
+  int win = c.mwin;
   bool done = !run;
-  bool first_round = true;
-  double my_lo = 0.0, my_hi = 2.0;  // this lane's sub-steps: max lo_e, min hi_e (first round only)
+  bool any_move = false;
+  double my_lo = 0.0, my_hi = 2.0;  // this lane's sub-steps: max lo_e, min hi_e
   while (wave_any(!done)) {
     STAT_WAVE(11, 1);
     const double lprior = (!done && !isnan(C_INB(S, gi))) ? prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(c.g)) : 0.0;
     bool found = false;
+    const int wstop = min(n, start + win);
 #pragma unroll 1
     for (int s = 0; s < nslots; s++) {
       const int p = gl + s * G;
-      const bool act = !done && !found && p >= start && p < n;
+      const bool act = !done && !found && p >= start && p < wstop;
       int h = 0, sh = 0, n_alleles = 2;
       double u = 2.0;
       if (act) {
@@ -1032,25 +1058,34 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
         found = true;
       }
     }
-    // a first round without any move evaluated every sub-step against the current genotype: remember the bounds
-    {
-      double lo = my_lo, hi = my_hi;
-#pragma unroll
-      for (int o = G / 2; o >= 1; o >>= 1) {
-        lo = fmax(lo, __shfl_xor(lo, o, G));
-        hi = fmin(hi, __shfl_xor(hi, o, G));
+    if (!done) {
+      if (found) {
+        any_move = true;
+        win = max(MCHAP_SPEC_WIN_MIN, win >> 1);
+      } else {
+        start = wstop;  // the window's sub-steps all stay
+        win = min(2 * win, 4 * G);
       }
-      if (!done && first_round && !found && c.memo_on) {
-        c.mvalid = true;
-        if (gl == 0) {  // read again by the next mutation step, after several lds_sync()
-          S.gval[gi * GV_N + GV_MLO] = lo;
-          S.gval[gi * GV_N + GV_MHI] = hi;
-        }
+      if (start >= n) done = true;
+    }
+  }
+  // a compound step without any move evaluated every sub-step against the current genotype: remember the bounds
+  {
+    double lo = my_lo, hi = my_hi;
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) {
+      lo = fmax(lo, __shfl_xor(lo, o, G));
+      hi = fmin(hi, __shfl_xor(hi, o, G));
+    }
+    if (run && !any_move && c.memo_on) {
+      c.mvalid = true;
+      if (gl == 0) {  // read again by the next mutation step, after several lds_sync()
+        S.gval[gi * GV_N + GV_MLO] = lo;
+        S.gval[gi * GV_N + GV_MHI] = hi;
       }
     }
-    first_round = false;
-    if (!done && (!found || start >= n)) done = true;
   }
+  if (run) c.mwin = win;
   GPHASE(c, 1);
 }
 
@@ -1585,6 +1620,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   c.llk = 0.0;
   c.memo_on = (T == 1) && !(P.flags & 1);
   c.mvalid = false;
+  c.mwin = MCHAP_SPEC_WIN0;
   c.gen = 1;
   c.memo_gen = 1;
   const int Mh = c.Mh;

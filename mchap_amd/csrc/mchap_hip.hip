@@ -450,7 +450,7 @@ int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipS
 int spec_group(int K, int max_pos);
 int pipe_group(int K) { return K < 2 || K > 8 ? 0 : (K <= 4 ? 16 : (K <= 6 ? 32 : 64)); }
 bool pipe_supported(const mchap_denovo_cfg *cfg, int K, int max_pos) {
-  if (cfg->kernel != 5 || cfg->n_temps != 1 || K < 2 || K > 8 || max_pos > 10) return false;
+  if ((cfg->kernel != 5 && cfg->kernel != 0) || cfg->n_temps != 1 || K < 2 || K > 8) return false;
   if (std::getenv("MCHAP_HIP_GROUP")) return false;
   if (const char *e = std::getenv("MCHAP_HIP_FLAGS"))
     if (std::atoi(e) & 3) return false;  // memos switched off
