@@ -1513,9 +1513,18 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   const int lane = threadIdx.x;
   const int gi = lane / G, gl = lane % G;
   int n_list = 0;
+  long long my_slot = (long long)blockIdx.x * NG + gi;  // the group's position in the launch's list of chains
   if constexpr (PIPE) {
     n_list = P.pipe_count ? *P.pipe_count : (int)((long long)P.n_units * D.chains);
-    if ((long long)blockIdx.x * NG >= n_list) return;  // the grid is sized for every chain
+    if (P.pipe_list) {
+      // a list of handed-back chains is usually short: its chains are dealt out over as many wavefronts as there
+      // are (one chain per wave while they last), because a wave serves its chains' evaluations one after the other
+      const int n_waves = min(n_list, (int)gridDim.x);
+      if ((int)blockIdx.x >= n_waves) return;
+      my_slot = (long long)gi * n_waves + blockIdx.x;
+    } else if ((long long)blockIdx.x * NG >= n_list) {
+      return;  // the grid is sized for every chain
+    }
   }
   const int T = D.n_temps, Cn = D.chains, Sn = D.steps;
   const int mmax = P.max_pos, nmax = KT * P.max_pos;
@@ -1568,7 +1577,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.ln[i] = c_ln[i];
     S.lninv[i] = c_ln_inv[i];
   }
-  long long q = (long long)blockIdx.x * NG + gi;  // chain index of the group
+  long long q = my_slot;  // chain index of the group
   const long long n_chains = (long long)P.n_units * Cn;
   Grp<KT> c;
   c.alive = q < n_chains;

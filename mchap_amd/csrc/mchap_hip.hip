@@ -69,6 +69,8 @@ MCHAP_LANE_DECL(8)
 MCHAP_SPECP_DECL(2, 16)
 MCHAP_SPECP_DECL(3, 16)
 MCHAP_SPECP_DECL(4, 16)
+MCHAP_SPECP_DECL(4, 32)
+MCHAP_SPECP_DECL(4, 64)
 MCHAP_SPECP_DECL(5, 32)
 MCHAP_SPECP_DECL(6, 32)
 MCHAP_SPECP_DECL(7, 64)
@@ -196,7 +198,7 @@ int ensure_init() {
                                                       mchap_v1_init_8,   mchap_v1_init_16,  mchap_lane_init_1, mchap_lane_init_2,
                                                       mchap_lane_init_3, mchap_lane_init_4, mchap_lane_init_5, mchap_lane_init_6,
                                                       mchap_lane_init_7, mchap_lane_init_8,
-                                                      mchap_specp_init_2_16, mchap_specp_init_3_16, mchap_specp_init_4_16,
+                                                      mchap_specp_init_2_16, mchap_specp_init_3_16, mchap_specp_init_4_16, mchap_specp_init_4_32, mchap_specp_init_4_64,
                                                       mchap_specp_init_5_32, mchap_specp_init_6_32, mchap_specp_init_7_64,
                                                       mchap_specp_init_8_64};
     for (auto f : inits)
@@ -447,19 +449,6 @@ int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipS
 // chains' long no-move stretches, denovo_spec_kernel again for the chains handed back.  Instantiated for each
 // ploidy's default group size; needs the interval memo (single temperature, table in LDS) and a mutation step whose
 // draws fit the staged window.
-int spec_group(int K, int max_pos);
-int pipe_group(int K) { return K < 2 || K > 8 ? 0 : (K <= 4 ? 16 : (K <= 6 ? 32 : 64)); }
-bool pipe_supported(const mchap_denovo_cfg *cfg, int K, int max_pos) {
-  if ((cfg->kernel != 5 && cfg->kernel != 0) || cfg->n_temps != 1 || K < 2 || K > 8) return false;
-  if (std::getenv("MCHAP_HIP_GROUP")) return false;
-  if (const char *e = std::getenv("MCHAP_HIP_FLAGS"))
-    if (std::atoi(e) & 3) return false;  // memos switched off
-  const int g = spec_group(K, max_pos);
-  if (g == 0 || g != pipe_group(K)) return false;
-  if (mchap::spec_memo_bytes(max_pos, 1, g) == 0) return false;
-  return K * max_pos <= mchap::spec_draws(K, max_pos);
-}
-
 int env_int(const char *name, int dflt, int lo, int hi) {
   if (const char *e = std::getenv(name)) {
     const int v = std::atoi(e);
@@ -468,15 +457,38 @@ int env_int(const char *name, int dflt, int lo, int hi) {
   return dflt;
 }
 
+int spec_group(int K, int max_pos);
+int pipe_group(int K) {
+  // Two chains per wavefront up to tetraploids: the phased form spends its time in likelihood evaluations, which a
+  // wave serves one after the other whatever the group size, and 32-lane groups halve the rounds of a fill and
+  // leave a shorter tail (MI355X, config #2: 16.4 ms with 16 lanes, 14.6 ms with 32 or 64).
+  if (K == 4) {  // (the other sizes stay instantiated for measurements)
+    const int g = env_int("MCHAP_HIP_PIPE_GROUP", 32, 16, 64);
+    if (g == 16 || g == 64) return g;
+  }
+  return K < 2 || K > 8 ? 0 : (K <= 3 ? 16 : (K <= 6 ? 32 : 64));
+}
+bool pipe_supported(const mchap_denovo_cfg *cfg, int K, int max_pos) {
+  if ((cfg->kernel != 5 && cfg->kernel != 0) || cfg->n_temps != 1 || K < 2 || K > 8) return false;
+  if (std::getenv("MCHAP_HIP_GROUP")) return false;
+  if (const char *e = std::getenv("MCHAP_HIP_FLAGS"))
+    if (std::atoi(e) & 3) return false;  // memos switched off
+  const int g = spec_group(K, max_pos);
+  if (g == 0 || g > pipe_group(K)) return false;
+  if (mchap::spec_memo_bytes(max_pos, 1, g) == 0) return false;
+  return K * max_pos <= mchap::spec_draws(K, max_pos);
+}
+
+
 int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *lists, int32_t *counts, hipStream_t stream) {
   const int G = pipe_group(K);
   int (*launch)(const mchap::SimtParams *, unsigned, size_t, hipStream_t) =
-      K == 2 ? mchap_specp_launch_2_16 : K == 3 ? mchap_specp_launch_3_16 : K == 4 ? mchap_specp_launch_4_16 :
+      K == 2 ? mchap_specp_launch_2_16 : K == 3 ? mchap_specp_launch_3_16 : K == 4 ? (G == 64 ? mchap_specp_launch_4_64 : G == 32 ? mchap_specp_launch_4_32 : mchap_specp_launch_4_16) :
       K == 5 ? mchap_specp_launch_5_32 : K == 6 ? mchap_specp_launch_6_32 : K == 7 ? mchap_specp_launch_7_64 : mchap_specp_launch_8_64;
   const size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, 1, G);
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
   const long long n_chains = (long long)n_units * chains;
-  const int s0 = env_int("MCHAP_HIP_PIPE_FIRST", 8, 1, 1 << 30);    // steps before the first hand-over
+  const int s0 = env_int("MCHAP_HIP_PIPE_FIRST", 5, 1, 1 << 30);    // steps before the first hand-over
   const int nr = env_int("MCHAP_HIP_PIPE_RESUME", 8, 1, 1 << 30);   // steps a handed-back chain runs before the next
   const int rounds = env_int("MCHAP_HIP_ROUNDS", 2, 0, PIPE_MAX_ROUNDS);
   P.pipe_iters_max = env_int("MCHAP_HIP_PIPE_MAX", 64, 1, 1 << 30);  // ... extended to while a chain of the wave is unsettled
