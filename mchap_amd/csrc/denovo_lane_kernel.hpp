@@ -198,6 +198,8 @@ template <int KT>
 __device__ __forceinline__ void lane_context_tabs(const LaneLds &LL, int cs, int rpad, SpecLds &S) {
   S.lds_ct = (LDSP(const uint8_t))(LL.tct + (size_t)cs * LL.tab_bytes);
   S.lds_cw = (LDSP(const double))(LL.tcw + (size_t)cs * rpad);
+  S.bpc = nullptr;
+  S.bpt = nullptr;
 }
 
 template <int KT>

@@ -65,6 +65,7 @@ struct SimtParams {
   int pipe_iters;             // compound steps per chain in this launch (<= 0: to the end)
   int pipe_iters_max;         // ... which a wave extends to while one of its chains is not settled (PIPE_EXPORT)
   int pipe_mode;              // PIPE_RESUME | PIPE_EXPORT
+  int bp_cache;               // speculative sampler with one chain per wave: base-product cache carved after its LDS
 };
 constexpr int PIPE_RESUME = 1;  // start from the chains' PipeState records
 constexpr int PIPE_EXPORT = 2;  // at the end: complete the interval memo of the current genotype, write the records

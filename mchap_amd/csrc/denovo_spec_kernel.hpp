@@ -125,6 +125,8 @@ struct SpecLds {
   LDSP(double) gval;      // [NG][GV_N] cold per-chain values: inbreeding, mutation memo bounds
   LDSP(uint32_t) gstream; // [NG][4] Philox key and counter words of the chain's current stream (Stream)
   LDSP(uint64_t) bw;      // [NG][K] the chain's current genotype while its proposals are evaluated (base words)
+  LDSP(double) bpc;       // [K][4][64] one chain per wave only (G = 64), else null: the haplotype products of ...
+  LDSP(uint64_t) bpt;     // [K + 1] ... these base words (bpt[K] != 0: valid), kept from one evaluation call to the next
   LDSP(uint64_t) tbuf;    // [NG][SPEC_TB][K + 1] trace records (K sorted words + llk) waiting to be written as a line
   uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
   bool cache_on;
@@ -149,6 +151,9 @@ __host__ __device__ inline size_t spec_memo_bytes(int Mmax, int T, int G) {
   if (T != 1 || per_group > 16 * 1024) return 0;
   return per_group * (64 / G);
 }
+
+// LDS of the base-product cache (SpecLds::bpc / bpt) of a one-chain-per-wave launch
+__host__ __device__ inline size_t spec_bp_cache_bytes(int K) { return (size_t)8 * K * 4 * 64 + (size_t)8 * (K + 1); }
 
 // dynamic LDS of denovo_coast_kernel (denovo_coast_kernel.hpp): a chain's two memo tables, its break distribution,
 // its sorted words
@@ -672,7 +677,8 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
                                                 LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab, LDSP(uint16_t) ndict_tab,
                                                 LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, LDSP(uint64_t) bw_tab,
                                                 bool reuse, int crow, int mmax, int Mh_lane, uint32_t amask_lane, int rpad,
-                                                int lane, LDSP(const uint8_t) lds_ct = nullptr, LDSP(const double) lds_cw = nullptr) {
+                                                int lane, LDSP(const uint8_t) lds_ct = nullptr, LDSP(const double) lds_cw = nullptr,
+                                                LDSP(double) bpc = nullptr, LDSP(uint64_t) bpt = nullptr) {
   SpecLds S;
   S.pw = pwbuf;
   S.shift = shift_tab;
@@ -707,17 +713,43 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
       typename TabPtr<LT>::u8 ct;
       if constexpr (LT) ct = lds_ct + (size_t)lane * cstride;
       else ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
-      const bool use_base = reuse && __popcll(reqs) >= 2;
+      // One chain per wave: the base products stay in LDS between calls (a lane reads back its own column), so the
+      // rounds of a compound step that does not move, and of a fill, form them once.  Same values either way.
+      bool cached = false;
+      if (G == 64 && bpc != nullptr) {
+        bool eq = bpt[KT] != 0ull;
+#pragma unroll
+        for (int h = 0; h < KT; h++) eq = eq & (bpt[h] == bw_tab[(size_t)sg * KT + h]);
+        cached = __builtin_amdgcn_readfirstlane((int)eq) != 0;
+      }
+      const bool use_base = reuse && (cached || __popcll(reqs) >= 2);
       double bp[KT][4];
 #pragma unroll
       for (int h = 0; h < KT; h++)
 #pragma unroll
         for (int i = 0; i < 4; i++) bp[h][i] = 0.0;
-      if (use_base) {
+      if (use_base && cached) {
+#pragma unroll
+        for (int h = 0; h < KT; h++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) bp[h][i] = bpc[(h * 4 + i) * WAVE + lane];
+      } else if (use_base) {
         if (nb0 == 1) spec_base_products<KT, 1, uint8_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
         else if (nb0 == 2) spec_base_products<KT, 2, uint16_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
         else if (nb0 == 3) spec_base_products<KT, 3, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
         else spec_base_products<KT, 4, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+        if (G == 64 && bpc != nullptr) {
+#pragma unroll
+          for (int h = 0; h < KT; h++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) bpc[(h * 4 + i) * WAVE + lane] = bp[h][i];
+          if (lane == 0) {
+#pragma unroll
+            for (int h = 0; h < KT; h++) bpt[h] = bw_tab[(size_t)sg * KT + h];
+            bpt[KT] = 1ull;
+          }
+          lds_sync();
+        }
       }
       while (reqs) {
         const int src = __ffsll((long long)reqs) - 1;
@@ -837,7 +869,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
       for (int h = 0; h < KT; h++) S.bw[(size_t)(lane / G) * KT + h] = cg.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G, LT>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw);
+    const double v = spec_coop_all<KT, G, LT>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw, S.bpc, S.bpt);
     if (miss) {
       val = v;
       if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
@@ -1572,6 +1604,15 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     S.memo_stride = (spec_memo_bytes(mmax, T, G) && !(P.flags & 2)) ? 2 * spec_memo_entries(mmax) : 0;
     S.memo_tot = lds_cast<double>(p);
     for (int i = lane; i < NG * S.memo_stride; i += WAVE) S.memo_tot[i] = NAN;  // nothing evaluated yet
+    S.bpc = nullptr;
+    S.bpt = nullptr;
+    if (G == 64 && P.bp_cache) {
+      p += spec_memo_bytes(mmax, T, G);
+      p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
+      S.bpc = lds_cast<double>(p); p += (size_t)8 * KT * 4 * 64;
+      S.bpt = lds_cast<uint64_t>(p);
+      if (lane == 0) S.bpt[KT] = 0ull;
+    }
   }
   for (int i = lane; i < SPEC_LN; i += WAVE) {
     S.ln[i] = c_ln[i];
@@ -1744,7 +1785,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = g0.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane);
+    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, nullptr, nullptr, S.bpc, S.bpt);
     lds_sync();
     c.llk = __shfl(v, 0, G);
     if (c.alive && gl == 0) {

@@ -365,6 +365,12 @@ int launch_simt(int KT, const mchap::SimtParams &P, int n_units, int chains, siz
   return MCHAP_OK;
 }
 
+// One chain per wave (G = 64): the base-product cache goes behind the sampler's LDS when eight waves per CU still fit
+int bp_cache_fits(int G, size_t lds, int K) {
+  if (G != 64 || std::getenv("MCHAP_HIP_NO_BP_CACHE")) return 0;
+  return ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K) <= 20 * 1024 ? 1 : 0;
+}
+
 int launch_spec(int K, int G, const mchap::SimtParams &P, int n_units, int chains, int n_temps, hipStream_t stream) {
   int n = 0;
   const SpecInst *insts = spec_insts(&n);
@@ -374,12 +380,15 @@ int launch_spec(int K, int G, const mchap::SimtParams &P, int n_units, int chain
   if (!inst) return fail(MCHAP_ERR_LIMIT, "speculative sampler: no instantiation for ploidy %d with %d lanes per chain", K, G);
   size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, n_temps, G);
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
+  mchap::SimtParams Q = P;
+  Q.bp_cache = bp_cache_fits(G, lds, K);
+  if (Q.bp_cache) lds = ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K);
   const long long n_chains = (long long)n_units * chains;
   const int per_wave = 64 / G;
   char name[96];
   snprintf(name, sizeof(name), "denovo_spec_kernel<%d, %d>", K, G);
   SamplerTimer timer(stream, name);
-  const int e = inst->launch(&P, (unsigned)((n_chains + per_wave - 1) / per_wave), lds, stream);
+  const int e = inst->launch(&Q, (unsigned)((n_chains + per_wave - 1) / per_wave), lds, stream);
   if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
 }
@@ -459,12 +468,14 @@ int env_int(const char *name, int dflt, int lo, int hi) {
 
 int spec_group(int K, int max_pos);
 int pipe_group(int K) {
-  // Two chains per wavefront up to tetraploids: the phased form spends its time in likelihood evaluations, which a
-  // wave serves one after the other whatever the group size, and 32-lane groups halve the rounds of a fill and
-  // leave a shorter tail (MI355X, config #2: 16.4 ms with 16 lanes, 14.6 ms with 32 or 64).
+  // One chain per wavefront for tetraploids: the phased form spends its time in likelihood evaluations, which a
+  // wave serves one after the other whatever the group size; wider groups need fewer rounds per fill, leave a shorter
+  // tail, and with a single chain the base products stay cached in LDS (MI355X, config #2: 16.4 ms with 16 lanes,
+  // 14.5 ms with 32, 13.7 ms with 64).
   if (K == 4) {  // (the other sizes stay instantiated for measurements)
-    const int g = env_int("MCHAP_HIP_PIPE_GROUP", 32, 16, 64);
-    if (g == 16 || g == 64) return g;
+    const int g = env_int("MCHAP_HIP_PIPE_GROUP", 64, 16, 64);
+    if (g == 16 || g == 32) return g;
+    return 64;
   }
   return K < 2 || K > 8 ? 0 : (K <= 3 ? 16 : (K <= 6 ? 32 : 64));
 }
@@ -485,10 +496,16 @@ int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *li
   int (*launch)(const mchap::SimtParams *, unsigned, size_t, hipStream_t) =
       K == 2 ? mchap_specp_launch_2_16 : K == 3 ? mchap_specp_launch_3_16 : K == 4 ? (G == 64 ? mchap_specp_launch_4_64 : G == 32 ? mchap_specp_launch_4_32 : mchap_specp_launch_4_16) :
       K == 5 ? mchap_specp_launch_5_32 : K == 6 ? mchap_specp_launch_6_32 : K == 7 ? mchap_specp_launch_7_64 : mchap_specp_launch_8_64;
-  const size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, 1, G);
+  size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, 1, G);
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
+  P.bp_cache = bp_cache_fits(G, lds, K);
+  if (P.bp_cache) lds = ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K);
   const long long n_chains = (long long)n_units * chains;
-  const int s0 = env_int("MCHAP_HIP_PIPE_FIRST", 5, 1, 1 << 30);    // steps before the first hand-over
+  // steps before the first hand-over: a chain handed over before it has settled comes back and has its tables
+  // completed a second time, which costs more the more sub-steps and intervals a step has (config #2: 32 sub-steps,
+  // best at 4; config #5: 160 sub-steps, 1251 / 912 / 570 / 632 ms at 4 / 8 / 16 / 32)
+  const int n_sub = K * P.max_pos;
+  const int s0 = env_int("MCHAP_HIP_PIPE_FIRST", n_sub / 10 < 4 ? 4 : (n_sub / 10 > 32 ? 32 : n_sub / 10), 1, 1 << 30);
   const int nr = env_int("MCHAP_HIP_PIPE_RESUME", 8, 1, 1 << 30);   // steps a handed-back chain runs before the next
   const int rounds = env_int("MCHAP_HIP_ROUNDS", 2, 0, PIPE_MAX_ROUNDS);
   P.pipe_iters_max = env_int("MCHAP_HIP_PIPE_MAX", 64, 1, 1 << 30);  // ... extended to while a chain of the wave is unsettled
