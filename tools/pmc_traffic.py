@@ -14,19 +14,29 @@ import json
 import sys
 
 tag, loci, steps, chains = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-SAMPLERS = ("denovo_spec", "denovo_simt_kernel", "denovo_mcmc")
+SAMPLERS = ("denovo_spec", "denovo_coast", "denovo_simt_kernel", "denovo_mcmc")
 
 
 def per_launch(dirname, match):
-    vals = collections.defaultdict(list)
+    """Counter totals per sampler call: a call of the phased sampler is several dispatches (speculative kernel phases +
+    coasting kernel), so the matching dispatches are summed and divided by the number of calls -- one
+    denovo_prepare_kernel dispatch precedes each; the calibration kernels are one dispatch per call."""
+    tot = collections.defaultdict(float)
+    calls = collections.defaultdict(int)
     for f in glob.glob("gpurun_out/%s_%s/*/*counter_collection.csv" % (tag, dirname)):
-        per_dispatch = collections.defaultdict(float)
+        seen = set()
+        n_prepare = set()
+        names = set()
         for row in csv.DictReader(open(f)):
+            if "denovo_prepare_kernel" in row["Kernel_Name"]:
+                n_prepare.add(row["Dispatch_Id"])
             if any(m in row["Kernel_Name"] for m in match):
-                per_dispatch[(row["Counter_Name"], row["Dispatch_Id"])] += float(row["Counter_Value"])
-        for (name, _), v in per_dispatch.items():
-            vals[name].append(v)
-    return {k: sum(v) / len(v) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
+                tot[row["Counter_Name"]] += float(row["Counter_Value"])
+                seen.add(row["Dispatch_Id"])
+                names.add(row["Counter_Name"])
+        for name in names:
+            calls[name] += len(n_prepare) if n_prepare else len(seen)
+    return {k: tot[k] / max(calls[k], 1) for k in tot}, dict(calls)
 
 
 fetch, nf = per_launch("pmc_fetch", SAMPLERS)
