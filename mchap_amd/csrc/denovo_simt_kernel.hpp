@@ -85,8 +85,11 @@ constexpr int SIMT_FLAG_PREP_GLOBAL = 1 << 30;  // table too large for the prepa
 // ---------------------------------------------------------------------------------------------------------
 // prepare: grid = units, block = 64
 // ---------------------------------------------------------------------------------------------------------
+#ifndef MCHAP_PREP_WPE
+#define MCHAP_PREP_WPE 4  // waves per SIMD the prepare pass is compiled for (it is latency-bound: one wave per unit)
+#endif
 template <int RPL>
-__global__ __launch_bounds__(64) void denovo_prepare_kernel(const SimtParams P) {
+__global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(const SimtParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DenovoParams &D = P.d;
   const int u = blockIdx.x;

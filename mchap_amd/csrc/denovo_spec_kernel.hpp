@@ -583,7 +583,7 @@ template <int RPL, class CT, bool LT = false>
 __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int row1, int p0, int Mh, typename TabPtr<LT>::u8 ct,
                                               int crow, double (&prod)[RPL]) {
   constexpr int UNR = 8;  // code loads in flight
-  constexpr int GB = 4;   // positions whose dictionary gathers are in flight together
+  constexpr int GB = 2;   // positions whose dictionary gathers are in flight together
 #pragma unroll
   for (int i = 0; i < RPL; i++) prod[i] = 1.0;
   for (int j0 = 0; j0 < Mh; j0 += UNR) {
