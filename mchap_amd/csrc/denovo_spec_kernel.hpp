@@ -664,9 +664,11 @@ __device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int
 // lanes of `reqs` whose request words equal those of lane `src` (src included)
 template <int KT>
 __device__ __forceinline__ unsigned long long spec_same_request(LDSP(uint64_t) pwbuf, unsigned long long reqs, int src, int lane) {
+  if ((reqs & (reqs - 1ull)) == 0ull) return reqs;  // a single request
+  // (no short-circuit: the 2 K LDS reads go out together instead of one round trip per word behind a branch)
   bool eq = ((reqs >> lane) & 1ull) != 0ull;
 #pragma unroll
-  for (int h = 0; h < KT; h++) eq = eq && pwbuf[(size_t)h * WAVE + lane] == pwbuf[(size_t)h * WAVE + src];
+  for (int h = 0; h < KT; h++) eq = eq & (pwbuf[(size_t)h * WAVE + lane] == pwbuf[(size_t)h * WAVE + src]);
   return __ballot(eq);
 }
 

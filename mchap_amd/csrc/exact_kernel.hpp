@@ -321,10 +321,12 @@ __global__ __launch_bounds__(64) void exact_mode_kernel(const ExactModeParams P)
 
 // Second pass: every genotype's joint value again, its probability under the known normaliser added to the allele
 // count / occurrence sums (calling/exact.py:108-153) and, when it consists of exactly the mode's alleles, to the
-// support probability (64-105).  Per-thread LDS columns, summed in thread order, then in block order by
-// exact_freq_kernel: deterministic.
+// support probability (64-105).  A wavefront takes 64 consecutive genotypes at a time; each of the 2H + 1 sums gets
+// the wavefront's 64 contributions by a shuffle reduction (fixed order) and is kept per wavefront in LDS -- a
+// kilobyte instead of a column per thread, so that two workgroups share a CU as in pass 1.  Wavefronts are summed
+// in order, blocks in order by exact_freq_kernel: deterministic.
 inline size_t exact_pass2_lds(int R, int H, int K, int threads) {
-  return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)(2 * H + 1) * threads) * 8;
+  return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)(2 * H + 1) * (threads / 64)) * 8;
 }
 __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -334,9 +336,12 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
   ExactLds E;
   PriorTab pt;
   exact_setup(P, unit, smem, E, pt);
-  double *acc = E.red;  // [2H + 1][nt]
-  const int nt = blockDim.x;
-  for (int h = 0; h < 2 * H + 1; h++) acc[(size_t)h * nt + threadIdx.x] = 0.0;
+  const int nt = blockDim.x, nw = nt >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int NS = 2 * H + 1;
+  double *acc = E.red;  // [nw][2H + 1]
+  for (int i = threadIdx.x; i < nw * NS; i += nt) acc[i] = 0.0;
+  __syncthreads();
   const double total = P.unit_total[unit];
   int ms[MCHAP_MAX_PLOIDY], ns = 0;  // distinct alleles of the mode, ascending
   for (int k = 0; k < K; k++) {
@@ -348,29 +353,48 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
   long long hi = lo + EXACT_GENOS_PER_BLOCK;
   if (hi > G) hi = G;
   const double invK = 1.0 / (double)K;
-  for (long long i = lo + threadIdx.x; i < hi; i += nt) {
+  double *mine = acc + (size_t)wave * NS;
+  for (long long i0 = lo + (long long)wave * 64; i0 < hi; i0 += nt) {  // wave-uniform trip count
+    const long long i = i0 + lane;
     int g[MCHAP_MAX_PLOIDY];
-    unrank_genotype(i, K, g);
-    const double llk = exact_llk(E, g, R, H, K, invK);
-    const double lpr = has_prior ? calling_log_prior(pt, g, K) : 0.0;
-    const double prob = exp((llk + lpr) - total);
-    int nd = 0;
-    bool same = true;
-    for (int k = 0; k < K; k++) {
-      acc[(size_t)g[k] * nt + threadIdx.x] += prob;
-      if (k == 0 || g[k] != g[k - 1]) {
-        acc[(size_t)(H + g[k]) * nt + threadIdx.x] += prob;
-        same = same && nd < ns && ms[nd] == g[k];
-        nd++;
+#pragma unroll
+    for (int k = 0; k < MCHAP_MAX_PLOIDY; k++) g[k] = -1;
+    double prob = 0.0;
+    bool support = false;
+    if (i < hi) {
+      unrank_genotype(i, K, g);
+      const double llk = exact_llk(E, g, R, H, K, invK);
+      const double lpr = has_prior ? calling_log_prior(pt, g, K) : 0.0;
+      prob = exp((llk + lpr) - total);
+      int nd = 0;
+      bool same = true;
+      for (int k = 0; k < K; k++) {
+        if (k == 0 || g[k] != g[k - 1]) {
+          same = same && nd < ns && ms[nd] == g[k];
+          nd++;
+        }
+      }
+      support = same && nd == ns;
+    }
+    for (int a = 0; a < H; a++) {
+      int cnt = 0;
+#pragma unroll
+      for (int k = 0; k < MCHAP_MAX_PLOIDY; k++) cnt += (k < K && g[k] == a) ? 1 : 0;
+      const double c1 = wave_sum(prob * (double)cnt);         // allele count
+      const double c2 = wave_sum(cnt > 0 ? prob : 0.0);       // allele occurrence
+      if (lane == 0) {
+        mine[a] += c1;
+        mine[H + a] += c2;
       }
     }
-    if (same && nd == ns) acc[(size_t)(2 * H) * nt + threadIdx.x] += prob;
+    const double c3 = wave_sum(support ? prob : 0.0);
+    if (lane == 0) mine[2 * H] += c3;
   }
   __syncthreads();
-  for (int h = threadIdx.x; h < 2 * H + 1; h += nt) {
+  for (int h = threadIdx.x; h < NS; h += nt) {
     double sum = 0.0;
-    for (int t = 0; t < nt; t++) sum += acc[(size_t)h * nt + t];
-    P.part_freq[((size_t)unit * P.nblk + blockIdx.x) * (2 * H + 1) + h] = sum;
+    for (int w = 0; w < nw; w++) sum += acc[(size_t)w * NS + h];
+    P.part_freq[((size_t)unit * P.nblk + blockIdx.x) * NS + h] = sum;
   }
 }
 struct ExactFreqParams {
