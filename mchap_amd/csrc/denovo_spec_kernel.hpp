@@ -615,11 +615,28 @@ __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int r
     }
   }
 }
+// Haplotype products of a chain's current genotype (first block of up to 4 read chunks): K x 4 doubles per lane, in
+// registers -- or, with one chain per wave (G = 64), in the wave's LDS cache, each lane its own column: K x 4 doubles
+// are 64 VGPRs at K = 4 and 128 at K = 8, which the evaluation code does not have to spare.
+template <int KT, bool IN_LDS>
+struct BaseProducts;
+template <int KT>
+struct BaseProducts<KT, false> {
+  double v[KT][4];
+  __device__ __forceinline__ double get(int h, int i, int) const { return v[h][i]; }
+  __device__ __forceinline__ void set(int h, int i, int, double x) { v[h][i] = x; }
+};
+template <int KT>
+struct BaseProducts<KT, true> {
+  LDSP(double) p;
+  __device__ __forceinline__ double get(int h, int i, int lane) const { return p[(h * 4 + i) * WAVE + lane]; }
+  __device__ __forceinline__ void set(int h, int i, int lane, double x) { p[(h * 4 + i) * WAVE + lane] = x; }
+};
 // One request with reuse: haplotypes whose word equals the base word take the base product bp[h].
-template <int KT, int RPL, class CT, bool LT = false>
+template <int KT, int RPL, class CT, bool LT = false, class BP>
 __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
                                                   typename TabPtr<LT>::u8 ct, typename TabPtr<LT>::f64 cw, int crow, int lane,
-                                                  const double (&bp)[KT][4], bool use_base) {
+                                                  const BP &bp, bool use_base) {
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   const double invK = 1.0 / (double)KT;
   int row0, row1;
@@ -634,7 +651,7 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
     double ph[RPL];
     if (same) {
 #pragma unroll
-      for (int i = 0; i < RPL; i++) ph[i] = bp[h][i];
+      for (int i = 0; i < RPL; i++) ph[i] = bp.get(h, i, lane);
     } else {
       spec_hap_prod<RPL, CT, LT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
     }
@@ -646,9 +663,9 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
   for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
   return s;
 }
-template <int KT, int RPL, class CT, bool LT = false>
+template <int KT, int RPL, class CT, bool LT = false, class BP>
 __device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int mmax, int Mh, uint32_t amask,
-                                                   typename TabPtr<LT>::u8 ct, int crow, int lane, double (&bp)[KT][4]) {
+                                                   typename TabPtr<LT>::u8 ct, int crow, int lane, BP &bp) {
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   int row0, row1;
   spec_pair_rows<KT>(S.bw + (size_t)sg * KT, 1, 0, S, sg, mmax, Mh, amask, lane, row0, row1);
@@ -657,7 +674,7 @@ __device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int
     double ph[RPL];
     spec_hap_prod<RPL, CT, LT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
 #pragma unroll
-    for (int i = 0; i < RPL; i++) bp[h][i] = ph[i];
+    for (int i = 0; i < RPL; i++) bp.set(h, i, lane, ph[i]);
   }
 }
 
@@ -715,36 +732,32 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
       typename TabPtr<LT>::u8 ct;
       if constexpr (LT) ct = lds_ct + (size_t)lane * cstride;
       else ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
-      // One chain per wave: the base products stay in LDS between calls (a lane reads back its own column), so the
-      // rounds of a compound step that does not move, and of a fill, form them once.  Same values either way.
+      // One chain per wave (G = 64): the base products live in the wave's LDS cache and stay there between calls, so
+      // the rounds of a compound step that does not move, and of a fill, form them once.  Same values either way.
+      constexpr bool BPL = (G == 64) && !LT;
       bool cached = false;
-      if (G == 64 && bpc != nullptr) {
+      if (BPL && bpc != nullptr) {
         bool eq = bpt[KT] != 0ull;
 #pragma unroll
         for (int h = 0; h < KT; h++) eq = eq & (bpt[h] == bw_tab[(size_t)sg * KT + h]);
         cached = __builtin_amdgcn_readfirstlane((int)eq) != 0;
       }
-      const bool use_base = reuse && (cached || __popcll(reqs) >= 2);
-      double bp[KT][4];
-#pragma unroll
-      for (int h = 0; h < KT; h++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) bp[h][i] = 0.0;
-      if (use_base && cached) {
+      const bool use_base = reuse && (!BPL || bpc != nullptr) && (cached || __popcll(reqs) >= 2);
+      BaseProducts<KT, BPL> bp;
+      if constexpr (BPL) {
+        bp.p = bpc;
+      } else {
 #pragma unroll
         for (int h = 0; h < KT; h++)
 #pragma unroll
-          for (int i = 0; i < 4; i++) bp[h][i] = bpc[(h * 4 + i) * WAVE + lane];
-      } else if (use_base) {
+          for (int i = 0; i < 4; i++) bp.v[h][i] = 0.0;
+      }
+      if (use_base && !cached) {
         if (nb0 == 1) spec_base_products<KT, 1, uint8_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
         else if (nb0 == 2) spec_base_products<KT, 2, uint16_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
         else if (nb0 == 3) spec_base_products<KT, 3, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
         else spec_base_products<KT, 4, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
-        if (G == 64 && bpc != nullptr) {
-#pragma unroll
-          for (int h = 0; h < KT; h++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) bpc[(h * 4 + i) * WAVE + lane] = bp[h][i];
+        if constexpr (BPL) {
           if (lane == 0) {
 #pragma unroll
             for (int h = 0; h < KT; h++) bpt[h] = bw_tab[(size_t)sg * KT + h];
@@ -1217,7 +1230,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
   // total move probability (the last cumulative sum of its options): it moves nothing iff its uniform is >= that
   // total.  The table describes genotype generation memo_gen and is wiped when the genotype has changed.
   LDSP(double) mtot = S.memo_tot + gi * S.memo_stride + step_type * spec_memo_entries(mmax);
-  const bool memo = S.memo_stride != 0;
+  const bool memo = PIPE || S.memo_stride != 0;  // (the phased form is only launched with the tables in place)
   if (memo && wave_any(c.alive && c.gen != c.memo_gen)) {
     if (c.alive && c.gen != c.memo_gen) {
       LDSP(double) all = S.memo_tot + gi * S.memo_stride;
@@ -1560,7 +1573,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       return;  // the grid is sized for every chain
     }
   }
-  const int T = D.n_temps, Cn = D.chains, Sn = D.steps;
+  const int T = PIPE ? 1 : D.n_temps;  // the phased form is single-temperature: the ladder code drops out
+  const int Cn = D.chains, Sn = D.steps;
   const int mmax = P.max_pos, nmax = KT * P.max_pos;
   const int rpad = D.rpad;
   SpecLds S;

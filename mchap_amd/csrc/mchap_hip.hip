@@ -365,10 +365,11 @@ int launch_simt(int KT, const mchap::SimtParams &P, int n_units, int chains, siz
   return MCHAP_OK;
 }
 
-// One chain per wave (G = 64): the base-product cache goes behind the sampler's LDS when eight waves per CU still fit
+// One chain per wave (G = 64): the haplotype products of the chain's current genotype live in an LDS cache behind the
+// sampler's LDS (8 KB at K = 4, 16 KB at K = 8) instead of 64-128 VGPRs
 int bp_cache_fits(int G, size_t lds, int K) {
   if (G != 64 || std::getenv("MCHAP_HIP_NO_BP_CACHE")) return 0;
-  return ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K) <= 20 * 1024 ? 1 : 0;
+  return ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K) <= 160 * 1024 ? 1 : 0;
 }
 
 int launch_spec(int K, int G, const mchap::SimtParams &P, int n_units, int chains, int n_temps, hipStream_t stream) {
