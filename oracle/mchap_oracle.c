@@ -15,8 +15,10 @@
  *        Whole traces of this oracle are compared step-for-step with traces captured
  *        from the reference in that mode (tests/golden).
  *   ORC_RNG_PHILOX  the counter-based Philox4x32-10 streams the HIP kernels use
- *        (same order of consumption, one stream per (unit, chain, temperature)), so
- *        that kernel traces can be compared step-for-step with this oracle.
+ *        (same order of consumption, one stream per (unit, chain, temperature); the draws
+ *        of MCMC step i are numbered from i * ORC_STEP_DRAWS, so a step's draws do not depend on
+ *        what earlier steps consumed), so that kernel traces can be compared step-for-step
+ *        with this oracle.
  */
 #include "mchap_oracle.h"
 
