@@ -238,3 +238,38 @@ def test_octoploid_three_substeps_per_lane(n_pos):
     reads, _, _ = synth_units(2, ploidy=8, n_pos=n_pos, n_reads=90, window=(6, n_pos))
     model = DenovoMCMC(ploidy=8, n_alleles=[2] * n_pos, steps=40, chains=2, random_seed=n_pos)
     _check(model, list(reads))
+
+
+@pytest.mark.parametrize("knobs", [{}, {"MCHAP_HIP_PIPE_FIRST": "1", "MCHAP_HIP_PIPE_RESUME": "1"}, {"MCHAP_HIP_ROUNDS": "0"},
+                                   {"MCHAP_HIP_PIPE_FIRST": "2", "MCHAP_HIP_ROUNDS": "6", "MCHAP_HIP_PIPE_MAX": "2"},
+                                   {"MCHAP_HIP_PIPE_GROUP": "16"}, {"MCHAP_HIP_PIPE_GROUP": "32", "MCHAP_HIP_PIPE_FIRST": "3"}],
+                         ids=["default", "hand-over-after-1-step", "no-resume-rounds", "many-short-rounds", "16-lane-groups", "32-lane-groups"])
+def test_phased_sampler_hand_over_paths(sampler_kernel, monkeypatch, knobs):
+    """The phased sampler (the library's default choice) against the speculative kernel on a batch with shallow reads,
+    where chains keep moving: whatever the hand-over schedule -- chains handed over unsettled, handed back at once,
+    resumed for a step at a time, or left to the final launch -- traces and llks are those of kernel 3, bit for bit."""
+    if sampler_kernel != 5:
+        pytest.skip("one pass is enough: the test picks its kernels itself")
+    import ctypes as C
+
+    from mchap_amd import DenovoMCMC, _lib
+    from mchap_amd.synth import synth_units
+
+    monkeypatch.delenv("MCHAP_HIP_KERNEL", raising=False)
+    kw = dict(ploidy=4, n_alleles=[2] * 7, steps=300, chains=3, random_seed=11)
+    shallow, _, _ = synth_units(24, ploidy=4, n_pos=7, n_reads=12, first_unit=5, window=(3, 7), qual=(3, 20))
+    deep, _, _ = synth_units(24, ploidy=4, n_pos=7, n_reads=80, first_unit=900, window=(3, 7), qual=(30, 40))
+    reads = list(shallow) + list(deep)  # (ragged: fit_batch pads the read axis)
+    ref = DenovoMCMC(kernel=3, **kw).fit_batch(reads)
+    L = _lib.lib()
+    L.mchap_last_sampler_name.restype = C.c_char_p
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    got = DenovoMCMC(kernel=0, **kw).fit_batch(reads)
+    assert b"phased" in L.mchap_last_sampler_name()
+    moved = 0
+    for a, b in zip(ref, got):
+        assert np.array_equal(a.genotypes, b.genotypes)
+        assert np.array_equal(a.llks, b.llks, equal_nan=True)
+        moved += int((np.diff(a.llks[:, 50:], axis=1) != 0).any())
+    assert moved > 0  # the batch does contain chains that still move late: the hand-back path ran
