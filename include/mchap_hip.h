@@ -29,7 +29,7 @@ extern "C" {
 #define MCHAP_MAX_TEMPS 16
 #define MCHAP_MAX_PLOIDY 8   /* nibble-packed labels; reference has no limit */
 #define MCHAP_MAX_ALLELE 8
-#define MCHAP_MAX_READS 1024 /* rows per unit after de-duplication */
+#define MCHAP_MAX_READS 4096 /* rows per unit after de-duplication (kernels 3 and 5; kernels 1 and 2: 1024) */
 
 enum {
   MCHAP_OK = 0,

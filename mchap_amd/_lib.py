@@ -17,7 +17,7 @@ SO = os.environ.get("MCHAP_HIP_LIB") or os.path.join(CSRC, "libmchap_hip.so")
 MAX_TEMPS = 16
 MAX_PLOIDY = 8
 MAX_ALLELE = 8
-MAX_READS = 1024
+MAX_READS = 4096
 
 OK = 0
 ERR_NAN_LLK = -1

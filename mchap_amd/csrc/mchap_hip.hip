@@ -591,15 +591,17 @@ int spec_group(int K, int max_pos);
 bool lane_supported(int K, int max_pos, int n_temps);
 
 // Read chunks (of 64) per unit for the prepare pass and the sampler behind it.  The speculative sampler takes any
-// count up to 8 (then 12, 16); the lanes-over-chains kernel is instantiated for powers of two.
+// count up to 8, then 12, 16, 24, 32, 48, 64 (4096 reads: the prepare pass is instantiated per count); the
+// lanes-over-chains kernel and kernel 1 are instantiated for powers of two up to 16 (1024 reads).
 int simt_rpl(const mchap_denovo_cfg *cfg, int uniform_ploidy, int max_pos, int max_reads) {
   const bool lane = cfg->kernel == 4 && uniform_ploidy > 0 && lane_supported(uniform_ploidy, max_pos, cfg->n_temps);
   const bool spec = lane || (cfg->kernel != 1 && cfg->kernel != 2 && uniform_ploidy > 0 && spec_group(uniform_ploidy, max_pos) != 0);
   if (!spec) return rpl_for(max_reads);
   const int need = (max_reads + 63) / 64;
   if (need <= 8) return need < 1 ? 1 : need;
-  if (need <= 12) return 12;
-  return need <= 16 ? 16 : -1;
+  for (int r : {12, 16, 24, 32, 48, 64})  // (the sampler takes its chunks four at a time: any count works there)
+    if (need <= r) return r;
+  return -1;
 }
 
 bool use_simt(const mchap_denovo_cfg *cfg) { return cfg->kernel != 1; }
@@ -743,7 +745,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
   rc = batch_dims(cfg, n_units, units_host, B);
   if (rc) return rc;
   const int rpl = use_simt(cfg) ? simt_rpl(cfg, B.uniform_ploidy, B.max_pos, B.max_reads) : rpl_for(B.max_reads);
-  if (rpl < 0) return fail(MCHAP_ERR_LIMIT, "n_reads %d not in 1..%d", B.max_reads, MCHAP_MAX_READS);
+  if (rpl < 0) return fail(MCHAP_ERR_LIMIT, "n_reads %d: the sampler kernel for this batch takes 1..%d reads", B.max_reads, (use_simt(cfg) && B.uniform_ploidy > 0 && spec_group(B.uniform_ploidy, B.max_pos)) ? MCHAP_MAX_READS : 1024);
   const int rpad = 64 * rpl;
 
   mchap::SimtParams SP;
@@ -858,7 +860,11 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
       case 7: rc = launch_prepare<7>(SP, n_units, lds_prep, stream); break;
       case 8: rc = launch_prepare<8>(SP, n_units, lds_prep, stream); break;
       case 12: rc = launch_prepare<12>(SP, n_units, lds_prep, stream); break;
-      default: rc = launch_prepare<16>(SP, n_units, lds_prep, stream); break;
+      case 16: rc = launch_prepare<16>(SP, n_units, lds_prep, stream); break;
+      case 24: rc = launch_prepare<24>(SP, n_units, lds_prep, stream); break;
+      case 32: rc = launch_prepare<32>(SP, n_units, lds_prep, stream); break;
+      case 48: rc = launch_prepare<48>(SP, n_units, lds_prep, stream); break;
+      default: rc = launch_prepare<64>(SP, n_units, lds_prep, stream); break;
     }
     if (rc) return rc;
     if (cfg->kernel == 4 && B.uniform_ploidy > 0 && lane_supported(B.uniform_ploidy, B.max_pos, cfg->n_temps))

@@ -273,3 +273,22 @@ def test_phased_sampler_hand_over_paths(sampler_kernel, monkeypatch, knobs):
         assert np.array_equal(a.llks, b.llks, equal_nan=True)
         moved += int((np.diff(a.llks[:, 50:], axis=1) != 0).any())
     assert moved > 0  # the batch does contain chains that still move late: the hand-back path ran
+
+
+@pytest.mark.parametrize("n_reads", [1100, 1537, 2600, 4096])
+def test_more_than_1024_reads(sampler_kernel, n_reads):
+    """Read depths beyond 1024 rows per unit (up to 4096) run on the speculative and the phased sampler, whose
+    likelihoods take the read chunks four at a time (kernel 4 shares that code); kernels 1 and 2 refuse them by name."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(2, ploidy=4, n_pos=6, n_reads=n_reads, first_unit=300 + n_reads, window=(2, 6), qual=(10, 40))
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 6, steps=40, chains=2, random_seed=5, kernel=sampler_kernel)
+    if sampler_kernel in (1, 2):
+        with pytest.raises(NotImplementedError):
+            model.fit_batch(list(reads))
+        return
+    try:
+        _check(model, list(reads))
+    except NotImplementedError:
+        assert sampler_kernel == 4  # its LDS copy of the unit tables does not fit at every depth
