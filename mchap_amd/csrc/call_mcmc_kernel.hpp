@@ -128,6 +128,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
   EP.freqs = P.freqs;
   EP.R = R; EP.M = P.M; EP.A = P.A; EP.H = H; EP.K = K;
   EP.has_prior = P.has_prior;
+  EP.Rcap = 0;  // the whole product table (the sampler does not tile the reads)
   ExactLds E;
   PriorTab pt;
   exact_setup(EP, unit, smem, E, pt);

@@ -25,6 +25,7 @@ struct ExactParams {
   long long G;
   int has_prior;
   int nblk;
+  int Rcap;                 // rows of the LDS product table (0: all R; less: the passes tile the reads, exact_tile)
   // outputs / workspace
   float *llk32;             // [U][G] or null
   double *llk64;            // [U][G] or null
@@ -144,8 +145,10 @@ struct ExactLds {
   double *red;    // reduction scratch (the rest of the allocation)
 };
 // Builds P[r][h], the read weights and the prior tables of `unit` (whole workgroup; ends with a barrier).
+// (with P.Rcap < R only the first Rcap reads are tabulated here: exact_tile brings in the others, tile by tile)
 __device__ __forceinline__ void exact_setup(const ExactParams &P, int unit, unsigned char *smem, ExactLds &E, PriorTab &pt) {
-  const int R = P.R, M = P.M, A = P.A, H = P.H, K = P.K;
+  const int M = P.M, A = P.A, H = P.H, K = P.K;
+  const int R = (P.Rcap > 0 && P.Rcap < P.R) ? P.Rcap : P.R;
   E.ptab = reinterpret_cast<double *>(smem);
   E.cnt = E.ptab + (size_t)R * H;
   E.lgd = E.cnt + R;
@@ -153,7 +156,7 @@ __device__ __forceinline__ void exact_setup(const ExactParams &P, int unit, unsi
   E.lfreq = E.lgf + (K + 1);
   E.red = E.lfreq + H;
   __shared__ double s_left;
-  const double *reads = P.reads + (size_t)unit * R * M * A;
+  const double *reads = P.reads + (size_t)unit * P.R * M * A;
   const int8_t *haps = P.haps + (size_t)unit * H * M;
   for (int q = threadIdx.x; q < R * H; q += blockDim.x) {
     const int r = q / H, h = q % H;
@@ -164,7 +167,7 @@ __device__ __forceinline__ void exact_setup(const ExactParams &P, int unit, unsi
     }
     E.ptab[q] = prod;
   }
-  for (int r = threadIdx.x; r < R; r += blockDim.x) E.cnt[r] = P.counts ? (double)P.counts[(size_t)unit * R + r] : 1.0;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) E.cnt[r] = P.counts ? (double)P.counts[(size_t)unit * P.R + r] : 1.0;
   double F = 0.0;
   const bool has_prior = P.has_prior != 0;
   const bool has_freqs = has_prior && P.freqs != nullptr;
@@ -213,6 +216,58 @@ __device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[MC
   return llk;
 }
 
+// Reads r0 .. r0 + rn - 1 of `unit` into the product table and the weights (whole workgroup; barriers on both sides)
+__device__ __forceinline__ void exact_tile(const ExactParams &P, int unit, const ExactLds &E, int r0, int rn) {
+  const int M = P.M, A = P.A, H = P.H;
+  const double *reads = P.reads + ((size_t)unit * P.R + r0) * M * A;
+  const int8_t *haps = P.haps + (size_t)unit * H * M;
+  __syncthreads();
+  for (int q = threadIdx.x; q < rn * H; q += blockDim.x) {
+    const int r = q / H, h = q % H;
+    double prod = 1.0;
+    for (int j = 0; j < M; j++) {
+      const double v = reads[((size_t)r * M + j) * A + haps[h * M + j]];
+      if (!isnan(v)) prod *= v;
+    }
+    E.ptab[q] = prod;
+  }
+  for (int r = threadIdx.x; r < rn; r += blockDim.x) E.cnt[r] = P.counts ? (double)P.counts[(size_t)unit * P.R + r0 + r] : 1.0;
+  __syncthreads();
+}
+// The log likelihoods of the thread's genotypes lo + threadIdx.x + t * blockDim.x (t < NGT) when the reads do not fit
+// the LDS at once: tile by tile, every genotype's sum continued in read order -- the values of the untiled loop.
+constexpr int EXACT_NGT = EXACT_GENOS_PER_BLOCK / EXACT_THREADS;
+__device__ __forceinline__ void exact_llk_tiled(const ExactParams &P, int unit, const ExactLds &E, long long lo, long long hi,
+                                                double (&llk)[EXACT_NGT]) {
+  const int H = P.H, K = P.K, cap = P.Rcap;
+  const double invK = 1.0 / (double)K;
+#pragma unroll
+  for (int t = 0; t < EXACT_NGT; t++) llk[t] = 0.0;
+  for (int r0 = 0; r0 < P.R; r0 += cap) {
+    const int rn = min(cap, P.R - r0);
+    if (r0 > 0) exact_tile(P, unit, E, r0, rn);  // (exact_setup brought the first tile)
+#pragma unroll
+    for (int t = 0; t < EXACT_NGT; t++) {
+      const long long i = lo + threadIdx.x + (long long)t * EXACT_THREADS;
+      if (i < hi) {
+        int g[MCHAP_MAX_PLOIDY];
+        unrank_genotype(i, K, g);
+        double acc = llk[t];
+        for (int r = 0; r < rn; r++) {
+          const double *row = E.ptab + (size_t)r * H;
+          double rp = 0.0;
+#pragma unroll
+          for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+            if (k < K) rp += row[g[k]] * invK;
+          acc += read_log(rp) * E.cnt[r];
+        }
+        llk[t] = acc;
+      }
+    }
+  }
+}
+
+template <bool TILED>
 __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int unit = blockIdx.y;
@@ -231,10 +286,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
   double best = -INFINITY, best_llk = -INFINITY;
   long long best_idx = 0x7fffffffffffffffll;
   double lse_m = -INFINITY, lse_s = 0.0;  // running log-sum-exp: max and scaled sum
-  for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    int g[MCHAP_MAX_PLOIDY];
-    unrank_genotype(i, K, g);
-    const double llk = exact_llk(E, g, R, H, K, invK);
+  auto visit = [&](long long i, const int (&g)[MCHAP_MAX_PLOIDY], double llk) {
     const size_t o = (size_t)unit * G + i;
     if (P.llk32) P.llk32[o] = (float)llk;  // calling/exact.py:254 float32 store
     if (P.llk64) P.llk64[o] = llk;
@@ -253,6 +305,25 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
       } else if (lj > -INFINITY) {
         lse_s += exp(lj - lse_m);
       }
+    }
+  };
+  if constexpr (TILED) {
+    double tl[EXACT_NGT];
+    exact_llk_tiled(P, unit, E, lo, hi, tl);
+#pragma unroll
+    for (int t = 0; t < EXACT_NGT; t++) {
+      const long long i = lo + threadIdx.x + (long long)t * EXACT_THREADS;
+      if (i < hi) {
+        int g[MCHAP_MAX_PLOIDY];
+        unrank_genotype(i, K, g);
+        visit(i, g, tl[t]);
+      }
+    }
+  } else {
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      int g[MCHAP_MAX_PLOIDY];
+      unrank_genotype(i, K, g);
+      visit(i, g, exact_llk(E, g, R, H, K, invK));
     }
   }
   if (!P.part_max) return;
@@ -328,6 +399,7 @@ __global__ __launch_bounds__(64) void exact_mode_kernel(const ExactModeParams P)
 inline size_t exact_pass2_lds(int R, int H, int K, int threads) {
   return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)(2 * H + 1) * (threads / 64)) * 8;
 }
+template <bool TILED>
 __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int unit = blockIdx.y;
@@ -354,7 +426,12 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
   if (hi > G) hi = G;
   const double invK = 1.0 / (double)K;
   double *mine = acc + (size_t)wave * NS;
-  for (long long i0 = lo + (long long)wave * 64; i0 < hi; i0 += nt) {  // wave-uniform trip count
+  double tl[EXACT_NGT];
+  if constexpr (TILED) exact_llk_tiled(P, unit, E, lo, hi, tl);  // (nt == EXACT_THREADS: thread t's genotypes lo + t + 256 q)
+#pragma unroll
+  for (int tqq = 0; tqq < EXACT_NGT; tqq++) {
+    const long long i0 = lo + (long long)wave * 64 + (long long)tqq * nt;  // wave-uniform
+    if (i0 >= hi) continue;
     const long long i = i0 + lane;
     int g[MCHAP_MAX_PLOIDY];
 #pragma unroll
@@ -363,7 +440,9 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
     bool support = false;
     if (i < hi) {
       unrank_genotype(i, K, g);
-      const double llk = exact_llk(E, g, R, H, K, invK);
+      double llk;
+      if constexpr (TILED) llk = tl[tqq];
+      else llk = exact_llk(E, g, R, H, K, invK);
       const double lpr = has_prior ? calling_log_prior(pt, g, K) : 0.0;
       prob = exp((llk + lpr) - total);
       int nd = 0;

@@ -48,7 +48,9 @@ def test_against_reference_goldens(golden_dir):
         assert calling.index_as_genotype_alleles(idx, K).tolist() == mode[0].tolist()
 
 
-@pytest.mark.parametrize("K,H,M,R,U", [(4, 8, 8, 120, 3), (6, 10, 10, 200, 2), (2, 30, 6, 64, 2), (8, 5, 5, 40, 2)])
+@pytest.mark.parametrize("K,H,M,R,U", [(4, 8, 8, 120, 3), (6, 10, 10, 200, 2), (2, 30, 6, 64, 2), (8, 5, 5, 40, 2),
+                                       (4, 24, 6, 1500, 2)],  # the last: 288 KB of products -- the passes tile the reads
+                         ids=["K4", "K6", "K2-H30", "K8", "tiled-reads"])
 def test_batch_against_oracle(K, H, M, R, U):
     from mchap_amd import calling
     from mchap_amd.synth import synth_units
@@ -97,7 +99,8 @@ def test_zero_frequency_allele_and_zero_reads():
     np.testing.assert_allclose(post, 1.0 / len(post), rtol=1e-12)
 
 
-@pytest.mark.parametrize("K,H,M,R,U", [(4, 6, 6, 60, 5), (6, 7, 5, 33, 3), (2, 12, 6, 64, 4)])
+@pytest.mark.parametrize("K,H,M,R,U", [(4, 6, 6, 60, 5), (6, 7, 5, 33, 3), (2, 12, 6, 64, 4), (3, 20, 6, 1100, 2)],
+                         ids=["K4", "K6", "K2", "tiled-reads"])
 def test_device_batch_arrays_and_streaming_against_oracle(K, H, M, R, U):
     """mchap_exact_call_batch_device: every output of the streaming form and of the array form (likelihoods, posteriors
     and the summaries call_exact.py:126-159 derives from the posterior array) for a batch, against the oracle unit by
