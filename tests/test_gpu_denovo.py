@@ -292,3 +292,22 @@ def test_more_than_1024_reads(sampler_kernel, n_reads):
         _check(model, list(reads))
     except NotImplementedError:
         assert sampler_kernel == 4  # its LDS copy of the unit tables does not fit at every depth
+
+
+@pytest.mark.parametrize("steps,chains", [(1, 2), (2, 1), (5, 3), (9, 2), (64, 5), (130, 40)])
+def test_phased_sampler_short_runs_and_many_chains(sampler_kernel, monkeypatch, steps, chains):
+    """Runs shorter than the phased sampler's first phase, runs that end inside a 64-step sweep of the coasting kernel,
+    single chains and many chains per unit: same traces as kernel 3."""
+    if sampler_kernel != 5:
+        pytest.skip("one pass is enough: the test picks its kernels itself")
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    monkeypatch.delenv("MCHAP_HIP_KERNEL", raising=False)
+    reads, _, _ = synth_units(5, ploidy=4, n_pos=8, n_reads=70, first_unit=41)
+    kw = dict(ploidy=4, n_alleles=[2] * 8, steps=steps, chains=chains, random_seed=3)
+    ref = DenovoMCMC(kernel=3, **kw).fit_batch(list(reads))
+    got = DenovoMCMC(kernel=0, **kw).fit_batch(list(reads))
+    for a, b in zip(ref, got):
+        assert np.array_equal(a.genotypes, b.genotypes)
+        assert np.array_equal(a.llks, b.llks, equal_nan=True)
