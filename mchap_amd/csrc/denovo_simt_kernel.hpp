@@ -64,11 +64,24 @@ struct SimtParams {
   int32_t *pipe_out_count;
   int pipe_iters;             // compound steps per chain in this launch (<= 0: to the end)
   int pipe_iters_max;         // ... which a wave extends to while one of its chains is not settled (PIPE_EXPORT)
-  int pipe_mode;              // PIPE_RESUME | PIPE_EXPORT
+  int pipe_mode;              // PIPE_RESUME | PIPE_EXPORT | PIPE_FILLONLY
+  int pipe_parts;             // wavefronts a short list of chains may spread the completion of one chain's tables over
   int bp_cache;               // speculative sampler with one chain per wave: base-product cache carved after its LDS
 };
 constexpr int PIPE_RESUME = 1;  // start from the chains' PipeState records
 constexpr int PIPE_EXPORT = 2;  // at the end: complete the interval memo of the current genotype, write the records
+// Completing a chain's tables is a few hundred likelihood evaluations served one after the other by its wavefront.
+// When a launch holds few chains (a list of handed-back chains; a small batch of a big shape) the chip is empty
+// and that latency is all there is: the exporting launch then leaves the tables as they are, and a PIPE_FILLONLY
+// launch follows in which pipe_parts_eff() wavefronts per chain each complete every pipe_parts_eff()-th unknown entry
+// (no steps, no records; the chain's likelihood cache is not used: the wavefronts would race on it).
+constexpr int PIPE_FILLONLY = 4;
+constexpr int PIPE_FILL_SLOTS = 1024;  // wavefront slots such a launch may occupy (one per SIMD: beyond that the chip is busy anyway)
+__host__ __device__ inline int pipe_parts_eff(int n_list, int parts) {
+  if (parts <= 1 || n_list <= 0) return 1;
+  const int pe = PIPE_FILL_SLOTS / n_list;
+  return pe < 1 ? 1 : (pe > parts ? parts : pe);
+}
 // hand-over record of a chain between the launches of the phased sampler
 struct PipeState {
   uint64_t g[8];     // haplotype words in the chain's own (unsorted) order

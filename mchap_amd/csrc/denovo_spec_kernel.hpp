@@ -388,6 +388,7 @@ struct Grp {
   // of its uniforms u satisfies mlo <= u < mhi; gen tags the interval-step memo entries
   bool memo_on, mvalid;  // bounds mlo / mhi: SpecLds::gval
   int mwin;              // sub-steps the next mutation compound step speculates over per round (spec_mutation)
+  int fill_part, fill_parts;  // PIPE_FILLONLY: this group completes the unknown entries e with e % fill_parts == fill_part
   uint32_t gen, memo_gen;  // memo_gen: the generation the interval memo table currently describes
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
   unsigned long long ph[12], pt0;
@@ -1376,7 +1377,8 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
       while (spec_memo_entries(stop) <= p) stop++;
       int start = p - spec_memo_index(0, stop);
       while (p < n_entries && cnt < nivs) {
-        if (isnan(mtot[p])) ivse[cnt++] = (uint32_t)start | ((uint32_t)stop << 8);
+        if (isnan(mtot[p]) && (step_type * spec_memo_entries(mmax) + p) % c.fill_parts == c.fill_part)
+          ivse[cnt++] = (uint32_t)start | ((uint32_t)stop << 8);
         p++;
         if (++start == stop) {
           start = 0;
@@ -1561,9 +1563,20 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   const int gi = lane / G, gl = lane % G;
   int n_list = 0;
   long long my_slot = (long long)blockIdx.x * NG + gi;  // the group's position in the launch's list of chains
+  int parts_eff = 1, my_part = 0;
+  const bool fillonly = PIPE && (P.pipe_mode & PIPE_FILLONLY);
   if constexpr (PIPE) {
     n_list = P.pipe_count ? *P.pipe_count : (int)((long long)P.n_units * D.chains);
-    if (P.pipe_list) {
+    parts_eff = pipe_parts_eff(n_list, P.pipe_parts);
+    if (fillonly) {
+      if (parts_eff <= 1) return;  // the exporting launch completed the tables itself
+      const int n_slots = n_list * parts_eff;
+      const int n_waves = min(n_slots, (int)gridDim.x);
+      if ((int)blockIdx.x >= n_waves) return;
+      const long long v = (long long)gi * n_waves + blockIdx.x;
+      my_slot = v < n_slots ? v / parts_eff : (long long)n_list;
+      my_part = (int)(v % parts_eff);
+    } else if (P.pipe_list) {
       // a list of handed-back chains is usually short: its chains are dealt out over as many wavefronts as there
       // are (one chain per wave while they last), because a wave serves its chains' evaluations one after the other
       const int n_waves = min(n_list, (int)gridDim.x);
@@ -1669,7 +1682,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   S.lds_ct = nullptr;
   S.lds_cw = nullptr;
   S.crow = WAVE * P.cstride;
-  S.cache_on = D.cache_slots > 0;
+  S.cache_on = D.cache_slots > 0 && !fillonly;
   S.cache_mask = S.cache_on ? (uint32_t)(D.cache_slots / 8) - 1u : 0u;  // sets of 8 ways
   if (gl == 0) {
     LDSP(uint64_t) gp = S.gptr + gi * GP_N;
@@ -1687,6 +1700,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   c.memo_on = (T == 1) && !(P.flags & 1);
   c.mvalid = false;
   c.mwin = MCHAP_SPEC_WIN0;
+  c.fill_part = fillonly ? my_part : 0;
+  c.fill_parts = fillonly ? parts_eff : 1;
   c.gen = 1;
   c.memo_gen = 1;
   const int Mh = c.Mh;
@@ -1826,6 +1841,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   if constexpr (PIPE) {
     int mine = c.alive ? Sn - base : 0;
     if (P.pipe_iters > 0 && mine > P.pipe_iters) mine = P.pipe_iters;
+    if (fillonly) mine = 0;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mine = max(mine, __shfl_xor(mine, o, WAVE));
     n_iter = mine;
@@ -1962,13 +1978,22 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_stats[3 + i_], c.ph[i_]);
 #endif
   if constexpr (PIPE) {
-    if (P.pipe_mode & PIPE_EXPORT) {
-      // the interval memo of the current genotype, completed (both step types), then the hand-over record
+    if (P.pipe_mode & (PIPE_EXPORT | PIPE_FILLONLY)) {
+      // the interval memo of the current genotype, completed (both step types) -- unless a PIPE_FILLONLY launch will
+      // do that with several wavefronts per chain -- then the hand-over record
+      if (fillonly || parts_eff <= 1) {
 #pragma unroll 1
-      for (int kind = 3; kind < 5; kind++)
-        spec_structural<KT, G, true>(c, S, D, kind, D.temps[0], break_dist, n_break_dist, mmax, rpad, lane, gi, gl);
+        for (int kind = 3; kind < 5; kind++)
+          spec_structural<KT, G, true>(c, S, D, kind, D.temps[0], break_dist, n_break_dist, mmax, rpad, lane, gi, gl);
+      }
       lds_sync();
-      if (listed) {
+      if (fillonly) {
+        if (listed && c.alive) {  // this group's share of the entries (known ones are rewritten with their value)
+          double *pm = P.pipe_memo + (size_t)q * S.memo_stride;
+          for (int i = gl; i < S.memo_stride; i += G)
+            if (i % parts_eff == my_part) pm[i] = S.memo_tot[gi * S.memo_stride + i];
+        }
+      } else if (listed) {
         PipeState *st = reinterpret_cast<PipeState *>(P.pipe_state) + q;
         const GWords<KT> ge = c.g;
         if (gl == 0) {

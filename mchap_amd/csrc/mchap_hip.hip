@@ -510,6 +510,8 @@ int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *li
   const int nr = env_int("MCHAP_HIP_PIPE_RESUME", 8, 1, 1 << 30);   // steps a handed-back chain runs before the next
   const int rounds = env_int("MCHAP_HIP_ROUNDS", 2, 0, PIPE_MAX_ROUNDS);
   P.pipe_iters_max = env_int("MCHAP_HIP_PIPE_MAX", 64, 1, 1 << 30);  // ... extended to while a chain of the wave is unsettled
+  P.pipe_parts = env_int("MCHAP_HIP_PIPE_PARTS", 8, 1, 64);  // wavefronts per chain completing tables when chains are few
+  const unsigned grid_f = (unsigned)((mchap::PIPE_FILL_SLOTS + 64 / G - 1) / (64 / G));
   const size_t lds_c = mchap::coast_lds_bytes(P.max_pos);
   const unsigned grid_s = (unsigned)((n_chains + 64 / G - 1) / (64 / G)), grid_c = (unsigned)n_chains;
   const size_t list_stride = up256((size_t)n_chains * 4) / 4;
@@ -523,6 +525,13 @@ int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *li
   P.pipe_iters = s0;
   P.pipe_mode = mchap::PIPE_EXPORT;
   int e = launch(&P, grid_s, lds, stream);
+  auto fill_launch = [&]() {  // (a no-op unless the chains of the list are few: pipe_parts_eff)
+    if (P.pipe_parts <= 1) return 0;
+    mchap::SimtParams F = P;
+    F.pipe_mode = mchap::PIPE_RESUME | mchap::PIPE_FILLONLY;
+    return launch(&F, grid_f, lds, stream);
+  };
+  if (e == 0) e = fill_launch();
   // coast; then rounds of (resume the chains handed back for a few steps, coast again); the rest runs to the end
   P.pipe_out = lists;
   P.pipe_out_count = counts;
@@ -536,6 +545,8 @@ int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *li
     P.pipe_mode = mchap::PIPE_RESUME | (last ? 0 : mchap::PIPE_EXPORT);
     e = launch(&P, grid_s, lds, stream);
     if (last || e != 0) break;
+    e = fill_launch();
+    if (e != 0) break;
     P.pipe_out = lists + (size_t)((r + 1) & 1) * list_stride;
     P.pipe_out_count = counts + r + 1;
     e = mchap_coast_launch(&P, grid_c, lds_c, stream);
