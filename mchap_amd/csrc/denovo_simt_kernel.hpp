@@ -175,8 +175,15 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
     __syncthreads();
     const int RPLT = rpad / WAVE;
     for (int q = 0; q < MA; q++) {
-      for (int r = lane; r < rpad; r += WAVE) {
-        const unsigned long long key = (unsigned long long)__double_as_longlong(rt[(size_t)q * rpad + r]);
+      // the lane's RPL values of this row: loaded together (one memory round trip per row, not one per value)
+      for (int i0 = 0; i0 < RPL; i0 += 4) {
+      unsigned long long keys[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) keys[k] = (unsigned long long)__double_as_longlong(rt[(size_t)q * rpad + lane + WAVE * min(i0 + k, RPL - 1)]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (i0 + k >= RPL) break;
+        const unsigned long long key = keys[k];
         unsigned slot = (unsigned)(mix64(key) & (DICT_HASH - 1));
         while (*(volatile int *)ndist <= DICT_MAX) {
           // plain read first: most entries repeat a value that is already in the set (same-address LDS atomics of a
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
           if (old == EMPTY || old == key) break;
           slot = (slot + 1) & (DICT_HASH - 1);
         }
+      }
       }
     }
     __syncthreads();
@@ -210,11 +218,18 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
       }
       __syncthreads();
       for (int q = 0; q < MA; q++) {
-        for (int r = lane; r < rpad; r += WAVE) {
-          const unsigned long long key = (unsigned long long)__double_as_longlong(rt[(size_t)q * rpad + r]);
-          unsigned slot = (unsigned)(mix64(key) & (DICT_HASH - 1));
-          while (hkeys[slot] != key) slot = (slot + 1) & (DICT_HASH - 1);
-          ct[((size_t)q * WAVE + lane) * P.cstride + r / WAVE] = (uint8_t)hcode[slot];
+        for (int i0 = 0; i0 < RPL; i0 += 4) {
+          unsigned long long keys[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) keys[k] = (unsigned long long)__double_as_longlong(rt[(size_t)q * rpad + lane + WAVE * min(i0 + k, RPL - 1)]);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (i0 + k >= RPL) break;
+            const unsigned long long key = keys[k];
+            unsigned slot = (unsigned)(mix64(key) & (DICT_HASH - 1));
+            while (hkeys[slot] != key) slot = (slot + 1) & (DICT_HASH - 1);
+            ct[((size_t)q * WAVE + lane) * P.cstride + i0 + k] = (uint8_t)hcode[slot];
+          }
         }
       }
     }
