@@ -9,7 +9,8 @@ from mchap_amd.synth import synth_units
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 reads, _, _ = synth_units(U, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20), first_unit=77)
-model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=2000, chains=4, random_seed=42)
+cache = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=2000, chains=4, random_seed=42, llk_cache_threshold=cache)
 b = DenovoDeviceBatch(model, reads)
 L = _lib.lib()
 L.mchap_set_profiling(1)
