@@ -8,7 +8,7 @@ Parity: the reference's RNG-free `call-exact` golden VCFs are reproduced line fo
 import numpy as np
 
 from . import encoding
-from .io import DenovoLocus, Locus, extract_read_variants, qual_of_prob, read_bam, read_bed4, read_vcf, vcfstr  # noqa: F401
+from .io import DenovoLocus, Locus, extract_read_variants, qual_of_prob, read_alignments, read_bam, read_bed4, read_vcf, vcfstr  # noqa: F401
 
 SAMPLE_FIELDS = ("GT", "GQ", "SQ", "DP", "RCOUNT", "RCALLS", "MEC", "MECP", "GPM", "SPM", "MCI")
 
@@ -253,7 +253,7 @@ def call_exact(vcf_path, sample_bams, ploidy=4, report=(), base_error_rate=0.002
     All (record x sample) units of the file are encoded first, grouped by shape and evaluated in one device call per
     shape; the records are then formatted from the results."""
     samples = list(sample_bams)
-    bams = {s: read_bam(p) for s, p in sample_bams.items()}
+    bams = {s: read_alignments(p) for s, p in sample_bams.items()}
     _, records = read_vcf(vcf_path)
     report = tuple(report)
     units = _exact_units(records, bams, samples, ploidy, report, base_error_rate, use_base_phred_scores, prior_frequencies_tag, inbreeding)
@@ -362,7 +362,7 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
     from .device import DenovoRaggedBatch
 
     samples = list(sample_bams)
-    bams = {s: read_bam(p) for s, p in sample_bams.items()}
+    bams = {s: read_alignments(p) for s, p in sample_bams.items()}
     ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
     _, variants = read_vcf(variants_vcf_path)
     loci = [DenovoLocus(contig, start, stop, name, variants, reference_sequences[contig][start:stop])
@@ -423,7 +423,7 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
     from . import calling
 
     samples = list(sample_bams)
-    bams = {s: read_bam(p) for s, p in sample_bams.items()}
+    bams = {s: read_alignments(p) for s, p in sample_bams.items()}
     _, records = read_vcf(vcf_path)
     report = tuple(report)
     ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)

@@ -12,6 +12,51 @@ SEQ_CODE = "=ACMGRSVTWYHKDBN"
 CIGAR_OPS = "MIDNSHP=X"
 
 
+def read_sam(path):
+    """-> (ref_names, {RG id: SM}, [record dicts]) of a SAM text file: the same records read_bam gives for the
+    equivalent BAM (0-based pos, CIGAR as (length, op) pairs, phred qualities as ints, RG tag)."""
+    refs, rg, recs = [], {}, []
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            if line.startswith("@"):
+                fields = line.split("\t")
+                kv = dict(x.split(":", 1) for x in fields[1:] if ":" in x)
+                if fields[0] == "@SQ":
+                    refs.append(kv["SN"])
+                elif fields[0] == "@RG":
+                    rg[kv["ID"]] = kv["SM"]
+                continue
+            c = line.split("\t")
+            cigar = []
+            if c[5] != "*":
+                n = ""
+                for ch in c[5]:
+                    if ch.isdigit():
+                        n += ch
+                    else:
+                        cigar.append((int(n), ch))
+                        n = ""
+            seq = "" if c[9] == "*" else c[9]
+            qual = [255] * len(seq) if c[10] == "*" else [ord(q) - 33 for q in c[10]]
+            tag_rg = None
+            for t in c[11:]:
+                if t.startswith("RG:Z:"):
+                    tag_rg = t[5:]
+            recs.append(dict(qname=c[0], flag=int(c[1]), ref=None if c[2] == "*" else c[2], pos=int(c[3]) - 1, mapq=int(c[4]),
+                             cigar=cigar, seq=seq, qual=qual, rg=tag_rg))
+    return refs, rg, recs
+
+
+def read_alignments(path):
+    """read_bam or read_sam by what the file is (BAM files are gzip streams)."""
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    return read_bam(path) if magic == b"\x1f\x8b" else read_sam(path)
+
+
 def read_bam(path):
     """-> (ref_names, {RG id: SM}, [record dicts]) of a (small) BAM file."""
     data = gzip.decompress(open(path, "rb").read())
@@ -253,8 +298,36 @@ def read_fasta(path):
     return seqs
 
 
+def _is_sam(path):
+    """A SAM text file: not gzip, and its first line is a header line (or an alignment line of >= 11 fields)."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(4096)
+    except OSError:
+        return False
+    if head[:2] == b"\x1f\x8b" or not head:
+        return False
+    try:
+        first = head.decode("ascii").splitlines()[0]
+    except (UnicodeDecodeError, IndexError):
+        return False
+    return first.startswith(("@HD", "@SQ", "@RG", "@PG", "@CO")) or len(first.split("\t")) >= 11
+
+
 def bam_header(path):
-    """(reference names with lengths, {read group id: sample}) of a BAM file."""
+    """(reference names with lengths, {read group id: sample}) of a BAM file (or of a SAM text file)."""
+    if _is_sam(path):
+        refs, rg = [], {}
+        for line in open(path):
+            if not line.startswith("@"):
+                break
+            f = line.rstrip("\n").split("\t")
+            kv = dict(x.split(":", 1) for x in f[1:] if ":" in x)
+            if f[0] == "@SQ":
+                refs.append((kv["SN"], int(kv.get("LN", 0))))
+            elif f[0] == "@RG":
+                rg[kv["ID"]] = kv.get("SM", kv["ID"])
+        return refs, rg
     data = gzip.open(path, "rb")
     head = data.read(8)
     assert head[:4] == b"BAM\1"
@@ -280,7 +353,7 @@ def sample_bam_table(bam_args):
     (reference application/arguments.py:135-152, 890-955).  Returns an ordered {sample: path}: for (1) and (2) every
     sample of every BAM's read groups."""
     paths, table = [], {}
-    if len(bam_args) == 1 and not _is_bam(bam_args[0]):
+    if len(bam_args) == 1 and not _is_bam(bam_args[0]) and not _is_sam(bam_args[0]):
         for line in open(bam_args[0]):
             f = line.rstrip("\n").split("\t")
             if not f or not f[0].strip():

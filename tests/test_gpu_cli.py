@@ -67,3 +67,14 @@ def test_call_program_agrees_with_call_exact_on_deep_data():
             assert gx[0] == gy[0]                      # GT
             assert gy[10] in ("0", "1", "2")           # MCI from the sampler's replicate chains
             assert abs(float(gx[8]) - float(gy[8])) < 0.05 if gx[8] != "." else True   # GPM
+
+
+def test_call_exact_program_from_sam_text_input():
+    """The same program over the reference's SAM renditions of its simple.sample*.bam fixtures (f3: SAM text input)."""
+    from mchap_amd import cli
+
+    common = ["--ploidy", "4", "--haplotypes", os.path.join(HERE, "mock.input.frequencies.vcf")]
+    a, b = _io.StringIO(), _io.StringIO()
+    cli.run(["mchap_amd", "call-exact", "--bam"] + [os.path.join(HERE, "simple.sample%d.bam" % i) for i in (1, 2, 3)] + common, a)
+    cli.run(["mchap_amd", "call-exact", "--bam"] + [os.path.join(HERE, "simple.sample%d.sam" % i) for i in (1, 2, 3)] + common, b)
+    assert _records(a.getvalue()) == _records(b.getvalue()) and len(_records(a.getvalue())) > 0
