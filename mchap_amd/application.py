@@ -36,13 +36,13 @@ def _mec(calls, genotype):
     return int(diff.sum(axis=-1).min(axis=-1).sum())
 
 
-def _exact_units(records, bams, samples, ploidy, report, error_rate, use_phred, prior_tag, inbreeding):
+def _exact_units(records, bams, samples, ploidy, report, error_rate, use_phred, prior_tag, inbreeding, allele_filter=None):
     """Everything `call-exact` needs from the input side, record by record: the locus, per sample the encoded reads,
     and which (record, sample) units need the kernel (a record with a single haplotype, or no variable position, has
     one genotype with probability 1; an invalid record is not called at all)."""
     out = []
     for rec in records:
-        locus = Locus(rec, prior_tag)
+        locus = Locus(rec, prior_tag, allele_filter)
         H, M = locus.haplotypes.shape
         invalid = None
         if locus.mask_reference_allele and H == 1:
@@ -212,7 +212,7 @@ def _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_ta
              ("DP", float(np.nansum(dps)) if M else np.nan), ("RCOUNT", int(np.nansum(rcounts))), ("END", locus.stop),
              ("NVAR", M), ("SNVPOS", np.array(locus.positions, int) - locus.start + 1)]
     null_r = np.full(H, np.nan)
-    if "AFPRIOR" in report or prior_tag is not None:
+    if "AFPRIOR" in report:  # (only on request: the reference's --report AFP GP golden carries no AFPRIOR)
         info.append(("AFPRIOR", locus.frequencies))
     for tag in report:
         if tag == "ACP":
@@ -246,8 +246,21 @@ def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024
     return _format_exact_record(units[0], samples, results, 0, ploidy_of, report, prior_tag)
 
 
+def _allele_filter(vcf_path, text):
+    """--filter-input-haplotypes text -> what io.Locus takes (None: no filter)."""
+    if text is None:
+        return None
+    from .io import parse_allele_filter, vcf_info_numbers
+
+    field, compare, number = parse_allele_filter(text)
+    numbers = vcf_info_numbers(vcf_path)
+    if field not in numbers:
+        raise ValueError("Allele filter field not found in header '%s'" % field)
+    return field, compare, number, numbers[field]
+
+
 def call_exact(vcf_path, sample_bams, ploidy=4, report=(), base_error_rate=0.0024, use_base_phred_scores=False,
-               prior_frequencies_tag=None, inbreeding=None, calling=None):
+               prior_frequencies_tag=None, inbreeding=None, calling=None, filter_input_haplotypes=None):
     """`mchap call-exact` over a VCF of known haplotypes: yields one VCF record line per input record (no header).
     sample_bams: ordered mapping sample name -> BAM path; ploidy / inbreeding: a value or {sample: value}.
     All (record x sample) units of the file are encoded first, grouped by shape and evaluated in one device call per
@@ -256,14 +269,16 @@ def call_exact(vcf_path, sample_bams, ploidy=4, report=(), base_error_rate=0.002
     bams = {s: read_alignments(p) for s, p in sample_bams.items()}
     _, records = read_vcf(vcf_path)
     report = tuple(report)
-    units = _exact_units(records, bams, samples, ploidy, report, base_error_rate, use_base_phred_scores, prior_frequencies_tag, inbreeding)
+    units = _exact_units(records, bams, samples, ploidy, report, base_error_rate, use_base_phred_scores, prior_frequencies_tag, inbreeding,
+                         _allele_filter(vcf_path, filter_input_haplotypes))
     full = ("GL" in report) or ("GP" in report)
     ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
     results = _run_exact_groups(units, ploidy_of, inbreeding_of, full, calling)
     for ri, unit in enumerate(units):
         rec = unit["rec"]
         flt, info, fmt, cols = _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_frequencies_tag)
-        alt = ",".join(rec["alts"]) if rec["alts"] else "."
+        alts = unit["locus"].sequences[1:]  # (the input's, minus the alleles --filter-input-haplotypes removed)
+        alt = ",".join(alts) if alts else "."
         yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
 
 
@@ -415,7 +430,7 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
 # ---------------------------------------------------------------------------------------------------------
 def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use_base_phred_scores=False,
          prior_frequencies_tag=None, inbreeding=None, steps=2000, burn=1000, chains=2, seed=None,
-         incongruence_threshold=0.60, step_type="Gibbs"):
+         incongruence_threshold=0.60, step_type="Gibbs", filter_input_haplotypes=None):
     """`mchap call`: yields one VCF record line per record of the input VCF (no header).  Units ((record x sample)) are
     grouped by shape and each group is one launch of the sampler kernel (CallingMCMC.fit_batch); as in the reference every
     unit restarts from the same seed."""
@@ -427,7 +442,8 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
     _, records = read_vcf(vcf_path)
     report = tuple(report)
     ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
-    units = _exact_units(records, bams, samples, ploidy, report, base_error_rate, use_base_phred_scores, prior_frequencies_tag, inbreeding)
+    units = _exact_units(records, bams, samples, ploidy, report, base_error_rate, use_base_phred_scores, prior_frequencies_tag, inbreeding,
+                         _allele_filter(vcf_path, filter_input_haplotypes))
     # haplotypes with zero prior frequency (and a masked reference) are left out of the sampler (call.py:72-84)
     groups = {}
     for ri, unit in enumerate(units):
@@ -505,7 +521,8 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
                 n_inc += int(res[(ri, s)]["mci"] > 0)
                 cols[s] = ":".join(f)
             info = info.replace(";MCI=0;", ";MCI=%d;" % n_inc)
-        alt = ",".join(rec["alts"]) if rec["alts"] else "."
+        alts = unit["locus"].sequences[1:]  # (the input's, minus the alleles --filter-input-haplotypes removed)
+        alt = ",".join(alts) if alts else "."
         yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
 
 

@@ -46,6 +46,8 @@ def build_parser(program):
         p.add_argument("--use-dirmul-prior", type=str, nargs=2, default=[None, None],
                        help="inbreeding (value or file) and the INFO field of prior allele frequencies")
         p.add_argument("--prior-frequencies", type=str, nargs=1, default=[None])
+        p.add_argument("--filter-input-haplotypes", type=str, nargs=1, default=[None],
+                       help="'<field><operator><value>': INFO field of Number A or R, one of = > < >= <= !=, a number")
         if program == "call":
             p.add_argument("--mcmc-steps", type=int, nargs=1, default=[2000])
             p.add_argument("--mcmc-burn", type=int, nargs=1, default=[1000])
@@ -85,15 +87,15 @@ def run(argv, out=None):
         if program == "call-exact":
             records = application.call_exact(args.haplotypes[0], sample_bams, ploidy=ploidy, report=report,
                                              base_error_rate=args.base_error_rate[0], use_base_phred_scores=args.use_base_phred_scores,
-                                             prior_frequencies_tag=tag, inbreeding=inbreeding)
+                                             prior_frequencies_tag=tag, inbreeding=inbreeding,
+                                             filter_input_haplotypes=args.filter_input_haplotypes[0])
         else:
             records = application.call(args.haplotypes[0], sample_bams, ploidy=ploidy, report=report,
                                        base_error_rate=args.base_error_rate[0], use_base_phred_scores=args.use_base_phred_scores,
                                        prior_frequencies_tag=tag, inbreeding=inbreeding, steps=args.mcmc_steps[0], burn=args.mcmc_burn[0],
                                        chains=args.mcmc_chains[0], seed=seed,
-                                       incongruence_threshold=args.mcmc_chain_incongruence_threshold[0])
-        if tag is not None and "AFPRIOR" not in report:
-            report = ["AFPRIOR"] + report
+                                       incongruence_threshold=args.mcmc_chain_incongruence_threshold[0],
+                                       filter_input_haplotypes=args.filter_input_haplotypes[0])
     for line in vcfheader.header_lines(program, ["mchap_amd"] + list(argv[1:]), samples, contigs, report=report, random_seed=seed):
         out.write(line + "\n")
     n = 0

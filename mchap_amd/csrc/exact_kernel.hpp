@@ -599,16 +599,13 @@ __global__ __launch_bounds__(EXACT_ARRAY_THREADS) void exact_array_kernel(const 
           }
         }
       }
-      double total = mm + log(ss);
-      if (is_f32) total = (double)(float)total;  // the reference's accumulator is float32 here (jitutils.py:7-74)
-      s_total = total;
+      // (float64 also for float32 likelihoods: the compiled reference's log-denominator is float64 -- numba unifies
+      // add_log_prob's result type -- and only the joint values are stored in float32; oracle: orc_genotype_posteriors_f32)
+      s_total = mm + log(ss);
     }
     __syncthreads();
     const double total = s_total;
-    for (long long i = threadIdx.x; i < G; i += nt) {
-      if (is_f32) out[i] = (double)expf((float)out[i] - (float)total);
-      else out[i] = exp(out[i] - total);
-    }
+    for (long long i = threadIdx.x; i < G; i += nt) out[i] = exp(out[i] - total);
     __syncthreads();
     post = out;
   }

@@ -142,21 +142,73 @@ def read_vcf(path):
     return samples, out
 
 
-class Locus:
-    """LocusPrior.from_variant_record (io/loci.py:193-303) without allele filters."""
+_FILTER_OPS = {"=": np.equal, "==": np.equal, "!=": np.not_equal, ">": np.greater, ">=": np.greater_equal,
+               "<": np.less, "<=": np.less_equal}
 
-    def __init__(self, rec, frequency_tag=None):
+
+def parse_allele_filter(text):
+    """`--filter-input-haplotypes` (application/arguments.py:389-401): '<INFO field><operator><number>' ->
+    (field, comparison, number).  Operators = == != > >= < <=."""
+    import re
+
+    m = re.fullmatch(r"(\w+?)(==|!=|>=|<=|=|>|<)([0-9]*[.,]?[0-9]*)", text)
+    if not m or m.group(3) in ("", ".", ","):
+        raise ValueError("Invalid allele filter '%s'" % text)
+    number = m.group(3).replace(",", ".")
+    return m.group(1), _FILTER_OPS[m.group(2)], (int(number) if number.isdigit() else float(number))
+
+
+def vcf_info_numbers(path):
+    """{INFO field id: its Number} from the ##INFO lines of a VCF file."""
+    out = {}
+    for line in open(path):
+        if not line.startswith("##"):
+            break
+        if line.startswith("##INFO=<"):
+            kv = dict(x.split("=", 1) for x in line.strip()[8:-1].split(",") if "=" in x)
+            out[kv.get("ID")] = kv.get("Number")
+    return out
+
+
+class Locus:
+    """The locus of a record of known haplotypes (LocusPrior.from_variant_record, io/loci.py:193-303).
+
+    allele_filter: (field, comparison, number) from parse_allele_filter plus the field's Number ('R': one value per
+    allele, 'A': one per alternate allele) as a 4-tuple.  Alleles whose value fails the comparison are left out of the
+    locus; a failing reference allele stays in the list but is masked (prior frequency 0) like a REFMASKED record; a
+    record without the field keeps every allele (io/filter_alleles.py:56-95)."""
+
+    def __init__(self, rec, frequency_tag=None, allele_filter=None):
         self.contig, self.start, self.stop = rec["chrom"], rec["pos"] - 1, rec["pos"] - 1 + len(rec["ref"])
-        self.sequences = (rec["ref"],) + rec["alts"]
-        n = len(self.sequences)
+        sequences = (rec["ref"],) + rec["alts"]
+        n = len(sequences)
+        self.mask_reference_allele = "REFMASKED" in rec["info"]
+        keep = np.ones(n, dtype=bool)
+        if allele_filter is not None:
+            field, compare, number, length = allele_filter
+            if length not in ("R", "A"):
+                raise ValueError("Allele filter of field of invalid length '%s'" % length)
+            if field in rec["info"] and rec["info"][field] is not True:
+                values = np.array([float(x) if x != "." else np.nan for x in str(rec["info"][field]).split(",")])
+                if length == "R":
+                    assert len(values) == n
+                    keep = np.asarray(compare(values, number), dtype=bool)
+                else:
+                    assert len(values) == n - 1
+                    keep[1:] = compare(values, number)
+            if not keep[0]:  # the reference allele is masked, not removed
+                self.mask_reference_allele = True
+                keep[0] = True
         if frequency_tag:
             fr = np.array([float(x) for x in rec["info"][frequency_tag].split(",")])
             assert len(fr) == n
         else:
             fr = np.ones(n) / n
-        self.mask_reference_allele = "REFMASKED" in rec["info"]
         if self.mask_reference_allele:
             fr[0] = 0
+        self.sequences = tuple(q for q, k in zip(sequences, keep) if k)
+        fr = fr[keep]
+        n = len(self.sequences)
         self.frequencies = fr / fr.sum() if fr.sum() > 0 else np.full(n, np.nan)
         haps = np.array([list(s) for s in self.sequences])
         offsets = np.where((haps != haps[0:1]).any(axis=0))[0]

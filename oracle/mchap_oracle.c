@@ -1336,14 +1336,8 @@ int orc_genotype_likelihoods(const double *reads, int n_reads, int n_pos, int ma
 }
 
 /* exact.py:295-329 with the float32 likelihood array genotype_likelihoods returns: the joint values are
- * stored into a float32 array (exact.py:317), and the log-sum-exp of jitutils.py:7-74 is then typed
- * float32 throughout (float32 operands under numba and under numpy scalars alike); the result array is
- * np.empty(n) -> float64 holding those float32-precision values. */
-static float add_log_prob_f32(float x, float y) {
-  if (x == -INFINITY && y == -INFINITY) return -INFINITY;
-  if (x > y) return x + log1pf(expf(y - x));
-  return y + log1pf(expf(x - y));
-}
+ * stored into a float32 array (exact.py:317); the log-sum-exp of jitutils.py:7-74 and the final exp run in float64
+ * (see the comment in the body). */
 int orc_genotype_posteriors_f32(const float *llks, int64_t G, int ploidy, int n_alleles, int has_prior,
                                 double inbreeding, const double *frequencies, double *out) {
   int64_t g[ORC_MAX_PLOIDY];
@@ -1354,9 +1348,14 @@ int orc_genotype_posteriors_f32(const float *llks, int64_t G, int ploidy, int n_
     joint[i] = (float)((double)llks[i] + lpr);
     orc_increment_genotype(g, ploidy);
   }
-  float acc = joint[0];
-  for (int64_t i = 1; i < G; i++) acc = add_log_prob_f32(acc, joint[i]);
-  for (int64_t i = 0; i < G; i++) out[i] = (double)expf(joint[i] - acc);
+  /* exact.py:320-329 + jitutils.py:7-74 as the COMPILED reference runs them: the joint values are stored in the
+     likelihoods' float32, but numba types the running log-denominator float64 (add_log_prob's `return -np.inf` branch
+     unifies its result to float64), so the sum and the final exp(joint - denominator) are float64.  The reference's
+     golden VCF simple.output.mixed_depth.call-exact.frequencies.posteriors.skiprare.vcf pins this: a float32
+     accumulator leaves 4.4e-6 of the probability mass unaccounted for (SQ 53 instead of the golden's 60). */
+  double acc = (double)joint[0];
+  for (int64_t i = 1; i < G; i++) acc = orc_add_log_prob(acc, (double)joint[i]);
+  for (int64_t i = 0; i < G; i++) out[i] = exp((double)joint[i] - acc);
   free(joint);
   return ORC_OK;
 }

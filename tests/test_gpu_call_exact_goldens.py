@@ -20,12 +20,17 @@ SCENARIOS = [
     ("simple.output.mixed_depth.assemble.vcf", MIXED, dict(report=("GL",), error_rate=0.0, use_phred=True),
      "simple.output.mixed_depth.call-exact.likelihoods.vcf"),
     ("simple.output.mixed_depth.assemble.vcf", MIXED, dict(report=("GP",)), "simple.output.mixed_depth.call-exact.posteriors.vcf"),
-    ("mock.input.frequencies.vcf", MIXED, dict(report=("AFP",), prior_tag="AFP", inbreeding=0.0),
+    ("mock.input.frequencies.vcf", MIXED, dict(report=("AFPRIOR", "AFP"), prior_tag="AFP", inbreeding=0.0),
      "simple.output.mixed_depth.call-exact.frequencies.prior.vcf"),
+    # --filter-input-haplotypes AFP>=0.1: rare alleles dropped, a rare reference allele masked
+    ("mock.input.frequencies.vcf", MIXED, dict(report=("AFPRIOR", "AFP"), prior_tag="AFP", inbreeding=0.0, allele_filter="AFP>=0.1"),
+     "simple.output.mixed_depth.call-exact.frequencies.skiprare.vcf"),
+    ("mock.input.frequencies.vcf", MIXED, dict(report=("AFP", "GP"), prior_tag="AFP", inbreeding=0.0, allele_filter="AFP>=0.1"),
+     "simple.output.mixed_depth.call-exact.frequencies.posteriors.skiprare.vcf"),
 ]
 
 
-@pytest.mark.parametrize("input_vcf,bam_files,kw,golden", SCENARIOS)
+@pytest.mark.parametrize("input_vcf,bam_files,kw,golden", [sc for sc in SCENARIOS if "allele_filter" not in sc[2]])
 def test_call_exact_golden_vcf(input_vcf, bam_files, kw, golden):
     import replay_call_exact as rp
 
@@ -51,7 +56,7 @@ def test_call_exact_whole_records(input_vcf, bam_files, kw, golden):
 
     args = dict(report=kw.get("report", ()), base_error_rate=kw.get("error_rate", 0.0024),
                 use_base_phred_scores=kw.get("use_phred", False), prior_frequencies_tag=kw.get("prior_tag"),
-                inbreeding=kw.get("inbreeding"))
+                inbreeding=kw.get("inbreeding"), filter_input_haplotypes=kw.get("allele_filter"))
     bams = {s: os.path.join(HERE, f) for s, f in zip(["SAMPLE1", "SAMPLE2", "SAMPLE3"], bam_files)}
     got = list(application.call_exact(os.path.join(HERE, input_vcf), bams, **args))
     assert got == _golden_lines(os.path.join(HERE, golden))
