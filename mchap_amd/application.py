@@ -400,10 +400,16 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
     summaries = {}
     if units:
         model = DenovoMCMC(ploidy=int(ploidy_of(samples[0])), n_alleles=[2], inbreeding=None, steps=steps, chains=chains, random_seed=seed, **mcmc_kw)
-        batch = DenovoRaggedBatch(model, units)
-        batch.run(burn, incongruence_threshold=incongruence_threshold)
-        for key, res in zip(where, batch.results()):
-            summaries[key] = res
+        # one launch per ploidy present (usually one): the library's fast samplers take one ploidy per launch, a
+        # launch of mixed ploidies would run on the general lanes-over-chains kernel
+        by_ploidy = {}
+        for i, u in enumerate(units):
+            by_ploidy.setdefault(u["ploidy"], []).append(i)
+        for idx in by_ploidy.values():
+            batch = DenovoRaggedBatch(model, [units[i] for i in idx])
+            batch.run(burn, incongruence_threshold=incongruence_threshold)
+            for i, res in zip(idx, batch.results()):
+                summaries[where[i]] = res
     for li, locus in enumerate(loci):
         M = len(locus.positions)
         per, posteriors = {}, []

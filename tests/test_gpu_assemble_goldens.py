@@ -87,10 +87,14 @@ def test_assemble_is_one_sampler_launch_per_vcf():
                                       inbreeding=0.0, steps=300, burn=100, chains=2, seed=11))
     assert DenovoRaggedBatch.n_runs - before == 1
     assert len(lines) == len(open(os.path.join(HERE, "simple.bed")).read().strip().splitlines())
-    # per-sample parameters (the reference's --sample-ploidy / --sample-inbreeding files): a mapping instead of a value
+    # per-sample parameters (the reference's --sample-ploidy / --sample-inbreeding files): a mapping instead of a value;
+    # one launch per ploidy present, so that each runs on the fast (single-ploidy) samplers -- and the tetraploid
+    # samples' columns are what they were in the all-tetraploid run
+    before = DenovoRaggedBatch.n_runs
     mixed = list(application.assemble(os.path.join(HERE, "simple.bed"), os.path.join(HERE, "simple.vcf"), ref, bams,
                                       ploidy={"SAMPLE1": 4, "SAMPLE2": 2, "SAMPLE3": 4}, inbreeding={"SAMPLE1": 0.0, "SAMPLE2": 0.1, "SAMPLE3": 0.0},
                                       steps=200, burn=50, chains=2, seed=11))
+    assert DenovoRaggedBatch.n_runs - before == 2
     for ln in mixed:
         cols = ln.split("\t")
         assert len(cols[10].split(":")[0].split("/")) == 2 and len(cols[9].split(":")[0].split("/")) == 4
