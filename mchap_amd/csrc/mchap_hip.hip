@@ -67,12 +67,16 @@ MCHAP_LANE_DECL(8)
   extern "C" int mchap_specp_init_##k##_##g(const double *, const double *); \
   extern "C" int mchap_specp_launch_##k##_##g(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 MCHAP_SPECP_DECL(2, 16)
+MCHAP_SPECP_DECL(2, 64)
+MCHAP_SPECP_DECL(3, 64)
 MCHAP_SPECP_DECL(3, 16)
 MCHAP_SPECP_DECL(4, 16)
 MCHAP_SPECP_DECL(4, 32)
 MCHAP_SPECP_DECL(4, 64)
 MCHAP_SPECP_DECL(5, 32)
+MCHAP_SPECP_DECL(5, 64)
 MCHAP_SPECP_DECL(6, 32)
+MCHAP_SPECP_DECL(6, 64)
 MCHAP_SPECP_DECL(7, 64)
 MCHAP_SPECP_DECL(8, 64)
 extern "C" int mchap_coast_launch(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
@@ -198,8 +202,8 @@ int ensure_init() {
                                                       mchap_v1_init_8,   mchap_v1_init_16,  mchap_lane_init_1, mchap_lane_init_2,
                                                       mchap_lane_init_3, mchap_lane_init_4, mchap_lane_init_5, mchap_lane_init_6,
                                                       mchap_lane_init_7, mchap_lane_init_8,
-                                                      mchap_specp_init_2_16, mchap_specp_init_3_16, mchap_specp_init_4_16, mchap_specp_init_4_32, mchap_specp_init_4_64,
-                                                      mchap_specp_init_5_32, mchap_specp_init_6_32, mchap_specp_init_7_64,
+                                                      mchap_specp_init_2_16, mchap_specp_init_2_64, mchap_specp_init_3_16, mchap_specp_init_3_64, mchap_specp_init_4_16, mchap_specp_init_4_32, mchap_specp_init_4_64,
+                                                      mchap_specp_init_5_32, mchap_specp_init_5_64, mchap_specp_init_6_32, mchap_specp_init_6_64, mchap_specp_init_7_64,
                                                       mchap_specp_init_8_64};
     for (auto f : inits)
       if (f(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of a sampler object");
@@ -469,16 +473,16 @@ int env_int(const char *name, int dflt, int lo, int hi) {
 
 int spec_group(int K, int max_pos);
 int pipe_group(int K) {
-  // One chain per wavefront for tetraploids: the phased form spends its time in likelihood evaluations, which a
-  // wave serves one after the other whatever the group size; wider groups need fewer rounds per fill, leave a shorter
-  // tail, and with a single chain the base products stay cached in LDS (MI355X, config #2: 16.4 ms with 16 lanes,
-  // 14.5 ms with 32, 13.7 ms with 64).
-  if (K == 4) {  // (the other sizes stay instantiated for measurements)
-    const int g = env_int("MCHAP_HIP_PIPE_GROUP", 64, 16, 64);
-    if (g == 16 || g == 32) return g;
-    return 64;
-  }
-  return K < 2 || K > 8 ? 0 : (K <= 3 ? 16 : (K <= 6 ? 32 : 64));
+  // One chain per wavefront at every ploidy: the phased form spends its time in likelihood evaluations, which a wave
+  // serves one after the other whatever the group size; wider groups need fewer rounds per table completion, leave a
+  // shorter tail, and with a single chain the base products live in LDS.  MI355X, 10 000 loci of config #2's shape:
+  // K = 2: 3.1 ms (16 or 64 lanes), K = 3: 7.9 -> 7.2 ms, K = 4: 16.4 (16) / 14.5 (32) / 13.7 (64), K = 5: 39.7 -> 32.1,
+  // K = 6: 87 -> 67 ms.  The narrower instantiations stay selectable for measurements.
+  if (K < 2 || K > 8) return 0;
+  const int g = env_int("MCHAP_HIP_PIPE_GROUP", 64, 16, 64);
+  if (g == 16 && K <= 4) return 16;
+  if (g == 32 && K >= 4 && K <= 6) return 32;
+  return 64;
 }
 bool pipe_supported(const mchap_denovo_cfg *cfg, int K, int max_pos) {
   if ((cfg->kernel != 5 && cfg->kernel != 0) || cfg->n_temps != 1 || K < 2 || K > 8) return false;
@@ -495,8 +499,8 @@ bool pipe_supported(const mchap_denovo_cfg *cfg, int K, int max_pos) {
 int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *lists, int32_t *counts, hipStream_t stream) {
   const int G = pipe_group(K);
   int (*launch)(const mchap::SimtParams *, unsigned, size_t, hipStream_t) =
-      K == 2 ? mchap_specp_launch_2_16 : K == 3 ? mchap_specp_launch_3_16 : K == 4 ? (G == 64 ? mchap_specp_launch_4_64 : G == 32 ? mchap_specp_launch_4_32 : mchap_specp_launch_4_16) :
-      K == 5 ? mchap_specp_launch_5_32 : K == 6 ? mchap_specp_launch_6_32 : K == 7 ? mchap_specp_launch_7_64 : mchap_specp_launch_8_64;
+      K == 2 ? (G == 64 ? mchap_specp_launch_2_64 : mchap_specp_launch_2_16) : K == 3 ? (G == 64 ? mchap_specp_launch_3_64 : mchap_specp_launch_3_16) : K == 4 ? (G == 64 ? mchap_specp_launch_4_64 : G == 32 ? mchap_specp_launch_4_32 : mchap_specp_launch_4_16) :
+      K == 5 ? (G == 64 ? mchap_specp_launch_5_64 : mchap_specp_launch_5_32) : K == 6 ? (G == 64 ? mchap_specp_launch_6_64 : mchap_specp_launch_6_32) : K == 7 ? mchap_specp_launch_7_64 : mchap_specp_launch_8_64;
   size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, 1, G);
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
   P.bp_cache = bp_cache_fits(G, lds, K);
