@@ -222,14 +222,19 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
           unsigned long long keys[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) keys[k] = (unsigned long long)__double_as_longlong(rt[(size_t)q * rpad + lane + WAVE * min(i0 + k, RPL - 1)]);
+          uint32_t packed = 0;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             if (i0 + k >= RPL) break;
             const unsigned long long key = keys[k];
             unsigned slot = (unsigned)(mix64(key) & (DICT_HASH - 1));
             while (hkeys[slot] != key) slot = (slot + 1) & (DICT_HASH - 1);
-            ct[((size_t)q * WAVE + lane) * P.cstride + i0 + k] = (uint8_t)hcode[slot];
+            if (RPL > 2) packed |= (uint32_t)(uint8_t)hcode[slot] << (8 * k);
+            else ct[((size_t)q * WAVE + lane) * P.cstride + i0 + k] = (uint8_t)hcode[slot];
           }
+          // (cstride is a multiple of 4 beyond two chunks: one aligned 4-byte store instead of four byte stores;
+          // bytes past the unit's chunks are padding the sampler never reads)
+          if (RPL > 2) *reinterpret_cast<uint32_t *>(ct + ((size_t)q * WAVE + lane) * P.cstride + i0) = packed;
         }
       }
     }
@@ -335,13 +340,25 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
       for (int a = 0; a < A; a++) {
         double tot = 0.0;
         int n_ok = 0, n_nz = 0;
-        for (int r = lane; r < R; r += WAVE) {
-          const double v = rawv(r, col + a);
-          if (!isnan(v)) {
-            tot += v;
-            n_ok++;
+        for (int i0 = 0; i0 < RPL; i0 += 4) {  // four of the lane's reads at a time: their loads are independent
+          double v4[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int r = lane + WAVE * (i0 + k);
+            v4[k] = (i0 + k < RPL && r < R) ? rawv(r, col + a) : 0.0;
           }
-          if (!(v == 0.0)) n_nz++;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int r = lane + WAVE * (i0 + k);
+            if (i0 + k < RPL && r < R) {
+              const double v = v4[k];
+              if (!isnan(v)) {
+                tot += v;
+                n_ok++;
+              }
+              if (!(v == 0.0)) n_nz++;
+            }
+          }
         }
         tot = wave_sum(tot);
         n_ok = wave_sum_i(n_ok);
