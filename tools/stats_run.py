@@ -12,7 +12,8 @@ from mchap_amd.synth import synth_units
 
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-reads, _, _ = synth_units(U)
+n_reads = int(sys.argv[4]) if len(sys.argv) > 4 else 200  # e.g. 12 with low qualities: chains that keep moving
+reads, _, _ = synth_units(U, n_reads=n_reads, qual=(3, 20) if n_reads < 100 else (20, 40))
 model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=steps, chains=2, random_seed=42)
 b = DenovoDeviceBatch(model, reads)
 out = (C.c_ulonglong * 24)()
