@@ -767,6 +767,67 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
           lds_sync();
         }
       }
+      // Shallow units (one chunk of reads, at most 32 of them): lanes over reads leave most of the wavefront idle, so
+      // two (17-32 reads) or four (up to 16) requests are evaluated side by side, a sub-group of 32 / 16 lanes each.
+      // A lane forms the same factors in the same order for its (request, read); the sum over the reads is the
+      // wavefront butterfly restricted to the sub-group -- the other lanes of a full-width evaluation hold padding
+      // reads with weight 0, whose terms are +0.0 -- so the values are those of the one-request path, bit for bit.
+      if constexpr (BPL) {
+        if (use_base && nch == 1 && nrd <= 32) {
+          const int RS = nrd <= 16 ? 16 : 32, NQ = WAVE / RS;
+          const int sub = lane / RS, r = lane % RS;
+          LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
+          LDSP(const uint8_t) shift = shift_tab + (size_t)sg * mmax;
+          LDSP(const uint16_t) cols = cols_tab + (size_t)sg * mmax;
+          GLBP(const uint8_t) ctb = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT];
+          const double cwr = ((GLBP(const double))(uintptr_t)gp[GP_CW])[r];
+          const double invK = 1.0 / (double)KT;
+          while (reqs) {
+            int srcs[4] = {0, 0, 0, 0};
+            unsigned long long dupm[4] = {0ull, 0ull, 0ull, 0ull};
+            int nq = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              if (k < NQ && reqs) {
+                const int src = __ffsll((long long)reqs) - 1;
+                const unsigned long long dups = spec_same_request<KT>(pwbuf, reqs, src, lane);
+                reqs &= ~dups;
+                srcs[k] = src;
+                dupm[k] = dups;
+                nq = k + 1;
+              }
+            }
+            const int my_src = sub == 0 ? srcs[0] : (sub == 1 ? srcs[1] : (sub == 2 ? srcs[2] : srcs[3]));
+            double sv = 0.0;
+            if (sub < nq) {
+              double acc = 0.0;
+#pragma unroll
+              for (int h = 0; h < KT; h++) {
+                const uint64_t wa = pwbuf[(size_t)h * WAVE + my_src], wb = bw_tab[(size_t)sg * KT + h];
+                double ph;
+                if (wa == wb) {
+                  ph = bpc[(h * 4) * WAVE + r];
+                } else {
+                  ph = 1.0;
+                  for (int j = 0; j < Mh; j++) {
+                    const uint32_t row = (uint32_t)cols[j] + ((uint32_t)(wa >> shift[j]) & amask);
+                    ph *= dict[ctb[(size_t)(row * WAVE + r) * cstride]];
+                  }
+                }
+                acc += ph * invK;
+              }
+              sv = read_log(acc) * cwr;
+            }
+            for (int o = RS / 2; o >= 1; o >>= 1) sv += __shfl_xor(sv, o, WAVE);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const double vk = __shfl(sv, (k * RS) & (WAVE - 1), WAVE);
+              if (k < nq && ((dupm[k] >> lane) & 1ull)) val = vk;
+            }
+          }
+          continue;  // next chain
+        }
+      }
       while (reqs) {
         const int src = __ffsll((long long)reqs) - 1;
         // requests for the same genotype (options of different intervals often coincide) are evaluated once
