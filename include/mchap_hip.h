@@ -247,6 +247,10 @@ int mchap_exact_posterior_mode_batch(int n_units, const double *reads, int n_rea
  * The workspace holds, per chain, the counterpart of the reference's llk dict (calling/likelihood.py:36-78), which never
  * forgets an entry.  Device pointers; enqueues on `stream`. */
 int64_t mchap_call_mcmc_workspace_bytes(int n_units, int n_haps, int ploidy, int steps, int chains);
+/* The same plus, when n_reads x n_haps x 8 B exceeds the LDS, room for every chain's product table P[r][h] (the sampler
+ * then reads it from the workspace: slower, but no limit on the read depth).  mchap_call_mcmc_batch_device needs this
+ * many bytes; for shapes that fit the LDS it equals mchap_call_mcmc_workspace_bytes. */
+int64_t mchap_call_mcmc_workspace_bytes_for(int n_units, int n_reads, int n_haps, int ploidy, int steps, int chains);
 int mchap_call_mcmc_batch_device(int n_units, const double *reads, int n_reads, int n_pos, int max_allele,
                                  const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy, int has_prior,
                                  const double *inbreeding, const double *frequencies, const int64_t *initial,

@@ -123,6 +123,7 @@ def lib():
         L.mchap_denovo_workspace_bytes.restype = C.c_int64
         L.mchap_exact_workspace_bytes.restype = C.c_int64
         L.mchap_call_mcmc_workspace_bytes.restype = C.c_int64
+        L.mchap_call_mcmc_workspace_bytes_for.restype = C.c_int64
         L.mchap_last_sampler_ms.restype = C.c_double
         L.mchap_last_sampler_name.restype = C.c_char_p
         _lib = L
@@ -144,6 +145,7 @@ EXPORTS = [
     "mchap_exact_posterior_summaries_batch_device",
     "mchap_exact_posterior_summaries",
     "mchap_call_mcmc_workspace_bytes",
+    "mchap_call_mcmc_workspace_bytes_for",
     "mchap_call_mcmc_batch_device",
     "mchap_call_mcmc_batch",
     "mchap_version",

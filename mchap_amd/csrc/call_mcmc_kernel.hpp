@@ -54,6 +54,7 @@ struct CallParams {
   // per-chain table of remembered likelihoods: [U * chains][cache_slots] of {key + 1, llk bits}; never evicts
   ulonglong2 *cache;
   long long cache_slots;     // power of two
+  double *ptab_ext;          // [U * chains][R * H + R] product tables in the workspace when R * H * 8 exceeds the LDS, else null
   int64_t *genotypes;        // [U][chains][steps][K] sorted alleles
   double *llks;              // [U][chains][steps]
   int32_t *status;           // [U]: 0 ok, MCHAP_ERR_LIMIT if a table filled up
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
   EP.R = R; EP.M = P.M; EP.A = P.A; EP.H = H; EP.K = K;
   EP.has_prior = P.has_prior;
   EP.Rcap = 0;  // the whole product table (the sampler does not tile the reads)
+  EP.ptab_ext = P.ptab_ext ? P.ptab_ext + ((size_t)unit * P.chains + chain) * ((size_t)R * H + R) : nullptr;
   ExactLds E;
   PriorTab pt;
   exact_setup(EP, unit, smem, E, pt);

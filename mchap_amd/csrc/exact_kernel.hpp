@@ -26,6 +26,7 @@ struct ExactParams {
   int has_prior;
   int nblk;
   int Rcap;                 // rows of the LDS product table (0: all R; less: the passes tile the reads, exact_tile)
+  double *ptab_ext;         // product table + read weights of THIS workgroup in global memory instead of LDS, or null
   // outputs / workspace
   float *llk32;             // [U][G] or null
   double *llk64;            // [U][G] or null
@@ -149,9 +150,15 @@ struct ExactLds {
 __device__ __forceinline__ void exact_setup(const ExactParams &P, int unit, unsigned char *smem, ExactLds &E, PriorTab &pt) {
   const int M = P.M, A = P.A, H = P.H, K = P.K;
   const int R = (P.Rcap > 0 && P.Rcap < P.R) ? P.Rcap : P.R;
-  E.ptab = reinterpret_cast<double *>(smem);
-  E.cnt = E.ptab + (size_t)R * H;
-  E.lgd = E.cnt + R;
+  if (P.ptab_ext) {  // (call sampler with a table that exceeds the LDS: slower reads, no limit)
+    E.ptab = P.ptab_ext;
+    E.cnt = E.ptab + (size_t)R * H;
+    E.lgd = reinterpret_cast<double *>(smem);
+  } else {
+    E.ptab = reinterpret_cast<double *>(smem);
+    E.cnt = E.ptab + (size_t)R * H;
+    E.lgd = E.cnt + R;
+  }
   E.lgf = E.lgd + (size_t)H * (K + 1);
   E.lfreq = E.lgf + (K + 1);
   E.red = E.lfreq + H;

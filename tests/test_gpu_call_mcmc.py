@@ -25,7 +25,8 @@ def _inputs(U, K, H, M, R, seed, qual=(5, 25)):
 
 
 @pytest.mark.parametrize("step_type", ["Gibbs", "Metropolis-Hastings"])
-@pytest.mark.parametrize("K,H,M,R", [(4, 6, 6, 40), (2, 9, 5, 20), (6, 5, 4, 70), (3, 12, 6, 130)])
+@pytest.mark.parametrize("K,H,M,R", [(4, 6, 6, 40), (2, 9, 5, 20), (6, 5, 4, 70), (3, 12, 6, 130), (4, 18, 6, 1400)],
+                         ids=["K4", "K2", "K6", "K3", "tables-in-workspace"])  # the last: 202 KB of products per chain
 def test_traces_match_oracle_step_for_step(step_type, K, H, M, R):
     from mchap_amd.calling_mcmc import CallingMCMC
 
