@@ -276,7 +276,15 @@ int validate_cfg(const mchap_denovo_cfg *cfg) {
   return MCHAP_OK;
 }
 
-constexpr int CACHE_SLOTS = 1024;  // {tag, llk} entries per chain (16 KiB)
+// {tag, llk} entries per chain (16 KiB); MCHAP_HIP_CACHE_SLOTS (a power of two, 64..65536) overrides it for measurements
+static int cache_slots_setting() {
+  if (const char *e = std::getenv("MCHAP_HIP_CACHE_SLOTS")) {
+    const int v = std::atoi(e);
+    if (v >= 64 && v <= 65536 && (v & (v - 1)) == 0) return v;
+  }
+  return 1024;
+}
+#define CACHE_SLOTS (cache_slots_setting())
 
 // The break table of a call lives at the head of the CALLER's workspace (no library-owned device state: two fits
 // on different streams, threads or devices never share a buffer).
