@@ -11,12 +11,13 @@ from mchap_amd.synth import synth_units
 
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+cache = int(sys.argv[3]) if len(sys.argv) > 3 else 100  # llk_cache_threshold (-1: no cache)
 L = _lib.lib()
 L.mchap_set_profiling(1)
 reads, _, _ = synth_units(U, n_reads=R, qual=(3, 20))
 out = {}
 for kernel in (3, 0):
-    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=1000, chains=2, random_seed=42, kernel=kernel)
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=1000, chains=2, random_seed=42, kernel=kernel, llk_cache_threshold=cache)
     b = DenovoDeviceBatch(model, reads)
     ms = []
     for _ in range(2):
