@@ -242,8 +242,11 @@ def test_octoploid_three_substeps_per_lane(n_pos):
 
 @pytest.mark.parametrize("knobs", [{}, {"MCHAP_HIP_PIPE_FIRST": "1", "MCHAP_HIP_PIPE_RESUME": "1"}, {"MCHAP_HIP_ROUNDS": "0"},
                                    {"MCHAP_HIP_PIPE_FIRST": "2", "MCHAP_HIP_ROUNDS": "6", "MCHAP_HIP_PIPE_MAX": "2"},
-                                   {"MCHAP_HIP_PIPE_GROUP": "16"}, {"MCHAP_HIP_PIPE_GROUP": "32", "MCHAP_HIP_PIPE_FIRST": "3"}],
-                         ids=["default", "hand-over-after-1-step", "no-resume-rounds", "many-short-rounds", "16-lane-groups", "32-lane-groups"])
+                                   {"MCHAP_HIP_PIPE_GROUP": "16"}, {"MCHAP_HIP_PIPE_GROUP": "32", "MCHAP_HIP_PIPE_FIRST": "3"},
+                                   {"MCHAP_HIP_PIPE_PARTS": "1"}, {"MCHAP_HIP_PIPE_PARTS": "16", "MCHAP_HIP_PIPE_FIRST": "2"},
+                                   {"MCHAP_HIP_NO_BP_CACHE": "1"}, {"MCHAP_HIP_CACHE_SLOTS": "64"}],
+                         ids=["default", "hand-over-after-1-step", "no-resume-rounds", "many-short-rounds", "16-lane-groups", "32-lane-groups",
+                              "tables-completed-in-place", "tables-completed-by-16-waves", "no-base-product-cache", "tiny-llk-cache"])
 def test_phased_sampler_hand_over_paths(sampler_kernel, monkeypatch, knobs):
     """The phased sampler (the library's default choice) against the speculative kernel on a batch with shallow reads,
     where chains keep moving: whatever the hand-over schedule -- chains handed over unsettled, handed back at once,
@@ -311,3 +314,27 @@ def test_phased_sampler_short_runs_and_many_chains(sampler_kernel, monkeypatch, 
     for a, b in zip(ref, got):
         assert np.array_equal(a.genotypes, b.genotypes)
         assert np.array_equal(a.llks, b.llks, equal_nan=True)
+
+
+def test_phased_sampler_equals_speculative_kernel_at_the_headline_shape(sampler_kernel, monkeypatch):
+    """1024 loci of BASELINE.json's configuration (tetraploid, 8 SNVs, 200 reads, 1000 steps x 2 chains): the default
+    (phased) sampler and kernel 3 write the same trace words, llks and status, bit for bit."""
+    if sampler_kernel != 5:
+        pytest.skip("one pass is enough: the test picks its kernels itself")
+    import torch
+
+    from mchap_amd import DenovoMCMC, _lib
+    from mchap_amd.device import DenovoDeviceBatch
+    from mchap_amd.synth import synth_units
+
+    monkeypatch.delenv("MCHAP_HIP_KERNEL", raising=False)
+    reads, _, _ = synth_units(1024)
+    out = {}
+    for kernel in (3, 0):
+        b = DenovoDeviceBatch(DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=1000, chains=2, random_seed=42, kernel=kernel), reads)
+        b.run()
+        torch.cuda.synchronize()
+        out[kernel] = (b.d_trace.cpu().numpy(), b.d_llks.cpu().numpy(), b.d_status.cpu().numpy(), _lib.lib().mchap_last_sampler_name())
+    assert b"phased" in out[0][3] and b"phased" not in out[3][3]
+    for a, c in zip(out[3][:3], out[0][:3]):
+        assert np.array_equal(a, c)
