@@ -244,6 +244,52 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
   // homozygous fix (assemble/mcmc.py:168-182, 494-541; snpcalling.py:14-70)
   int Mh = 0;
   double luh = 0.0;
+  const bool pow2_ploidy = (K & (K - 1)) == 0;
+  const double inv_ploidy = 1.0 / (double)K;
+  // The SNV prior (snv_log_prior: calling/prior.py:116-179 with flat frequencies) needs lgamma(dose + 1) and, with
+  // inbreeding, lgamma(dose + alpha_n), lgamma(alpha_n) and the normaliser for every allele count n: a few dozen
+  // distinct values per unit.  Every lane used to recompute K + 1 of them per genotype (200 calls of ~400
+  // instructions per unit: 60 % of this pass); now each value is formed once, one per lane.
+  __shared__ double s_lg1[MCHAP_MAX_PLOIDY + 1];                              // lgamma(d + 1)
+  __shared__ double s_lga[(MCHAP_MAX_ALLELE + 1) * (MCHAP_MAX_PLOIDY + 1)];   // lgamma(d + alpha_n), d >= 1
+  __shared__ double s_lgb[MCHAP_MAX_ALLELE + 1], s_left[MCHAP_MAX_ALLELE + 1];  // lgamma(alpha_n); normaliser
+  const double Fp = U.inbreeding;
+  const bool with_prior = !isnan(Fp);
+  if (with_prior) {
+    for (int d = lane; d <= K; d += WAVE) s_lg1[d] = lgamma((double)d + 1.0);
+    if (Fp != 0.0) {
+      for (int e = lane; e < (A + 1) * (K + 1); e += WAVE) {
+        const int n = e / (K + 1), d = e % (K + 1);
+        if (n >= 1 && d >= 1) s_lga[n * (MCHAP_MAX_PLOIDY + 1) + d] = lgamma((double)d + (1.0 / (double)n) * ((1.0 - Fp) / Fp));
+      }
+      for (int n = 1 + lane; n <= A; n += WAVE) {
+        const double alpha = (1.0 / (double)n) * ((1.0 - Fp) / Fp);
+        const double sum_alphas = alpha * (double)n;
+        s_lgb[n] = lgamma(alpha);
+        s_left[n] = (lgamma((double)K + 1.0) + lgamma(sum_alphas)) - lgamma((double)K + sum_alphas);
+      }
+    }
+    __syncthreads();
+  }
+  // snv_log_prior(g, K, n, F) from the tables: same arguments to the same lgamma, same order of the sums
+  auto snv_prior = [&](uint32_t g, int n) -> double {
+    int dose[MCHAP_MAX_PLOIDY];
+    for (int i = 0; i < K; i++) dose[i] = 0;
+    for (int i = 0; i < K; i++) {
+      int j = 0;
+      while (nib(g, i) != nib(g, j)) j++;
+      dose[j] += 1;
+    }
+    if (Fp == 0.0) {
+      double den = 0.0;
+      for (int i = 0; i < K; i++) den += s_lg1[dose[i]];
+      return (s_lg1[K] - den) - (double)K * c_ln[n];
+    }
+    double prod = 0.0;
+    for (int i = 0; i < K; i++)
+      if (dose[i] > 0) prod += s_lga[n * (MCHAP_MAX_PLOIDY + 1) + dose[i]] - (s_lg1[dose[i]] + s_lgb[n]);
+    return s_left[n] + prod;
+  };
   // without the LDS copy of the whole table, the A rows of the current position are staged in LDS (each lane its own
   // reads): the genotype loop below re-reads them K times per genotype
   double *pl = reinterpret_cast<double *>(smem + P.prep_rows_off);  // [A][rpad]
@@ -260,12 +306,17 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
     uint32_t g = 0;
     for (int q = 0; q < u_gens; q++) {
       double lprior = 0.0;
-      if (!isnan(U.inbreeding)) lprior = snv_log_prior(g, K, n, U.inbreeding);
+      if (with_prior) lprior = snv_prior(g, n);
       double s = 0.0;
 #pragma unroll
       for (int i = 0; i < RPL; i++) {
         double rp = 0.0;
-        for (int h = 0; h < K; h++) rp += rowp[(size_t)nib(g, h) * rpad + lane + WAVE * i] / (double)K;
+        // x / K (snpcalling.py / likelihood.py:61); for K = 2, 4, 8 the product with 1 / K is the same double
+        if (pow2_ploidy) {
+          for (int h = 0; h < K; h++) rp += rowp[(size_t)nib(g, h) * rpad + lane + WAVE * i] * inv_ploidy;
+        } else {
+          for (int h = 0; h < K; h++) rp += rowp[(size_t)nib(g, h) * rpad + lane + WAVE * i] / (double)K;
+        }
         s += read_log(rp) * cnt[i];
       }
       const double llk = wave_sum(s);
