@@ -223,6 +223,28 @@ __device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[MC
   return llk;
 }
 
+// Two genotypes of one thread at once: each sum runs over the reads in order as in exact_llk (same values); the two
+// chains of LDS reads, adds and logs are independent and hide each other's latency (two waves per SIMD is all the 64 KB
+// table leaves).
+__device__ __forceinline__ void exact_llk2(const ExactLds &E, const int (&ga)[MCHAP_MAX_PLOIDY], const int (&gb)[MCHAP_MAX_PLOIDY],
+                                           int R, int H, int K, double invK, double &la, double &lb) {
+  la = 0.0;
+  lb = 0.0;
+  for (int r = 0; r < R; r++) {
+    const double *row = E.ptab + (size_t)r * H;
+    double ra = 0.0, rb = 0.0;
+#pragma unroll
+    for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+      if (k < K) {
+        ra += row[ga[k]] * invK;
+        rb += row[gb[k]] * invK;
+      }
+    const double w = E.cnt[r];
+    la += read_log(ra) * w;
+    lb += read_log(rb) * w;
+  }
+}
+
 // Reads r0 .. r0 + rn - 1 of `unit` into the product table and the weights (whole workgroup; barriers on both sides)
 __device__ __forceinline__ void exact_tile(const ExactParams &P, int unit, const ExactLds &E, int r0, int rn) {
   const int M = P.M, A = P.A, H = P.H;
@@ -327,7 +349,18 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
       }
     }
   } else {
-    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    // the thread's genotypes i, i + 256, ... two at a time (visited in index order: the first maximum stays the first)
+    long long i = lo + threadIdx.x;
+    for (; i + (long long)blockDim.x < hi; i += 2 * (long long)blockDim.x) {
+      int ga[MCHAP_MAX_PLOIDY], gb[MCHAP_MAX_PLOIDY];
+      unrank_genotype(i, K, ga);
+      unrank_genotype(i + blockDim.x, K, gb);
+      double la, lb;
+      exact_llk2(E, ga, gb, R, H, K, invK, la, lb);
+      visit(i, ga, la);
+      visit(i + blockDim.x, gb, lb);
+    }
+    if (i < hi) {
       int g[MCHAP_MAX_PLOIDY];
       unrank_genotype(i, K, g);
       visit(i, g, exact_llk(E, g, R, H, K, invK));
@@ -434,7 +467,27 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
   const double invK = 1.0 / (double)K;
   double *mine = acc + (size_t)wave * NS;
   double tl[EXACT_NGT];
-  if constexpr (TILED) exact_llk_tiled(P, unit, E, lo, hi, tl);  // (nt == EXACT_THREADS: thread t's genotypes lo + t + 256 q)
+  if constexpr (TILED) {
+    exact_llk_tiled(P, unit, E, lo, hi, tl);  // (nt == EXACT_THREADS: thread t's genotypes lo + t + 256 q)
+  } else {
+    // the likelihoods of the thread's genotypes, two at a time (exact_llk2), ahead of the accounting loop
+#pragma unroll
+    for (int tqq = 0; tqq < EXACT_NGT; tqq += 2) {
+      const long long ia = lo + threadIdx.x + (long long)tqq * nt, ib = ia + nt;
+      tl[tqq] = 0.0;
+      tl[tqq + 1] = 0.0;
+      if (ib < hi) {
+        int ga[MCHAP_MAX_PLOIDY], gb[MCHAP_MAX_PLOIDY];
+        unrank_genotype(ia, K, ga);
+        unrank_genotype(ib, K, gb);
+        exact_llk2(E, ga, gb, R, H, K, invK, tl[tqq], tl[tqq + 1]);
+      } else if (ia < hi) {
+        int ga[MCHAP_MAX_PLOIDY];
+        unrank_genotype(ia, K, ga);
+        tl[tqq] = exact_llk(E, ga, R, H, K, invK);
+      }
+    }
+  }
 #pragma unroll
   for (int tqq = 0; tqq < EXACT_NGT; tqq++) {
     const long long i0 = lo + (long long)wave * 64 + (long long)tqq * nt;  // wave-uniform
@@ -447,9 +500,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
     bool support = false;
     if (i < hi) {
       unrank_genotype(i, K, g);
-      double llk;
-      if constexpr (TILED) llk = tl[tqq];
-      else llk = exact_llk(E, g, R, H, K, invK);
+      const double llk = tl[tqq];
       const double lpr = has_prior ? calling_log_prior(pt, g, K) : 0.0;
       prob = exp((llk + lpr) - total);
       int nd = 0;
