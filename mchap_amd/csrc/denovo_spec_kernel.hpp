@@ -41,6 +41,9 @@
 #ifndef MCHAP_SPEC_LOW
 #define MCHAP_SPEC_LOW 8   // staged draws a structural step wants to find before it refills the window
 #endif
+#ifndef MCHAP_SPEC_CG
+#define MCHAP_SPEC_CG 4  // pairs whose dictionary gathers are in flight together in spec_coop_coded (ploidy > 4)
+#endif
 #ifndef MCHAP_SPEC_WIN0
 #define MCHAP_SPEC_WIN0 4     // mutation sub-steps a chain's first compound step speculates over per round
 #endif
@@ -533,17 +536,30 @@ __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int
         const int row = __builtin_amdgcn_readlane(myrow, q < lim ? q : 0);
         cd[u] = TabPtr<LT>::template ld<CT>(ct + (size_t)row * crow);
       }
+      // the dictionary gathers of CG pairs are issued together, ahead of the (scalar) branches on the haplotype
+      // boundaries: one LDS round trip per CG pairs instead of one per pair (as in spec_hap_prod)
+      constexpr int CG = KT <= 4 ? 2 : MCHAP_SPEC_CG;  // measured: 4 costs ploidy <= 4 more in spills than it hides
 #pragma unroll
-      for (int u = 0; u < UNR; u++) {
-        if (q0 + u < lim) {
+      for (int u0 = 0; u0 < UNR; u0 += CG) {
+        if (q0 + u0 < lim) {
+          double f[CG][RPL];
 #pragma unroll
-          for (int i = 0; i < RPL; i++) prod[i] *= dict[((uint32_t)cd[u] >> (8 * i)) & 255u];
-          if (++jj == Mh) {
-            jj = 0;
+          for (int u = 0; u < CG; u++)
 #pragma unroll
-            for (int i = 0; i < RPL; i++) {
-              acc[i] += prod[i] * invK;
-              prod[i] = 1.0;
+            for (int i = 0; i < RPL; i++) f[u][i] = dict[((uint32_t)cd[u0 + u] >> (8 * i)) & 255u];
+#pragma unroll
+          for (int u = 0; u < CG; u++) {
+            if (q0 + u0 + u < lim) {
+#pragma unroll
+              for (int i = 0; i < RPL; i++) prod[i] *= f[u][i];
+              if (++jj == Mh) {
+                jj = 0;
+#pragma unroll
+                for (int i = 0; i < RPL; i++) {
+                  acc[i] += prod[i] * invK;
+                  prod[i] = 1.0;
+                }
+              }
             }
           }
         }
