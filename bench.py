@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)   # 0.7 s of timed passes at the default workload
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--loci", type=int, default=10000, help="loci per GPU")
     ap.add_argument("--mcmc-steps", type=int, default=1000)
     ap.add_argument("--chains", type=int, default=2)
