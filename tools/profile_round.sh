@@ -7,7 +7,8 @@ OUT=/root/repo/gpurun_out
 mkdir -p $OUT
 [ -f /root/repo/tools/libpmc_calib.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o /root/repo/tools/libpmc_calib.so /root/repo/tools/pmc_calib.hip
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 /root/repo/bench.py --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace1 -- python3 /root/repo/bench.py --inflight 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_trace1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 /root/repo/tools/prof_run.py full 10000 > $OUT/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- python3 /root/repo/tools/prof_run.py full 10000 > $OUT/${TAG}_pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_cal_fetch -- python3 /root/repo/tools/pmc_calib_run.py > $OUT/${TAG}_cal_fetch.log 2>&1
