@@ -18,6 +18,42 @@ def _torch():
     return torch
 
 
+class PassesInFlight:
+    """Round-robin issue of whole passes (one device batch each: prepare pass, sampler, posterior summary) over
+    `n` HIP streams.  A pass is a few dozen launches and several of them occupy a fraction of the chip (the prepare
+    pass, the hand-back rounds of the phased sampler, every launch's last wave round); with three or four passes in
+    flight those phases overlap the first phase of the next pass: 13.8 -> 10.6 ms per pass at 10 000 tetraploid loci
+    (DESIGN.md 6).  Each pass needs device buffers of its own (its DenovoDeviceBatch / DenovoRaggedBatch).  The HIP
+    runtime shares GPU_MAX_HW_QUEUES (default 4) hardware queues among a process's streams: export
+    GPU_MAX_HW_QUEUES=8 before the process touches the GPU so that four streams and the null stream get one each.
+
+        flight = PassesInFlight(4)
+        for batch in batches:
+            flight.submit(lambda b=batch: (b.run(), b.posterior(burn)))
+        flight.join()            # torch's current stream then waits for every pass
+    """
+
+    def __init__(self, n=4):
+        torch = _torch()
+        self.torch = torch
+        self.streams = [torch.cuda.Stream() for _ in range(max(1, int(n)))]
+        self.issued = 0
+
+    def submit(self, enqueue):
+        """Call `enqueue()` with the next stream current; what it enqueues starts after the work already on torch's
+        current stream (inputs uploaded there are seen)."""
+        s = self.streams[self.issued % len(self.streams)]
+        self.issued += 1
+        s.wait_stream(self.torch.cuda.current_stream())
+        with self.torch.cuda.stream(s):
+            return enqueue()
+
+    def join(self):
+        cur = self.torch.cuda.current_stream()
+        for s in self.streams:
+            cur.wait_stream(s)
+
+
 class DenovoDeviceBatch:
     """A batch of uniformly shaped units resident on one GPU.
 
