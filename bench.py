@@ -171,11 +171,14 @@ def incl_h2d(args, model):
     rng = np.random.default_rng(5)
     quals = rng.integers(20, 41, size=calls.shape).astype(np.int16)
 
-    def once():
+    def start():
         b = DenovoDeviceBatch(model, None, calls=calls, quals=quals)
         b.run()
         b.posterior(args.burn)
-        return b.posterior_host()
+        return b
+
+    def once():
+        return start().posterior_host()
 
     once()
     torch.cuda.synchronize()
@@ -185,9 +188,41 @@ def incl_h2d(args, model):
         once()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n
-    return {"value": U / dt, "unit": "loci/s", "ms_per_pass": dt * 1e3, "h2d_bytes_per_locus": int(calls[0].size * 3),
-            "d2h_bytes_per_locus": int(32 * args.ploidy * 8 + 32 * 4 + 40),
-            "note": "device buffers allocated, compact input uploaded, posterior records downloaded inside the timed region"}
+    out = {"value": U / dt, "unit": "loci/s", "ms_per_pass": dt * 1e3, "h2d_bytes_per_locus": int(calls[0].size * 3),
+           "d2h_bytes_per_locus": int(32 * args.ploidy * 8 + 32 * 4 + 40),
+           "note": "device buffers allocated, compact input uploaded, posterior records downloaded inside the timed region"}
+    nfl = max(1, args.inflight)
+    if nfl > 1:
+        # the same with several passes in flight: pass i is uploaded and enqueued on stream i % nfl, its records are
+        # downloaded when its stream comes round again -- the PCIe legs of one pass overlap the kernels of the others
+        from mchap_amd.device import PassesInFlight, pinned
+
+        calls, quals = pinned(calls), pinned(quals)  # (a loader would read into page-locked buffers: uploads are asynchronous)
+        flight = PassesInFlight(nfl)
+        slots = [None] * nfl
+
+        def turn(i, n_pass):
+            k = i % nfl
+            with torch.cuda.stream(flight.streams[k]):
+                if slots[k] is not None:
+                    slots[k].posterior_host()
+                    slots[k] = None
+                if i < n_pass:
+                    slots[k] = start()
+
+        for i in range(2 * nfl):
+            turn(i, nfl)
+        torch.cuda.synchronize()
+        n = 6 * nfl
+        t = time.perf_counter()
+        for i in range(n + nfl):
+            turn(i, n)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / n
+        out = dict(out, value_one_in_flight=out["value"], ms_per_pass_one_in_flight=out["ms_per_pass"], value=U / dt, ms_per_pass=dt * 1e3,
+                   passes_in_flight=nfl)
+        out["note"] += "; %d passes in flight on separate streams (one host thread, input in page-locked host memory)" % nfl
+    return out
 
 
 def bench_config4(args):

@@ -18,6 +18,12 @@ def _torch():
     return torch
 
 
+def pinned(a):
+    """A copy of numpy array `a` in page-locked host memory (as a numpy array): uploads from it are asynchronous."""
+    torch = _torch()
+    return torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
+
+
 class PassesInFlight:
     """Round-robin issue of whole passes (one device batch each: prepare pass, sampler, posterior summary) over
     `n` HIP streams.  A pass is a few dozen launches and several of them occupy a fraction of the chip (the prepare
@@ -63,7 +69,9 @@ class DenovoDeviceBatch:
                  error_rate=0.0024):
         """reads: float64 [U, R, M, A]; or reads=None with calls int8 [U, R, M] (< 0 = gap), optional quals int16 of the
         same shape and the base error rate: the compact form the reference's encoders start from, turned into the
-        probability tensor on the device (5x fewer bytes to upload, same traces)."""
+        probability tensor on the device (5x fewer bytes to upload, same traces).  The input arrays are copied on torch's
+        current stream; when they live in page-locked host memory (mchap_amd.device.pinned) the copy does not block the
+        host, and the caller keeps them unchanged until the stream has passed it."""
         torch = _torch()
         self.torch = torch
         self.model = model
@@ -96,16 +104,16 @@ class DenovoDeviceBatch:
         dev = self.device
         self.d_units = torch.from_numpy(units.view(np.uint8).reshape(-1)).to(dev)
         if reads is not None:
-            self.d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+            self.d_reads = torch.from_numpy(reads.reshape(-1)).to(dev, non_blocking=True)
         else:
             from .encoding import prob_of_qual
 
             self.d_reads = None
-            self.d_calls = torch.from_numpy(calls.reshape(-1)).to(dev)
+            self.d_calls = torch.from_numpy(calls.reshape(-1)).to(dev, non_blocking=True)
             if quals is not None:
                 quals = np.ascontiguousarray(quals, dtype=np.int16)
                 assert quals.shape == calls.shape
-                self.d_quals = torch.from_numpy(quals.reshape(-1)).to(dev)
+                self.d_quals = torch.from_numpy(quals.reshape(-1)).to(dev, non_blocking=True)
                 table = prob_of_qual(np.arange(int(quals.max(initial=0)) + 1)) * (1.0 - error_rate)  # reference io/bam.py:280-288
             else:
                 table = np.array([1.0 - error_rate])
