@@ -307,6 +307,29 @@ def bench_config5(args):
         "roofline": {"bound": "issue", "achieved": substeps / (kms * 1e-3), "unit": "sub-steps/s",
                      "note": "serial sub-step latency bound like configs[1]; 160 mutation sub-steps per chain step"},
     }
+    nfl = max(1, args.inflight)
+    if nfl > 1:
+        # the same pass with several batches in flight (256 loci are 1024 chains: half of the chip's wavefront slots)
+        from mchap_amd.device import PassesInFlight
+
+        L.mchap_set_profiling(0)
+        batches = [batch] + [DenovoDeviceBatch(model, reads) for _ in range(nfl - 1)]
+        flight = PassesInFlight(nfl)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for b in batches:
+            flight.submit(lambda b=b: (b.run(), b.posterior(S // 2)))
+        flight.join()
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t
+        same = all(torch.equal(b.d_trace, batch.d_trace) for b in batches[1:])
+        out["value_one_in_flight"] = out["value"]
+        out["value"] = nfl * U / dtf
+        out["passes_in_flight"] = nfl
+        out["pass_ms_in_flight"] = dtf * 1e3 / nfl
+        out["workload"] = out["workload"].replace("one pass", "%d batches in flight on separate streams (kernel_ms / pass_ms: one alone)" % nfl)
+        out["ok"] = bool(out["ok"] and same)
+        del batches
     if not args.no_cpu_baseline:
         from oracle import binding as orc
         from mchap_amd.assemble import break_table
