@@ -522,7 +522,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%d synthetic tetraploid loci per GPU, %d SNVs, %d reads, %d MCMC steps x %d chains, burn %d, "
-                            "posterior summary (BASELINE.json configs[1])" % (U, args.snvs, args.reads, args.mcmc_steps, args.chains, args.burn),
+                            "posterior summary (BASELINE.json configs[1]); %d passes in flight on separate HIP streams, each with its own "
+                            "device buffers" % (U, args.snvs, args.reads, args.mcmc_steps, args.chains, args.burn, nfl),
                 "loci_per_gpu": U, "ploidy": args.ploidy, "snvs": args.snvs, "reads": args.reads,
                 "mcmc_steps": args.mcmc_steps, "chains": args.chains, "burn": args.burn,
                 "llk_cache": not args.no_cache, "passes_in_flight": nfl,
