@@ -212,6 +212,11 @@ typedef struct mchap_exact_out {
   double *arr_mode_prob, *arr_support_prob, *arr_freqs, *arr_counts, *arr_occur;
 } mchap_exact_out;
 int64_t mchap_exact_workspace_bytes(int n_units, int n_haps, int ploidy);
+/* ... plus room for llk + log prior of every genotype (U * G float64): the second pass of the streaming form (support,
+ * frequencies, occurrence) then reads them back instead of forming every likelihood again (calling/exact.py:156-249 makes
+ * both passes from scratch to keep its memory flat; on the device 54 264 genotypes are 434 KB per unit).  Same results;
+ * a workspace of either size is accepted. */
+int64_t mchap_exact_workspace_bytes_cached(int n_units, int n_haps, int ploidy);
 int mchap_exact_call_batch_device(int n_units, const double *reads, int n_reads, int n_pos, int max_allele,
                                   const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy, int has_prior,
                                   const double *inbreeding, const double *frequencies, const mchap_exact_out *out,

@@ -122,6 +122,7 @@ def lib():
         L.mchap_denovo_lds_bytes.restype = C.c_int64
         L.mchap_denovo_workspace_bytes.restype = C.c_int64
         L.mchap_exact_workspace_bytes.restype = C.c_int64
+        L.mchap_exact_workspace_bytes_cached.restype = C.c_int64
         L.mchap_call_mcmc_workspace_bytes.restype = C.c_int64
         L.mchap_call_mcmc_workspace_bytes_for.restype = C.c_int64
         L.mchap_last_sampler_ms.restype = C.c_double
@@ -141,6 +142,7 @@ EXPORTS = [
     "mchap_exact_genotype_posteriors",
     "mchap_exact_posterior_mode_batch",
     "mchap_exact_workspace_bytes",
+    "mchap_exact_workspace_bytes_cached",
     "mchap_exact_call_batch_device",
     "mchap_exact_posterior_summaries_batch_device",
     "mchap_exact_posterior_summaries",

@@ -451,15 +451,21 @@ __global__ __launch_bounds__(64) void exact_mode_kernel(const ExactModeParams P)
 inline size_t exact_pass2_lds(int R, int H, int K, int threads) {
   return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)(2 * H + 1) * (threads / 64)) * 8;
 }
-template <bool TILED>
+// HAVE_LJ: pass 1 left llk + log prior of every genotype in P.ljoint (the caller's workspace had room for U * G
+// doubles): the pass then reads them back instead of forming every likelihood a second time -- same values, same sums.
+template <bool TILED, bool HAVE_LJ = false>
 __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int unit = blockIdx.y;
   const int R = P.R, H = P.H, K = P.K;
-  const bool has_prior = P.has_prior != 0;
+  const bool has_prior = !HAVE_LJ && P.has_prior != 0;
   ExactLds E;
   PriorTab pt;
-  exact_setup(P, unit, smem, E, pt);
+  if constexpr (HAVE_LJ) {
+    E.red = reinterpret_cast<double *>(smem);  // only the per-wavefront sums live in LDS
+  } else {
+    exact_setup(P, unit, smem, E, pt);
+  }
   const int nt = blockDim.x, nw = nt >> 6;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int NS = 2 * H + 1;
@@ -479,7 +485,13 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
   const double invK = 1.0 / (double)K;
   double *mine = acc + (size_t)wave * NS;
   double tl[EXACT_NGT];
-  if constexpr (TILED) {
+  if constexpr (HAVE_LJ) {
+#pragma unroll
+    for (int t = 0; t < EXACT_NGT; t++) {
+      const long long i = lo + threadIdx.x + (long long)t * nt;
+      tl[t] = i < hi ? P.ljoint[(size_t)unit * G + i] : 0.0;
+    }
+  } else if constexpr (TILED) {
     exact_llk_tiled(P, unit, E, lo, hi, tl);  // (nt == EXACT_THREADS: thread t's genotypes lo + t + 256 q)
   } else {
     // the likelihoods of the thread's genotypes, four at a time (exact_llkn), ahead of the accounting loop

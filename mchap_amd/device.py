@@ -234,7 +234,7 @@ class ExactDeviceBatch:
     reads float64 [U, R, M, A]; haplotypes int8 [U, H, M] (or [H, M] for all units); read_counts int64 [U, R] or None;
     prior None | (inbreeding scalar or [U], frequencies None | [H] | [U, H])."""
 
-    def __init__(self, reads, ploidy, haplotypes, read_counts=None, prior=None, device=None):
+    def __init__(self, reads, ploidy, haplotypes, read_counts=None, prior=None, device=None, cache_joint=True):
         torch = _torch()
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -263,6 +263,11 @@ class ExactDeviceBatch:
                 fr = np.array(np.broadcast_to(np.asarray(prior[1], dtype=np.float64), (U, H)))
                 self.d_fr = torch.from_numpy(fr.reshape(-1)).to(dev)
         self.ws_bytes = int(_lib.lib().mchap_exact_workspace_bytes(U, H, int(ploidy)))
+        if cache_joint:
+            # room for llk + log prior of every genotype between the two passes of the streaming form (8 bytes each)
+            big = int(_lib.lib().mchap_exact_workspace_bytes_cached(U, H, int(ploidy)))
+            if big <= (16 << 30):
+                self.ws_bytes = big
         self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
         self.out = {}
 

@@ -124,6 +124,12 @@ def test_device_batch_arrays_and_streaming_against_oracle(K, H, M, R, U):
         batch.run(streaming=True, arrays=True, llks64=True)
         mode = batch.mode_results()
         arr = batch.array_results()
+        # second pass from the joint log-probabilities kept in the (larger) workspace == second pass from scratch
+        plain = ExactDeviceBatch(reads, K, haps, counts, prior, cache_joint=False)
+        assert plain.ws_bytes < batch.ws_bytes
+        plain.run(streaming=True, arrays=False)
+        for a, b in zip(mode, plain.mode_results()):
+            assert np.array_equal(a, b, equal_nan=True)
         for u in range(U):
             pr = None if prior is None else (float(F[u]), None if prior[1] is None else fr[u])
             a, ml, mp, sp, fq, oc = orc.posterior_mode(reads[u], K, haps[u], counts[u], pr)
