@@ -37,6 +37,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+_FLIGHTS = {}
+
+
+def passes_in_flight(n):
+    """One set of streams per process and count: every stream a process creates takes a share of its hardware queues
+    (GPU_MAX_HW_QUEUES above), so the sections of this benchmark reuse the same ones."""
+    from mchap_amd.device import PassesInFlight
+
+    if n not in _FLIGHTS:
+        _FLIGHTS[n] = PassesInFlight(n)
+    return _FLIGHTS[n]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,10 +208,10 @@ def incl_h2d(args, model):
     if nfl > 1:
         # the same with several passes in flight: pass i is uploaded and enqueued on stream i % nfl, its records are
         # downloaded when its stream comes round again -- the PCIe legs of one pass overlap the kernels of the others
-        from mchap_amd.device import PassesInFlight, pinned
+        from mchap_amd.device import pinned
 
         calls, quals = pinned(calls), pinned(quals)  # (a loader would read into page-locked buffers: uploads are asynchronous)
-        flight = PassesInFlight(nfl)
+        flight = passes_in_flight(nfl)
         slots = [None] * nfl
 
         def turn(i, n_pass):
@@ -320,11 +333,9 @@ def bench_config5(args):
     nfl = max(1, args.inflight)
     if nfl > 1:
         # the same pass with several batches in flight (256 loci are 1024 chains: half of the chip's wavefront slots)
-        from mchap_amd.device import PassesInFlight
-
         L.mchap_set_profiling(0)
         batches = [batch] + [DenovoDeviceBatch(model, reads) for _ in range(nfl - 1)]
-        flight = PassesInFlight(nfl)
+        flight = passes_in_flight(nfl)
         torch.cuda.synchronize()
         t = time.perf_counter()
         for b in batches:
@@ -392,9 +403,7 @@ def main():
                        random_seed=42, llk_cache_threshold=-1 if args.no_cache else 100)
     nfl = max(1, args.inflight)
     batches = [DenovoDeviceBatch(model, reads, first_stream=first) for _ in range(nfl)]
-    from mchap_amd.device import PassesInFlight
-
-    streams = PassesInFlight(nfl).streams if nfl > 1 else [torch.cuda.current_stream()]
+    streams = passes_in_flight(nfl).streams if nfl > 1 else [torch.cuda.current_stream()]
     batch = batches[0]
     del reads
 
