@@ -99,8 +99,8 @@ def test_zero_frequency_allele_and_zero_reads():
     np.testing.assert_allclose(post, 1.0 / len(post), rtol=1e-12)
 
 
-@pytest.mark.parametrize("K,H,M,R,U", [(4, 6, 6, 60, 5), (6, 7, 5, 33, 3), (2, 12, 6, 64, 4), (3, 20, 6, 1100, 2)],
-                         ids=["K4", "K6", "K2", "tiled-reads"])
+@pytest.mark.parametrize("K,H,M,R,U", [(4, 6, 6, 60, 5), (6, 7, 5, 33, 3), (2, 12, 6, 64, 4), (3, 20, 6, 1100, 2), (1, 6, 5, 40, 3), (8, 5, 6, 50, 2)],
+                         ids=["K4", "K6", "K2", "tiled-reads", "haploid", "K8"])
 def test_device_batch_arrays_and_streaming_against_oracle(K, H, M, R, U):
     """mchap_exact_call_batch_device: every output of the streaming form and of the array form (likelihoods, posteriors
     and the summaries call_exact.py:126-159 derives from the posterior array) for a batch, against the oracle unit by
