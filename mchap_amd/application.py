@@ -374,7 +374,7 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
     assemble/mcmc.py:140-142), so the result does not depend on the order or the batching of the targets."""
     from .assemble import DenovoMCMC
     from .classes import PosteriorGenotypeDistribution
-    from .device import DenovoRaggedBatch
+    from .device import DenovoRaggedBatch, PassesInFlight
 
     samples = list(sample_bams)
     bams = {s: read_alignments(p) for s, p in sample_bams.items()}
@@ -405,9 +405,19 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
         by_ploidy = {}
         for i, u in enumerate(units):
             by_ploidy.setdefault(u["ploidy"], []).append(i)
+        # (several ploidies: their launches go out on separate HIP streams and fill each other's thin phases)
+        flight = PassesInFlight(min(4, len(by_ploidy))) if len(by_ploidy) > 1 else None
+        pending = []
         for idx in by_ploidy.values():
             batch = DenovoRaggedBatch(model, [units[i] for i in idx])
-            batch.run(burn, incongruence_threshold=incongruence_threshold)
+            if flight is not None:
+                flight.submit(lambda b=batch: b.run(burn, incongruence_threshold=incongruence_threshold))
+            else:
+                batch.run(burn, incongruence_threshold=incongruence_threshold)
+            pending.append((idx, batch))
+        if flight is not None:
+            flight.join()
+        for idx, batch in pending:
             for i, res in zip(idx, batch.results()):
                 summaries[where[i]] = res
     for li, locus in enumerate(loci):
