@@ -27,9 +27,9 @@ import numpy as np
 
 # The timed region keeps several passes in flight on separate HIP streams.  The HIP runtime multiplexes a process's
 # streams over GPU_MAX_HW_QUEUES hardware queues (default 4: with the null stream, two of four side streams then share
-# a queue and run one after the other -- measured 868 k loci/s against 942 k with a queue each); read at HIP start-up,
+# a queue and run one after the other -- measured 868 k loci/s against 942 k with a queue each: 8 or 16); read at HIP start-up,
 # so it is set here, before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -330,9 +330,10 @@ def bench_config5(args):
         "roofline": {"bound": "issue", "achieved": substeps / (kms * 1e-3), "unit": "sub-steps/s",
                      "note": "serial sub-step latency bound like configs[1]; 160 mutation sub-steps per chain step"},
     }
-    nfl = max(1, args.inflight)
+    nfl = 2 * args.inflight if args.inflight > 1 else 1
     if nfl > 1:
-        # the same pass with several batches in flight (256 loci are 1024 chains: half of the chip's wavefront slots)
+        # the same pass with several batches in flight (256 loci are 1024 chains: half of the chip's wavefront slots,
+        # and at ploidy 8 a pass spends most of its time behind a thinning front of chains: twice the headline's count)
         L.mchap_set_profiling(0)
         batches = [batch] + [DenovoDeviceBatch(model, reads) for _ in range(nfl - 1)]
         flight = passes_in_flight(nfl)
