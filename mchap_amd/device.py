@@ -31,7 +31,7 @@ class PassesInFlight:
     flight those phases overlap the first phase of the next pass: 13.8 -> 10.6 ms per pass at 10 000 tetraploid loci
     (DESIGN.md 6).  Each pass needs device buffers of its own (its DenovoDeviceBatch / DenovoRaggedBatch).  The HIP
     runtime shares GPU_MAX_HW_QUEUES (default 4) hardware queues among a process's streams: export
-    GPU_MAX_HW_QUEUES=8 before the process touches the GPU so that four streams and the null stream get one each.
+    GPU_MAX_HW_QUEUES=8 (or 16) before the process touches the GPU so that four streams and the null stream get one each.
 
         flight = PassesInFlight(4)
         for batch in batches:
