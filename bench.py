@@ -312,20 +312,20 @@ def bench_config5(args):
     reads, _, _ = synth_units(U, ploidy=K, n_pos=M, n_reads=R, window=(8, 20), first_unit=77)
     model = DenovoMCMC(ploidy=K, n_alleles=[2] * M, steps=S, chains=C_, random_seed=42)
     batch = DenovoDeviceBatch(model, reads)
-    L = _lib.lib()
-    L.mchap_set_profiling(1)
+    batch.time_sampler(True)
     t = time.perf_counter()
     batch.run()
     batch.posterior(S // 2)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
-    kms = L.mchap_last_sampler_ms()
+    kms = batch.sampler_ms()
+    batch.time_sampler(False)
     status = batch.d_status.cpu().numpy()
     n = K * M
     substeps = float(U) * C_ * S * (n + 3)  # mutation sub-steps + the three structural compound steps, per chain step
     out = {
         "workload": "%d loci: octoploid, %d SNVs, %d reads, %d chains x %d steps, burn %d; HBM resident; one pass" % (U, M, R, C_, S, S // 2),
-        "value": U / dt, "unit": "loci/s", "kernel": L.mchap_last_sampler_name().decode(), "kernel_ms": kms, "pass_ms": dt * 1e3,
+        "value": U / dt, "unit": "loci/s", "kernel": batch.sampler_name, "kernel_ms": kms, "pass_ms": dt * 1e3,
         "ok": bool((status <= 1).all()),
         "roofline": {"bound": "issue", "achieved": substeps / (kms * 1e-3), "unit": "sub-steps/s",
                      "note": "serial sub-step latency bound like configs[1]; 160 mutation sub-steps per chain step"},
@@ -334,7 +334,6 @@ def bench_config5(args):
     if nfl > 1:
         # the same pass with several batches in flight (256 loci are 1024 chains: half of the chip's wavefront slots,
         # and at ploidy 8 a pass spends most of its time behind a thinning front of chains: twice the headline's count)
-        L.mchap_set_profiling(0)
         batches = [batch] + [DenovoDeviceBatch(model, reads) for _ in range(nfl - 1)]
         flight = passes_in_flight(nfl)
         torch.cuda.synchronize()
@@ -408,10 +407,6 @@ def main():
     batch = batches[0]
     del reads
 
-    from mchap_amd import _lib
-
-    L = _lib.lib()
-    L.mchap_set_profiling(0)
     kernel_ms = []
     gather_ev = []
     K = args.ploidy
@@ -448,7 +443,7 @@ def main():
                 if events is not None:
                     gather_ev.append((g0, g1))
         if isolated:
-            kernel_ms.append(L.mchap_last_sampler_ms())  # waits for that launch only
+            kernel_ms.append(b.sampler_ms())  # waits for that launch only
 
     def _gather_equal(rec, dist_):
         parts = [torch.empty_like(rec) for _ in range(world)]
@@ -478,7 +473,7 @@ def main():
         dt = float(t.item())
     # The kernel's own launch duration (roofline): one pass in flight, HIP events on the launch stream right around
     # the sampler's launches -- with several passes in flight those spans overlap and say nothing about the kernel
-    L.mchap_set_profiling(1)
+    batches[0].time_sampler(True)  # (per-call events, owned by this batch: nothing process-wide)
     events = []
     n_iso = max(1, min(args.steps, 10))
     one_pass(0, isolated=True)
@@ -489,10 +484,10 @@ def main():
         one_pass(i, events, isolated=True)
     torch.cuda.synchronize()
     dt_iso = time.perf_counter() - t1
-    L.mchap_set_profiling(0)
+    batches[0].time_sampler(False)
     span_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # prepare pass + sampler + memsets
     kern_ms = float(np.mean(kernel_ms))
-    kern_name = L.mchap_last_sampler_name().decode()
+    kern_name = batches[0].sampler_name
 
     for b in batches:
         status = b.d_status.cpu().numpy()

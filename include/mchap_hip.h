@@ -50,6 +50,25 @@ enum {
   MCHAP_UNIT_BAD_INITIAL = 4 /* initial.shape != (ploidy, n_het_base): AssertionError, assemble/mcmc.py:207 */
 };
 
+/* Measurement / test knobs of the sampler (optional: mchap_denovo_cfg.tuning == NULL selects every default).  Results never
+ * depend on them -- every setting produces the same traces (tests/test_gpu_denovo.py runs the extremes) -- only the time does.
+ * A zero field means "default". */
+typedef struct mchap_denovo_tuning {
+  int32_t cache_slots;   /* {tag, llk} entries per chain of the likelihood cache: a power of two in 64..65536 (default 1024) */
+  int32_t flags;         /* 1: no mutation memo, 2: no interval memo, 4: no coded read table, 8: no product reuse,
+                            16: no LDS base-product cache, 32: skip the phased sampler's table completion (timing only: with
+                            pipe_stop), 64: table completion inside the exporting launch instead of denovo_fill_kernel */
+  int32_t spec_group;    /* kernel 3: lanes per chain, 16 / 32 / 64 (default: the smallest the shape allows) */
+  int32_t pipe_first;    /* kernel 5: MCMC steps before the first hand-over (default ploidy * n_pos / 10, clamped to 4..32) */
+  int32_t pipe_resume;   /*           steps a handed-back chain runs before it is handed over again (default 8) */
+  int32_t pipe_rounds;   /*           resume rounds + 1 before the rest runs to the end in kernel 3 (default 2 + 1; 1 = none) */
+  int32_t pipe_max;      /*           cap of a launch's extension while a chain of the wave is unsettled (default 64) */
+  int32_t pipe_parts;    /*           wavefronts per chain completing tables when the chains are few (default 8) */
+  int32_t prep_lds_limit; /* bytes of table the prepare pass copies to LDS (default 8192) */
+  int32_t pipe_stop;     /* 1: stop after the first coasting launch (traces incomplete: timing of the first phase only) */
+  int32_t reserved[6];
+} mchap_denovo_tuning;
+
 /* The fields of the DenovoMCMC dataclass (assemble/mcmc.py:24-40) that are common to a batch. */
 typedef struct mchap_denovo_cfg {
   int32_t steps;                            /* steps */
@@ -66,13 +85,16 @@ typedef struct mchap_denovo_cfg {
                                                increments over m het bases (assemble/mcmc.py:429-452) */
   int32_t max_pos;                          /* leading dimension of break_table */
   int32_t llk_cache;                        /* llk_cache_threshold >= 0: 1 = cache likelihoods per chain, 0 = recompute */
-  int32_t kernel;                           /* 0 = default (5 when the batch's shape allows, else 3, else 2), 1 = wavefront
-                                               per chain with LDS-staged reads, 2 = lanes over chains, 3 = speculative
-                                               sub-steps with a group of lanes per chain, 4 = settle/steady pipeline
-                                               (experimental), 5 = phased: kernel 3 for a chain's first steps, then its
-                                               settled stretches one lane per MCMC step (single temperature, one ploidy
-                                               per launch).  Identical results whichever runs. */
+  int32_t kernel;                           /* 0 = default (5 when the batch's shape allows, else 3, else 2), 2 = lanes over
+                                               chains, 3 = speculative sub-steps with a group of lanes per chain, 5 = phased:
+                                               kernel 3 for a chain's first steps, then its settled stretches one lane per
+                                               MCMC step (single temperature, one ploidy per launch).  Identical results
+                                               whichever runs.  (1 = wavefront per chain and 4 = settle/steady pipeline are
+                                               earlier designs kept for the parity suite: libmchap_hip_test.so only.) */
   int32_t reserved;
+  const mchap_denovo_tuning *tuning;        /* HOST pointer or NULL */
+  void *timer;                              /* mchap_timer_create() handle or NULL: the sampler launches of this call are
+                                               bracketed by HIP events on the call's stream (not the prepare pass) */
 } mchap_denovo_cfg;
 
 /* One unit = one (locus x sample) call of DenovoMCMC.fit.  Offsets are in ELEMENTS of the
@@ -147,6 +169,10 @@ int mchap_log_likelihood_batch(const double *reads, int n_reads, int n_pos, int 
                                const int64_t *read_counts, const int8_t *genotypes, int n_genotypes, int ploidy,
                                double *llks_out);
 
+/* Test hook: the logarithm the likelihood kernels take of their per-read terms (csrc/read_log.hpp: < 1 ulp; 0 -> -inf,
+ * negative or NaN -> NaN), for n arguments.  Host pointers. */
+int mchap_read_log_batch(const double *x, int64_t n, double *out);
+
 /* Posterior summary of a batch of traces: replaces GenotypeMultiTrace.burn(n).posterior() and the
  * mode/support statistics the assemble program reads from it (assemble/classes.py:280-325,87-128,194-205;
  * application/assemble.py:144-157).  Device pointers.
@@ -166,9 +192,9 @@ int mchap_trace_posterior_batch_device(int n_units, const mchap_unit *units_dev,
                                        double *mode_stats, int32_t *mode_index, uint64_t *mode_words,
                                        int32_t *mode_count, void *stream);
 
-/* Exact caller: replaces calling.exact.genotype_likelihoods (calling/exact.py:266-292, float32 store) and,
- * when post_out != NULL, genotype_posteriors (295-329).  Host pointers, one unit.
- * prior: has_prior == 0 -> None; else (inbreeding, frequencies or NULL). */
+/* Exact caller: replaces calling.exact.genotype_likelihoods (calling/exact.py:266-292): llks_out float32 [G] as the
+ * reference stores them and / or llks64_out float64 [G] (the unrounded values), G = C(n_haps + ploidy - 1, ploidy) genotypes in
+ * VCF order; either may be NULL.  Host pointers, one unit. */
 int mchap_exact_genotype_likelihoods(const double *reads, int n_reads, int n_pos, int max_allele,
                                      const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy,
                                      float *llks_out, double *llks64_out);
@@ -268,13 +294,14 @@ int mchap_call_mcmc_batch(int n_units, const double *reads, int n_reads, int n_p
                           const double *frequencies, const int64_t *initial, const uint64_t *stream_ids, int steps, int chains,
                           int step_type, uint64_t seed, int64_t *genotypes, double *llks, int32_t *status);
 
-/* Measurement hooks (bench.py): when enabled, mchap_denovo_fit_batch_device records HIP events on the launch
- * stream right around its sampler kernel (not the prepare pass or the memsets); mchap_last_sampler_ms waits for
- * that launch and returns its duration in milliseconds (< 0 if nothing was recorded). */
-int mchap_set_profiling(int enabled);
-double mchap_last_sampler_ms(void);
-/* name of the sampler kernel the last mchap_denovo_fit_batch_device call launched */
-const char *mchap_last_sampler_name(void);
+/* Measurement (bench.py): a timer is a pair of HIP events owned by the caller.  A fit whose cfg.timer is set records them on
+ * its own stream right around its sampler launches; mchap_timer_ms waits for the second event and returns the span in
+ * milliseconds (< 0: nothing recorded).  No process-wide state: fits on different threads / streams use different timers. */
+int mchap_timer_create(void **timer);
+double mchap_timer_ms(void *timer);
+int mchap_timer_destroy(void *timer);
+/* name of the sampler kernel(s) a fit of this batch dispatches to (a pure function of cfg and the units' shapes) */
+int mchap_denovo_sampler_name(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host, char *out, int out_len);
 
 /* Introspection */
 const char *mchap_version(void);

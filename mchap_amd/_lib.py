@@ -11,8 +11,11 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-# MCHAP_HIP_LIB: an alternative build of the same library (debug variants made by tools/)
+# MCHAP_HIP_LIB: an alternative build of the same library (profiling variants made by `make stats` / `make phases`)
 SO = os.environ.get("MCHAP_HIP_LIB") or os.path.join(CSRC, "libmchap_hip.so")
+# The parity suite's library: the same C ABI plus the two earlier sampler designs (kernels 1 and 4) and the narrower
+# instantiations of the phased sampler.  Loaded instead of SO while MCHAP_HIP_TEST_KERNELS is set (tests only).
+TEST_SO = os.path.join(CSRC, "libmchap_hip_test.so")
 
 MAX_TEMPS = 16
 MAX_PLOIDY = 8
@@ -34,6 +37,56 @@ UNIT_BREAKS = 3
 UNIT_BAD_INITIAL = 4
 
 
+class DenovoTuning(C.Structure):
+    """mchap_denovo_tuning: measurement / test knobs (0 = default); results never depend on them."""
+
+    _fields_ = [
+        ("cache_slots", C.c_int32),
+        ("flags", C.c_int32),
+        ("spec_group", C.c_int32),
+        ("pipe_first", C.c_int32),
+        ("pipe_resume", C.c_int32),
+        ("pipe_rounds", C.c_int32),
+        ("pipe_max", C.c_int32),
+        ("pipe_parts", C.c_int32),
+        ("prep_lds_limit", C.c_int32),
+        ("pipe_stop", C.c_int32),
+        ("reserved", C.c_int32 * 6),
+    ]
+
+
+# environment variable -> field of DenovoTuning.  Read by the Python mirror (DenovoMCMC._cfg) when a fit is set up, so that
+# the test-suite and tools/ can sweep them; the library itself reads no environment.
+TUNING_ENV = {
+    "MCHAP_HIP_CACHE_SLOTS": "cache_slots", "MCHAP_HIP_FLAGS": "flags", "MCHAP_HIP_GROUP": "spec_group",
+    "MCHAP_HIP_PIPE_FIRST": "pipe_first", "MCHAP_HIP_PIPE_RESUME": "pipe_resume", "MCHAP_HIP_PIPE_MAX": "pipe_max",
+    "MCHAP_HIP_PIPE_PARTS": "pipe_parts", "MCHAP_HIP_PREP_LDS": "prep_lds_limit", "MCHAP_HIP_PIPE_STOP": "pipe_stop",
+}
+
+
+def tuning_from_env():
+    """A DenovoTuning filled from the MCHAP_HIP_* variables that are set, or None."""
+    t = DenovoTuning()
+    used = False
+    for env, field in TUNING_ENV.items():
+        v = os.environ.get(env)
+        if v is not None and v != "":
+            setattr(t, field, int(v))
+            used = True
+    v = os.environ.get("MCHAP_HIP_ROUNDS")  # resume rounds: the field holds rounds + 1 (0 = default)
+    if v is not None and v != "":
+        t.pipe_rounds = int(v) + 1
+        used = True
+    if os.environ.get("MCHAP_HIP_NO_BP_CACHE"):
+        t.flags |= 16
+        used = True
+    v = os.environ.get("MCHAP_HIP_PIPE_GROUP")  # lanes per chain of the phased sampler: test library only
+    if v is not None and v != "":
+        t.reserved[0] = int(v)
+        used = True
+    return t if used else None
+
+
 class DenovoCfg(C.Structure):
     _fields_ = [
         ("steps", C.c_int32),
@@ -51,6 +104,8 @@ class DenovoCfg(C.Structure):
         ("llk_cache", C.c_int32),
         ("kernel", C.c_int32),
         ("reserved", C.c_int32),
+        ("tuning", C.POINTER(DenovoTuning)),
+        ("timer", C.c_void_p),
     ]
 
 
@@ -98,16 +153,18 @@ def build(force=False):
     return SO
 
 
-_lib = None
+_libs = {}
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(SO):
+    """The loaded library: libmchap_hip.so, or the parity suite's libmchap_hip_test.so while MCHAP_HIP_TEST_KERNELS is set."""
+    path = TEST_SO if os.environ.get("MCHAP_HIP_TEST_KERNELS") else SO
+    L = _libs.get(path)
+    if L is None:
+        if not os.path.exists(path):
             raise MchapLibraryError(
-                "libmchap_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C mchap_amd/csrc`. There is no CPU fallback." % SO
+                "%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mchap_amd/csrc`. There is no CPU fallback." % path
             )
         # PyTorch-ROCm bundles its own libamdhip64.so.7; whichever HIP runtime is loaded first serves the whole
         # process (same soname).  Load torch's first when torch is installed so that tensors handed to the
@@ -116,7 +173,7 @@ def lib():
             import torch  # noqa: F401
         except Exception:  # torch is optional for the host-pointer entry points
             pass
-        L = C.CDLL(SO)
+        L = C.CDLL(path)
         L.mchap_version.restype = C.c_char_p
         L.mchap_last_error.restype = C.c_char_p
         L.mchap_denovo_lds_bytes.restype = C.c_int64
@@ -125,10 +182,43 @@ def lib():
         L.mchap_exact_workspace_bytes_cached.restype = C.c_int64
         L.mchap_call_mcmc_workspace_bytes.restype = C.c_int64
         L.mchap_call_mcmc_workspace_bytes_for.restype = C.c_int64
-        L.mchap_last_sampler_ms.restype = C.c_double
-        L.mchap_last_sampler_name.restype = C.c_char_p
-        _lib = L
-    return _lib
+        L.mchap_timer_ms.restype = C.c_double
+        L.mchap_timer_ms.argtypes = [C.c_void_p]
+        L.mchap_timer_destroy.argtypes = [C.c_void_p]
+        _libs[path] = L
+    return L
+
+
+class SamplerTimer:
+    """A pair of HIP events owned by the caller (mchap_timer_create): set `cfg.timer = timer.handle` and the fit brackets
+    its sampler launches with them on its own stream; `ms()` waits for the second event."""
+
+    def __init__(self):
+        self.L = lib()
+        h = C.c_void_p()
+        check(self.L.mchap_timer_create(C.byref(h)))
+        self.handle = h.value
+
+    def ms(self):
+        return float(self.L.mchap_timer_ms(C.c_void_p(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.L.mchap_timer_destroy(C.c_void_p(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sampler_name(cfg, units_host):
+    """Name of the sampler kernel(s) a fit of this batch dispatches to."""
+    buf = C.create_string_buffer(160)
+    check(lib().mchap_denovo_sampler_name(C.byref(cfg), len(units_host), ptr(units_host), buf, 160))
+    return buf.value.decode()
 
 
 EXPORTS = [
@@ -155,9 +245,11 @@ EXPORTS = [
     "mchap_device_count",
     "mchap_denovo_lds_bytes",
     "mchap_denovo_workspace_bytes",
-    "mchap_set_profiling",
-    "mchap_last_sampler_ms",
-    "mchap_last_sampler_name",
+    "mchap_timer_create",
+    "mchap_timer_ms",
+    "mchap_timer_destroy",
+    "mchap_denovo_sampler_name",
+    "mchap_read_log_batch",
 ]
 
 

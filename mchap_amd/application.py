@@ -13,11 +13,46 @@ from .io import DenovoLocus, Locus, extract_read_variants, qual_of_prob, read_al
 SAMPLE_FIELDS = ("GT", "GQ", "SQ", "DP", "RCOUNT", "RCALLS", "MEC", "MECP", "GPM", "SPM", "MCI")
 
 
-def sample_reads(locus, bam, sample, error_rate=0.0024, use_phred=False):
-    """encode_sample_reads (application/baseclass.py:140-210) for one sample:
-    -> dict(chars, calls, depth, dists (distinct rows), counts)."""
-    chars, quals = extract_read_variants(locus, bam, sample)
+READ_FILTER = dict(min_quality=20, skip_duplicates=True, skip_qcfail=True, skip_supplementary=True)
+
+
+class ReadSource:
+    """The alignment files of a run, each read once, and the read encoding settings (application/baseclass.py:48-57).
+    sample_bams: ordered {sample: path}, or {pool: [(sample, path), ...]} when samples are pooled (--sample-pool: a pool's
+    reads are those of its samples, concatenated: baseclass.py:153-187)."""
+
+    def __init__(self, sample_bams, error_rate=0.0024, use_phred=False, read_group_field="SM", mapping_quality=20,
+                 skip_duplicates=True, skip_qcfail=True, skip_supplementary=True, workers=1):
+        self.pools = {k: ([(k, v)] if isinstance(v, str) else list(v)) for k, v in sample_bams.items()}
+        self.samples = list(self.pools)
+        self.error_rate, self.use_phred = error_rate, use_phred
+        self.filter = dict(min_quality=mapping_quality, skip_duplicates=skip_duplicates, skip_qcfail=skip_qcfail,
+                           skip_supplementary=skip_supplementary)
+        paths = list(dict.fromkeys(p for pairs in self.pools.values() for _, p in pairs))
+        if workers > 1 and len(paths) > 1:
+            # --cores: the files are inflated and parsed by a pool of threads (zlib releases the interpreter lock)
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=int(workers)) as ex:
+                loaded = list(ex.map(lambda q: read_alignments(q, read_group_field), paths))
+        else:
+            loaded = [read_alignments(q, read_group_field) for q in paths]
+        self.bams = dict(zip(paths, loaded))
+
+    def reads(self, locus, sample):
+        return sample_reads(locus, [(name, self.bams[path]) for name, path in self.pools[sample]], self.error_rate, self.use_phred,
+                            self.filter)
+
+
+def sample_reads(locus, pairs, error_rate=0.0024, use_phred=False, read_filter=None):
+    """encode_sample_reads (application/baseclass.py:140-210) for one sample (or pool): pairs = [(read-group sample name,
+    alignment as read_alignments returns it), ...] -> dict(chars, calls, depth, dists (distinct rows), counts)."""
     M = len(locus.positions)
+    parts = [extract_read_variants(locus, bam, name, **(read_filter or READ_FILTER)) for name, bam in pairs]
+    if parts:
+        chars, quals = np.concatenate([c for c, _ in parts]), np.concatenate([q for _, q in parts])
+    else:
+        chars, quals = np.empty((0, M), dtype="U1"), np.empty((0, M), dtype=np.int16)
     calls = np.full(chars.shape, -1, dtype=np.int8)
     for j in range(M):
         for a, c in enumerate(locus.alleles[j]):
@@ -28,6 +63,26 @@ def sample_reads(locus, bam, sample, error_rate=0.0024, use_phred=False):
     return dict(chars=chars, calls=calls, depth=depth, dists=uniq, counts=counts)
 
 
+def resolve_seed(seed):
+    """The run's random seed: the reference's programs default to 42 (application/arguments.py:538-546) and give every
+    unit the same value (baseclass.py:360-388, assemble/mcmc.py:140-142).  None (library use) draws one value, once."""
+    if seed is None:
+        return int(np.random.randint(0, 2 ** 31 - 1))
+    return int(seed)
+
+
+def device_unit_budget(bytes_per_unit, fraction=0.5, least=1, most=1 << 20):
+    """How many units of `bytes_per_unit` device bytes a launch may hold: a share of the free HBM (the reference streams
+    record by record; here a file is processed in blocks of records, each block one launch per shape)."""
+    try:
+        import torch
+
+        free, _ = torch.cuda.mem_get_info()
+    except Exception:
+        free = 8 << 30
+    return int(max(least, min(most, (free * fraction) // max(1, int(bytes_per_unit)))))
+
+
 def _mec(calls, genotype):
     """minimum_error_correction summed over reads (encoding/integer/stats.py:18-39)."""
     if len(calls) == 0:
@@ -36,7 +91,7 @@ def _mec(calls, genotype):
     return int(diff.sum(axis=-1).min(axis=-1).sum())
 
 
-def _exact_units(records, bams, samples, ploidy, report, error_rate, use_phred, prior_tag, inbreeding, allele_filter=None):
+def _exact_units(records, source, samples, prior_tag, allele_filter=None):
     """Everything `call-exact` needs from the input side, record by record: the locus, per sample the encoded reads,
     and which (record, sample) units need the kernel (a record with a single haplotype, or no variable position, has
     one genotype with probability 1; an invalid record is not called at all)."""
@@ -49,7 +104,7 @@ def _exact_units(records, bams, samples, ploidy, report, error_rate, use_phred, 
             invalid = "NOA"
         elif np.any(np.isnan(locus.frequencies)):
             invalid = "AF0"
-        per = {s: sample_reads(locus, bams[s], s, error_rate, use_phred) for s in samples}
+        per = {s: source.reads(locus, s) for s in samples}
         out.append(dict(rec=rec, locus=locus, invalid=invalid, reads=per, needs_kernel=(invalid is None and M > 0 and H > 1)))
     return out
 
@@ -81,6 +136,24 @@ def _run_exact_groups(units, ploidy_of, inbreeding_of, full, backend=None):
                 results[(ri, s)] = _exact_one(backend, sr, locus.haplotypes, K, prior, full)
             continue
         Rmax = max(max(len(units[ri]["reads"][s]["dists"]), 1) for ri, s in members)
+        from math import comb
+
+        G = comb(H + K - 1, K)
+        # device bytes per unit: reads + haplotypes + (array form) the float32 / float64 genotype arrays, or (streaming
+        # form) the joint values kept between the passes -- the group is cut into chunks that fit the free HBM
+        per_unit = Rmax * M * A * 8 + Rmax * 8 + H * M + (G * 20 if full else G * 8) + 4096
+        step = device_unit_budget(per_unit)
+        if len(members) > step:
+            for c0 in range(0, len(members), step):
+                sub = {}
+                part = members[c0:c0 + step]
+                keep = sorted({ri for ri, _ in part})
+                remap = {ri: i for i, ri in enumerate(keep)}
+                sub_units = [dict(units[ri], reads={s: units[ri]["reads"][s] for r2, s in part if r2 == ri}) for ri in keep]
+                sub = _run_exact_groups(sub_units, ploidy_of, inbreeding_of, full, backend)
+                for (i, s), v in sub.items():
+                    results[(keep[i], s)] = v
+            continue
         U = len(members)
         reads = np.full((U, Rmax, M, A), np.nan)
         counts = np.zeros((U, Rmax), dtype=np.int64)
@@ -140,6 +213,9 @@ def _per_sample(value, samples):
 def _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_tag):
     """(FILTER, INFO, FORMAT, {sample: column}) of one record from the units' results (application/baseclass.py:220-302,
     call_exact.py:84-199)."""
+    from .vcfheader import report_fields
+
+    info_opt, fmt_opt = report_fields(report)
     rec, locus, invalid = unit["rec"], unit["locus"], unit["invalid"]
     haps = locus.haplotypes
     H, M = haps.shape
@@ -166,7 +242,7 @@ def _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_ta
         if invalid:
             gts[sample] = np.full(ploidy, -1, int)
             fields = ["/".join(["."] * ploidy), ".", ".", vcfstr(float(dp)), str(rcount), str(rcalls), ".", ".", ".", ".", "."]
-            fields += ["."] * len([t for t in report if t in ("AFP", "ACP", "AOP", "SNVDP", "GL", "GP")])
+            fields += ["."] * len(fmt_opt)
             cols[sample] = ":".join(fields)
             nan_arrays = True
             continue
@@ -187,7 +263,7 @@ def _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_ta
         mecp = mec / denom if denom > 0 else np.nan
         fields = ["/".join(str(a) for a in alleles), vcfstr(qual_of_prob(gprob)), vcfstr(qual_of_prob(sprob)), vcfstr(float(dp)),
                   str(rcount), str(rcalls), str(mec), vcfstr(float(mecp)), vcfstr(float(gprob)), vcfstr(float(sprob)), "."]
-        for tag in report:
+        for tag in fmt_opt:
             if tag == "AFP":
                 fields.append(vcfstr(freqs))
             elif tag == "ACP":
@@ -212,15 +288,16 @@ def _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_ta
              ("DP", float(np.nansum(dps)) if M else np.nan), ("RCOUNT", int(np.nansum(rcounts))), ("END", locus.stop),
              ("NVAR", M), ("SNVPOS", np.array(locus.positions, int) - locus.start + 1)]
     null_r = np.full(H, np.nan)
-    if "AFPRIOR" in report:  # (only on request: the reference's --report AFP GP golden carries no AFPRIOR)
-        info.append(("AFPRIOR", locus.frequencies))
-    for tag in report:
-        if tag == "ACP":
+    for tag in info_opt:
+        if tag == "AFPRIOR":
+            info.append(("AFPRIOR", locus.frequencies))
+        elif tag == "ACP":
             info.append(("ACP", null_r if nan_arrays else acp_sum))
         elif tag == "AFP":
             info.append(("AFP", null_r if nan_arrays else acp_sum / ploidy_total))
         elif tag == "AOP":
             info.append(("AOP", null_r if nan_arrays else 1 - aop_not))
+        elif tag == "AOPSUM":
             info.append(("AOPSUM", null_r if nan_arrays else aop_sum))
         elif tag == "SNVDP":
             info.append(("SNVDP", snvdp_sum))
@@ -231,16 +308,27 @@ def _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_ta
                 parts.append(k)
         else:
             parts.append("%s=%s" % (k, vcfstr(np.asarray(v) if isinstance(v, np.ndarray) else v)))
-    fmt = ":".join(SAMPLE_FIELDS + tuple(t for t in report if t in ("AFP", "ACP", "AOP", "SNVDP", "GL", "GP")))
+    fmt = ":".join(SAMPLE_FIELDS + tuple(fmt_opt))
     return invalid or "PASS", ";".join(parts), fmt, cols
+
+
+def _source(sample_bams, base_error_rate, use_base_phred_scores, read_kw):
+    if isinstance(sample_bams, ReadSource):
+        return sample_bams
+    return ReadSource(sample_bams, error_rate=base_error_rate, use_phred=use_base_phred_scores, **(read_kw or {}))
 
 
 def call_exact_record(rec, bams, samples, ploidy=4, report=(), error_rate=0.0024, use_phred=False, prior_tag=None,
                       inbreeding=None, calling=None):
     """One record of the input VCF -> (FILTER, INFO string, FORMAT string, {sample: column}) as `mchap call-exact` writes
-    them.  `calling`: None = the device batch; or an object with the reference's functions (test replays)."""
-    units = _exact_units([rec], bams, samples, ploidy, report, error_rate, use_phred, prior_tag, inbreeding)
-    full = ("GL" in report) or ("GP" in report)
+    them.  bams: {sample: alignment as read_alignments returns it}.  `calling`: None = the device batch; or an object with
+    the reference's functions (test replays)."""
+    source = ReadSource({}, error_rate=error_rate, use_phred=use_phred)
+    source.pools = {s: [(s, s)] for s in samples}
+    source.bams = {s: bams[s] for s in samples}
+    units = _exact_units([rec], source, samples, prior_tag)
+    _, fmt_opt = __import__("mchap_amd.vcfheader", fromlist=["report_fields"]).report_fields(report)
+    full = ("GL" in fmt_opt) or ("GP" in fmt_opt)
     ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
     results = _run_exact_groups(units, ploidy_of, inbreeding_of, full, calling)
     return _format_exact_record(units[0], samples, results, 0, ploidy_of, report, prior_tag)
@@ -259,27 +347,52 @@ def _allele_filter(vcf_path, text):
     return field, compare, number, numbers[field]
 
 
+def _blocks(items, n):
+    for i in range(0, len(items), max(1, n)):
+        yield items[i:i + max(1, n)]
+
+
 def call_exact(vcf_path, sample_bams, ploidy=4, report=(), base_error_rate=0.0024, use_base_phred_scores=False,
-               prior_frequencies_tag=None, inbreeding=None, calling=None, filter_input_haplotypes=None):
+               prior_frequencies_tag=None, inbreeding=None, calling=None, filter_input_haplotypes=None, read_kw=None,
+               records_per_block=4096, shard=None):
     """`mchap call-exact` over a VCF of known haplotypes: yields one VCF record line per input record (no header).
-    sample_bams: ordered mapping sample name -> BAM path; ploidy / inbreeding: a value or {sample: value}.
-    All (record x sample) units of the file are encoded first, grouped by shape and evaluated in one device call per
-    shape; the records are then formatted from the results."""
-    samples = list(sample_bams)
-    bams = {s: read_alignments(p) for s, p in sample_bams.items()}
+    sample_bams: ordered mapping sample name -> BAM path (or pool -> [(sample, path)], or a ReadSource); ploidy /
+    inbreeding: a value or {sample: value}.  The records are processed in blocks: the (record x sample) units of a block
+    are encoded, grouped by shape and evaluated in one device call per shape (cut further when a group would not fit the
+    free HBM), and the block's lines are yielded before the next block is read: host and device memory stay bounded by
+    the block, as with the reference's record-by-record stream.  shard = (rank, world): this process's contiguous share
+    of the records (mchap_amd.shard.shard_range)."""
+    from .vcfheader import report_fields
+
+    source = _source(sample_bams, base_error_rate, use_base_phred_scores, read_kw)
+    samples = source.samples
     _, records = read_vcf(vcf_path)
+    records = _shard(records, shard)
     report = tuple(report)
-    units = _exact_units(records, bams, samples, ploidy, report, base_error_rate, use_base_phred_scores, prior_frequencies_tag, inbreeding,
-                         _allele_filter(vcf_path, filter_input_haplotypes))
-    full = ("GL" in report) or ("GP" in report)
+    full = bool({"GL", "GP"} & set(report_fields(report)[1]))
     ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
-    results = _run_exact_groups(units, ploidy_of, inbreeding_of, full, calling)
-    for ri, unit in enumerate(units):
-        rec = unit["rec"]
-        flt, info, fmt, cols = _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_frequencies_tag)
-        alts = unit["locus"].sequences[1:]  # (the input's, minus the alleles --filter-input-haplotypes removed)
-        alt = ",".join(alts) if alts else "."
-        yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
+    allele_filter = _allele_filter(vcf_path, filter_input_haplotypes)
+    for block in _blocks(records, records_per_block):
+        units = _exact_units(block, source, samples, prior_frequencies_tag, allele_filter)
+        results = _run_exact_groups(units, ploidy_of, inbreeding_of, full, calling)
+        for ri, unit in enumerate(units):
+            rec = unit["rec"]
+            flt, info, fmt, cols = _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_frequencies_tag)
+            alts = unit["locus"].sequences[1:]  # (the input's, minus the alleles --filter-input-haplotypes removed)
+            alt = ",".join(alts) if alts else "."
+            yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
+
+
+def _shard(items, shard):
+    """This rank's contiguous share of the items (targets or records): loci are independent, so the programs shard the
+    work list before anything touches the GPU (application/baseclass.py:360-388 deals blocks of loci to its workers)."""
+    if shard is None:
+        return items
+    from .shard import shard_range
+
+    rank, world = shard
+    lo, hi = shard_range(len(items), rank, world)
+    return items[lo:hi]
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -316,9 +429,29 @@ def call_posterior_haplotypes(posteriors, threshold=0.01):
     return haplotypes[np.flip(np.argsort(value))], ref_observed
 
 
-def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold):
+def _genotype_posterior_array(post, labels, ploidy):
+    """Posterior probabilities of all genotypes over the record's labelled alleles, in VCF order (application/assemble.py:
+    276-305): a posterior genotype that holds an allele the record does not list cannot be encoded and is left out."""
+    from math import comb
+
+    from .calling_mcmc import _vcf_index
+
+    n_alleles = len(labels)
+    out = np.zeros(comb(n_alleles + ploidy - 1, ploidy), float)
+    for haps, prob in zip(post.genotypes, post.probabilities):
+        alleles = np.sort([labels.get(np.asarray(h, dtype=np.int8).tobytes(), -1) for h in haps])
+        if alleles[0] >= 0:
+            out[int(_vcf_index(alleles[None])[0])] = prob
+    return out
+
+
+def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold, report=(), ploidy_of=None, encoded=None):
     """The VCF record line of `mchap assemble` from the per-sample summaries (application/assemble.py:144-252,
-    baseclass.py:220-302).  per[sample]: genotype [K, M], gprob, sprob, mec, mecp, mci, rcount, rcalls, dp."""
+    baseclass.py:220-302).  per[sample]: genotype [K, M], gprob, sprob, mec, mecp, mci, rcount, rcalls, dp, depth;
+    encoded[sample]: the sample's encoded reads (for --report GL)."""
+    from .vcfheader import report_fields
+
+    info_opt, fmt_opt = report_fields(report)
     M = len(locus.positions)
     haplotypes, ref_called = call_posterior_haplotypes(posteriors, threshold=haplotype_posterior_threshold)
     labels = {h.tobytes(): i for i, h in enumerate(haplotypes)}
@@ -327,11 +460,17 @@ def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_t
         labels.pop(haplotypes[0].tobytes())
         if len(haplotypes) == 1:
             flt = "NOA"
+    H = len(haplotypes)
     alts = [locus.format_haplotype(h) for h in haplotypes[1:]]
-    counts = np.zeros(len(haplotypes), int)
+    counts = np.zeros(H, int)
     cols = []
-    for sample in samples:
+    want_afp = bool({"ACP", "AFP", "AOP", "AOPSUM"} & set(info_opt)) or bool({"ACP", "AFP", "AOP"} & set(fmt_opt))
+    acp_sum, aop_sum, aop_not, snvdp_sum = np.zeros(H), np.zeros(H), np.ones(H), np.zeros(M)
+    ploidy_total = 0
+    for sample, post in zip(samples, posteriors):
         d = per[sample]
+        K = len(d["genotype"])
+        ploidy_total += K
         a = np.sort([labels.get(np.asarray(h, dtype=np.int8).tobytes(), -1) for h in d["genotype"]])
         a = np.append(a[a >= 0], a[a < 0])
         for x in a:
@@ -341,6 +480,45 @@ def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_t
         fields = ["/".join(str(x) if x >= 0 else "." for x in a), vcfstr(qual_of_prob(d["gprob"])), vcfstr(qual_of_prob(d["sprob"])),
                   vcfstr(float(d["dp"])), str(d["rcount"]), str(d["rcalls"]), str(d["mec"]), vcfstr(float(d["mecp"])),
                   vcfstr(d["gprob"]), vcfstr(d["sprob"]), str(d["mci"])]
+        depth = np.asarray(d.get("depth", np.zeros(M)), float)
+        if M:
+            snvdp_sum += np.round(depth)
+        freqs = occur = None
+        if want_afp:
+            # posterior allele frequencies / occurrences of the record's haplotypes (assemble.py:213-226)
+            freqs, occur = np.zeros(H), np.zeros(H)
+            hp, fq, oc = post.allele_frequencies()
+            index = {np.asarray(h, dtype=np.int8).tobytes(): i for i, h in enumerate(haplotypes)}
+            for h, f_, o_ in zip(hp, fq, oc):
+                i = index.get(np.asarray(h, dtype=np.int8).tobytes())
+                if i is not None:
+                    freqs[i], occur[i] = f_, o_
+            acp_sum += freqs * K
+            aop_sum += occur
+            aop_not *= 1 - occur
+        for tag in fmt_opt:
+            if tag == "AFP":
+                fields.append(vcfstr(freqs))
+            elif tag == "ACP":
+                fields.append(vcfstr(freqs * K))
+            elif tag == "AOP":
+                fields.append(vcfstr(occur))
+            elif tag == "GP":
+                fields.append(vcfstr(_genotype_posterior_array(post, labels, K)))
+            elif tag == "GL":
+                # likelihoods of every genotype over the record's haplotypes (assemble.py:236-244): the exact caller's kernel
+                from . import calling
+
+                sr = encoded[sample]
+                if M and len(sr["dists"]):
+                    llks = calling.genotype_likelihoods(sr["dists"], K, haplotypes, read_counts=sr["counts"])
+                else:
+                    from math import comb
+
+                    llks = np.zeros(comb(H + K - 1, K), np.float32)
+                fields.append(vcfstr(np.asarray(llks, np.float64) / np.log(10)))
+            elif tag == "SNVDP":
+                fields.append(vcfstr(np.round(depth)) if M else ".")
         cols.append(":".join(fields))
     info = [("AN", int(counts.sum())), ("UAN", int((counts > 0).sum())), ("AC", counts[1:])]
     if not ref_called:
@@ -349,6 +527,19 @@ def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_t
              ("DP", float(np.nansum([per[s]["dp"] for s in samples])) if M else np.nan),
              ("RCOUNT", int(sum(per[s]["rcount"] for s in samples))), ("END", locus.stop), ("NVAR", M),
              ("SNVPOS", np.array(locus.positions, int) - locus.start + 1)]
+    for tag in info_opt:
+        if tag == "AFPRIOR":
+            info.append(("AFPRIOR", np.full(H, np.nan)))  # (the assembler has no prior allele frequencies)
+        elif tag == "ACP":
+            info.append(("ACP", acp_sum))
+        elif tag == "AFP":
+            info.append(("AFP", acp_sum / ploidy_total))
+        elif tag == "AOP":
+            info.append(("AOP", 1 - aop_not))
+        elif tag == "AOPSUM":
+            info.append(("AOPSUM", aop_sum))
+        elif tag == "SNVDP":
+            info.append(("SNVDP", snvdp_sum))
     parts = []
     for k, v in info:
         if isinstance(v, bool):
@@ -357,189 +548,235 @@ def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_t
         else:
             parts.append("%s=%s" % (k, vcfstr(v)))
     return "\t".join([locus.contig, str(locus.start + 1), locus.name, locus.sequence, ",".join(alts) if alts else ".", ".", flt,
-                      ";".join(parts), ":".join(SAMPLE_FIELDS)] + cols)
+                      ";".join(parts), ":".join(SAMPLE_FIELDS + tuple(fmt_opt))] + cols)
+
+
+def assemble_targets(bed_path=None, region=None, region_id=None):
+    """The target loci of `mchap assemble`: the lines of a BED4 file, or one --region (application/assemble.py:75-85)."""
+    from .io import parse_region
+
+    if bed_path is None and region is None:
+        raise ValueError("No region or targets bedfile is specified.")
+    if bed_path is not None and region is not None:
+        raise ValueError("Cannot combine --targets and --region arguments.")
+    if bed_path is not None:
+        return read_bed4(bed_path)
+    contig, start, stop = parse_region(region)
+    return [(contig, start, stop, region_id if region_id is not None else ".")]
 
 
 def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploidy=4, inbreeding=None, steps=1000, burn=500,
-             chains=2, seed=None, error_rate=0.0024, use_phred=False, haplotype_posterior_threshold=0.20,
-             incongruence_threshold=0.60, **mcmc_kw):
-    """`mchap assemble` over the targets of a BED4 file: yields one VCF record line per target (no header).
-    reference_sequences: {contig: sequence string}; sample_bams: ordered mapping sample name -> BAM path; ploidy /
-    inbreeding: a value or {sample: value}.
+             chains=2, seed=42, error_rate=0.0024, use_phred=False, haplotype_posterior_threshold=0.20,
+             incongruence_threshold=0.60, report=(), temperatures=(1.0,), read_kw=None, targets=None, units_per_block=None,
+             shard=None, **mcmc_kw):
+    """`mchap assemble` over the targets of a BED4 file (or `targets`: a list of (contig, start, stop, name)): yields one
+    VCF record line per target (no header).  reference_sequences: {contig: sequence string} or an io.Reference;
+    sample_bams: ordered mapping sample name -> BAM path (or pool -> [(sample, path)], or a ReadSource); ploidy /
+    inbreeding: a value or {sample: value}; temperatures: a ladder for every sample or {sample: ladder}.
 
-    Batched: every (target x sample) unit of the file is encoded first, all units go through ONE sampler launch
-    (ragged: loci differ in SNVs, samples in depth), the posterior summary (distinct genotypes, SPM, GPM, mode) and the
-    replicate incongruence (MCI) are taken on the device, and the records are formatted from those few hundred bytes
-    per unit.  As in the reference every unit restarts from the same seed (application/baseclass.py:360-388,
+    Batched: the targets are processed in blocks; every (target x sample) unit of a block is encoded and all of them go
+    through ONE sampler launch per (ploidy, temperature ladder) present (ragged: loci differ in SNVs, samples in depth),
+    the posterior summary (distinct genotypes, SPM, GPM, mode) and the replicate incongruence (MCI) are taken on the
+    device, and the block's records are formatted from those few hundred bytes per unit and yielded before the next
+    block is read.  A block holds as many units as fit a share of the free HBM (`units_per_block`; a small file is one
+    block, one launch).  As in the reference every unit restarts from the same seed (application/baseclass.py:360-388,
     assemble/mcmc.py:140-142), so the result does not depend on the order or the batching of the targets."""
     from .assemble import DenovoMCMC
     from .classes import PosteriorGenotypeDistribution
     from .device import DenovoRaggedBatch, PassesInFlight
+    from .io import Reference
 
-    samples = list(sample_bams)
-    bams = {s: read_alignments(p) for s, p in sample_bams.items()}
+    source = _source(sample_bams, error_rate, use_phred, read_kw)
+    samples = source.samples
+    seed = resolve_seed(seed)
     ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
+    temps_of = _per_sample(temperatures if isinstance(temperatures, dict) else tuple(temperatures), samples)
     _, variants = read_vcf(variants_vcf_path)
-    loci = [DenovoLocus(contig, start, stop, name, variants, reference_sequences[contig][start:stop])
-            for contig, start, stop, name in read_bed4(bed_path)]
-    encoded = {}
-    units, where = [], []
-    for li, locus in enumerate(loci):
-        M = len(locus.positions)
-        for sample in samples:
-            sr = sample_reads(locus, bams[sample], sample, error_rate, use_phred)
-            encoded[(li, sample)] = sr
-            if M == 0:
-                continue  # nothing to sample: the empty genotype with probability 1
-            dists, counts = sr["dists"], sr["counts"]
-            if len(dists) == 0:  # no reads: one all-gap read (assemble/mcmc.py:132-137)
-                dists, counts = np.full((1, M, int(max(locus.n_alleles))), np.nan), None
-            units.append(dict(reads=dists, counts=counts, n_alleles=locus.n_alleles, ploidy=int(ploidy_of(sample)),
-                              inbreeding=inbreeding_of(sample), stream_id=0))
-            where.append((li, sample))
-    summaries = {}
-    if units:
-        model = DenovoMCMC(ploidy=int(ploidy_of(samples[0])), n_alleles=[2], inbreeding=None, steps=steps, chains=chains, random_seed=seed, **mcmc_kw)
-        # one launch per ploidy present (usually one): the library's fast samplers take one ploidy per launch, a
-        # launch of mixed ploidies would run on the general lanes-over-chains kernel
-        by_ploidy = {}
-        for i, u in enumerate(units):
-            by_ploidy.setdefault(u["ploidy"], []).append(i)
-        # (several ploidies: their launches go out on separate HIP streams and fill each other's thin phases)
-        flight = PassesInFlight(min(4, len(by_ploidy))) if len(by_ploidy) > 1 else None
-        pending = []
-        for idx in by_ploidy.values():
-            batch = DenovoRaggedBatch(model, [units[i] for i in idx])
+    if targets is None:
+        targets = read_bed4(bed_path)
+    targets = _shard(list(targets), shard)
+    fetch = reference_sequences.fetch if isinstance(reference_sequences, Reference) else (lambda c, a, b: reference_sequences[c][a:b])
+    by_contig = {}
+    for r in variants:
+        by_contig.setdefault(r["chrom"], []).append(r)
+    if units_per_block is None:
+        # device bytes of one unit: its traces (chains x steps x (ploidy words + llk)), the per-chain likelihood cache and
+        # tables of the workspace, a typical read tensor
+        kmax = max(int(ploidy_of(s_)) for s_ in samples)
+        units_per_block = device_unit_budget(chains * steps * (kmax + 1) * 8 + chains * 1024 * 16 * 2 + (256 << 10), fraction=0.4)
+    loci_per_block = max(1, units_per_block // max(1, len(samples)))
+    for block in _blocks(targets, loci_per_block):
+        loci = [DenovoLocus(contig, start, stop, name, by_contig.get(contig, ()), fetch(contig, start, stop))
+                for contig, start, stop, name in block]
+        encoded = {}
+        units, where = [], []
+        for li, locus in enumerate(loci):
+            M = len(locus.positions)
+            for sample in samples:
+                sr = source.reads(locus, sample)
+                encoded[(li, sample)] = sr
+                if M == 0:
+                    continue  # nothing to sample: the empty genotype with probability 1
+                dists, counts = sr["dists"], sr["counts"]
+                if len(dists) == 0:  # no reads: one all-gap read (assemble/mcmc.py:132-137)
+                    dists, counts = np.full((1, M, int(max(locus.n_alleles))), np.nan), None
+                units.append(dict(reads=dists, counts=counts, n_alleles=locus.n_alleles, ploidy=int(ploidy_of(sample)),
+                                  inbreeding=inbreeding_of(sample), stream_id=0, temps=tuple(temps_of(sample))))
+                where.append((li, sample))
+        summaries = {}
+        if units:
+            # one launch per (ploidy, temperature ladder) present (usually one): the library's fast samplers take one ploidy
+            # per launch (mixed ploidies would run on the general lanes-over-chains kernel), and a ladder is a launch setting
+            groups = {}
+            for i, u in enumerate(units):
+                groups.setdefault((u["ploidy"], u["temps"]), []).append(i)
+            # (several groups: their launches go out on separate HIP streams and fill each other's thin phases)
+            flight = PassesInFlight(min(4, len(groups))) if len(groups) > 1 else None
+            pending = []
+            for (K, temps), idx in groups.items():
+                model = DenovoMCMC(ploidy=K, n_alleles=[2], inbreeding=None, steps=steps, chains=chains, random_seed=seed,
+                                   temperatures=temps, **mcmc_kw)
+                batch = DenovoRaggedBatch(model, [units[i] for i in idx])
+                if flight is not None:
+                    flight.submit(lambda b=batch: b.run(burn, incongruence_threshold=incongruence_threshold))
+                else:
+                    batch.run(burn, incongruence_threshold=incongruence_threshold)
+                pending.append((idx, batch))
             if flight is not None:
-                flight.submit(lambda b=batch: b.run(burn, incongruence_threshold=incongruence_threshold))
-            else:
-                batch.run(burn, incongruence_threshold=incongruence_threshold)
-            pending.append((idx, batch))
-        if flight is not None:
-            flight.join()
-        for idx, batch in pending:
-            for i, res in zip(idx, batch.results()):
-                summaries[where[i]] = res
-    for li, locus in enumerate(loci):
-        M = len(locus.positions)
-        per, posteriors = {}, []
-        for sample in samples:
-            sr = encoded[(li, sample)]
-            K = int(ploidy_of(sample))
-            if M == 0:
-                res = dict(genotypes=np.zeros((1, K, 0), np.int8), probabilities=np.ones(1), spm=1.0, gpm=1.0,
-                           mode_genotype=np.zeros((K, 0), np.int8), mci=0)
-            else:
-                res = summaries[(li, sample)]
-            posteriors.append(PosteriorGenotypeDistribution(res["genotypes"], res["probabilities"]))
-            calls, depth = sr["calls"], sr["depth"]
-            mec = _mec(calls, res["mode_genotype"])
-            denom = int((calls >= 0).sum())
-            per[sample] = dict(genotype=res["mode_genotype"], gprob=float(res["gpm"]), sprob=float(res["spm"]), mec=mec,
-                               mecp=mec / denom if denom > 0 else np.nan, mci=int(res["mci"]), rcount=len(calls), rcalls=denom,
-                               dp=np.round(np.mean(depth)) if len(depth) else np.nan)
-        yield _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold)
+                flight.join()
+            for idx, batch in pending:
+                for i, res in zip(idx, batch.results()):
+                    summaries[where[i]] = res
+        for li, locus in enumerate(loci):
+            M = len(locus.positions)
+            per, posteriors = {}, []
+            for sample in samples:
+                sr = encoded[(li, sample)]
+                K = int(ploidy_of(sample))
+                if M == 0:
+                    res = dict(genotypes=np.zeros((1, K, 0), np.int8), probabilities=np.ones(1), spm=1.0, gpm=1.0,
+                               mode_genotype=np.zeros((K, 0), np.int8), mci=0)
+                else:
+                    res = summaries[(li, sample)]
+                posteriors.append(PosteriorGenotypeDistribution(res["genotypes"], res["probabilities"]))
+                calls, depth = sr["calls"], sr["depth"]
+                mec = _mec(calls, res["mode_genotype"])
+                denom = int((calls >= 0).sum())
+                per[sample] = dict(genotype=res["mode_genotype"], gprob=float(res["gpm"]), sprob=float(res["spm"]), mec=mec,
+                                   mecp=mec / denom if denom > 0 else np.nan, mci=int(res["mci"]), rcount=len(calls), rcalls=denom,
+                                   dp=np.round(np.mean(depth)) if len(depth) else np.nan, depth=depth)
+            yield _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold, report, ploidy_of,
+                                        {s_: encoded[(li, s_)] for s_ in samples})
 
 
 # ---------------------------------------------------------------------------------------------------------
 # mchap call (application/call.py:52-199): Gibbs sampler over the known haplotypes of an input VCF
 # ---------------------------------------------------------------------------------------------------------
 def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use_base_phred_scores=False,
-         prior_frequencies_tag=None, inbreeding=None, steps=2000, burn=1000, chains=2, seed=None,
-         incongruence_threshold=0.60, step_type="Gibbs", filter_input_haplotypes=None):
-    """`mchap call`: yields one VCF record line per record of the input VCF (no header).  Units ((record x sample)) are
-    grouped by shape and each group is one launch of the sampler kernel (CallingMCMC.fit_batch); as in the reference every
-    unit restarts from the same seed."""
+         prior_frequencies_tag=None, inbreeding=None, steps=2000, burn=1000, chains=2, seed=42,
+         incongruence_threshold=0.60, step_type="Gibbs", filter_input_haplotypes=None, read_kw=None, records_per_block=1024,
+         shard=None):
+    """`mchap call`: yields one VCF record line per record of the input VCF (no header).  The records are processed in
+    blocks; the (record x sample) units of a block are grouped by shape and each group is one launch of the sampler kernel
+    (CallingMCMC.fit_batch), cut into several when its traces and per-chain likelihood tables would not fit the free HBM.
+    As in the reference every unit restarts from the same seed."""
     from .calling_mcmc import CallingMCMC, GenotypeAllelesMultiTrace
-    from . import calling
+    from . import _lib, calling
 
-    samples = list(sample_bams)
-    bams = {s: read_alignments(p) for s, p in sample_bams.items()}
+    source = _source(sample_bams, base_error_rate, use_base_phred_scores, read_kw)
+    samples = source.samples
+    seed = resolve_seed(seed)
     _, records = read_vcf(vcf_path)
+    records = _shard(records, shard)
     report = tuple(report)
     ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
-    units = _exact_units(records, bams, samples, ploidy, report, base_error_rate, use_base_phred_scores, prior_frequencies_tag, inbreeding,
-                         _allele_filter(vcf_path, filter_input_haplotypes))
-    # haplotypes with zero prior frequency (and a masked reference) are left out of the sampler (call.py:72-84)
-    groups = {}
-    for ri, unit in enumerate(units):
-        locus = unit["locus"]
-        H, M = locus.haplotypes.shape
-        keep = np.ones(H, bool)
-        if locus.mask_reference_allele:
-            keep[0] = False
-        keep &= ~(np.nan_to_num(locus.frequencies, nan=1.0) == 0)
-        unit["keep"] = keep
-        if unit["invalid"] is None and keep.sum() == 0:
-            unit["invalid"] = "NOA"
-        if unit["invalid"] is not None or M == 0:
-            continue
-        for s in samples:
-            groups.setdefault((M, int(max(locus.n_alleles)), int(keep.sum()), int(ploidy_of(s))), []).append((ri, s))
-    results = {}
-    for (M, A, H, K), members in groups.items():
-        Rmax = max(max(len(units[ri]["reads"][s]["dists"]), 1) for ri, s in members)
-        U = len(members)
-        reads = np.full((U, Rmax, M, A), np.nan)
-        counts = np.zeros((U, Rmax), dtype=np.int64)
-        haps = np.zeros((U, H, M), dtype=np.int8)
-        has_prior = inbreeding_of(members[0][1]) is not None
-        Fs, frs = np.zeros(U), np.zeros((U, H))
-        for i, (ri, s) in enumerate(members):
-            sr, locus = units[ri]["reads"][s], units[ri]["locus"]
-            n = len(sr["dists"])
-            if n:
-                reads[i, :n] = sr["dists"]
-                counts[i, :n] = sr["counts"]
-            haps[i] = locus.haplotypes[units[ri]["keep"]]
-            if has_prior:
-                Fs[i] = inbreeding_of(s)
-                frs[i] = locus.frequencies[units[ri]["keep"]]
-        model = CallingMCMC(ploidy=K, haplotypes=haps[0], steps=steps, chains=chains, random_seed=seed, step_type=step_type)
-        traces = model.fit_batch(reads, counts, haplotypes=haps, prior=(Fs, frs) if has_prior else None,
-                                 stream_ids=np.zeros(U, dtype=np.uint64))
-        for key, tr in zip(members, traces):
-            results[key] = tr
-    for ri, unit in enumerate(units):
-        rec, locus = unit["rec"], unit["locus"]
-        H, M = locus.haplotypes.shape
-        res = {}
-        if unit["invalid"] is None:
+    allele_filter = _allele_filter(vcf_path, filter_input_haplotypes)
+    for block in _blocks(records, records_per_block):
+        units = _exact_units(block, source, samples, prior_frequencies_tag, allele_filter)
+        # haplotypes with zero prior frequency (and a masked reference) are left out of the sampler (call.py:72-84)
+        groups = {}
+        for ri, unit in enumerate(units):
+            locus = unit["locus"]
+            H, M = locus.haplotypes.shape
+            keep = np.ones(H, bool)
+            if locus.mask_reference_allele:
+                keep[0] = False
+            keep &= ~(np.nan_to_num(locus.frequencies, nan=1.0) == 0)
+            unit["keep"] = keep
+            if unit["invalid"] is None and keep.sum() == 0:
+                unit["invalid"] = "NOA"
+            if unit["invalid"] is not None or M == 0:
+                continue
             for s in samples:
-                K = int(ploidy_of(s))
-                if M == 0:
-                    trace = GenotypeAllelesMultiTrace(np.zeros((chains, steps, K), np.int8), np.full((chains, steps), np.nan), 1)
-                else:
-                    trace = results[(ri, s)]
-                trace = trace.burn(burn)
-                if not unit["keep"].all() and M > 0:
-                    trace = trace.relabel(np.flatnonzero(unit["keep"]))
-                post = trace.posterior()
-                alleles, gprob, sprob = post.mode(genotype_support=True)
-                f0, _, o0 = trace.posterior_frequencies()  # over the alleles the trace knows: pad to the record's
-                freqs, occur = np.zeros(H), np.zeros(H)
-                freqs[: len(f0)], occur[: len(o0)] = f0[:H], o0[:H]
-                r = dict(alleles=np.asarray(alleles), gprob=float(gprob), sprob=float(sprob), freqs=freqs, occur=occur,
-                         mci=int(trace.replicate_incongruence(threshold=incongruence_threshold)))
-                if "GP" in report:
-                    r["GP"] = post.as_array(H)
-                if "GL" in report:
-                    sr = unit["reads"][s]
-                    r["GL"] = calling.genotype_likelihoods(sr["dists"], K, locus.haplotypes, read_counts=sr["counts"]).astype(np.float64) / np.log(10)
-                res[(ri, s)] = r
-        flt, info, fmt, cols = _format_exact_record(dict(unit, invalid=unit["invalid"]), samples, _Forced(res), ri, ploidy_of, report, prior_frequencies_tag)
-        # MCI is a sampler statistic here: per sample in the FORMAT column, the number of incongruent samples in INFO
-        if unit["invalid"] is None:
-            n_inc = 0
-            for s in samples:
-                f = cols[s].split(":")
-                f[10] = str(res[(ri, s)]["mci"])
-                n_inc += int(res[(ri, s)]["mci"] > 0)
-                cols[s] = ":".join(f)
-            info = info.replace(";MCI=0;", ";MCI=%d;" % n_inc)
-        alts = unit["locus"].sequences[1:]  # (the input's, minus the alleles --filter-input-haplotypes removed)
-        alt = ",".join(alts) if alts else "."
-        yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
+                groups.setdefault((M, int(max(locus.n_alleles)), int(keep.sum()), int(ploidy_of(s))), []).append((ri, s))
+        results = {}
+        for (M, A, H, K), all_members in groups.items():
+            Rmax = max(max(len(units[ri]["reads"][s]["dists"]), 1) for ri, s in all_members)
+            # device bytes per unit: reads, traces, and the chains' tables of remembered likelihoods (the workspace)
+            ws1 = int(_lib.lib().mchap_call_mcmc_workspace_bytes_for(1, Rmax, H, K, int(steps), int(chains)))
+            per_unit = Rmax * M * A * 8 + Rmax * 8 + chains * steps * (K + 1) * 8 + ws1 + 4096
+            for members in _blocks(all_members, device_unit_budget(per_unit)):
+                U = len(members)
+                reads = np.full((U, Rmax, M, A), np.nan)
+                counts = np.zeros((U, Rmax), dtype=np.int64)
+                haps = np.zeros((U, H, M), dtype=np.int8)
+                has_prior = inbreeding_of(members[0][1]) is not None
+                Fs, frs = np.zeros(U), np.zeros((U, H))
+                for i, (ri, s) in enumerate(members):
+                    sr, locus = units[ri]["reads"][s], units[ri]["locus"]
+                    n = len(sr["dists"])
+                    if n:
+                        reads[i, :n] = sr["dists"]
+                        counts[i, :n] = sr["counts"]
+                    haps[i] = locus.haplotypes[units[ri]["keep"]]
+                    if has_prior:
+                        Fs[i] = inbreeding_of(s)
+                        frs[i] = locus.frequencies[units[ri]["keep"]]
+                model = CallingMCMC(ploidy=K, haplotypes=haps[0], steps=steps, chains=chains, random_seed=seed, step_type=step_type)
+                traces = model.fit_batch(reads, counts, haplotypes=haps, prior=(Fs, frs) if has_prior else None,
+                                         stream_ids=np.zeros(U, dtype=np.uint64))
+                for key, tr in zip(members, traces):
+                    results[key] = tr
+        for ri, unit in enumerate(units):
+            rec, locus = unit["rec"], unit["locus"]
+            H, M = locus.haplotypes.shape
+            res = {}
+            if unit["invalid"] is None:
+                for s in samples:
+                    K = int(ploidy_of(s))
+                    if M == 0:
+                        trace = GenotypeAllelesMultiTrace(np.zeros((chains, steps, K), np.int8), np.full((chains, steps), np.nan), 1)
+                    else:
+                        trace = results[(ri, s)]
+                    trace = trace.burn(burn)
+                    if not unit["keep"].all() and M > 0:
+                        trace = trace.relabel(np.flatnonzero(unit["keep"]))
+                    post = trace.posterior()
+                    alleles, gprob, sprob = post.mode(genotype_support=True)
+                    f0, _, o0 = trace.posterior_frequencies()  # over the alleles the trace knows: pad to the record's
+                    freqs, occur = np.zeros(H), np.zeros(H)
+                    freqs[: len(f0)], occur[: len(o0)] = f0[:H], o0[:H]
+                    r = dict(alleles=np.asarray(alleles), gprob=float(gprob), sprob=float(sprob), freqs=freqs, occur=occur,
+                             mci=int(trace.replicate_incongruence(threshold=incongruence_threshold)))
+                    if "GP" in report or "FORMAT/GP" in report:
+                        r["GP"] = post.as_array(H)
+                    if "GL" in report or "FORMAT/GL" in report:
+                        sr = unit["reads"][s]
+                        r["GL"] = calling.genotype_likelihoods(sr["dists"], K, locus.haplotypes, read_counts=sr["counts"]).astype(np.float64) / np.log(10)
+                    res[(ri, s)] = r
+            flt, info, fmt, cols = _format_exact_record(dict(unit, invalid=unit["invalid"]), samples, _Forced(res), ri, ploidy_of, report, prior_frequencies_tag)
+            # MCI is a sampler statistic here: per sample in the FORMAT column, the number of incongruent samples in INFO
+            if unit["invalid"] is None:
+                n_inc = 0
+                for s in samples:
+                    f = cols[s].split(":")
+                    f[10] = str(res[(ri, s)]["mci"])
+                    n_inc += int(res[(ri, s)]["mci"] > 0)
+                    cols[s] = ":".join(f)
+                info = info.replace(";MCI=0;", ";MCI=%d;" % n_inc)
+            alts = unit["locus"].sequences[1:]  # (the input's, minus the alleles --filter-input-haplotypes removed)
+            alt = ",".join(alts) if alts else "."
+            yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
 
 
 class _Forced(dict):

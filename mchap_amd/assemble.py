@@ -80,7 +80,7 @@ class DenovoMCMC(Assembler):
     temperatures: tuple = (1.0,)
     random_seed: int = None
     llk_cache_threshold: int = 100
-    kernel: int = 0  # not a reference field: 0 default, 1 wavefront-per-chain, 2 lanes-over-chains (same results)
+    kernel: int = 0  # not a reference field: 0 default, 2 lanes over chains, 3 speculative, 5 phased (same results)
 
     # ---- configuration shared by a batch ----
     def _cfg(self, max_pos):
@@ -111,6 +111,11 @@ class DenovoMCMC(Assembler):
         # reference assemble/mcmc.py:306-312: a negative threshold disables the likelihood cache
         cfg.llk_cache = 0 if (self.llk_cache_threshold is not None and self.llk_cache_threshold < 0) else 1
         cfg.kernel = int(self.kernel) if self.kernel else int(os.environ.get("MCHAP_HIP_KERNEL", "0"))
+        # measurement / test knobs (results-neutral): MCHAP_HIP_* variables, read here -- the library reads no environment
+        tuning = _lib.tuning_from_env()
+        if tuning is not None:
+            cfg._tuning = tuning
+            cfg.tuning = C.pointer(tuning)
         return cfg
 
     def fit(self, reads, read_counts=None, initial=None):
@@ -204,6 +209,7 @@ class DenovoMCMC(Assembler):
         fixed = np.zeros(f_off, dtype=np.int8)
         status = np.zeros(n_units, dtype=np.int32)
         L = _lib.lib()
+        self.last_sampler = _lib.sampler_name(cfg, units)  # (not a reference field: which kernel(s) the batch ran on)
         rc = L.mchap_denovo_fit_batch(
             C.byref(cfg), n_units, _lib.ptr(units), _lib.ptr(reads_flat), C.c_int64(reads_flat.size),
             _lib.ptr(counts_flat), C.c_int64(0 if counts_flat is None else counts_flat.size),

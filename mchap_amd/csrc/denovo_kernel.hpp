@@ -57,6 +57,11 @@ struct DenovoParams {
   // optional per-chain likelihood cache in HBM/L2: [units*chains][cache_slots] of {tag, llk}; 0 slots = off
   uint64_t *cache;
   int cache_slots;  // power of two
+  // genotypes wider than 63 bits are tagged by a hash; their full words [units*chains][cache_slots][cache_key_words]
+  // are kept beside the entries and compared on every tag match, so a hit is always the genotype itself
+  // (cache_key_words = the batch's largest ploidy; 0 when every unit's genotypes fit the tag)
+  uint64_t *cache_keys;
+  int cache_key_words;
   // compact input (kernels 2 / 3 only): int8 allele calls [R][M0] per unit instead of the float64 tensor, optional
   // int16 base qualities, and the probability of a correct call per quality (qual_prob[0] when there are none)
   const int8_t *calls;
@@ -296,7 +301,7 @@ __device__ __forceinline__ double eval_llk(const Chain &c, const uint64_t *hw, c
 
 template <int RPL>
 __device__ __forceinline__ double eval_llk_cached(const Chain &c, const uint64_t *hw, const double (&cnt)[RPL]) {
-  if (!c.cache) return eval_llk<RPL>(c, hw, cnt);
+  if (!c.cache || c.key_bits * c.K > 63) return eval_llk<RPL>(c, hw, cnt);  // (wide genotypes: not cached by this kernel)
   const uint64_t tag = genotype_tag(c, hw);
   const uint64_t slot = (c.key_bits * c.K <= 63 ? mix64(tag) : tag >> 1) & c.cache_mask;
   ulonglong2 *e = reinterpret_cast<ulonglong2 *>(c.cache) + slot;

@@ -803,6 +803,7 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
     gp[GP_CW] = (uint64_t)(uintptr_t)(P.cntw + (size_t)u * rpad);
     gp[GP_CT] = (uint64_t)(uintptr_t)(P.codes + (size_t)u * P.max_ma * WAVE * P.cstride);
     gp[GP_CACHE] = cache_on ? (uint64_t)(uintptr_t)(reinterpret_cast<ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots) : 0ull;
+    gp[GP_CKEYS] = (cache_on && D.cache_keys) ? (uint64_t)(uintptr_t)(D.cache_keys + (size_t)q * (size_t)D.cache_slots * D.cache_key_words) : 0ull;
     gp[GP_TRACE] = (uint64_t)(uintptr_t)(D.trace + U.trace_off + (size_t)chain * D.steps * KT);
     gp[GP_LLK] = (uint64_t)(uintptr_t)(D.llks + U.llk_off + (size_t)chain * D.steps);
     LL.nreads[ci] = (uint16_t)(c.alive ? U.n_reads : 0);
@@ -950,6 +951,7 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
     lane_context<KT>(LL, cs, mmax, S);
     S.cache_on = cache_on;
     S.cache_mask = cache_on ? (uint32_t)(D.cache_slots / 8) - 1u : 0u;
+    S.key_words = D.cache_key_words;
     S.reuse_on = !(P.flags & 8);
     S.crow = WAVE * P.cstride;
     cu.Mh = __builtin_amdgcn_readlane(c.Mh, owner);

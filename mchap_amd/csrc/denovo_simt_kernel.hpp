@@ -67,6 +67,7 @@ struct SimtParams {
   int pipe_mode;              // PIPE_RESUME | PIPE_EXPORT | PIPE_FILLONLY
   int pipe_parts;             // wavefronts a short list of chains may spread the completion of one chain's tables over
   int bp_cache;               // speculative sampler with one chain per wave: base-product cache carved after its LDS
+  int fill_lt, fill_kw;       // denovo_fill_kernel: lanes per tile of the read table, words kept per distinct request
 };
 constexpr int PIPE_RESUME = 1;  // start from the chains' PipeState records
 constexpr int PIPE_EXPORT = 2;  // at the end: complete the interval memo of the current genotype, write the records
@@ -76,6 +77,7 @@ constexpr int PIPE_EXPORT = 2;  // at the end: complete the interval memo of the
 // launch follows in which pipe_parts_eff() wavefronts per chain each complete every pipe_parts_eff()-th unknown entry
 // (no steps, no records; the chain's likelihood cache is not used: the wavefronts would race on it).
 constexpr int PIPE_FILLONLY = 4;
+constexpr int PIPE_NOFILL = 8;  // PIPE_EXPORT without the table completion: denovo_fill_kernel (one lane per request) follows
 constexpr int PIPE_FILL_SLOTS = 1024;  // wavefront slots such a launch may occupy (one per SIMD: beyond that the chip is busy anyway)
 __host__ __device__ inline int pipe_parts_eff(int n_list, int parts) {
   if (parts <= 1 || n_list <= 0) return 1;
@@ -471,6 +473,8 @@ struct Lane {
   const double *rt;      // unit's transposed reads [ma][rpad]
   const double *cw;      // unit's counts [rpad]
   ulonglong2 *cache;
+  uint64_t *ckeys;  // words of the cached genotypes when they are wider than the tag (else nullptr)
+  int key_words;
   uint32_t cache_mask;
   Rng rng;
 };
@@ -673,7 +677,8 @@ __device__ __forceinline__ uint64_t lane_genotype_tag(const SimtLds &S, const La
 }
 
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
-static __device__ unsigned long long g_stats[24];
+constexpr int N_STATS = 48;  // [0..23] event counters, [24..35] phase timers of the steps, [36..47] ... of the table completion
+static __device__ unsigned long long g_stats[N_STATS];
 #endif
 #ifdef MCHAP_STATS
 #define STAT_ADD(i, pred)                                                         \
@@ -704,9 +709,13 @@ __device__ inline double lane_eval_cached(bool need, const SimtLds &S, const Lan
   bool miss = need;
   uint64_t tag = 0;
   ulonglong2 *set = nullptr;
-  if (need && c.cache) {
+  // genotypes wider than 63 bits are tagged by a hash: a tag match is verified against the genotype's words kept beside
+  // the entry (c.ckeys), hits do not move entries and a miss replaces the way its tag picks (or the entry it collided with)
+  const bool wide = c.key_bits * c.K > 63;
+  int wway = 3;
+  if (need && c.cache && !wide) {
     tag = lane_genotype_tag(S, c, lane);
-    const uint64_t si = (c.key_bits * c.K <= 63 ? mix64(tag) : tag >> 1) & c.cache_mask;
+    const uint64_t si = mix64(tag) & c.cache_mask;
     set = c.cache + 4 * si;
     const ulonglong2 e0 = set[0], e1 = set[1], e2 = set[2], e3 = set[3];
     if (e0.x == tag) {
@@ -728,6 +737,28 @@ __device__ inline double lane_eval_cached(bool need, const SimtLds &S, const Lan
       set[2] = e3;
       set[3] = e2;
     }
+  } else if (need && c.cache && c.ckeys) {
+    tag = lane_genotype_tag(S, c, lane);
+    const uint64_t si = (tag >> 1) & c.cache_mask;
+    set = c.cache + 4 * si;
+    wway = (int)((tag >> 40) & 3u);
+    int hit = -1;
+    for (int w = 3; w >= 0; w--) {
+      const ulonglong2 e = set[w];
+      if (e.x == tag) hit = w;
+      if (e.x == 0ull) wway = w;
+    }
+    if (hit >= 0) {
+      const uint64_t *kw = c.ckeys + (4 * si + hit) * c.key_words;
+      bool same = true;
+      for (int h = 0; h < c.K; h++) same = same && (kw[h] == L_(S.pw, h));
+      if (same) {
+        val = __longlong_as_double((long long)set[hit].y);
+        miss = false;
+      } else {
+        wway = hit;
+      }
+    }
   }
   STAT_ADD(0, need);
   STAT_ADD(1, miss);
@@ -735,7 +766,13 @@ __device__ inline double lane_eval_cached(bool need, const SimtLds &S, const Lan
   const double v = coop_eval(miss, S, c, rpad, lane);
   if (miss) {
     val = v;
-    if (set) set[3] = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(v));
+    if (set) {
+      if (wide) {
+        uint64_t *kw = c.ckeys + ((size_t)(set - c.cache) + wway) * c.key_words;
+        for (int h = 0; h < c.K; h++) kw[h] = L_(S.pw, h);
+      }
+      set[wide ? wway : 3] = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(v));
+    }
   }
   return val;
 }
@@ -1002,8 +1039,11 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
   c.cw = P.cntw + (size_t)u * rpad;
   c.cache = nullptr;
   c.cache_mask = 0;
+  c.ckeys = nullptr;
+  c.key_words = D.cache_key_words;
   if (D.cache_slots > 0) {
     c.cache = reinterpret_cast<ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots;
+    if (D.cache_keys) c.ckeys = D.cache_keys + (size_t)q * (size_t)D.cache_slots * D.cache_key_words;
     c.cache_mask = (uint32_t)(D.cache_slots / 4) - 1u;  // sets of 4 ways
   }
   const int K = KT ? KT : c.K;

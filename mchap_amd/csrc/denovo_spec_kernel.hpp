@@ -98,7 +98,7 @@ struct TabPtr<true> {
   static __device__ __forceinline__ CT ld(u8 p) { return *reinterpret_cast<LDSP(const CT)>(p); }
 };
 
-enum { GP_RT = 0, GP_CW, GP_CT, GP_CACHE, GP_TRACE, GP_LLK, GP_N };
+enum { GP_RT = 0, GP_CW, GP_CT, GP_CACHE, GP_CKEYS, GP_TRACE, GP_LLK, GP_N };
 enum { GV_INB = 0, GV_MLO, GV_MHI, GV_N };
 struct SpecLds {
   LDSP(uint64_t) pw;      // [K][64] request words of missing lanes (lane strided)
@@ -132,6 +132,7 @@ struct SpecLds {
   LDSP(uint64_t) bpt;     // [K + 1] ... these base words (bpt[K] != 0: valid), kept from one evaluation call to the next
   LDSP(uint64_t) tbuf;    // [NG][SPEC_TB][K + 1] trace records (K sorted words + llk) waiting to be written as a line
   uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
+  int key_words;          // words per entry of the wide-genotype key table (DenovoParams::cache_key_words)
   bool cache_on;
   bool reuse_on;          // haplotype products of the chain's current genotype are reused by its proposals
   LDSP(const uint8_t) lds_ct;  // the unit's coded table / read weights copied into LDS (settling kernel), else null
@@ -913,6 +914,10 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
   uint64_t tag = 0;
   ulonglong2 *slot = nullptr;
   GSUB_T0();
+  // Genotypes wider than 63 bits: the tag is a hash, so a tag match is verified against the genotype's words kept
+  // beside the entry (SimtParams::d.cache_keys) -- a hit is always the genotype itself, never a colliding one.
+  const bool wide = C_KEYBITS(c) * KT > 63;
+  uint64_t *kslot = nullptr;
   if (need && S.cache_on) {
     // 8-way sets (one 128-byte line).  The lanes of a group probe and fill the chain's table concurrently, so the
     // policy must not depend on read-modify-write sequences: hits never move entries, a miss goes to the first
@@ -927,22 +932,34 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
     hsh ^= hsh >> 15;
     hsh *= 0x846CA68Bu;
     hsh ^= hsh >> 16;
-    ulonglong2 *set = reinterpret_cast<ulonglong2 *>((uintptr_t)S.gptr[(lane / G) * GP_N + GP_CACHE]) + 8 * (size_t)((hsh >> 12) & S.cache_mask);
+    const size_t set_i = (size_t)((hsh >> 12) & S.cache_mask);
+    ulonglong2 *set = reinterpret_cast<ulonglong2 *>((uintptr_t)S.gptr[(lane / G) * GP_N + GP_CACHE]) + 8 * set_i;
     int way = (int)((hsh >> 24) & 7u);
-    bool empty_seen = false;
+    int hit_way = -1;
 #pragma unroll
     for (int w = 7; w >= 0; w--) {
       const ulonglong2 e = set[w];
       if (e.x == tag) {
         val = __longlong_as_double((long long)e.y);
         miss = false;
+        hit_way = w;
       }
-      if (e.x == 0ull) {
-        way = w;  // lowest empty way wins
-        empty_seen = true;
-      }
+      if (e.x == 0ull) way = w;  // lowest empty way wins
     }
-    (void)empty_seen;
+    if (wide) {
+      uint64_t *kset = reinterpret_cast<uint64_t *>((uintptr_t)S.gptr[(lane / G) * GP_N + GP_CKEYS]) + 8 * set_i * S.key_words;
+      if (hit_way >= 0) {
+        const uint64_t *kw = kset + (size_t)hit_way * S.key_words;
+        bool same = true;
+#pragma unroll
+        for (int h = 0; h < KT; h++) same = same & (kw[h] == pw.w[h]);
+        if (!same) {  // another genotype with this tag: evaluate, and take over its entry (one entry per tag and set)
+          miss = true;
+          way = hit_way;
+        }
+      }
+      kslot = kset + (size_t)way * S.key_words;
+    }
     slot = set + way;
   }
   STAT_ADD(0, need);
@@ -963,9 +980,28 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
     }
     lds_sync();
     const double v = spec_coop_all<KT, G, LT>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw, S.bpc, S.bpt);
-    if (miss) {
-      val = v;
-      if (slot) *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
+    if (miss) val = v;
+    bool writer = miss && slot != nullptr;
+    if (wave_any(writer && wide)) {
+      // wide entries are two stores (words, then tag + value): of the lanes that picked the same way only the first
+      // writes, so that an entry's words always belong to its tag
+      unsigned long long pend = __ballot(writer);
+      bool mine = false;
+      while (pend) {
+        const int l = __ffsll((long long)pend) - 1;
+        const unsigned long long sl = __shfl((unsigned long long)(uintptr_t)slot, l, WAVE);
+        const unsigned long long same = __ballot(writer && (unsigned long long)(uintptr_t)slot == sl);
+        if (lane == l) mine = true;
+        pend &= ~same;
+      }
+      writer = mine;
+    }
+    if (writer) {
+      if (wide) {
+#pragma unroll
+        for (int h = 0; h < KT; h++) kslot[h] = pw.w[h];
+      }
+      *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
     }
     lds_sync();
     GSUB(c, 10);
@@ -1761,12 +1797,14 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   S.crow = WAVE * P.cstride;
   S.cache_on = D.cache_slots > 0 && !fillonly;
   S.cache_mask = S.cache_on ? (uint32_t)(D.cache_slots / 8) - 1u : 0u;  // sets of 8 ways
+  S.key_words = D.cache_key_words;
   if (gl == 0) {
     LDSP(uint64_t) gp = S.gptr + gi * GP_N;
     gp[GP_RT] = (uint64_t)(uintptr_t)(P.rt + (size_t)u * P.max_ma * rpad);
     gp[GP_CW] = (uint64_t)(uintptr_t)(P.cntw + (size_t)u * rpad);
     gp[GP_CT] = (uint64_t)(uintptr_t)(P.codes + (size_t)u * P.max_ma * WAVE * P.cstride);
     gp[GP_CACHE] = S.cache_on ? (uint64_t)(uintptr_t)(reinterpret_cast<ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots) : 0ull;
+    gp[GP_CKEYS] = (S.cache_on && D.cache_keys) ? (uint64_t)(uintptr_t)(D.cache_keys + (size_t)q * (size_t)D.cache_slots * D.cache_key_words) : 0ull;
     gp[GP_TRACE] = (uint64_t)(uintptr_t)(D.trace + U.trace_off + (size_t)chain * D.steps * KT);
     gp[GP_LLK] = (uint64_t)(uintptr_t)(D.llks + U.llk_off + (size_t)chain * D.steps);
   }
@@ -2052,18 +2090,24 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   }
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
   if (threadIdx.x == 0)
-    for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_stats[3 + i_], c.ph[i_]);
+    for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_stats[24 + i_], c.ph[i_]);
+  for (int i_ = 0; i_ < 12; i_++) c.ph[i_] = 0;
+  c.pt0 = __builtin_amdgcn_s_memtime();
 #endif
   if constexpr (PIPE) {
     if (P.pipe_mode & (PIPE_EXPORT | PIPE_FILLONLY)) {
       // the interval memo of the current genotype, completed (both step types) -- unless a PIPE_FILLONLY launch will
       // do that with several wavefronts per chain -- then the hand-over record
-      if (fillonly || parts_eff <= 1) {
+      if ((fillonly || parts_eff <= 1) && !(P.flags & 32) && !(P.pipe_mode & PIPE_NOFILL)) {
 #pragma unroll 1
         for (int kind = 3; kind < 5; kind++)
           spec_structural<KT, G, true>(c, S, D, kind, D.temps[0], break_dist, n_break_dist, mmax, rpad, lane, gi, gl);
       }
       lds_sync();
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+      if (threadIdx.x == 0)
+        for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_stats[36 + i_], c.ph[i_]);
+#endif
       if (fillonly) {
         if (listed && c.alive) {  // this group's share of the entries (known ones are rewritten with their value)
           double *pm = P.pipe_memo + (size_t)q * S.memo_stride;

@@ -33,7 +33,7 @@ extern "C" __attribute__((visibility("hidden"))) int LANE_CAT(mchap_lane_launch_
 
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
 extern "C" __attribute__((visibility("hidden"))) int LANE_CAT(mchap_lane_stats_, LANE_K)(unsigned long long *out, int reset) {
-  unsigned long long z[24] = {0};
+  unsigned long long z[mchap::N_STATS] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_stats), sizeof(z)) != hipSuccess) return 1;
   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(mchap::g_stats), z, sizeof(z)) != hipSuccess) return 1;
   return 0;

@@ -14,112 +14,69 @@
 #include "denovo_kernel.hpp"
 #include "denovo_simt_kernel.hpp"
 #include "denovo_spec_kernel.hpp"
+#include "denovo_fill_kernel.hpp"
+#ifdef MCHAP_TEST_KERNELS
 #include "denovo_lane_kernel.hpp"
+#endif
 #include "exact_kernel.hpp"
 #include "call_mcmc_kernel.hpp"
 #include "posterior_kernel.hpp"
 
-// entry points of the speculative sampler's object files (spec_inst.hip), internal to the library
-extern "C" int mchap_spec_init_2_16(const double *, const double *);
-extern "C" int mchap_spec_launch_2_16(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_2_32(const double *, const double *);
-extern "C" int mchap_spec_launch_2_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_2_64(const double *, const double *);
-extern "C" int mchap_spec_launch_2_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_3_16(const double *, const double *);
-extern "C" int mchap_spec_launch_3_16(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_3_32(const double *, const double *);
-extern "C" int mchap_spec_launch_3_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_3_64(const double *, const double *);
-extern "C" int mchap_spec_launch_3_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_5_32(const double *, const double *);
-extern "C" int mchap_spec_launch_5_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_5_64(const double *, const double *);
-extern "C" int mchap_spec_launch_5_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_7_64(const double *, const double *);
-extern "C" int mchap_spec_launch_7_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_4_16(const double *, const double *);
-extern "C" int mchap_spec_launch_4_16(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_4_32(const double *, const double *);
-extern "C" int mchap_spec_launch_4_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_4_64(const double *, const double *);
-extern "C" int mchap_spec_launch_4_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_6_32(const double *, const double *);
-extern "C" int mchap_spec_launch_6_32(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_6_64(const double *, const double *);
-extern "C" int mchap_spec_launch_6_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_spec_init_8_64(const double *, const double *);
-extern "C" int mchap_spec_launch_8_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+// ---- sampler objects ------------------------------------------------------------------------------------------
+// Every instantiation of a sampler kernel is its own object file (spec_inst.hip, simt_inst.hip, ...: they compile in
+// parallel) with two internal entry points: init (its copy of the constant log tables) and launch.
+#define SPEC_LIST(X) X(2, 16) X(2, 32) X(2, 64) X(3, 16) X(3, 32) X(3, 64) X(4, 16) X(4, 32) X(4, 64) X(5, 32) X(5, 64) X(6, 32) X(6, 64) X(7, 64) X(8, 64)
+// phased form: one chain per wavefront at every ploidy (the narrower groups were measured slower; they
+// stay in the test library so that the parity suite keeps covering hand-over with several chains per wave)
+#ifdef MCHAP_TEST_KERNELS
+#define SPECP_LIST(X) X(2, 64) X(3, 64) X(4, 64) X(5, 64) X(6, 64) X(7, 64) X(8, 64) X(2, 16) X(3, 16) X(4, 16) X(4, 32) X(5, 32) X(6, 32)
+#else
+#define SPECP_LIST(X) X(2, 64) X(3, 64) X(4, 64) X(5, 64) X(6, 64) X(7, 64) X(8, 64)
+#endif
+#define SIMT_LIST(X) X(0) X(2) X(4) X(6) X(8)
+#define V1_LIST(X) X(1) X(2) X(4) X(8) X(16)
+#define LANE_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 
-#define MCHAP_LANE_DECL(k)                                              \
-  extern "C" int mchap_lane_init_##k(const double *, const double *); \
-  extern "C" int mchap_lane_launch_##k(const mchap::SimtParams *, int, int, unsigned, size_t, hipStream_t);
-MCHAP_LANE_DECL(1)
-MCHAP_LANE_DECL(2)
-MCHAP_LANE_DECL(3)
-MCHAP_LANE_DECL(4)
-MCHAP_LANE_DECL(5)
-MCHAP_LANE_DECL(6)
-MCHAP_LANE_DECL(7)
-MCHAP_LANE_DECL(8)
-
-#define MCHAP_SPECP_DECL(k, g)                                                   \
+typedef int (*init_fn)(const double *, const double *);
+typedef int (*simt_launch_fn)(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+#define DECL_SPEC(k, g)                                                    \
+  extern "C" int mchap_spec_init_##k##_##g(const double *, const double *); \
+  extern "C" int mchap_spec_launch_##k##_##g(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+#define DECL_SPECP(k, g)                                                    \
   extern "C" int mchap_specp_init_##k##_##g(const double *, const double *); \
   extern "C" int mchap_specp_launch_##k##_##g(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-MCHAP_SPECP_DECL(2, 16)
-MCHAP_SPECP_DECL(2, 64)
-MCHAP_SPECP_DECL(3, 64)
-MCHAP_SPECP_DECL(3, 16)
-MCHAP_SPECP_DECL(4, 16)
-MCHAP_SPECP_DECL(4, 32)
-MCHAP_SPECP_DECL(4, 64)
-MCHAP_SPECP_DECL(5, 32)
-MCHAP_SPECP_DECL(5, 64)
-MCHAP_SPECP_DECL(6, 32)
-MCHAP_SPECP_DECL(6, 64)
-MCHAP_SPECP_DECL(7, 64)
-MCHAP_SPECP_DECL(8, 64)
+#define DECL_SIMT(k)                                                \
+  extern "C" int mchap_simt_init_##k(const double *, const double *); \
+  extern "C" int mchap_simt_launch_##k(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+SPEC_LIST(DECL_SPEC)
+SPECP_LIST(DECL_SPECP)
+SIMT_LIST(DECL_SIMT)
 extern "C" int mchap_coast_launch(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-
-extern "C" int mchap_simt_init_0(const double *, const double *);
-extern "C" int mchap_simt_launch_0(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_simt_init_2(const double *, const double *);
-extern "C" int mchap_simt_launch_2(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_simt_init_4(const double *, const double *);
-extern "C" int mchap_simt_launch_4(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_simt_init_6(const double *, const double *);
-extern "C" int mchap_simt_launch_6(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_simt_init_8(const double *, const double *);
-extern "C" int mchap_simt_launch_8(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_v1_init_1(const double *, const double *);
-extern "C" int mchap_v1_launch_1(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
-extern "C" int mchap_v1_init_2(const double *, const double *);
-extern "C" int mchap_v1_launch_2(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
-extern "C" int mchap_v1_init_4(const double *, const double *);
-extern "C" int mchap_v1_launch_4(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
-extern "C" int mchap_v1_init_8(const double *, const double *);
-extern "C" int mchap_v1_launch_8(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
-extern "C" int mchap_v1_init_16(const double *, const double *);
-extern "C" int mchap_v1_launch_16(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
-
+#define FILL_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#define DECL_FILL(k)                                                \
+  extern "C" int mchap_fill_init_##k(const double *, const double *); \
+  extern "C" int mchap_fill_launch_##k(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+FILL_LIST(DECL_FILL)
+#ifdef MCHAP_TEST_KERNELS
+#define DECL_V1(r)                                                \
+  extern "C" int mchap_v1_init_##r(const double *, const double *); \
+  extern "C" int mchap_v1_launch_##r(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
+#define DECL_LANE(k)                                                \
+  extern "C" int mchap_lane_init_##k(const double *, const double *); \
+  extern "C" int mchap_lane_launch_##k(const mchap::SimtParams *, int, int, unsigned, size_t, hipStream_t);
+V1_LIST(DECL_V1)
+LANE_LIST(DECL_LANE)
+#endif
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
-extern "C" int mchap_spec_stats_2_16(unsigned long long *, int);
-extern "C" int mchap_spec_stats_2_32(unsigned long long *, int);
-extern "C" int mchap_spec_stats_2_64(unsigned long long *, int);
-extern "C" int mchap_spec_stats_3_16(unsigned long long *, int);
-extern "C" int mchap_spec_stats_3_32(unsigned long long *, int);
-extern "C" int mchap_spec_stats_3_64(unsigned long long *, int);
-extern "C" int mchap_spec_stats_5_32(unsigned long long *, int);
-extern "C" int mchap_spec_stats_5_64(unsigned long long *, int);
-extern "C" int mchap_spec_stats_7_64(unsigned long long *, int);
-extern "C" int mchap_spec_stats_4_16(unsigned long long *, int);
-extern "C" int mchap_spec_stats_4_32(unsigned long long *, int);
-extern "C" int mchap_spec_stats_4_64(unsigned long long *, int);
-extern "C" int mchap_spec_stats_6_32(unsigned long long *, int);
-extern "C" int mchap_spec_stats_6_64(unsigned long long *, int);
-extern "C" int mchap_spec_stats_8_64(unsigned long long *, int);
+#define DECL_SPEC_STATS(k, g) extern "C" int mchap_spec_stats_##k##_##g(unsigned long long *, int);
+#define DECL_SPECP_STATS(k, g) extern "C" int mchap_specp_stats_##k##_##g(unsigned long long *, int);
+SPEC_LIST(DECL_SPEC_STATS)
+SPECP_LIST(DECL_SPECP_STATS)
+#ifdef MCHAP_TEST_KERNELS
 extern "C" int mchap_lane_stats_4(unsigned long long *, int);
 #endif
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -141,39 +98,40 @@ int fail(int code, const char *fmt, ...) {
 std::mutex g_init_mu;
 bool g_init_done[64] = {false};
 
-// measurement hooks
-bool g_profiling = false;
-hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-bool g_ev_valid = false;
-char g_sampler_name[96] = "";
-
+// A caller-owned pair of events (mchap_timer_create): the only profiling state there is, and it travels with the call.
+struct Timer {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool recorded = false;
+};
 struct SamplerTimer {
+  Timer *t;
   hipStream_t stream;
-  explicit SamplerTimer(hipStream_t s, const char *name) : stream(s) {
-    snprintf(g_sampler_name, sizeof(g_sampler_name), "%s", name);
-    if (!g_profiling) return;
-    if (!g_ev0) {
-      (void)hipEventCreate(&g_ev0);
-      (void)hipEventCreate(&g_ev1);
-    }
-    (void)hipEventRecord(g_ev0, stream);
+  SamplerTimer(void *timer, hipStream_t s) : t(reinterpret_cast<Timer *>(timer)), stream(s) {
+    if (t) (void)hipEventRecord(t->e0, stream);
   }
   ~SamplerTimer() {
-    if (!g_profiling) return;
-    (void)hipEventRecord(g_ev1, stream);
-    g_ev_valid = true;
+    if (!t) return;
+    (void)hipEventRecord(t->e1, stream);
+    t->recorded = true;
   }
 };
 
-
-
-// the speculative sampler's instantiations live in their own object files (spec_inst.hip)
 struct SpecInst {
   int K, G;
-  int (*init)(const double *, const double *);
-  int (*launch)(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+  init_fn init;
+  simt_launch_fn launch;
 };
-const SpecInst *spec_insts(int *n);
+#define ROW_SPEC(k, g) {k, g, mchap_spec_init_##k##_##g, mchap_spec_launch_##k##_##g},
+#define ROW_SPECP(k, g) {k, g, mchap_specp_init_##k##_##g, mchap_specp_launch_##k##_##g},
+const SpecInst SPEC_INSTS[] = {SPEC_LIST(ROW_SPEC)};
+const SpecInst SPECP_INSTS[] = {SPECP_LIST(ROW_SPECP)};
+const SpecInst *find_inst(const SpecInst *tab, size_t n, int K, int G) {
+  for (size_t i = 0; i < n; i++)
+    if (tab[i].K == K && tab[i].G == G) return &tab[i];
+  return nullptr;
+}
+#define FIND_SPEC(K, G) find_inst(SPEC_INSTS, sizeof(SPEC_INSTS) / sizeof(SPEC_INSTS[0]), K, G)
+#define FIND_SPECP(K, G) find_inst(SPECP_INSTS, sizeof(SPECP_INSTS) / sizeof(SPECP_INSTS[0]), K, G)
 
 int ensure_init() {
   int dev = 0;
@@ -190,22 +148,21 @@ int ensure_init() {
   }
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln), ln, sizeof(ln)));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln_inv), ln_inv, sizeof(ln_inv)));
+  for (const SpecInst &i : SPEC_INSTS)
+    if (i.init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the speculative sampler <%d, %d>", i.K, i.G);
+  for (const SpecInst &i : SPECP_INSTS)
+    if (i.init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the phased sampler <%d, %d>", i.K, i.G);
   {
-    int n = 0;
-    const SpecInst *insts = spec_insts(&n);  // every object file has its own copy of the tables
-    for (int i = 0; i < n; i++)
-      if (insts[i].init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the speculative sampler <%d, %d>", insts[i].K, insts[i].G);
-  }
-  {
-    int (*inits[])(const double *, const double *) = {mchap_simt_init_0, mchap_simt_init_2, mchap_simt_init_4, mchap_simt_init_6,
-                                                      mchap_simt_init_8, mchap_v1_init_1,   mchap_v1_init_2,   mchap_v1_init_4,
-                                                      mchap_v1_init_8,   mchap_v1_init_16,  mchap_lane_init_1, mchap_lane_init_2,
-                                                      mchap_lane_init_3, mchap_lane_init_4, mchap_lane_init_5, mchap_lane_init_6,
-                                                      mchap_lane_init_7, mchap_lane_init_8,
-                                                      mchap_specp_init_2_16, mchap_specp_init_2_64, mchap_specp_init_3_16, mchap_specp_init_3_64, mchap_specp_init_4_16, mchap_specp_init_4_32, mchap_specp_init_4_64,
-                                                      mchap_specp_init_5_32, mchap_specp_init_5_64, mchap_specp_init_6_32, mchap_specp_init_6_64, mchap_specp_init_7_64,
-                                                      mchap_specp_init_8_64};
-    for (auto f : inits)
+#define ROW_SIMT_INIT(k) mchap_simt_init_##k,
+#define ROW_V1_INIT(r) mchap_v1_init_##r,
+#define ROW_LANE_INIT(k) mchap_lane_init_##k,
+#define ROW_FILL_INIT(k) mchap_fill_init_##k,
+    const init_fn inits[] = {SIMT_LIST(ROW_SIMT_INIT) FILL_LIST(ROW_FILL_INIT)
+#ifdef MCHAP_TEST_KERNELS
+                                 V1_LIST(ROW_V1_INIT) LANE_LIST(ROW_LANE_INIT)
+#endif
+    };
+    for (init_fn f : inits)
       if (f(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of a sampler object");
   }
   if (dev < 64) g_init_done[dev] = true;
@@ -221,7 +178,37 @@ struct DevBuf {
   T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-size_t up256(size_t x);
+// A host-pointer entry point works on a stream of its own (non-blocking: it neither waits for nor stalls the caller's
+// other streams) and synchronises that stream only.
+struct HostCall {
+  hipStream_t stream = nullptr;
+  int open() {
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    return MCHAP_OK;
+  }
+  ~HostCall() {
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int up(void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    return MCHAP_OK;
+  }
+  int down(void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+    return MCHAP_OK;
+  }
+  int sync() {
+    HIP_TRY(hipStreamSynchronize(stream));
+    return MCHAP_OK;
+  }
+};
+#define MCHAP_TRY(expr)       \
+  do {                        \
+    const int rc_ = (expr);   \
+    if (rc_) return rc_;      \
+  } while (0)
+
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 // one device allocation for a host-pointer call: pieces handed out 256-byte aligned
 struct DevArena {
   DevBuf buf;
@@ -239,7 +226,6 @@ struct DevArena {
   }
 };
 
-
 // bytes per lane and row of the coded table: 1, 2, or a multiple of 4 (the sampler loads 1 / 2 / 4 bytes at a time)
 int code_stride(int rpl) { return rpl <= 2 ? rpl : (rpl + 3) & ~3; }
 
@@ -248,18 +234,6 @@ int rpl_for(int max_reads) {
   for (int r : {1, 2, 4, 8, 16})
     if (need <= r) return r;
   return -1;
-}
-
-int launch_denovo(int rpl, const mchap::DenovoParams &P, int n_units, int chains, size_t lds, hipStream_t stream) {
-  int (*launch)(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t) =
-      rpl == 1 ? mchap_v1_launch_1 : rpl == 2 ? mchap_v1_launch_2 : rpl == 4 ? mchap_v1_launch_4 : rpl == 8 ? mchap_v1_launch_8 : mchap_v1_launch_16;
-  const int cpb = chains < mchap::CHAINS_PER_BLOCK ? chains : mchap::CHAINS_PER_BLOCK;
-  char name[96];
-  snprintf(name, sizeof(name), "denovo_mcmc_kernel<%d>", rpl);
-  SamplerTimer timer(stream, name);
-  const int e = launch(&P, (unsigned)n_units, (unsigned)((chains + cpb - 1) / cpb), (unsigned)(64 * cpb), lds, stream);
-  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
-  return MCHAP_OK;
 }
 
 int validate_cfg(const mchap_denovo_cfg *cfg) {
@@ -273,18 +247,40 @@ int validate_cfg(const mchap_denovo_cfg *cfg) {
   if (cfg->temperatures[0] < 0.0) return fail(MCHAP_ERR_BAD_ARG, "temperatures must be >= 0");
   if (cfg->temperatures[cfg->n_temps - 1] != 1.0) return fail(MCHAP_ERR_BAD_ARG, "last temperature must be 1.0");
   if (cfg->n_intervals == 0 && !cfg->break_table) return fail(MCHAP_ERR_BAD_ARG, "break_table required when n_intervals is None");
+#ifndef MCHAP_TEST_KERNELS
+  if (cfg->kernel == 1 || cfg->kernel == 4)
+    return fail(MCHAP_ERR_BAD_ARG, "kernel %d is only built into libmchap_hip_test.so (make test-kernels)", cfg->kernel);
+#endif
+  if (cfg->kernel < 0 || cfg->kernel > 5) return fail(MCHAP_ERR_BAD_ARG, "kernel %d: not one of 0..5", cfg->kernel);
   return MCHAP_OK;
 }
 
-// {tag, llk} entries per chain (16 KiB); MCHAP_HIP_CACHE_SLOTS (a power of two, 64..65536) overrides it for measurements
-static int cache_slots_setting() {
-  if (const char *e = std::getenv("MCHAP_HIP_CACHE_SLOTS")) {
-    const int v = std::atoi(e);
-    if (v >= 64 && v <= 65536 && (v & (v - 1)) == 0) return v;
-  }
-  return 1024;
+// The knobs of mchap_denovo_tuning with their defaults filled in.
+struct Tune {
+  int cache_slots = 1024, flags = 0, spec_group = 0, pipe_first = 0, pipe_resume = 8, pipe_rounds = 2, pipe_max = 64, pipe_parts = 8;
+  int pipe_group = 64;
+  size_t prep_lds_limit = 8 * 1024;
+  bool pipe_stop = false;
+};
+Tune tune_of(const mchap_denovo_cfg *cfg) {
+  Tune t;
+  const mchap_denovo_tuning *u = cfg->tuning;
+  if (!u) return t;
+  if (u->cache_slots >= 64 && u->cache_slots <= 65536 && (u->cache_slots & (u->cache_slots - 1)) == 0) t.cache_slots = u->cache_slots;
+  t.flags = u->flags;
+  if (u->spec_group == 16 || u->spec_group == 32 || u->spec_group == 64) t.spec_group = u->spec_group;
+  if (u->pipe_first > 0) t.pipe_first = u->pipe_first;
+  if (u->pipe_resume > 0) t.pipe_resume = u->pipe_resume;
+  if (u->pipe_rounds > 0) t.pipe_rounds = u->pipe_rounds - 1;
+  if (u->pipe_max > 0) t.pipe_max = u->pipe_max;
+  if (u->pipe_parts > 0 && u->pipe_parts <= 64) t.pipe_parts = u->pipe_parts;
+  if (u->prep_lds_limit > 0) t.prep_lds_limit = (size_t)u->prep_lds_limit;
+  t.pipe_stop = u->pipe_stop != 0;
+#ifdef MCHAP_TEST_KERNELS
+  if (u->reserved[0] == 16 || u->reserved[0] == 32) t.pipe_group = u->reserved[0];  // narrower phased groups: test library only
+#endif
+  return t;
 }
-#define CACHE_SLOTS (cache_slots_setting())
 
 // The break table of a call lives at the head of the CALLER's workspace (no library-owned device state: two fits
 // on different streams, threads or devices never share a buffer).
@@ -292,10 +288,6 @@ size_t break_table_bytes(const mchap_denovo_cfg *cfg) {
   const size_t mp = cfg->max_pos > 0 ? (size_t)cfg->max_pos : 1;
   return ((mp + 1) * mp * sizeof(double) + 255) & ~(size_t)255;
 }
-
-}  // namespace
-
-namespace {
 
 struct BatchDims {
   int max_reads = 1, max_pos = 1, max_allele = 1, max_ploidy = 1, max_ma = 1, max_ugens = 1;
@@ -321,31 +313,133 @@ int batch_dims(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units
   return MCHAP_OK;
 }
 
+// lanes per chain for the speculative sampler: every option of an interval step (<= K(K-1)) and half the
+// sub-steps of a mutation step (K * n_pos) must fit; 0 if the shape is not supported by it
+int spec_group(const Tune &T, int K, int max_pos) {
+  if (K < 2 || K > 8) return 0;
+  const int n = K * max_pos;
+  int g = T.spec_group ? T.spec_group : 16;
+  while (g < 64 && (g < K * (K - 1) || 2 * g < n)) g *= 2;
+  const int slots = (K == 8) ? 3 : 2;  // sub-steps per lane the instantiation supports (denovo_spec_kernel.hpp)
+  if (g < K * (K - 1) || slots * g < n) return 0;
+  if ((K == 5 || K == 6) && g < 32) g = 32;  // instantiated group sizes: 2..4: 16/32/64, 5..6: 32/64, 7..8: 64
+  if (K >= 7) g = 64;
+  return g;
+}
+
+// The steady-state sampler (kernel 4, test library): any ploidy 1..8 with a single temperature
+bool lane_supported(int K, int max_pos, int n_temps) {
+#ifdef MCHAP_TEST_KERNELS
+  if (n_temps != 1 || K < 1 || K > 8) return false;
+  const int slots = (K == 8) ? 3 : 2;
+  return K * max_pos <= slots * 64 && K * (K - 1) <= 64;
+#else
+  return false;
+#endif
+}
+
+// The phased sampler (kernel 5): one chain per wavefront at every ploidy -- it spends its time in likelihood
+// evaluations, which a wave serves one after the other whatever the group size; wider groups need fewer rounds per table
+// completion and leave a shorter tail (MI355X, 10 000 loci of config #2's shape: K = 4: 16.4 ms with 16 lanes, 14.5 with
+// 32, 13.7 with 64; K = 6: 87 -> 67 ms).  Needs the interval memo (single temperature, tables in LDS) and a mutation
+// step whose draws fit the staged window.
+int pipe_group(const Tune &T, int K) {
+  if (K < 2 || K > 8) return 0;
+  if (T.pipe_group != 64 && FIND_SPECP(K, T.pipe_group)) return T.pipe_group;
+  return 64;
+}
+bool pipe_supported(const mchap_denovo_cfg *cfg, const Tune &T, int K, int max_pos) {
+  if ((cfg->kernel != 5 && cfg->kernel != 0) || cfg->n_temps != 1 || K < 2 || K > 8) return false;
+  if (T.spec_group || (T.flags & 3)) return false;  // measurement settings of kernel 3 / memos switched off
+  const int g = spec_group(T, K, max_pos);
+  if (g == 0 || g > pipe_group(T, K)) return false;
+  if (mchap::spec_memo_bytes(max_pos, 1, g) == 0) return false;
+  return K * max_pos <= mchap::spec_draws(K, max_pos);
+}
+
+// Read chunks (of 64) per unit for the prepare pass and the sampler behind it.  The speculative sampler takes any
+// count up to 8, then 12, 16, 24, 32, 48, 64 (4096 reads: the prepare pass is instantiated per count); the
+// lanes-over-chains kernel and kernel 1 are instantiated for powers of two up to 16 (1024 reads).
+int simt_rpl(const mchap_denovo_cfg *cfg, const Tune &T, int uniform_ploidy, int max_pos, int max_reads) {
+  const bool lane = cfg->kernel == 4 && uniform_ploidy > 0 && lane_supported(uniform_ploidy, max_pos, cfg->n_temps);
+  const bool spec = lane || (cfg->kernel != 1 && cfg->kernel != 2 && uniform_ploidy > 0 && spec_group(T, uniform_ploidy, max_pos) != 0);
+  if (!spec) return rpl_for(max_reads);
+  const int need = (max_reads + 63) / 64;
+  if (need <= 8) return need < 1 ? 1 : need;
+  for (int r : {12, 16, 24, 32, 48, 64})  // (the sampler takes its chunks four at a time: any count works there)
+    if (need <= r) return r;
+  return -1;
+}
+
+bool use_simt(const mchap_denovo_cfg *cfg) { return cfg->kernel != 1; }
+
+// Which sampler a batch runs on (mchap_denovo_cfg.kernel, the shapes, the ploidies present).
+enum SamplerKind { SAMPLER_V1 = 1, SAMPLER_SIMT = 2, SAMPLER_SPEC = 3, SAMPLER_LANE = 4, SAMPLER_PIPE = 5 };
+struct Plan {
+  int kind = 0, K = 0, G = 0, rpl = 0;
+};
+int plan_sampler(const mchap_denovo_cfg *cfg, const Tune &T, const BatchDims &B, Plan &pl) {
+  pl.K = B.uniform_ploidy;
+  pl.rpl = use_simt(cfg) ? simt_rpl(cfg, T, B.uniform_ploidy, B.max_pos, B.max_reads) : rpl_for(B.max_reads);
+  if (pl.rpl < 0)
+    return fail(MCHAP_ERR_LIMIT, "n_reads %d: the sampler kernel for this batch takes 1..%d reads", B.max_reads,
+                (use_simt(cfg) && B.uniform_ploidy > 0 && spec_group(T, B.uniform_ploidy, B.max_pos)) ? MCHAP_MAX_READS : 1024);
+  if (!use_simt(cfg)) {
+    pl.kind = SAMPLER_V1;
+  } else if (cfg->kernel == 4 && B.uniform_ploidy > 0 && lane_supported(B.uniform_ploidy, B.max_pos, cfg->n_temps)) {
+    pl.kind = SAMPLER_LANE;
+  } else if (pipe_supported(cfg, T, B.uniform_ploidy, B.max_pos)) {
+    pl.kind = SAMPLER_PIPE;
+    pl.G = pipe_group(T, pl.K);
+  } else if (cfg->kernel != 2 && B.uniform_ploidy > 0 && spec_group(T, B.uniform_ploidy, B.max_pos)) {
+    pl.kind = SAMPLER_SPEC;
+    pl.G = spec_group(T, B.uniform_ploidy, B.max_pos);
+  } else {
+    pl.kind = SAMPLER_SIMT;
+    pl.K = (pl.K == 2 || pl.K == 4 || pl.K == 6 || pl.K == 8) ? pl.K : 0;  // (specialised for even ploidies, else generic)
+  }
+  return MCHAP_OK;
+}
+void plan_name(const Plan &pl, char *out, size_t n) {
+  switch (pl.kind) {
+    case SAMPLER_V1: snprintf(out, n, "denovo_mcmc_kernel<%d>", pl.rpl); break;
+    case SAMPLER_SIMT: snprintf(out, n, "denovo_simt_kernel<%d>", pl.K); break;
+    case SAMPLER_SPEC: snprintf(out, n, "denovo_spec_kernel<%d, %d>", pl.K, pl.G); break;
+    case SAMPLER_LANE: snprintf(out, n, "denovo_settle_kernel<%d> + denovo_steady_kernel<%d>", pl.K, pl.K); break;
+    default: snprintf(out, n, "denovo_spec_kernel<%d, %d, phased> + denovo_coast_kernel", pl.K, pl.G); break;
+  }
+}
+
 struct SimtCarve {
-  size_t cache = 0, rt = 0, cntw = 0, codes = 0, dict = 0, meta_i = 0, meta_f = 0, lane_state = 0, lane_memo = 0, total = 0;
+  size_t cache = 0, ckeys = 0, rt = 0, cntw = 0, codes = 0, dict = 0, meta_i = 0, meta_f = 0, lane_state = 0, lane_memo = 0, total = 0;
   size_t pipe_state = 0, pipe_memo = 0, pipe_lists = 0, pipe_counts = 0;
+  int key_words = 0;
 };
 constexpr int PIPE_MAX_ROUNDS = 6;  // resume rounds of the phased sampler (counters in the workspace)
-bool pipe_supported(const mchap_denovo_cfg *cfg, int K, int max_pos);
 
-size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-SimtCarve simt_carve(const mchap_denovo_cfg *cfg, int n_units, const BatchDims &B, int rpad, int cache_slots) {
+SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, const BatchDims &B, int rpad, int cache_slots) {
   SimtCarve c;
   size_t o = 0;
-  c.cache = o; o += up256((size_t)n_units * cfg->chains * cache_slots * 16);
+  const size_t nc = (size_t)n_units * cfg->chains;
+  c.cache = o; o += up256(nc * cache_slots * 16);
+  // genotypes of more than 63 bits: their words beside the (hashed) tags, so that a cache hit is always exact
+  if (cache_slots > 0 && B.max_ploidy * mchap::allele_bits(B.max_allele) * B.max_pos > 63) {
+    c.key_words = B.max_ploidy;
+    c.ckeys = o; o += up256(nc * cache_slots * c.key_words * 8);
+  }
   c.rt = o; o += up256((size_t)n_units * B.max_ma * rpad * 8);
   c.cntw = o; o += up256((size_t)n_units * rpad * 8);
   c.codes = o; o += up256((size_t)n_units * B.max_ma * 64 * code_stride(rpad / 64));
   c.dict = o; o += up256((size_t)n_units * mchap::DICT_MAX * 8);
   c.meta_i = o; o += up256((size_t)n_units * mchap::meta_i_stride(B.max_pos) * 4);
   c.meta_f = o; o += up256((size_t)n_units * mchap::meta_f_stride(B.max_ploidy, B.max_pos, B.max_allele) * 8);
-  if (cfg->kernel == 4) {  // hand-over records of the steady-state pipeline
-    c.lane_state = o; o += up256((size_t)n_units * cfg->chains * sizeof(mchap::LaneState));
-    c.lane_memo = o; o += up256((size_t)n_units * cfg->chains * 2 * mchap::spec_memo_entries(B.max_pos) * 4);
+#ifdef MCHAP_TEST_KERNELS
+  if (pl.kind == SAMPLER_LANE) {  // hand-over records of the steady-state pipeline
+    c.lane_state = o; o += up256(nc * sizeof(mchap::LaneState));
+    c.lane_memo = o; o += up256(nc * 2 * mchap::spec_memo_entries(B.max_pos) * 4);
   }
-  if (pipe_supported(cfg, B.uniform_ploidy, B.max_pos)) {  // hand-over records of the phased sampler
-    const size_t nc = (size_t)n_units * cfg->chains;
+#endif
+  if (pl.kind == SAMPLER_PIPE) {  // hand-over records of the phased sampler
     c.pipe_state = o; o += up256(nc * sizeof(mchap::PipeState));
     c.pipe_memo = o; o += up256(nc * 2 * mchap::spec_memo_entries(B.max_pos) * 8);
     c.pipe_lists = o; o += up256(nc * 4) * 2;
@@ -365,97 +459,76 @@ int launch_prepare(const mchap::SimtParams &P, int n_units, size_t lds_prep, hip
   return MCHAP_OK;
 }
 
-int launch_simt(int KT, const mchap::SimtParams &P, int n_units, int chains, size_t lds_simt, hipStream_t stream) {
-  int (*launch)(const mchap::SimtParams *, unsigned, size_t, hipStream_t) =
+int launch_simt(int KT, const mchap::SimtParams &P, int n_units, int chains, size_t lds_simt, void *timer, hipStream_t stream) {
+  simt_launch_fn launch =
       KT == 2 ? mchap_simt_launch_2 : KT == 4 ? mchap_simt_launch_4 : KT == 6 ? mchap_simt_launch_6 : KT == 8 ? mchap_simt_launch_8 : mchap_simt_launch_0;
   const long long n_chains = (long long)n_units * chains;
-  char name[96];
-  snprintf(name, sizeof(name), "denovo_simt_kernel<%d>", KT);
-  SamplerTimer timer(stream, name);
+  SamplerTimer tm(timer, stream);
   const int e = launch(&P, (unsigned)((n_chains + 63) / 64), lds_simt, stream);
-  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of denovo_simt_kernel<%d>: %s", KT, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
 }
 
 // One chain per wave (G = 64): the haplotype products of the chain's current genotype live in an LDS cache behind the
 // sampler's LDS (8 KB at K = 4, 16 KB at K = 8) instead of 64-128 VGPRs
-int bp_cache_fits(int G, size_t lds, int K) {
-  if (G != 64 || std::getenv("MCHAP_HIP_NO_BP_CACHE")) return 0;
+int bp_cache_fits(const Tune &T, int G, size_t lds, int K) {
+  if (G != 64 || (T.flags & 16)) return 0;
   return ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K) <= 160 * 1024 ? 1 : 0;
 }
 
-int launch_spec(int K, int G, const mchap::SimtParams &P, int n_units, int chains, int n_temps, hipStream_t stream) {
-  int n = 0;
-  const SpecInst *insts = spec_insts(&n);
-  const SpecInst *inst = nullptr;
-  for (int i = 0; i < n; i++)
-    if (insts[i].K == K && insts[i].G == G) inst = &insts[i];
+int launch_spec(const Tune &T, int K, int G, const mchap::SimtParams &P, int n_units, int chains, int n_temps, void *timer, hipStream_t stream) {
+  const SpecInst *inst = FIND_SPEC(K, G);
   if (!inst) return fail(MCHAP_ERR_LIMIT, "speculative sampler: no instantiation for ploidy %d with %d lanes per chain", K, G);
   size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, n_temps, G);
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
   mchap::SimtParams Q = P;
-  Q.bp_cache = bp_cache_fits(G, lds, K);
+  Q.bp_cache = bp_cache_fits(T, G, lds, K);
   if (Q.bp_cache) lds = ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K);
   const long long n_chains = (long long)n_units * chains;
   const int per_wave = 64 / G;
-  char name[96];
-  snprintf(name, sizeof(name), "denovo_spec_kernel<%d, %d>", K, G);
-  SamplerTimer timer(stream, name);
+  SamplerTimer tm(timer, stream);
   const int e = inst->launch(&Q, (unsigned)((n_chains + per_wave - 1) / per_wave), lds, stream);
-  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of denovo_spec_kernel<%d, %d>: %s", K, G, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
 }
 
-// The steady-state sampler (kernel 4, denovo_lane_kernel.hpp): any ploidy 1..8 with a single temperature; its serving
-// code is the speculative kernel's with the whole wavefront per chain, whose mutation step holds 2 (octoploids: 3)
-// sub-steps per lane.
-bool lane_supported(int K, int max_pos, int n_temps) {
-  if (n_temps != 1 || K < 1 || K > 8) return false;
-  const int slots = (K == 8) ? 3 : 2;
-  return K * max_pos <= slots * 64 && K * (K - 1) <= 64;
+#ifdef MCHAP_TEST_KERNELS
+int launch_denovo(int rpl, const mchap::DenovoParams &P, int n_units, int chains, size_t lds, void *timer, hipStream_t stream) {
+  int (*launch)(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t) =
+      rpl == 1 ? mchap_v1_launch_1 : rpl == 2 ? mchap_v1_launch_2 : rpl == 4 ? mchap_v1_launch_4 : rpl == 8 ? mchap_v1_launch_8 : mchap_v1_launch_16;
+  const int cpb = chains < mchap::CHAINS_PER_BLOCK ? chains : mchap::CHAINS_PER_BLOCK;
+  SamplerTimer tm(timer, stream);
+  const int e = launch(&P, (unsigned)n_units, (unsigned)((chains + cpb - 1) / cpb), (unsigned)(64 * cpb), lds, stream);
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of denovo_mcmc_kernel<%d>: %s", rpl, hipGetErrorString((hipError_t)e));
+  return MCHAP_OK;
 }
 
-// lanes per chain in its fast path: few enough that the launch still fills the SIMDs twice over
 // Lanes per chain of the settling kernel (it runs one wave per SIMD -- its serving code needs the registers -- so a
 // wave may use a quarter of a CU's LDS: the unit tables of its chains live there).  -1: does not fit.
-int lane_shift(long long n_chains, int K, int max_pos, int max_allele, int tab_bytes, int rpad) {
+int lane_shift(int K, int max_pos, int max_allele, int tab_bytes, int rpad) {
   int s = 4;
-  if (const char *e = std::getenv("MCHAP_HIP_LANES")) {
-    const int l = std::atoi(e);
-    for (int q = 0; q <= 6; q++)
-      if ((1 << q) == l) s = q;
-  }
   while (s < 6 && mchap::lane_lds_bytes(K, max_pos, max_allele, 1 << s, tab_bytes, rpad) > 40 * 1024) s++;
   if (mchap::lane_lds_bytes(K, max_pos, max_allele, 1 << s, tab_bytes, rpad) > 160 * 1024) return -1;
   return s;
 }
 
-int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipStream_t stream) {
-  int (*launch)(const mchap::SimtParams *, int, int, unsigned, size_t, hipStream_t) =
-      K == 1 ? mchap_lane_launch_1 : K == 2 ? mchap_lane_launch_2 : K == 3 ? mchap_lane_launch_3 : K == 4 ? mchap_lane_launch_4 :
-      K == 5 ? mchap_lane_launch_5 : K == 6 ? mchap_lane_launch_6 : K == 7 ? mchap_lane_launch_7 : mchap_lane_launch_8;
+int launch_lane(const Tune &T, int K, const mchap::SimtParams &P, int n_units, int chains, void *timer, hipStream_t stream) {
+#define ROW_LANE_LAUNCH(k) mchap_lane_launch_##k,
+  int (*const launches[])(const mchap::SimtParams *, int, int, unsigned, size_t, hipStream_t) = {LANE_LIST(ROW_LANE_LAUNCH)};
+  auto launch = launches[K - 1];
   const long long n_chains = (long long)n_units * chains;
   const int tab_bytes = P.max_ma * 64 * P.cstride;
-  const int lsh = lane_shift(n_chains, K, P.max_pos, P.max_allele, tab_bytes, P.d.rpad);
+  const int lsh = lane_shift(K, P.max_pos, P.max_allele, tab_bytes, P.d.rpad);
   if (lsh < 0) return fail(MCHAP_ERR_LIMIT, "steady-state sampler: the unit tables do not fit the LDS");
   const size_t lds = mchap::lane_lds_bytes(K, P.max_pos, P.max_allele, 1 << lsh, tab_bytes, P.d.rpad);
   const int per_wave = 64 >> lsh;
   // the steady kernel's own geometry: it is lean, so more lanes per chain (more waves) only help the SIMDs' issue rate
   int fsh = 0;
-  if (const char *e = std::getenv("MCHAP_HIP_STEADY_LANES")) {
-    const int l = std::atoi(e);
-    for (int s = 0; s <= 6; s++)
-      if ((1 << s) == l) fsh = s;
-  } else {
-    while (fsh < 4 && n_chains * (1ll << fsh) / 64 < 4096) fsh++;
-  }
+  while (fsh < 4 && n_chains * (1ll << fsh) / 64 < 4096) fsh++;
   const size_t lds_f = mchap::steady_lds_bytes(P.max_pos, 1 << fsh);
   const int per_wave_f = 64 >> fsh;
-  int rounds = 2;
-  if (const char *e = std::getenv("MCHAP_HIP_ROUNDS")) rounds = std::atoi(e);
-  char name[96];
-  snprintf(name, sizeof(name), "denovo_settle_kernel<%d> L=%d + denovo_steady_kernel<%d> L=%d", K, 1 << lsh, K, 1 << fsh);
-  SamplerTimer timer(stream, name);
+  const int rounds = T.pipe_rounds;
+  SamplerTimer tm(timer, stream);
   const unsigned grid_w = (unsigned)((n_chains + per_wave - 1) / per_wave), grid_f = (unsigned)((n_chains + per_wave_f - 1) / per_wave_f);
   // settle (park the chains whose thresholds are complete) -> steady -> settle the ones handed back -> ... -> finish
   int e = launch(&P, lsh, rounds > 0 ? mchap::LANE_MODE_PARK : 0, grid_w, lds, stream);
@@ -463,82 +536,57 @@ int launch_lane(int K, const mchap::SimtParams &P, int n_units, int chains, hipS
     e = launch(&P, fsh, -1, grid_f, lds_f, stream);
     if (e == 0) e = launch(&P, lsh, mchap::LANE_MODE_RESUME | (r + 1 < rounds ? mchap::LANE_MODE_PARK : 0), grid_w, lds, stream);
   }
-  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of the settle / steady pipeline <%d>: %s", K, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
 }
+#endif  // MCHAP_TEST_KERNELS
 
 // The phased sampler (kernel 5): denovo_spec_kernel<K, G, true> for the first steps, denovo_coast_kernel for the
-// chains' long no-move stretches, denovo_spec_kernel again for the chains handed back.  Instantiated for each
-// ploidy's default group size; needs the interval memo (single temperature, table in LDS) and a mutation step whose
-// draws fit the staged window.
-int env_int(const char *name, int dflt, int lo, int hi) {
-  if (const char *e = std::getenv(name)) {
-    const int v = std::atoi(e);
-    if (v >= lo && v <= hi) return v;
-  }
-  return dflt;
-}
-
-int spec_group(int K, int max_pos);
-int pipe_group(int K) {
-  // One chain per wavefront at every ploidy: the phased form spends its time in likelihood evaluations, which a wave
-  // serves one after the other whatever the group size; wider groups need fewer rounds per table completion, leave a
-  // shorter tail, and with a single chain the base products live in LDS.  MI355X, 10 000 loci of config #2's shape:
-  // K = 2: 3.1 ms (16 or 64 lanes), K = 3: 7.9 -> 7.2 ms, K = 4: 16.4 (16) / 14.5 (32) / 13.7 (64), K = 5: 39.7 -> 32.1,
-  // K = 6: 87 -> 67 ms.  The narrower instantiations stay selectable for measurements.
-  if (K < 2 || K > 8) return 0;
-  const int g = env_int("MCHAP_HIP_PIPE_GROUP", 64, 16, 64);
-  if (g == 16 && K <= 4) return 16;
-  if (g == 32 && K >= 4 && K <= 6) return 32;
-  return 64;
-}
-bool pipe_supported(const mchap_denovo_cfg *cfg, int K, int max_pos) {
-  if ((cfg->kernel != 5 && cfg->kernel != 0) || cfg->n_temps != 1 || K < 2 || K > 8) return false;
-  if (std::getenv("MCHAP_HIP_GROUP")) return false;
-  if (const char *e = std::getenv("MCHAP_HIP_FLAGS"))
-    if (std::atoi(e) & 3) return false;  // memos switched off
-  const int g = spec_group(K, max_pos);
-  if (g == 0 || g > pipe_group(K)) return false;
-  if (mchap::spec_memo_bytes(max_pos, 1, g) == 0) return false;
-  return K * max_pos <= mchap::spec_draws(K, max_pos);
-}
-
-
-int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *lists, int32_t *counts, hipStream_t stream) {
-  const int G = pipe_group(K);
-  int (*launch)(const mchap::SimtParams *, unsigned, size_t, hipStream_t) =
-      K == 2 ? (G == 64 ? mchap_specp_launch_2_64 : mchap_specp_launch_2_16) : K == 3 ? (G == 64 ? mchap_specp_launch_3_64 : mchap_specp_launch_3_16) : K == 4 ? (G == 64 ? mchap_specp_launch_4_64 : G == 32 ? mchap_specp_launch_4_32 : mchap_specp_launch_4_16) :
-      K == 5 ? (G == 64 ? mchap_specp_launch_5_64 : mchap_specp_launch_5_32) : K == 6 ? (G == 64 ? mchap_specp_launch_6_64 : mchap_specp_launch_6_32) : K == 7 ? mchap_specp_launch_7_64 : mchap_specp_launch_8_64;
+// chains' long no-move stretches, denovo_spec_kernel again for the chains handed back.
+int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, int chains, int32_t *lists, int32_t *counts, void *timer,
+                hipStream_t stream) {
+  const SpecInst *inst = FIND_SPECP(K, G);
+  if (!inst) return fail(MCHAP_ERR_LIMIT, "phased sampler: no instantiation for ploidy %d with %d lanes per chain", K, G);
+  simt_launch_fn launch = inst->launch;
   size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, 1, G);
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
-  P.bp_cache = bp_cache_fits(G, lds, K);
+  P.bp_cache = bp_cache_fits(T, G, lds, K);
   if (P.bp_cache) lds = ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K);
   const long long n_chains = (long long)n_units * chains;
   // steps before the first hand-over: a chain handed over before it has settled comes back and has its tables
   // completed a second time, which costs more the more sub-steps and intervals a step has (config #2: 32 sub-steps,
   // best at 4; config #5: 160 sub-steps, 1251 / 912 / 570 / 632 ms at 4 / 8 / 16 / 32)
   const int n_sub = K * P.max_pos;
-  const int s0 = env_int("MCHAP_HIP_PIPE_FIRST", n_sub / 10 < 4 ? 4 : (n_sub / 10 > 32 ? 32 : n_sub / 10), 1, 1 << 30);
-  const int nr = env_int("MCHAP_HIP_PIPE_RESUME", 8, 1, 1 << 30);   // steps a handed-back chain runs before the next
-  const int rounds = env_int("MCHAP_HIP_ROUNDS", 2, 0, PIPE_MAX_ROUNDS);
-  P.pipe_iters_max = env_int("MCHAP_HIP_PIPE_MAX", 64, 1, 1 << 30);  // ... extended to while a chain of the wave is unsettled
-  P.pipe_parts = env_int("MCHAP_HIP_PIPE_PARTS", 8, 1, 64);  // wavefronts per chain completing tables when chains are few
+  const int s0 = T.pipe_first > 0 ? T.pipe_first : (n_sub / 10 < 4 ? 4 : (n_sub / 10 > 32 ? 32 : n_sub / 10));
+  const int nr = T.pipe_resume;   // steps a handed-back chain runs before the next hand-over
+  const int rounds = T.pipe_rounds < PIPE_MAX_ROUNDS ? T.pipe_rounds : PIPE_MAX_ROUNDS;
+  P.pipe_iters_max = T.pipe_max;  // ... extended to while a chain of the wave is unsettled
+  P.pipe_parts = T.pipe_parts;    // wavefronts per chain completing tables when chains are few
   const unsigned grid_f = (unsigned)((mchap::PIPE_FILL_SLOTS + 64 / G - 1) / (64 / G));
   const size_t lds_c = mchap::coast_lds_bytes(P.max_pos);
   const unsigned grid_s = (unsigned)((n_chains + 64 / G - 1) / (64 / G)), grid_c = (unsigned)n_chains;
   const size_t list_stride = up256((size_t)n_chains * 4) / 4;
   HIP_TRY(hipMemsetAsync(counts, 0, (PIPE_MAX_ROUNDS + 2) * 4, stream));
-  char name[96];
-  snprintf(name, sizeof(name), "denovo_spec_kernel<%d, %d, phased> + denovo_coast_kernel", K, G);
-  SamplerTimer timer(stream, name);
+  SamplerTimer tm(timer, stream);
   // every chain: first steps from scratch, complete tables, records
+  // Table completion: denovo_fill_kernel (one lane per request) after every exporting launch; shapes it does not take
+  // (and tuning flag 64) keep the completion inside the exporting launch, spread over several wavefronts per chain by a
+  // PIPE_FILLONLY launch when the chains are few
+  const bool lpr = mchap::fill_supported(K, P.max_pos, P.max_allele, P.d.rpad) && !(T.flags & 64);
+  const size_t lds_fill = lpr ? mchap::fill_lds_bytes(K, P.max_pos, P.max_allele, P.d.rpad) : 0;
+  const int export_mode = mchap::PIPE_EXPORT | (lpr ? mchap::PIPE_NOFILL : 0);
+  P.fill_lt = lpr ? mchap::fill_tile_lanes(K, P.max_pos, P.max_allele, P.d.rpad) : 0;
+  P.fill_kw = mchap::fill_key_words(K, P.max_pos, P.max_allele);
+#define ROW_FILL_LAUNCH(k) mchap_fill_launch_##k,
+  const simt_launch_fn fill_launches[] = {FILL_LIST(ROW_FILL_LAUNCH)};
   P.pipe_list = nullptr;
   P.pipe_count = nullptr;
   P.pipe_iters = s0;
-  P.pipe_mode = mchap::PIPE_EXPORT;
+  P.pipe_mode = export_mode;
   int e = launch(&P, grid_s, lds, stream);
-  auto fill_launch = [&]() {  // (a no-op unless the chains of the list are few: pipe_parts_eff)
-    if (P.pipe_parts <= 1) return 0;
+  auto fill_launch = [&]() {
+    if (lpr) return fill_launches[K - 2](&P, (unsigned)n_chains, lds_fill, stream);
+    if (P.pipe_parts <= 1) return 0;  // (a no-op unless the chains of the list are few: pipe_parts_eff)
     mchap::SimtParams F = P;
     F.pipe_mode = mchap::PIPE_RESUME | mchap::PIPE_FILLONLY;
     return launch(&F, grid_f, lds, stream);
@@ -548,13 +596,12 @@ int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *li
   P.pipe_out = lists;
   P.pipe_out_count = counts;
   if (e == 0) e = mchap_coast_launch(&P, grid_c, lds_c, stream);
-  const bool stop_early = std::getenv("MCHAP_HIP_PIPE_STOP") != nullptr;  // measurement aid: traces are incomplete
-  for (int r = 0; r <= rounds && e == 0 && !stop_early; r++) {
+  for (int r = 0; r <= rounds && e == 0 && !T.pipe_stop; r++) {
     P.pipe_list = lists + (size_t)(r & 1) * list_stride;
     P.pipe_count = counts + r;
     const bool last = r == rounds;
     P.pipe_iters = last ? 0 : nr;
-    P.pipe_mode = mchap::PIPE_RESUME | (last ? 0 : mchap::PIPE_EXPORT);
+    P.pipe_mode = mchap::PIPE_RESUME | (last ? 0 : export_mode);
     e = launch(&P, grid_s, lds, stream);
     if (last || e != 0) break;
     e = fill_launch();
@@ -563,71 +610,9 @@ int launch_pipe(int K, mchap::SimtParams P, int n_units, int chains, int32_t *li
     P.pipe_out_count = counts + r + 1;
     e = mchap_coast_launch(&P, grid_c, lds_c, stream);
   }
-  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of %s: %s", name, hipGetErrorString((hipError_t)e));
+  if (e != 0) return fail(MCHAP_ERR_HIP, "launch of the phased sampler <%d, %d>: %s", K, G, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
 }
-
-// lanes per chain for the speculative sampler: every option of an interval step (<= K(K-1)) and half the
-// sub-steps of a mutation step (K * n_pos) must fit; 0 if the shape is not supported by it
-int spec_group(int K, int max_pos) {
-  if (K < 2 || K > 8) return 0;
-  const int n = K * max_pos;
-  int g = 16;
-  if (const char *e = std::getenv("MCHAP_HIP_GROUP")) g = std::atoi(e);
-  if (g != 16 && g != 32 && g != 64) g = 16;
-  while (g < 64 && (g < K * (K - 1) || 2 * g < n)) g *= 2;
-  const int slots = (K == 8) ? 3 : 2;  // sub-steps per lane the instantiation supports (denovo_spec_kernel.hpp)
-  if (g < K * (K - 1) || slots * g < n) return 0;
-  if ((K == 5 || K == 6) && g < 32) g = 32;  // instantiated group sizes: 2..4: 16/32/64, 5..6: 32/64, 7..8: 64
-  if (K >= 7) g = 64;
-  return g;
-}
-
-const SpecInst *spec_insts(int *n) {
-  static const SpecInst insts[] = {
-    {2, 16, mchap_spec_init_2_16, mchap_spec_launch_2_16},
-    {2, 32, mchap_spec_init_2_32, mchap_spec_launch_2_32},
-    {2, 64, mchap_spec_init_2_64, mchap_spec_launch_2_64},
-    {3, 16, mchap_spec_init_3_16, mchap_spec_launch_3_16},
-    {3, 32, mchap_spec_init_3_32, mchap_spec_launch_3_32},
-    {3, 64, mchap_spec_init_3_64, mchap_spec_launch_3_64},
-    {5, 32, mchap_spec_init_5_32, mchap_spec_launch_5_32},
-    {5, 64, mchap_spec_init_5_64, mchap_spec_launch_5_64},
-    {7, 64, mchap_spec_init_7_64, mchap_spec_launch_7_64},
-    {4, 16, mchap_spec_init_4_16, mchap_spec_launch_4_16},
-    {4, 32, mchap_spec_init_4_32, mchap_spec_launch_4_32},
-    {4, 64, mchap_spec_init_4_64, mchap_spec_launch_4_64},
-    {6, 32, mchap_spec_init_6_32, mchap_spec_launch_6_32},
-    {6, 64, mchap_spec_init_6_64, mchap_spec_launch_6_64},
-    {8, 64, mchap_spec_init_8_64, mchap_spec_launch_8_64},
-  };
-  *n = (int)(sizeof(insts) / sizeof(insts[0]));
-  return insts;
-}
-
-size_t prep_lds_copy_limit() {
-  if (const char *e = std::getenv("MCHAP_HIP_PREP_LDS")) return (size_t)std::atol(e);
-  return 8 * 1024;
-}
-
-int spec_group(int K, int max_pos);
-bool lane_supported(int K, int max_pos, int n_temps);
-
-// Read chunks (of 64) per unit for the prepare pass and the sampler behind it.  The speculative sampler takes any
-// count up to 8, then 12, 16, 24, 32, 48, 64 (4096 reads: the prepare pass is instantiated per count); the
-// lanes-over-chains kernel and kernel 1 are instantiated for powers of two up to 16 (1024 reads).
-int simt_rpl(const mchap_denovo_cfg *cfg, int uniform_ploidy, int max_pos, int max_reads) {
-  const bool lane = cfg->kernel == 4 && uniform_ploidy > 0 && lane_supported(uniform_ploidy, max_pos, cfg->n_temps);
-  const bool spec = lane || (cfg->kernel != 1 && cfg->kernel != 2 && uniform_ploidy > 0 && spec_group(uniform_ploidy, max_pos) != 0);
-  if (!spec) return rpl_for(max_reads);
-  const int need = (max_reads + 63) / 64;
-  if (need <= 8) return need < 1 ? 1 : need;
-  for (int r : {12, 16, 24, 32, 48, 64})  // (the sampler takes its chunks four at a time: any count works there)
-    if (need <= r) return r;
-  return -1;
-}
-
-bool use_simt(const mchap_denovo_cfg *cfg) { return cfg->kernel != 1; }
 
 }  // namespace
 
@@ -636,38 +621,70 @@ extern "C" {
 const char *mchap_version(void) { return "mchap-hip 0.1 (gfx950; restates MCHap v0.11.1 assemble + calling.exact)"; }
 const char *mchap_last_error(void) { return g_err; }
 
-int mchap_set_profiling(int enabled) {
-  g_profiling = enabled != 0;
-  g_ev_valid = false;
+int mchap_timer_create(void **timer) {
+  if (!timer) return fail(MCHAP_ERR_BAD_ARG, "timer is NULL");
+  int rc = ensure_init();
+  if (rc) return rc;
+  Timer *t = new Timer();
+  if (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess) {
+    delete t;
+    return fail(MCHAP_ERR_HIP, "hipEventCreate");
+  }
+  *timer = t;
   return MCHAP_OK;
 }
 
-double mchap_last_sampler_ms(void) {
-  if (!g_ev_valid) return -1.0;
-  if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
+double mchap_timer_ms(void *timer) {
+  Timer *t = reinterpret_cast<Timer *>(timer);
+  if (!t || !t->recorded) return -1.0;
+  if (hipEventSynchronize(t->e1) != hipSuccess) return -1.0;
   float ms = 0.f;
-  if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, t->e0, t->e1) != hipSuccess) return -1.0;
   return (double)ms;
 }
 
-const char *mchap_last_sampler_name(void) { return g_sampler_name; }
+int mchap_timer_destroy(void *timer) {
+  Timer *t = reinterpret_cast<Timer *>(timer);
+  if (!t) return MCHAP_OK;
+  if (t->e0) (void)hipEventDestroy(t->e0);
+  if (t->e1) (void)hipEventDestroy(t->e1);
+  delete t;
+  return MCHAP_OK;
+}
+
+int mchap_denovo_sampler_name(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host, char *out, int out_len) {
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  if (!out || out_len < 1 || !units_host || n_units < 1) return fail(MCHAP_ERR_BAD_ARG, "NULL buffer");
+  BatchDims B;
+  rc = batch_dims(cfg, n_units, units_host, B);
+  if (rc) return rc;
+  Plan pl;
+  rc = plan_sampler(cfg, tune_of(cfg), B, pl);
+  if (rc) return rc;
+  plan_name(pl, out, (size_t)out_len);
+  return MCHAP_OK;
+}
 
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
-/* profiling builds only (make STATS=1): [0] likelihood requests, [1] cache misses, [2] probe slots */
+/* profiling builds only (make stats / make phases): [0] likelihood requests, [1] cache misses, [2] probe slots, ... */
 int mchap_debug_stats(unsigned long long *out, int reset) {
-  unsigned long long z[24] = {0};
+  unsigned long long z[mchap::N_STATS] = {0};
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_stats), sizeof(z)));
   if (reset) HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mchap::g_stats), z, sizeof(z)));
   // plus the copies of the speculative sampler's object files
-  int (*fs[])(unsigned long long *, int) = {mchap_spec_stats_2_16, mchap_spec_stats_2_32, mchap_spec_stats_2_64, mchap_spec_stats_3_16, mchap_spec_stats_3_32, mchap_spec_stats_3_64, mchap_spec_stats_5_32, mchap_spec_stats_5_64, mchap_spec_stats_7_64, mchap_spec_stats_4_16, mchap_spec_stats_4_32, mchap_spec_stats_4_64, mchap_spec_stats_6_32, mchap_spec_stats_6_64, mchap_spec_stats_8_64};
+#define ROW_SPEC_STATS(k, g) mchap_spec_stats_##k##_##g,
+#define ROW_SPECP_STATS(k, g) mchap_specp_stats_##k##_##g,
+  int (*fs[])(unsigned long long *, int) = {SPEC_LIST(ROW_SPEC_STATS) SPECP_LIST(ROW_SPECP_STATS)};
   for (auto f : fs) {
-    unsigned long long t[24];
+    unsigned long long t[mchap::N_STATS];
     if (f(t, reset) != 0) return fail(MCHAP_ERR_HIP, "reading the counters of a sampler object");
-    for (int i = 0; i < 24; i++) out[i] += t[i];
+    for (int i = 0; i < mchap::N_STATS; i++) out[i] += t[i];
   }
   return MCHAP_OK;
 }
+#ifdef MCHAP_TEST_KERNELS
 /* counters of the steady-state sampler's K = 4 object (its own layout: denovo_lane_kernel.hpp LPH / LCNT) */
 int mchap_debug_lane_stats(unsigned long long *out, int reset) {
   HIP_TRY(hipDeviceSynchronize());
@@ -675,23 +692,40 @@ int mchap_debug_lane_stats(unsigned long long *out, int reset) {
   return MCHAP_OK;
 }
 #endif
+#endif
 
-/* measurement aid (tools/pipe_records.py; not declared in mchap_hip.h): the phased sampler's hand-over records and
- * round counters as the last fit on this workspace left them.  records: [n_units * chains] PipeState (128 bytes each),
- * counts: [8] int32. */
+#ifdef MCHAP_TEST_KERNELS
+/* test library only (tools/pipe_records.py, tests): the phased sampler's hand-over records and round counters as the
+ * last fit on this workspace left them.  records: [n_units * chains] PipeState (128 bytes each), counts: [8] int32. */
 int mchap_debug_pipe_records(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host, const void *workspace,
                              void *records, int32_t *counts) {
   BatchDims B;
   if (batch_dims(cfg, n_units, units_host, B)) return MCHAP_ERR_BAD_ARG;
-  const int rpl = simt_rpl(cfg, B.uniform_ploidy, B.max_pos, B.max_reads);
-  if (rpl < 0 || !pipe_supported(cfg, B.uniform_ploidy, B.max_pos)) return fail(MCHAP_ERR_BAD_ARG, "not a phased-sampler batch");
-  const SimtCarve cv = simt_carve(cfg, n_units, B, 64 * rpl, cfg->llk_cache ? CACHE_SLOTS : 0);
+  const Tune T = tune_of(cfg);
+  Plan pl;
+  if (plan_sampler(cfg, T, B, pl) || pl.kind != SAMPLER_PIPE) return fail(MCHAP_ERR_BAD_ARG, "not a phased-sampler batch");
+  const SimtCarve cv = simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, cfg->llk_cache ? T.cache_slots : 0);
   const unsigned char *ws = reinterpret_cast<const unsigned char *>(workspace) + break_table_bytes(cfg);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(records, ws + cv.pipe_state, (size_t)n_units * cfg->chains * sizeof(mchap::PipeState), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(counts, ws + cv.pipe_counts, (PIPE_MAX_ROUNDS + 2) * 4, hipMemcpyDeviceToHost));
   return MCHAP_OK;
 }
+/* ... and the chains' interval tables [n_units * chains][2][max_pos (max_pos + 1) / 2] float64 (NaN: not evaluated,
+ * -1: the step has no options, else the total move probability) */
+int mchap_debug_pipe_memo(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host, const void *workspace, double *memo) {
+  BatchDims B;
+  if (batch_dims(cfg, n_units, units_host, B)) return MCHAP_ERR_BAD_ARG;
+  const Tune T = tune_of(cfg);
+  Plan pl;
+  if (plan_sampler(cfg, T, B, pl) || pl.kind != SAMPLER_PIPE) return fail(MCHAP_ERR_BAD_ARG, "not a phased-sampler batch");
+  const SimtCarve cv = simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, cfg->llk_cache ? T.cache_slots : 0);
+  const unsigned char *ws = reinterpret_cast<const unsigned char *>(workspace) + break_table_bytes(cfg);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(memo, ws + cv.pipe_memo, (size_t)n_units * cfg->chains * 2 * mchap::spec_memo_entries(B.max_pos) * 8, hipMemcpyDeviceToHost));
+  return MCHAP_OK;
+}
+#endif
 
 int mchap_device_count(void) {
   int n = 0;
@@ -709,15 +743,16 @@ int64_t mchap_denovo_lds_bytes(int n_reads, int n_pos, int max_allele, int ploid
 
 int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host) {
   if (!cfg || n_units <= 0) return 0;
-  const int slots = cfg->llk_cache ? CACHE_SLOTS : 0;
+  const Tune T = tune_of(cfg);
+  const int slots = cfg->llk_cache ? T.cache_slots : 0;
   const int64_t bt = (int64_t)break_table_bytes(cfg);
   if (!use_simt(cfg)) return bt + (int64_t)n_units * cfg->chains * slots * 16;
   if (!units_host) return -1;
   BatchDims B;
   if (batch_dims(cfg, n_units, units_host, B)) return -1;
-  const int rpl = simt_rpl(cfg, B.uniform_ploidy, B.max_pos, B.max_reads);
-  if (rpl < 0) return -1;
-  return bt + (int64_t)simt_carve(cfg, n_units, B, 64 * rpl, slots).total;
+  Plan pl;
+  if (plan_sampler(cfg, T, B, pl)) return -1;
+  return bt + (int64_t)simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, slots).total;
 }
 
 static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
@@ -767,8 +802,11 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
   BatchDims B;
   rc = batch_dims(cfg, n_units, units_host, B);
   if (rc) return rc;
-  const int rpl = use_simt(cfg) ? simt_rpl(cfg, B.uniform_ploidy, B.max_pos, B.max_reads) : rpl_for(B.max_reads);
-  if (rpl < 0) return fail(MCHAP_ERR_LIMIT, "n_reads %d: the sampler kernel for this batch takes 1..%d reads", B.max_reads, (use_simt(cfg) && B.uniform_ploidy > 0 && spec_group(B.uniform_ploidy, B.max_pos)) ? MCHAP_MAX_READS : 1024);
+  const Tune T = tune_of(cfg);
+  Plan pl;
+  rc = plan_sampler(cfg, T, B, pl);
+  if (rc) return rc;
+  const int rpl = pl.rpl;
   const int rpad = 64 * rpl;
 
   mchap::SimtParams SP;
@@ -819,16 +857,16 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
   P.cache_slots = 0;
 
   if (use_simt(cfg)) {
-    const int want_slots = cfg->llk_cache ? CACHE_SLOTS : 0;
+    const int want_slots = cfg->llk_cache ? T.cache_slots : 0;
     int slots = want_slots;
-    SimtCarve cv = simt_carve(cfg, n_units, B, rpad, slots);
+    SimtCarve cv = simt_carve(cfg, pl, n_units, B, rpad, slots);
     while (slots >= 32 && (int64_t)cv.total > workspace_bytes) {
       slots >>= 1;
-      cv = simt_carve(cfg, n_units, B, rpad, slots);
+      cv = simt_carve(cfg, pl, n_units, B, rpad, slots);
     }
     if (slots < 32 && want_slots) {
       slots = 0;
-      cv = simt_carve(cfg, n_units, B, rpad, 0);
+      cv = simt_carve(cfg, pl, n_units, B, rpad, 0);
     }
     if (!workspace || (int64_t)cv.total > workspace_bytes)
       return fail(MCHAP_ERR_BAD_ARG, "workspace of %lld bytes is too small: kernel %d needs at least %zu (mchap_denovo_workspace_bytes)",
@@ -837,7 +875,12 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     if (slots > 0) {
       P.cache = reinterpret_cast<uint64_t *>(ws + cv.cache);
       P.cache_slots = slots;
+      // (the words of wide genotypes need no clearing: they are only read behind a matching tag)
       HIP_TRY(hipMemsetAsync(ws + cv.cache, 0, (size_t)n_units * cfg->chains * slots * 16, stream));
+      if (cv.key_words) {
+        P.cache_keys = reinterpret_cast<uint64_t *>(ws + cv.ckeys);
+        P.cache_key_words = cv.key_words;
+      }
     }
     SP.rt = reinterpret_cast<double *>(ws + cv.rt);
     SP.cntw = reinterpret_cast<double *>(ws + cv.cntw);
@@ -855,15 +898,14 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.max_ploidy = B.max_ploidy;
     SP.max_ma = B.max_ma;
     SP.cstride = code_stride(rpl);
-    SP.flags = 0;
-    if (const char *e = std::getenv("MCHAP_HIP_FLAGS")) SP.flags = std::atoi(e);
+    SP.flags = T.flags & 63;
     // the prepare pass keeps the transposed table in LDS when it fits, else it re-reads its own global copy
     SP.max_ugens_pad = (B.max_ugens + 8) & ~7;
     const size_t lds_dict = (size_t)mchap::DICT_HASH * (8 + 2) + 64;  // hash set of the dictionary pass
     size_t lds_prep = (size_t)B.max_ma * rpad * 8 + (size_t)SP.max_ugens_pad * 8 + lds_dict;
     // (an LDS copy of more than a few KB costs the prepare pass its occupancy: one wavefront per workgroup)
     SP.prep_rows_off = 0;
-    if (lds_prep > 160 * 1024 || (size_t)B.max_ma * rpad * 8 > (size_t)prep_lds_copy_limit()) {
+    if (lds_prep > 160 * 1024 || (size_t)B.max_ma * rpad * 8 > T.prep_lds_limit) {
       lds_prep = (size_t)SP.max_ugens_pad * 8 + lds_dict;
       lds_prep = (lds_prep + 15) & ~(size_t)15;
       SP.prep_rows_off = (int)lds_prep;  // the rows of one position: [max_allele][rpad] float64
@@ -890,30 +932,19 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
       default: rc = launch_prepare<64>(SP, n_units, lds_prep, stream); break;
     }
     if (rc) return rc;
-    if (cfg->kernel == 4 && B.uniform_ploidy > 0 && lane_supported(B.uniform_ploidy, B.max_pos, cfg->n_temps))
-      return launch_lane(B.uniform_ploidy, SP, n_units, cfg->chains, stream);
-    if (pipe_supported(cfg, B.uniform_ploidy, B.max_pos))
-      return launch_pipe(B.uniform_ploidy, SP, n_units, cfg->chains, reinterpret_cast<int32_t *>(ws + cv.pipe_lists),
-                         reinterpret_cast<int32_t *>(ws + cv.pipe_counts), stream);
-    // default: the speculative sampler when every unit shares a supported ploidy, else lanes over chains
-    if (cfg->kernel != 2) {
-      const int K = B.uniform_ploidy;
-      const int g = K > 0 ? spec_group(K, B.max_pos) : 0;
-      const int T = cfg->n_temps;
-      if (g) {
-        return launch_spec(K, g, SP, n_units, cfg->chains, T, stream);
-      }
-    }
-    // a launch whose units share one ploidy runs the kernel specialised for it
-    switch (B.uniform_ploidy) {
-      case 2: return launch_simt(2, SP, n_units, cfg->chains, lds_simt, stream);
-      case 4: return launch_simt(4, SP, n_units, cfg->chains, lds_simt, stream);
-      case 6: return launch_simt(6, SP, n_units, cfg->chains, lds_simt, stream);
-      case 8: return launch_simt(8, SP, n_units, cfg->chains, lds_simt, stream);
-      default: return launch_simt(0, SP, n_units, cfg->chains, lds_simt, stream);
+    switch (pl.kind) {
+#ifdef MCHAP_TEST_KERNELS
+      case SAMPLER_LANE: return launch_lane(T, pl.K, SP, n_units, cfg->chains, cfg->timer, stream);
+#endif
+      case SAMPLER_PIPE:
+        return launch_pipe(T, pl.K, pl.G, SP, n_units, cfg->chains, reinterpret_cast<int32_t *>(ws + cv.pipe_lists),
+                           reinterpret_cast<int32_t *>(ws + cv.pipe_counts), cfg->timer, stream);
+      case SAMPLER_SPEC: return launch_spec(T, pl.K, pl.G, SP, n_units, cfg->chains, cfg->n_temps, cfg->timer, stream);
+      default: return launch_simt(pl.K, SP, n_units, cfg->chains, lds_simt, cfg->timer, stream);  // lanes over chains
     }
   }
 
+#ifdef MCHAP_TEST_KERNELS
   // ---- kernel 1: wavefront per chain, reads staged in LDS ----
   size_t lds = 0;
   for (int u = 0; u < n_units; u++) {
@@ -927,7 +958,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     return fail(MCHAP_ERR_LIMIT, "a unit needs %zu bytes of LDS (> 160 KiB): dense float64 staging does not fit", lds);
   if (cfg->llk_cache && workspace && workspace_bytes > 0) {
     const int64_t rows = (int64_t)n_units * cfg->chains;
-    int slots = CACHE_SLOTS;
+    int slots = T.cache_slots;
     while (slots >= 16 && rows * slots * 16 > workspace_bytes) slots >>= 1;
     if (slots >= 16) {
       P.cache = reinterpret_cast<uint64_t *>(workspace);
@@ -935,14 +966,10 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
       HIP_TRY(hipMemsetAsync(workspace, 0, (size_t)(rows * slots * 16), stream));
     }
   }
-  switch (rpl) {
-    case 1: return launch_denovo(1, P, n_units, cfg->chains, lds, stream);
-    case 2: return launch_denovo(2, P, n_units, cfg->chains, lds, stream);
-    case 4: return launch_denovo(4, P, n_units, cfg->chains, lds, stream);
-    case 8: return launch_denovo(8, P, n_units, cfg->chains, lds, stream);
-    case 16: return launch_denovo(16, P, n_units, cfg->chains, lds, stream);
-  }
-  return fail(MCHAP_ERR_LIMIT, "unsupported reads-per-lane");
+  return launch_denovo(rpl, P, n_units, cfg->chains, lds, cfg->timer, stream);
+#else
+  return fail(MCHAP_ERR_BAD_ARG, "kernel 1 is only built into libmchap_hip_test.so");
+#endif
 }
 
 int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units, const double *reads,
@@ -958,6 +985,8 @@ int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap
   DevBuf d_units, d_reads, d_counts, d_nal, d_init, d_trace, d_llk, d_fixed, d_status, d_ws;
   const int64_t ws_bytes = mchap_denovo_workspace_bytes(cfg, n_units, units);
   if (ws_bytes < 0) return fail(MCHAP_ERR_LIMIT, "unsupported unit shape");
+  HostCall hc;
+  MCHAP_TRY(hc.open());
   if (ws_bytes > 0) HIP_TRY(hipMalloc(&d_ws.p, (size_t)ws_bytes));
   HIP_TRY(hipMalloc(&d_units.p, sizeof(mchap_unit) * n_units));
   HIP_TRY(hipMalloc(&d_reads.p, sizeof(double) * (size_t)reads_len));
@@ -966,28 +995,30 @@ int mchap_denovo_fit_batch(const mchap_denovo_cfg *cfg, int n_units, const mchap
   HIP_TRY(hipMalloc(&d_llk.p, sizeof(double) * (size_t)llks_len));
   HIP_TRY(hipMalloc(&d_fixed.p, (size_t)fixed_len));
   HIP_TRY(hipMalloc(&d_status.p, sizeof(int32_t) * n_units));
-  HIP_TRY(hipMemcpy(d_units.p, units, sizeof(mchap_unit) * n_units, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_reads.p, reads, sizeof(double) * (size_t)reads_len, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_nal.p, n_alleles, (size_t)nalleles_len, hipMemcpyHostToDevice));
+  MCHAP_TRY(hc.up(d_units.p, units, sizeof(mchap_unit) * n_units));
+  MCHAP_TRY(hc.up(d_reads.p, reads, sizeof(double) * (size_t)reads_len));
+  MCHAP_TRY(hc.up(d_nal.p, n_alleles, (size_t)nalleles_len));
   if (read_counts && counts_len > 0) {
     HIP_TRY(hipMalloc(&d_counts.p, sizeof(int64_t) * (size_t)counts_len));
-    HIP_TRY(hipMemcpy(d_counts.p, read_counts, sizeof(int64_t) * (size_t)counts_len, hipMemcpyHostToDevice));
+    MCHAP_TRY(hc.up(d_counts.p, read_counts, sizeof(int64_t) * (size_t)counts_len));
   }
   if (initial && initial_len > 0) {
     HIP_TRY(hipMalloc(&d_init.p, (size_t)initial_len));
-    HIP_TRY(hipMemcpy(d_init.p, initial, (size_t)initial_len, hipMemcpyHostToDevice));
+    MCHAP_TRY(hc.up(d_init.p, initial, (size_t)initial_len));
   }
   rc = mchap_denovo_fit_batch_device(cfg, n_units, d_units.as<mchap_unit>(), units, d_reads.as<double>(),
                                      d_counts.as<int64_t>(), d_nal.as<int8_t>(), d_init.as<int8_t>(),
                                      d_trace.as<uint64_t>(), d_llk.as<double>(), d_fixed.as<int8_t>(),
-                                     d_status.as<int32_t>(), d_ws.p, ws_bytes, nullptr);
-  if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(trace_words, d_trace.p, sizeof(uint64_t) * (size_t)trace_len, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(llks, d_llk.p, sizeof(double) * (size_t)llks_len, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(fixed_alleles, d_fixed.p, (size_t)fixed_len, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(status, d_status.p, sizeof(int32_t) * n_units, hipMemcpyDeviceToHost));
-  return MCHAP_OK;
+                                     d_status.as<int32_t>(), d_ws.p, ws_bytes, hc.stream);
+  if (rc) {
+    (void)hipStreamSynchronize(hc.stream);
+    return rc;
+  }
+  MCHAP_TRY(hc.down(trace_words, d_trace.p, sizeof(uint64_t) * (size_t)trace_len));
+  MCHAP_TRY(hc.down(llks, d_llk.p, sizeof(double) * (size_t)llks_len));
+  MCHAP_TRY(hc.down(fixed_alleles, d_fixed.p, (size_t)fixed_len));
+  MCHAP_TRY(hc.down(status, d_status.p, sizeof(int32_t) * n_units));
+  return hc.sync();
 }
 
 int mchap_log_likelihood_batch(const double *reads, int n_reads, int n_pos, int max_allele, const int64_t *read_counts,
@@ -1002,22 +1033,24 @@ int mchap_log_likelihood_batch(const double *reads, int n_reads, int n_pos, int 
   const size_t lds = (size_t)n_pos * max_allele * 64 * rpl * 8 + 4 * (8 * ploidy + 4 * n_pos + 64);
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "unit needs %zu bytes of LDS", lds);
   DevBuf d_reads, d_counts, d_g, d_out;
+  HostCall hc;
+  MCHAP_TRY(hc.open());
   const size_t nr = (size_t)n_reads * n_pos * max_allele;
   HIP_TRY(hipMalloc(&d_reads.p, nr * 8));
-  HIP_TRY(hipMemcpy(d_reads.p, reads, nr * 8, hipMemcpyHostToDevice));
+  MCHAP_TRY(hc.up(d_reads.p, reads, nr * 8));
   if (read_counts) {
     HIP_TRY(hipMalloc(&d_counts.p, (size_t)n_reads * 8));
-    HIP_TRY(hipMemcpy(d_counts.p, read_counts, (size_t)n_reads * 8, hipMemcpyHostToDevice));
+    MCHAP_TRY(hc.up(d_counts.p, read_counts, (size_t)n_reads * 8));
   }
   const size_t ng = (size_t)n_genotypes * ploidy * n_pos;
   HIP_TRY(hipMalloc(&d_g.p, ng));
-  HIP_TRY(hipMemcpy(d_g.p, genotypes, ng, hipMemcpyHostToDevice));
+  MCHAP_TRY(hc.up(d_g.p, genotypes, ng));
   HIP_TRY(hipMalloc(&d_out.p, (size_t)n_genotypes * 8));
   const int blocks = n_genotypes < 1024 ? (n_genotypes + 3) / 4 : 256;
   auto go = [&](auto kern) -> int {
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_reads.as<double>(), n_reads, n_pos, max_allele,
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, hc.stream, d_reads.as<double>(), n_reads, n_pos, max_allele,
                        d_counts.as<int64_t>(), d_g.as<int8_t>(), n_genotypes, ploidy, 64 * rpl, d_out.as<double>());
     HIP_TRY(hipGetLastError());
     return MCHAP_OK;
@@ -1030,9 +1063,28 @@ int mchap_log_likelihood_batch(const double *reads, int n_reads, int n_pos, int 
     default: rc = go(mchap::llk_batch_kernel<16>); break;
   }
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(llks_out, d_out.p, (size_t)n_genotypes * 8, hipMemcpyDeviceToHost));
-  return MCHAP_OK;
+  MCHAP_TRY(hc.down(llks_out, d_out.p, (size_t)n_genotypes * 8));
+  return hc.sync();
+}
+
+/* Test hook: read_log (csrc/read_log.hpp), the logarithm every likelihood kernel takes of its per-read terms, for n
+ * arguments.  Host pointers. */
+int mchap_read_log_batch(const double *x, int64_t n, double *out) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (n <= 0) return MCHAP_OK;
+  if (!x || !out) return fail(MCHAP_ERR_BAD_ARG, "NULL buffer");
+  DevBuf d_x, d_o;
+  HostCall hc;
+  MCHAP_TRY(hc.open());
+  HIP_TRY(hipMalloc(&d_x.p, (size_t)n * 8));
+  HIP_TRY(hipMalloc(&d_o.p, (size_t)n * 8));
+  MCHAP_TRY(hc.up(d_x.p, x, (size_t)n * 8));
+  hipLaunchKernelGGL(mchap::read_log_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, hc.stream,
+                     d_x.as<double>(), (long long)n, d_o.as<double>());
+  HIP_TRY(hipGetLastError());
+  MCHAP_TRY(hc.down(out, d_o.p, (size_t)n * 8));
+  return hc.sync();
 }
 
 #include "api_posterior_exact.inc"

@@ -47,13 +47,20 @@ extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_launch_
   return (int)hipGetLastError();
 }
 
+#endif  // SPEC_PIPE
+
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
 // profiling builds: this object's copy of the event counters
-extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_stats_, SPEC_K, SPEC_G)(unsigned long long *out, int reset) {
-  unsigned long long z[24] = {0};
+#ifdef SPEC_PIPE
+#define SPEC_STATS_NAME SPEC_CAT(mchap_specp_stats_, SPEC_K, SPEC_G)
+#else
+#define SPEC_STATS_NAME SPEC_CAT(mchap_spec_stats_, SPEC_K, SPEC_G)
+#endif
+extern "C" __attribute__((visibility("hidden"))) int SPEC_STATS_NAME(unsigned long long *out, int reset) {
+  unsigned long long z[mchap::N_STATS] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_stats), sizeof(z)) != hipSuccess) return 1;
   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(mchap::g_stats), z, sizeof(z)) != hipSuccess) return 1;
   return 0;
 }
 #endif
-#endif  // SPEC_PIPE
+

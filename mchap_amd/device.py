@@ -132,6 +132,17 @@ class DenovoDeviceBatch:
             raise NotImplementedError("mchap_hip: unsupported unit shape")
         self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
         self.post = None
+        self.sampler_name = _lib.sampler_name(self.cfg, units)
+        self.timer = None
+
+    def time_sampler(self, on=True):
+        """Bracket the sampler launches of every run() with HIP events on its stream; `sampler_ms()` reads the last span."""
+        if on and self.timer is None:
+            self.timer = _lib.SamplerTimer()
+        self.cfg.timer = self.timer.handle if (on and self.timer is not None) else None
+
+    def sampler_ms(self):
+        return -1.0 if self.timer is None else self.timer.ms()
 
     def _p(self, t):
         return None if t is None else C.c_void_p(t.data_ptr())
@@ -265,8 +276,10 @@ class ExactDeviceBatch:
         self.ws_bytes = int(_lib.lib().mchap_exact_workspace_bytes(U, H, int(ploidy)))
         if cache_joint:
             # room for llk + log prior of every genotype between the two passes of the streaming form (8 bytes each)
+            # (taken only when it fits comfortably: else the plain workspace, whose second pass forms the values again)
             big = int(_lib.lib().mchap_exact_workspace_bytes_cached(U, H, int(ploidy)))
-            if big <= (16 << 30):
+            free, _ = torch.cuda.mem_get_info()
+            if big <= min(16 << 30, free // 2):
                 self.ws_bytes = big
         self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
         self.out = {}
@@ -433,6 +446,7 @@ class DenovoRaggedBatch:
             U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), K, C.c_double(float(incongruence_threshold)),
             self._p(self.p_mci), C.c_void_p(stream)))
         self.burn = int(burn)
+        self.incongruence_threshold = float(incongruence_threshold)
 
     def results(self):
         """Per unit: dict(genotypes int8 [n, K, M] distinct states (probability descending), probabilities [n], spm, gpm,
@@ -476,7 +490,7 @@ class DenovoRaggedBatch:
                 sup = post.mode_genotype_support()
                 mg, gp = sup.mode_genotype()
                 out.append(dict(genotypes=post.genotypes, probabilities=post.probabilities, spm=float(sup.probabilities.sum()),
-                                gpm=float(gp), mode_genotype=mg, mci=int(tr.replicate_incongruence(0.6)), status=st))
+                                gpm=float(gp), mode_genotype=mg, mci=int(tr.replicate_incongruence(self.incongruence_threshold)), status=st))
                 continue
             k = int(n[u])
             out.append(dict(genotypes=unpack_trace(words[u, :k, :Ku], fx, A), probabilities=counts[u, :k] / total,

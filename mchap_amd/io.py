@@ -50,11 +50,16 @@ def read_sam(path):
     return refs, rg, recs
 
 
-def read_alignments(path):
-    """read_bam or read_sam by what the file is (BAM files are gzip streams)."""
+def read_alignments(path, id_field="SM"):
+    """read_bam or read_sam by what the file is (BAM files are gzip streams).  id_field: the read-group field that names
+    the sample, "SM" or "ID" (--read-group-field; io/bam.py:21-51)."""
+    assert id_field in ("SM", "ID")
     with open(path, "rb") as f:
         magic = f.read(2)
-    return read_bam(path) if magic == b"\x1f\x8b" else read_sam(path)
+    refs, rg, recs = read_bam(path) if magic == b"\x1f\x8b" else read_sam(path)
+    if id_field == "ID":
+        rg = {k: k for k in rg}
+    return refs, rg, recs
 
 
 def read_bam(path):
@@ -119,10 +124,31 @@ def read_bam(path):
     return refs, rg, recs
 
 
+def open_text(path):
+    """A text file that may be gzip / bgzip compressed (`.vcf.gz` inputs: a BGZF file is a multi-member gzip stream)."""
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    return gzip.open(path, "rt") if magic == b"\x1f\x8b" else open(path)
+
+
+def vcf_contigs(path):
+    """[(name, length)] of the ##contig lines of a VCF file (the header contigs of `call` / `call-exact`,
+    application/baseclass.py:86-89)."""
+    out = []
+    with open_text(path) as f:
+        for line in f:
+            if not line.startswith("##"):
+                break
+            if line.startswith("##contig=<"):
+                kv = dict(x.split("=", 1) for x in line.strip()[10:-1].split(",") if "=" in x)
+                out.append((kv.get("ID"), int(kv.get("length", 0))))
+    return out
+
+
 def read_vcf(path):
-    """-> (sample names, [record dicts]) of a VCF text file."""
+    """-> (sample names, [record dicts]) of a VCF file (plain text or gzip / bgzip compressed)."""
     samples, out = [], []
-    for line in open(path):
+    for line in open_text(path):
         line = line.rstrip("\n")
         if line.startswith("##") or not line:
             continue
@@ -161,7 +187,7 @@ def parse_allele_filter(text):
 def vcf_info_numbers(path):
     """{INFO field id: its Number} from the ##INFO lines of a VCF file."""
     out = {}
-    for line in open(path):
+    for line in open_text(path):
         if not line.startswith("##"):
             break
         if line.startswith("##INFO=<"):
@@ -227,9 +253,11 @@ class Locus:
             self.haplotypes[:, j] = [lut[c] for c in haps[:, o]]
 
 
-def extract_read_variants(locus, bam, sample, min_quality=20):
-    """io/bam.py:54-229 for one sample: chars [n_reads, n_snv] ('-' gap, 'N' conflict) and summed quals."""
+def extract_read_variants(locus, bam, sample, min_quality=20, skip_duplicates=True, skip_qcfail=True, skip_supplementary=True):
+    """io/bam.py:54-229 for one sample: chars [n_reads, n_snv] ('-' gap, 'N' conflict) and summed quals.  `bam`: what
+    read_alignments returned (its read-group table maps the group id to the sample field chosen there)."""
     _, rg, recs = bam
+    skip = (0x400 if skip_duplicates else 0) | (0x200 if skip_qcfail else 0) | (0x800 if skip_supplementary else 0)
     positions = {p: i for i, p in enumerate(locus.positions)}
     n = len(locus.positions)
     data = {}
@@ -239,7 +267,7 @@ def extract_read_variants(locus, bam, sample, min_quality=20):
         ref_len = sum(l for l, op in r["cigar"] if op in "MDN=X")
         if not (r["pos"] < locus.stop and r["pos"] + ref_len > locus.start):
             continue  # pysam fetch(contig, start, stop): overlapping reads
-        if r["mapq"] < min_quality or r["flag"] & (0x400 | 0x200 | 0x800):
+        if r["mapq"] < min_quality or r["flag"] & skip:
             continue
         if rg.get(r["rg"]) != sample:
             continue
@@ -317,6 +345,13 @@ class DenovoLocus:
         self.positions = list(snps)
         self.alleles = [snps[p] for p in self.positions]
         self.n_alleles = [len(a) for a in self.alleles]
+        if self.sequence is not None and "N" in self.sequence:
+            # a reference known by its index only (io.Reference): the variants' REF alleles at their positions
+            chars = list(self.sequence)
+            for p, tup in zip(self.positions, self.alleles):
+                if chars[p - start] == "N":
+                    chars[p - start] = tup[0]
+            self.sequence = "".join(chars)
 
     def format_haplotype(self, alleles):
         chars = list(self.sequence)
@@ -400,11 +435,16 @@ def bam_header(path):
     return refs, rg
 
 
-def sample_bam_table(bam_args):
+def sample_bam_table(bam_args, id_field="SM"):
     """--bam: (1) BAM paths, (2) a text file with one path per line, (3) a text file of `sample<TAB>path` lines
     (reference application/arguments.py:135-152, 890-955).  Returns an ordered {sample: path}: for (1) and (2) every
-    sample of every BAM's read groups."""
+    sample of every BAM's read groups (named by their `id_field`, --read-group-field)."""
     paths, table = [], {}
+
+    def groups(p):
+        rg = bam_header(p)[1]
+        return list(rg) if id_field == "ID" else list(rg.values())
+
     if len(bam_args) == 1 and not _is_bam(bam_args[0]) and not _is_sam(bam_args[0]):
         for line in open(bam_args[0]):
             f = line.rstrip("\n").split("\t")
@@ -418,17 +458,102 @@ def sample_bam_table(bam_args):
                 table[f[0]] = f[1].strip()
         if table:
             for s, p in table.items():
-                if s not in bam_header(p)[1].values():
+                if s not in groups(p):
                     raise IOError('Sample "%s" was not found in bam "%s"' % (s, p))
             return table
     else:
         paths = list(bam_args)
     for p in paths:
-        for s in dict.fromkeys(bam_header(p)[1].values()):
+        for s in dict.fromkeys(groups(p)):
             if s in table:
                 raise IOError('Duplicate input sample name "%s"' % s)
             table[s] = p
     return table
+
+
+def sample_pools(sample_bams, pool_arg):
+    """--sample-pool (application/arguments.py:848-887): None -> every sample is its own pool; a name -> one pool of all
+    samples; a file of `sample<TAB>pool` lines -> custom pools (a sample may be in several).  Returns an ordered
+    {pool: [(sample, bam path), ...]}: the pool names take the place of the sample names everywhere else."""
+    import os
+
+    if pool_arg is None:
+        return {s: [(s, p)] for s, p in sample_bams.items()}
+    if not os.path.isfile(pool_arg):
+        return {pool_arg: list(sample_bams.items())}
+    pools, seen = {}, set()
+    for line in open(pool_arg):
+        f = line.strip().split("\t")
+        if len(f) < 2:
+            continue
+        sample, pool = f[0], f[1]
+        seen.add(sample)
+        if sample not in sample_bams:
+            raise ValueError("The following names in the sample-pool file do not match a known sample : {%r}" % sample)
+        pools.setdefault(pool, []).append((sample, sample_bams[sample]))
+    missing = set(sample_bams) - seen
+    if missing:
+        raise ValueError("The following samples have not been assigned to a pool: %s" % sorted(missing))
+    return pools
+
+
+def sample_temperatures(args, samples):
+    """--mcmc-temperatures (application/arguments.py:1122-1166): a list of inverse temperatures for every sample, or a file
+    of `sample<TAB>t1<TAB>t2...` lines (samples not listed: no tempering).  Sorted, 1.0 appended when missing.
+    Returns {sample: tuple of floats}."""
+    def ladder(values):
+        temps = sorted(float(v) for v in values)
+        assert temps[0] > 0.0 and temps[-1] <= 1.0
+        if temps[-1] != 1.0:
+            temps.append(1.0)
+        return tuple(temps)
+
+    args = [str(a) for a in args]
+    if len(args) > 1 or args[0].replace(".", "", 1).isdigit():
+        t = ladder(args)
+        return {s: t for s in samples}
+    data = {s: (1.0,) for s in samples}
+    for line in open(args[0]):
+        f = line.strip().split("\t")
+        if len(f) >= 2:
+            data[f[0]] = ladder(f[1:])
+    assert len(data) == len(samples), "a sample of the temperatures file is not an input sample"
+    return data
+
+
+def parse_region(text):
+    """--region contig:start-stop (io/loci.py:161-172: the numbers are used as a 0-based half-open interval, like a BED line)."""
+    contig, interval = text.strip().split(":")
+    start, stop = interval.strip().split("-")
+    return contig, int(start), int(stop)
+
+
+class Reference:
+    """The reference genome of `mchap assemble`: contig lengths and sequence slices (io/loci.py:86-92).  From a FASTA file
+    (plain or gzip / bgzip compressed); or, when only its `.fai` index is at hand, the contig lengths with every base
+    unknown (`N`): the assembled haplotypes then carry the variants' own alleles at the SNV positions and N elsewhere."""
+
+    def __init__(self, path):
+        import os
+
+        self.path = path
+        self.known = os.path.isfile(path)
+        if self.known:
+            self.seqs = read_fasta(path)
+            self.contigs = [(n, len(q)) for n, q in self.seqs.items()]
+        else:
+            fai = path + ".fai"
+            if not os.path.isfile(fai):
+                raise IOError("reference '%s' not found (nor its index '%s')" % (path, fai))
+            self.seqs = None
+            self.contigs = [(f[0], int(f[1])) for f in (line.split("\t") for line in open(fai)) if len(f) >= 2]
+            self.lengths = dict(self.contigs)
+
+    def fetch(self, contig, start, stop):
+        if self.known:
+            return self.seqs[contig][start:stop]
+        n = self.lengths[contig]
+        return "N" * (max(0, min(stop, n) - max(0, start)))
 
 
 def _is_bam(path):

@@ -58,27 +58,18 @@ OPTIONAL_FORMAT_FIELDS = {
 
 
 def report_fields(report):
-    """--report arguments -> (optional INFO ids, optional FORMAT ids) in their header order.  A bare name asks for both
-    variants of the field; an `INFO/` or `FORMAT/` prefix for one (reference application/arguments.py:405-426)."""
-    info, fmt = [], []
-    for name in report:
-        if name.startswith("INFO/"):
-            info.append(name[5:])
-        elif name.startswith("FORMAT/"):
-            fmt.append(name[7:])
-        else:
-            if name in OPTIONAL_INFO_FIELDS:
-                info.append(name)
-            if name in OPTIONAL_FORMAT_FIELDS:
-                fmt.append(name)
-    if "AOP" in info and "AOPSUM" not in info:
-        info.insert(info.index("AOP") + 1, "AOPSUM")
-    for x in info:
-        if x not in OPTIONAL_INFO_FIELDS:
-            raise ValueError("Unknown INFO field to report: %s" % x)
-    for x in fmt:
-        if x not in OPTIONAL_FORMAT_FIELDS:
-            raise ValueError("Unknown FORMAT field to report: %s" % x)
+    """--report arguments -> (optional INFO ids, optional FORMAT ids).  A bare name asks for both variants of the field; an
+    `INFO/` or `FORMAT/` prefix for one.  Whatever the order of the arguments, the fields come out in the order of the
+    reference's field tables (io/vcf/infofields.py:125, formatfields.py:157; application/arguments.py:1169-1185) -- which is
+    the order of the header lines and of the INFO / FORMAT columns.  Unknown names are an error (the reference ignores them)."""
+    asked = set(report or ())
+    for name in asked:
+        base = name.split("/", 1)[1] if name.startswith(("INFO/", "FORMAT/")) else name
+        ok = (base in OPTIONAL_INFO_FIELDS and not name.startswith("FORMAT/")) or (base in OPTIONAL_FORMAT_FIELDS and not name.startswith("INFO/"))
+        if not ok:
+            raise ValueError("Unknown %s field to report: %s" % ("INFO" if name.startswith("INFO/") else "FORMAT" if name.startswith("FORMAT/") else "INFO/FORMAT", name))
+    info = [f for f in OPTIONAL_INFO_FIELDS if f in asked or "INFO/" + f in asked]
+    fmt = [f for f in OPTIONAL_FORMAT_FIELDS if f in asked or "FORMAT/" + f in asked]
     return info, fmt
 
 

@@ -38,5 +38,5 @@ def call_record(rec, bams, sample_names, calling=None, **kw):
 
 def sample_reads(locus, bam, sample, error_rate=0.0024):
     """-> (calls, distinct read distributions, counts)"""
-    sr = _sample_reads(locus, bam, sample, error_rate)
+    sr = _sample_reads(locus, [(sample, bam)], error_rate)
     return sr["calls"], sr["dists"], sr["counts"]

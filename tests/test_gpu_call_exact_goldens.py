@@ -16,7 +16,7 @@ SCENARIOS = [
     ("simple.output.mixed_depth.assemble.vcf", MIXED, dict(report=("SNVDP",)), "simple.output.mixed_depth.call-exact.vcf"),
     ("simple.output.mixed_depth.assemble.vcf", MIXED, dict(report=("AFP",)), "simple.output.mixed_depth.call-exact.frequencies.vcf"),
     ("simple.output.mixed_depth.assemble.vcf", MIXED, dict(report=("ACP",)), "simple.output.mixed_depth.call-exact.counts.vcf"),
-    ("simple.output.mixed_depth.assemble.vcf", MIXED, dict(report=("AOP",)), "simple.output.mixed_depth.call-exact.occurrence.vcf"),
+    ("simple.output.mixed_depth.assemble.vcf", MIXED, dict(report=("AOP", "AOPSUM")), "simple.output.mixed_depth.call-exact.occurrence.vcf"),
     ("simple.output.mixed_depth.assemble.vcf", MIXED, dict(report=("GL",), error_rate=0.0, use_phred=True),
      "simple.output.mixed_depth.call-exact.likelihoods.vcf"),
     ("simple.output.mixed_depth.assemble.vcf", MIXED, dict(report=("GP",)), "simple.output.mixed_depth.call-exact.posteriors.vcf"),

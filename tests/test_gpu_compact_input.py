@@ -40,8 +40,10 @@ def test_calls_input_equals_tensor_input(use_quals, n_alleles):
     assert np.array_equal(la, lb, equal_nan=True)
 
 
-def test_calls_input_needs_the_prepare_pass():
+def test_calls_input_needs_the_prepare_pass(monkeypatch):
     from mchap_amd import DenovoMCMC
+
+    monkeypatch.setenv("MCHAP_HIP_TEST_KERNELS", "1")  # kernel 1 lives in the parity suite's library
     from mchap_amd.device import DenovoDeviceBatch
 
     calls = np.zeros((1, 8, 3), dtype=np.int8)

@@ -100,38 +100,106 @@ def test_config4_likelihood_and_posterior_arrays_full_size():
         np.testing.assert_allclose(ap.sum(), mode[3], rtol=1e-6)
 
 
-@pytest.mark.parametrize("variant", ["four_chains", "tempered"])
-def test_config5_full_shape(variant, monkeypatch):
-    """configs[4]: K = 8, 20 SNVs, 1000 reads; 4 parallel chains, and the one-chain four-temperature variant.  25 steps
-    of every chain step for step against the oracle (the speculative kernel with three sub-steps per lane, and the
-    lanes-over-chains kernel)."""
-    from mchap_amd import DenovoMCMC
+def _config5_oracle(reads, steps, chains, temperatures, seed):
     from mchap_amd.classes import sort_haplotypes
-    from mchap_amd.synth import synth_units
     from tests.helpers import beta_break_table
 
-    reads, _, _ = synth_units(2, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20), first_unit=77)
-    if variant == "four_chains":
-        kw = dict(chains=4, temperatures=(1.0,))
-    else:
-        kw = dict(chains=1, temperatures=(0.001, 0.01, 0.1, 1.0))
-    ref = None
-    for kernel in (3, 2):
+    ref = []
+    for u, rd in enumerate(reads):
+        # (the oracle's llk cache is the reference's own: same values, a quarter of the time at this shape)
+        cfg = orc.make_cfg(8, steps, chains, None, temperatures, llk_cache_threshold=100, rng_kind=orc.RNG_PHILOX,
+                           seed=seed, stream_id=u, break_table=beta_break_table(20, 1.0, 3.0))
+        g, l, code = orc.denovo_fit(cfg, rd, [2] * 20)
+        assert code == 0
+        ref.append((sort_haplotypes(g), l))
+    return ref
+
+
+def test_config5_full_shape_four_chains_300_steps(monkeypatch):
+    """configs[4]: K = 8, 20 SNVs, 1000 reads, 4 parallel chains -- 300 steps of every chain step for step against the
+    oracle on the kernels the benchmark number rests on: the default dispatch (0), the phased sampler named explicitly (5)
+    and the speculative kernel (3).  The window holds the hand-over at step 16, four coasting sweeps of 64 steps and, for
+    the second unit (200 reads of base quality 5..15: its chains move 7-25 times in these 300 steps, the last time after
+    step 230), hand-backs, resume rounds and a second table completion."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    clean, _, _ = synth_units(1, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20), first_unit=77)
+    noisy, _, _ = synth_units(1, ploidy=8, n_pos=20, n_reads=200, window=(8, 20), first_unit=78, qual=(5, 15))
+    reads = [clean[0], noisy[0]]
+    kw = dict(chains=4, temperatures=(1.0,))
+    ref = _config5_oracle(reads, 300, 4, (1.0,), 11)
+    moves = [int((np.diff(ref[u][1], axis=1) != 0).sum()) for u in range(2)]
+    late = int(max(np.flatnonzero(np.diff(ref[1][1], axis=1).any(axis=0))))
+    assert moves[1] >= 12 and late > 150, (moves, late)  # the noisy unit does exercise the hand-back path
+    for kernel in (0, 5, 3):
         monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
-        model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=25, random_seed=11, **kw)
-        traces = model.fit_batch(list(reads))
-        if ref is None:
-            ref = []
-            for u in range(len(reads)):
-                cfg = orc.make_cfg(8, 25, kw["chains"], None, kw["temperatures"], llk_cache_threshold=-1, rng_kind=orc.RNG_PHILOX,
-                                   seed=11, stream_id=u, break_table=beta_break_table(20, 1.0, 3.0))
-                g, l, code = orc.denovo_fit(cfg, reads[u], [2] * 20)
-                assert code == 0
-                ref.append((sort_haplotypes(g), l))
+        model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=300, random_seed=11, **kw)
+        traces = model.fit_batch(reads)
+        assert ("phased" in model.last_sampler) == (kernel != 3), model.last_sampler
         for u, tr in enumerate(traces):
-            assert tr.genotypes.shape == (kw["chains"], 25, 8, 20)
+            assert tr.genotypes.shape == (4, 300, 8, 20)
             assert np.array_equal(tr.genotypes, ref[u][0]), "kernel %d unit %d" % (kernel, u)
             np.testing.assert_allclose(tr.llks, ref[u][1], rtol=1e-10)
+
+
+def test_config5_full_shape_tempered(monkeypatch):
+    """configs[4]'s secondary variant: one chain under the temperature ladder (0.001, 0.01, 0.1, 1.0), 25 steps
+    step for step against the oracle: the speculative kernel with three sub-steps per lane (which is also what the default
+    dispatch selects for a ladder) and the lanes-over-chains kernel."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    reads, _, _ = synth_units(2, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20), first_unit=77)
+    temps = (0.001, 0.01, 0.1, 1.0)
+    ref = _config5_oracle(list(reads), 25, 1, temps, 11)
+    for kernel in (3, 2, 0):
+        monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
+        model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=25, random_seed=11, chains=1, temperatures=temps)
+        traces = model.fit_batch(list(reads))
+        for u, tr in enumerate(traces):
+            assert tr.genotypes.shape == (1, 25, 8, 20)
+            assert np.array_equal(tr.genotypes, ref[u][0]), "kernel %d unit %d" % (kernel, u)
+            np.testing.assert_allclose(tr.llks, ref[u][1], rtol=1e-10)
+
+
+def test_config2_default_dispatch_1000_steps_against_the_oracle(monkeypatch):
+    """BASELINE.json configs[1] as benchmarked: tetraploid, 8 SNVs, 200 reads, 1000 steps x 2 chains through the library's
+    DEFAULT dispatch (the phased sampler: first phase, table completion, coasting, resume rounds) -- every step of every
+    chain of 64 loci against the oracle on the same Philox streams; the device-side posterior summary (mode genotype,
+    GPM, SPM) against the reference's classes on the oracle's trace."""
+    import torch
+
+    from mchap_amd import DenovoMCMC, GenotypeMultiTrace
+    from mchap_amd.assemble import break_table, unpack_trace
+    from mchap_amd.classes import sort_haplotypes
+    from mchap_amd.device import DenovoDeviceBatch
+    from mchap_amd.synth import synth_units
+
+    monkeypatch.delenv("MCHAP_HIP_KERNEL", raising=False)
+    U = 64
+    reads, _, _ = synth_units(U)
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=1000, chains=2, random_seed=42)
+    batch = DenovoDeviceBatch(model, reads)
+    assert "phased" in batch.sampler_name and "coast" in batch.sampler_name
+    batch.run()
+    batch.posterior(500)
+    torch.cuda.synchronize()
+    words, fixed, llks, status = batch.traces()
+    assert (status == 0).all()
+    cfg = orc.make_cfg(4, 1000, 2, None, (1.0,), llk_cache_threshold=100, seed=42, rng_kind=orc.RNG_PHILOX,
+                       break_table=break_table(8, 1.0, 3.0))
+    g, l, code, _ = orc.denovo_fit_batch(cfg, reads, [2] * 8, n_threads=0, keep_traces=True)
+    assert code == 0
+    post = batch.posterior_host()
+    for u in range(U):
+        ref = sort_haplotypes(g[u])
+        assert np.array_equal(batch.genotypes(u, words, fixed), ref), "unit %d" % u
+        np.testing.assert_allclose(llks[u], l[u], rtol=1e-10)
+        sup = GenotypeMultiTrace._from_sorted(ref, l[u]).burn(500).posterior().mode_genotype_support()
+        mg, gpm = sup.mode_genotype()
+        assert np.array_equal(unpack_trace(post["mode_words"][u][None], fixed[u], 2)[0], mg)
+        assert abs(post["stats"][u][1] - gpm) < 1e-12 and abs(post["stats"][u][0] - sup.probabilities.sum()) < 1e-12
 
 
 def test_config4_call_exact_arrays_batched_on_the_device():

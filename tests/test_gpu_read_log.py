@@ -1,0 +1,64 @@
+"""GPU test of read_log (mchap_amd/csrc/read_log.hpp), the logarithm every likelihood kernel takes of its per-read terms
+(assemble/likelihood.py:54-59: log of the mean haplotype probability of a read).  The kernels' parity tolerance on
+log-likelihoods (1e-10 relative) only bounds it indirectly; this pins it directly: within one unit in the last place of
+numpy's float64 log (and below one ulp of the long-double value) over 10^6 arguments, including subnormals, the values a
+likelihood actually sees (products of a few probabilities), exact powers of two, 0, negatives and NaN."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _read_log(x):
+    from mchap_amd import _lib
+
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    _lib.check(_lib.lib().mchap_read_log_batch(_lib.ptr(x), C.c_int64(x.size), _lib.ptr(out)))
+    return out
+
+
+def _ulps(a, b):
+    """distance in representable doubles between a and b (same sign, finite)"""
+    ia, ib = a.view(np.int64), b.view(np.int64)
+    return np.abs(ia - ib)
+
+
+def test_read_log_within_one_ulp_of_float64_log():
+    rng = np.random.default_rng(7)
+    parts = [
+        rng.random(300_000),                                   # (0, 1): single probabilities
+        np.exp(rng.uniform(-700.0, 700.0, 200_000)),           # the whole exponent range
+        rng.random(150_000) * rng.random(150_000) * rng.random(150_000) / 4.0 + rng.random(150_000) / 4.0,  # means of products
+        1.0 + rng.uniform(-1e-3, 1e-3, 100_000),               # around 1: cancellation in f = m - 1
+        np.ldexp(rng.random(100_000), rng.integers(-1074, -1021, 100_000)),  # subnormals and the smallest normals
+        np.ldexp(1.0, np.arange(-1074, 1024)).astype(np.float64),            # exact powers of two
+        np.sqrt(0.5) * (1.0 + rng.uniform(-1e-12, 1e-12, 50_000)),           # the reduction's branch point
+        np.array([np.nextafter(1.0, 0.0), 1.0, np.nextafter(1.0, 2.0), np.finfo(np.float64).tiny, np.finfo(np.float64).max, 5e-324]),
+    ]
+    x = np.concatenate(parts)
+    x = x[x > 0]
+    assert x.size >= 1_000_000
+    got = _read_log(x)
+    ref = np.log(x)
+    assert np.isfinite(got).all()
+    both_zero = (got == 0) & (ref == 0)
+    d = _ulps(got, ref)
+    d[both_zero] = 0
+    assert d.max() <= 1, "max distance %d ulp at x = %r" % (d.max(), x[int(np.argmax(d))])
+    # ... and below one ulp of the true value (long double on the host: 64-bit significand)
+    sub = rng.choice(x.size, 200_000, replace=False)
+    true = np.log(x[sub].astype(np.longdouble))
+    err = np.abs(got[sub].astype(np.longdouble) - true) / np.spacing(np.abs(ref[sub])).astype(np.longdouble)
+    err = err[np.abs(ref[sub]) > 0]
+    assert float(err.max()) < 1.0, float(err.max())
+    assert (d == 0).mean() > 0.9  # (it is the correctly rounded value for most arguments)
+
+
+def test_read_log_special_values():
+    got = _read_log(np.array([0.0, -0.0, -1.0, -np.inf, np.nan, -5e-324, 1.0]))
+    assert got[0] == -np.inf and got[1] == -np.inf      # log(0) = -inf: a read no haplotype explains
+    assert np.isnan(got[2:6]).all()
+    assert got[6] == 0.0

@@ -38,7 +38,7 @@ def test_read_matrices_of_the_reference_test(ext):
     # the allele calls the application derives from them (encode_sample_reads, application/baseclass.py:140-210)
     from mchap_amd.application import sample_reads
 
-    sr = sample_reads(_locus(), bam, "SAMPLE1")
+    sr = sample_reads(_locus(), [("SAMPLE1", bam)])
     np.testing.assert_array_equal(sr["calls"], EXPECT_CALLS)
     np.testing.assert_array_equal(sr["depth"], (EXPECT_CHARS != "-").sum(axis=0))
     assert int(sr["counts"].sum()) == len(EXPECT_CHARS)

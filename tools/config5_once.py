@@ -12,11 +12,10 @@ reads, _, _ = synth_units(U, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20), f
 cache = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=2000, chains=4, random_seed=42, llk_cache_threshold=cache)
 b = DenovoDeviceBatch(model, reads)
-L = _lib.lib()
-L.mchap_set_profiling(1)
+b.time_sampler(True)
 for _ in range(reps):
     t = time.perf_counter()
     b.run()
     torch.cuda.synchronize()
-    print("%s  %.1f ms sampler, %.1f ms wall -> %.1f loci/s  %s" % (L.mchap_last_sampler_name().decode(), L.mchap_last_sampler_ms(), (time.perf_counter() - t) * 1e3, U / (time.perf_counter() - t),
+    print("%s  %.1f ms sampler, %.1f ms wall -> %.1f loci/s  %s" % (b.sampler_name, b.sampler_ms(), (time.perf_counter() - t) * 1e3, U / (time.perf_counter() - t),
                                                          {k: v for k, v in os.environ.items() if k.startswith("MCHAP_HIP_")}), flush=True)

@@ -10,8 +10,6 @@ from mchap_amd.synth import synth_units
 
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-L = _lib.lib()
-L.mchap_set_profiling(0)
 reads, _, _ = synth_units(U)
 model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=1000, chains=2, random_seed=42)
 ref = None

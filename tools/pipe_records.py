@@ -12,6 +12,7 @@ from mchap_amd.synth import synth_units
 
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 os.environ["MCHAP_HIP_PIPE_STOP"] = "1"
+os.environ["MCHAP_HIP_TEST_KERNELS"] = "1"  # mchap_debug_pipe_records lives in the parity suite's library
 reads, _, _ = synth_units(U)
 model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=1000, chains=2, random_seed=42, kernel=5)
 b = DenovoDeviceBatch(model, reads)

@@ -10,8 +10,6 @@ from mchap_amd.device import DenovoDeviceBatch
 from mchap_amd.synth import synth_units
 
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-L = _lib.lib()
-L.mchap_set_profiling(1)
 reads, _, _ = synth_units(U)
 
 
@@ -23,12 +21,13 @@ def run(kernel, env=None, reps=3):
         os.environ[k] = str(v)
     model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=1000, chains=2, random_seed=42, kernel=kernel)
     b = DenovoDeviceBatch(model, reads)
+    b.time_sampler(True)
     ms = []
     for _ in range(reps):
         b.run()
         torch.cuda.synchronize()
-        ms.append(L.mchap_last_sampler_ms())
-    name = L.mchap_last_sampler_name().decode()
+        ms.append(b.sampler_ms())
+    name = b.sampler_name
     out = (b.d_trace.cpu().numpy().copy(), b.d_llks.cpu().numpy().copy(), b.d_status.cpu().numpy().copy())
     del b
     return name, ms, out

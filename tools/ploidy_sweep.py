@@ -10,15 +10,14 @@ from mchap_amd.synth import synth_units
 
 K = int(sys.argv[1])
 U = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-L = _lib.lib()
-L.mchap_set_profiling(1)
 reads, _, _ = synth_units(U, ploidy=K)
 model = DenovoMCMC(ploidy=K, n_alleles=[2] * 8, steps=1000, chains=2, random_seed=42)
 b = DenovoDeviceBatch(model, reads)
+b.time_sampler(True)
 ms = []
 for _ in range(3):
     b.run()
     torch.cuda.synchronize()
-    ms.append(L.mchap_last_sampler_ms())
-print("K=%d loci %d  %-64s %s  -> %.0f k loci/s (sampler only)  %s" % (K, U, L.mchap_last_sampler_name().decode(), " ".join("%.2f" % m for m in ms), U / min(ms),
+    ms.append(b.sampler_ms())
+print("K=%d loci %d  %-64s %s  -> %.0f k loci/s (sampler only)  %s" % (K, U, b.sampler_name, " ".join("%.2f" % m for m in ms), U / min(ms),
       {k: v for k, v in os.environ.items() if k.startswith("MCHAP_HIP_")}), flush=True)
