@@ -366,6 +366,168 @@ def bench_config5(args):
     return out
 
 
+def bench_config1(args):
+    """BASELINE.json configs[0]: `mchap assemble` on docs/example (20 target loci x 22 tetraploid samples, 2-23 SNVs, 0-534
+    read pairs) through the program itself -- application.assemble, the notebook's settings (2000 steps, burn 1000, 2 chains,
+    seed 42) -- from the pileup fixture tests/golden/example_biparental.npz (the BAM files are not in the repository; the
+    fixture holds what extract_read_variants yields for them).  End-to-end = read encoding + one ragged sampler launch +
+    device-side summaries + record formatting."""
+    from mchap_amd import application
+
+    path = os.path.join(ROOT, "tests", "golden", "example_biparental.npz")
+    samples, targets, variants, matrices, contigs = application.load_matrices(path)
+
+    class NSeq:
+        def __getitem__(self, sl):
+            return "N" * (sl.stop - sl.start)
+
+    def once(timings):
+        source = application.MatrixSource(samples, matrices)
+        return list(application.assemble(None, variants, {c: NSeq() for c, _ in contigs}, source, ploidy=4, steps=2000, burn=1000, chains=2,
+                                         seed=42, targets=targets, timings=timings))
+
+    once({})
+    tm = {}
+    t = time.perf_counter()
+    lines = once(tm)
+    dt = time.perf_counter() - t
+    out = {
+        "workload": "docs/example bi-parental population: %d target loci x %d samples = %d (locus x sample) units, tetraploid, 2-23 SNVs, "
+                    "0-534 read pairs (de-duplicated rows + counts), 2000 steps x 2 chains, burn 1000; python program end to end from "
+                    "the pileup fixture" % (len(targets), len(samples), tm["units"]),
+        "value": len(lines) / dt, "unit": "loci/s", "units_per_s": tm["units"] / dt, "wall_ms": dt * 1e3,
+        "sampler_units_per_s": tm["units"] / max(tm["sampler_s"], 1e-9), "sampler_ms": tm["sampler_s"] * 1e3,
+        "encode_ms": tm["encode_s"] * 1e3, "format_ms": tm["format_s"] * 1e3, "records": len(lines),
+        "note": "sampler_ms: one ragged launch (440 units of 20 shapes), posterior summary and MCI on the device, results on the host",
+    }
+    if not args.no_cpu_baseline:
+        from oracle import binding as orc
+        from mchap_amd import io
+        from mchap_amd.assemble import break_table
+
+        source = application.MatrixSource(samples, matrices)
+        n_cpu, t = 0, time.perf_counter()
+        for contig, start, stop, name in targets[:4]:
+            locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start))
+            M = len(locus.positions)
+            for s_ in samples:
+                sr = source.reads(locus, s_)
+                if M == 0 or len(sr["dists"]) == 0:
+                    continue
+                cfg = orc.make_cfg(4, 2000, 2, None, (1.0,), llk_cache_threshold=100, seed=42, rng_kind=orc.RNG_PHILOX, stream_id=0,
+                                   break_table=break_table(M, 1.0, 3.0))
+                assert orc.denovo_fit(cfg, sr["dists"], [2] * M, sr["counts"])[2] == 0
+                n_cpu += 1
+        dc = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": n_cpu / dc, "unit": "units/s", "cores": 1, "kind": "port",
+                               "sample": "the %d units of the first 4 targets through oracle/mchap_oracle.c (sampler only), one thread, %.1f s" % (n_cpu, dc)}
+    return out
+
+
+def _sampler_rate(model, reads, counts=None, reps=3, burn=None):
+    """loci/s of DenovoRaggedBatch passes (sampler + device summaries; inputs resident) over ragged units, one at a time."""
+    import torch
+    from mchap_amd.device import DenovoRaggedBatch
+
+    units = [dict(reads=r, counts=None if counts is None else counts[i], n_alleles=list(model.n_alleles), ploidy=int(model.ploidy),
+                  inbreeding=None, stream_id=i) for i, r in enumerate(reads)]
+    b = DenovoRaggedBatch(model, units)
+    burn = model.steps // 2 if burn is None else burn
+    b.run(burn)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        b.run(burn)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    status = b.d_status.cpu().numpy()
+    return len(units) / dt, dt * 1e3, bool((status <= 1).all())
+
+
+def bench_config2_dedup(args):
+    """SURVEY 8d's secondary variant of configs[1]: base phred scores ignored (the programs' default) -> every read row is
+    one of a few dozen distinct rows, de-duplicated with read_counts (application/baseclass.py:207)."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import dedup_unit, synth_units
+
+    U = args.loci
+    reads, _, _ = synth_units(U, ploidy=args.ploidy, n_pos=args.snvs, n_reads=args.reads, dedup=True)
+    pairs = [dedup_unit(r) for r in reads]
+    rows = [len(p[0]) for p in pairs]
+    model = DenovoMCMC(ploidy=args.ploidy, n_alleles=[2] * args.snvs, steps=args.mcmc_steps, chains=args.chains, random_seed=42)
+    rate, ms, ok = _sampler_rate(model, [p[0] for p in pairs], [p[1] for p in pairs], burn=args.burn)
+    out = {"workload": "%d loci of configs[1]'s shape with base qualities ignored: %d reads -> %d-%d distinct rows (median %d) with counts; "
+                       "ragged batch, HBM resident, one pass at a time" % (U, args.reads, min(rows), max(rows), int(np.median(rows))),
+           "value": rate, "unit": "loci/s", "pass_ms": ms, "ok": ok}
+    if not args.no_cpu_baseline:
+        from oracle import binding as orc
+        from mchap_amd.assemble import break_table
+
+        cfg = orc.make_cfg(args.ploidy, args.mcmc_steps, args.chains, None, (1.0,), llk_cache_threshold=100, seed=42, rng_kind=orc.RNG_PHILOX,
+                           break_table=break_table(args.snvs, 1.0, 3.0))
+        n_cpu = 64
+        t = time.perf_counter()
+        for i in range(n_cpu):
+            assert orc.denovo_fit(cfg, pairs[i][0], [2] * args.snvs, pairs[i][1])[2] == 0
+        dc = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": 1, "kind": "port", "sample": "%d loci, oracle, one thread" % n_cpu}
+    return out
+
+
+def bench_moving(args):
+    """Chains that never settle (shallow, low-quality pileups: 16 and 40 reads of base quality 3-20): the regime in which the
+    phased sampler's coasting cannot help (VERDICT r2 weak #8)."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    out = {}
+    U = args.loci
+    for R in (16, 40):
+        reads, _, _ = synth_units(U, ploidy=args.ploidy, n_pos=args.snvs, n_reads=R, qual=(3, 20))
+        model = DenovoMCMC(ploidy=args.ploidy, n_alleles=[2] * args.snvs, steps=args.mcmc_steps, chains=args.chains, random_seed=42)
+        rate, ms, ok = _sampler_rate(model, list(reads), reps=1, burn=args.burn)
+        row = {"workload": "%d loci of configs[1]'s shape with %d reads of base quality 3-20: every chain keeps moving" % (U, R),
+               "value": rate, "unit": "loci/s", "pass_ms": ms, "ok": ok}
+        if not args.no_cpu_baseline:
+            from oracle import binding as orc
+            from mchap_amd.assemble import break_table
+
+            cfg = orc.make_cfg(args.ploidy, args.mcmc_steps, args.chains, None, (1.0,), llk_cache_threshold=100, seed=42, rng_kind=orc.RNG_PHILOX,
+                               break_table=break_table(args.snvs, 1.0, 3.0))
+            cores, _ = usable_cores()
+            n_cpu = 8 * cores
+            t = time.perf_counter()
+            _, _, code, _ = orc.denovo_fit_batch(cfg, reads[:n_cpu], [2] * args.snvs, n_threads=cores, keep_traces=False)
+            dc = time.perf_counter() - t
+            assert code == 0
+            row["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": cores, "kind": "port", "sample": "%d loci, oracle with llk cache" % n_cpu}
+        out["reads_%d" % R] = row
+    return out
+
+
+def bench_config5_tempered(args):
+    """configs[4]'s secondary variant (SURVEY 8d): one chain under the temperature ladder (0.001, 0.01, 0.1, 1.0)."""
+    import torch
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.device import DenovoDeviceBatch
+    from mchap_amd.synth import synth_units
+
+    U, K, M, R, S = args.config5_loci, 8, 20, 1000, 2000
+    reads, _, _ = synth_units(U, ploidy=K, n_pos=M, n_reads=R, window=(8, 20), first_unit=77)
+    model = DenovoMCMC(ploidy=K, n_alleles=[2] * M, steps=S, chains=1, temperatures=(0.001, 0.01, 0.1, 1.0), random_seed=42)
+    batch = DenovoDeviceBatch(model, reads)
+    batch.time_sampler(True)
+    t = time.perf_counter()
+    batch.run()
+    batch.posterior(S // 2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    status = batch.d_status.cpu().numpy()
+    return {"workload": "%d loci: octoploid, %d SNVs, %d reads, 1 chain x 4 temperatures (0.001, 0.01, 0.1, 1.0) x %d steps; HBM resident; one pass" % (U, M, R, S),
+            "value": U / dt, "unit": "loci/s", "kernel": batch.sampler_name, "kernel_ms": batch.sampler_ms(), "pass_ms": dt * 1e3,
+            "ok": bool((status <= 1).all())}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -565,7 +727,8 @@ def main():
             out["gather_checked_units"] = gather_checked
         if world == 1 and not args.no_extras:
             out["value_incl_h2d"] = incl_h2d(args, model)
-            out["extra"] = {"config4": bench_config4(args), "config5": bench_config5(args)}
+            out["extra"] = {"config1": bench_config1(args), "config2_dedup": bench_config2_dedup(args), "moving": bench_moving(args),
+                            "config4": bench_config4(args), "config5": bench_config5(args), "config5_tempered": bench_config5_tempered(args)}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline leg runs at N = 1 only
             cores, quota = usable_cores()
             out["cpu_baseline"] = cpu_baseline(args, cores, quota)

@@ -57,7 +57,7 @@ typedef struct mchap_denovo_tuning {
   int32_t cache_slots;   /* {tag, llk} entries per chain of the likelihood cache: a power of two in 64..65536 (default 1024) */
   int32_t flags;         /* 1: no mutation memo, 2: no interval memo, 4: no coded read table, 8: no product reuse,
                             16: no LDS base-product cache, 32: skip the phased sampler's table completion (timing only: with
-                            pipe_stop), 64: table completion inside the exporting launch instead of denovo_fill_kernel */
+                            pipe_stop), 64 (libmchap_hip_test.so only): the tables completed by denovo_fill_kernel, one lane per request */
   int32_t spec_group;    /* kernel 3: lanes per chain, 16 / 32 / 64 (default: the smallest the shape allows) */
   int32_t pipe_first;    /* kernel 5: MCMC steps before the first hand-over (default ploidy * n_pos / 10, clamped to 4..32) */
   int32_t pipe_resume;   /*           steps a handed-back chain runs before it is handed over again (default 8) */
@@ -65,7 +65,7 @@ typedef struct mchap_denovo_tuning {
   int32_t pipe_max;      /*           cap of a launch's extension while a chain of the wave is unsettled (default 64) */
   int32_t pipe_parts;    /*           wavefronts per chain completing tables when the chains are few (default 8) */
   int32_t prep_lds_limit; /* bytes of table the prepare pass copies to LDS (default 8192) */
-  int32_t pipe_stop;     /* 1: stop after the first coasting launch (traces incomplete: timing of the first phase only) */
+  int32_t pipe_stop;     /* n > 0: stop after the n-th coasting launch (traces incomplete: timing / inspection of the phases) */
   int32_t reserved[6];
 } mchap_denovo_tuning;
 

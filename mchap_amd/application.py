@@ -44,6 +44,44 @@ class ReadSource:
                             self.filter)
 
 
+class MatrixSource:
+    """Reads given as what extract_read_variants yields -- {(target name, sample): (chars [n_reads, n_snv] as str or uint8
+    ASCII codes, summed base qualities [n_reads, n_snv])} -- instead of alignment files: a caller that has its pileups
+    already (and the docs/example fixture of the tests and of bench.py's extra.config1)."""
+
+    def __init__(self, samples, matrices, error_rate=0.0024, use_phred=False):
+        self.samples = list(samples)
+        self.matrices = matrices
+        self.error_rate, self.use_phred = error_rate, use_phred
+        self.bams = {}
+
+    def reads(self, locus, sample):
+        chars, quals = self.matrices[(locus.name, sample)]
+        chars = np.asarray(chars)
+        if chars.dtype == np.uint8:
+            chars = chars.view("S1").astype("U1").reshape(chars.shape)
+        return encode_reads(locus, chars, np.asarray(quals, dtype=np.int16), self.error_rate, self.use_phred)
+
+
+def load_matrices(path):
+    """A pileup file written as numpy .npz (tests/golden/make_example_fixture.py documents the layout: samples, contigs,
+    targets, per target its SNV positions and alleles, per (target, sample) the character matrix and the qualities) ->
+    (samples, targets [(contig, start, stop, name)], variant records, {(target name, sample): (chars, quals)},
+    contigs [(name, length)])."""
+    z = np.load(path)
+    samples = [str(x) for x in z["samples"]]
+    targets = [(str(c), int(a), int(b), str(n)) for c, a, b, n in zip(z["target_contig"], z["target_start"], z["target_stop"], z["target_name"])]
+    variants, matrices = [], {}
+    for li, (contig, start, stop, name) in enumerate(targets):
+        for p, al in zip(z["pos_%d" % li], z["alleles_%d" % li]):
+            al = str(al)
+            variants.append(dict(chrom=contig, pos=int(p) + 1, id=".", ref=al[0], alts=tuple(al[1:]), info={}))
+        for si, s_ in enumerate(samples):
+            matrices[(name, s_)] = (z["chars_%d_%d" % (li, si)], z["quals_%d_%d" % (li, si)])
+    contigs = [(str(c), int(n)) for c, n in zip(z["contigs"], z["contig_lengths"])]
+    return samples, targets, variants, matrices, contigs
+
+
 def sample_reads(locus, pairs, error_rate=0.0024, use_phred=False, read_filter=None):
     """encode_sample_reads (application/baseclass.py:140-210) for one sample (or pool): pairs = [(read-group sample name,
     alignment as read_alignments returns it), ...] -> dict(chars, calls, depth, dists (distinct rows), counts)."""
@@ -53,6 +91,13 @@ def sample_reads(locus, pairs, error_rate=0.0024, use_phred=False, read_filter=N
         chars, quals = np.concatenate([c for c, _ in parts]), np.concatenate([q for _, q in parts])
     else:
         chars, quals = np.empty((0, M), dtype="U1"), np.empty((0, M), dtype=np.int16)
+    return encode_reads(locus, chars, quals, error_rate, use_phred)
+
+
+def encode_reads(locus, chars, quals, error_rate=0.0024, use_phred=False):
+    """Character matrix + qualities -> allele calls, probabilistic rows, de-duplicated rows with counts, depth
+    (application/baseclass.py:189-207)."""
+    M = len(locus.positions)
     calls = np.full(chars.shape, -1, dtype=np.int8)
     for j in range(M):
         for a, c in enumerate(locus.alleles[j]):
@@ -313,7 +358,7 @@ def _format_exact_record(unit, samples, results, ri, ploidy_of, report, prior_ta
 
 
 def _source(sample_bams, base_error_rate, use_base_phred_scores, read_kw):
-    if isinstance(sample_bams, ReadSource):
+    if hasattr(sample_bams, "reads") and hasattr(sample_bams, "samples"):  # a ReadSource / MatrixSource
         return sample_bams
     return ReadSource(sample_bams, error_rate=base_error_rate, use_phred=use_base_phred_scores, **(read_kw or {}))
 
@@ -436,7 +481,9 @@ def _genotype_posterior_array(post, labels, ploidy):
 
     from .calling_mcmc import _vcf_index
 
-    n_alleles = len(labels)
+    # (every allele of the record counts, a masked reference allele included: Number=G.  The reference sizes the array by
+    # len(labels), one short when the reference allele is masked, and then fails with an IndexError on the last allele.)
+    n_alleles = max(labels.values()) + 1 if labels else 1
     out = np.zeros(comb(n_alleles + ploidy - 1, ploidy), float)
     for haps, prob in zip(post.genotypes, post.probabilities):
         alleles = np.sort([labels.get(np.asarray(h, dtype=np.int8).tobytes(), -1) for h in haps])
@@ -568,7 +615,7 @@ def assemble_targets(bed_path=None, region=None, region_id=None):
 def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploidy=4, inbreeding=None, steps=1000, burn=500,
              chains=2, seed=42, error_rate=0.0024, use_phred=False, haplotype_posterior_threshold=0.20,
              incongruence_threshold=0.60, report=(), temperatures=(1.0,), read_kw=None, targets=None, units_per_block=None,
-             shard=None, **mcmc_kw):
+             shard=None, sampler=None, timings=None, **mcmc_kw):
     """`mchap assemble` over the targets of a BED4 file (or `targets`: a list of (contig, start, stop, name)): yields one
     VCF record line per target (no header).  reference_sequences: {contig: sequence string} or an io.Reference;
     sample_bams: ordered mapping sample name -> BAM path (or pool -> [(sample, path)], or a ReadSource); ploidy /
@@ -580,7 +627,11 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
     device, and the block's records are formatted from those few hundred bytes per unit and yielded before the next
     block is read.  A block holds as many units as fit a share of the free HBM (`units_per_block`; a small file is one
     block, one launch).  As in the reference every unit restarts from the same seed (application/baseclass.py:360-388,
-    assemble/mcmc.py:140-142), so the result does not depend on the order or the batching of the targets."""
+    assemble/mcmc.py:140-142), so the result does not depend on the order or the batching of the targets.
+
+    variants_vcf_path may be the list of variant records itself.  sampler: None = the device batch; or a callable
+    (units, settings dict) -> per-unit summaries (the oracle-backed replay of the tests).  timings: a dict that receives
+    the seconds spent encoding reads, in the sampler (launch to results on the host) and formatting records."""
     from .assemble import DenovoMCMC
     from .classes import PosteriorGenotypeDistribution
     from .device import DenovoRaggedBatch, PassesInFlight
@@ -591,7 +642,14 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
     seed = resolve_seed(seed)
     ploidy_of, inbreeding_of = _per_sample(ploidy, samples), _per_sample(inbreeding, samples)
     temps_of = _per_sample(temperatures if isinstance(temperatures, dict) else tuple(temperatures), samples)
-    _, variants = read_vcf(variants_vcf_path)
+    import time as _time
+
+    variants = variants_vcf_path if isinstance(variants_vcf_path, (list, tuple)) else read_vcf(variants_vcf_path)[1]
+    if timings is None:
+        timings = {}
+    for k_ in ("encode_s", "sampler_s", "format_s"):
+        timings.setdefault(k_, 0.0)
+    timings.setdefault("units", 0)
     if targets is None:
         targets = read_bed4(bed_path)
     targets = _shard(list(targets), shard)
@@ -610,6 +668,7 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
                 for contig, start, stop, name in block]
         encoded = {}
         units, where = [], []
+        t0_ = _time.perf_counter()
         for li, locus in enumerate(loci):
             M = len(locus.positions)
             for sample in samples:
@@ -624,7 +683,14 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
                                   inbreeding=inbreeding_of(sample), stream_id=0, temps=tuple(temps_of(sample))))
                 where.append((li, sample))
         summaries = {}
-        if units:
+        t1_ = _time.perf_counter()
+        timings["encode_s"] += t1_ - t0_
+        timings["units"] += len(units)
+        if units and sampler is not None:
+            settings = dict(steps=steps, chains=chains, seed=seed, burn=burn, incongruence_threshold=incongruence_threshold, **mcmc_kw)
+            for w_, res in zip(where, sampler(units, settings)):
+                summaries[w_] = res
+        elif units:
             # one launch per (ploidy, temperature ladder) present (usually one): the library's fast samplers take one ploidy
             # per launch (mixed ploidies would run on the general lanes-over-chains kernel), and a ladder is a launch setting
             groups = {}
@@ -647,6 +713,8 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
             for idx, batch in pending:
                 for i, res in zip(idx, batch.results()):
                     summaries[where[i]] = res
+        t2_ = _time.perf_counter()
+        timings["sampler_s"] += t2_ - t1_
         for li, locus in enumerate(loci):
             M = len(locus.positions)
             per, posteriors = {}, []
@@ -665,8 +733,11 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
                 per[sample] = dict(genotype=res["mode_genotype"], gprob=float(res["gpm"]), sprob=float(res["spm"]), mec=mec,
                                    mecp=mec / denom if denom > 0 else np.nan, mci=int(res["mci"]), rcount=len(calls), rcalls=denom,
                                    dp=np.round(np.mean(depth)) if len(depth) else np.nan, depth=depth)
-            yield _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold, report, ploidy_of,
-                                        {s_: encoded[(li, s_)] for s_ in samples})
+            line = _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold, report, ploidy_of,
+                                         {s_: encoded[(li, s_)] for s_ in samples})
+            timings["format_s"] += _time.perf_counter() - t2_
+            yield line
+            t2_ = _time.perf_counter()
 
 
 # ---------------------------------------------------------------------------------------------------------

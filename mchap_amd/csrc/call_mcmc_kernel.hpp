@@ -336,7 +336,16 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
       const double v = coop_llk(K);
       if (lane == src) {
         val = v;
-        if (slot) *slot = make_ulonglong2((unsigned long long)key + 1ull, (unsigned long long)__double_as_longlong(v));
+        // The lanes probed together: two of them (different keys) may have ended their probes on the same empty slot.
+        // The table never forgets an entry -- the reference's dict keeps the value of whichever allele order was
+        // evaluated first (calling/likelihood.py:36-78), and a lost key would be evaluated again later in a possibly
+        // different order -- so the slot is looked up again now, behind the entries the earlier lanes of this loop wrote.
+        double seen;
+        ulonglong2 *free_slot = nullptr;
+        if (!probe(key, seen, free_slot)) {
+          if (free_slot) *free_slot = make_ulonglong2((unsigned long long)key + 1ull, (unsigned long long)__double_as_longlong(v));
+          else s_full = 1;
+        }
       }
       __syncthreads();
     }

@@ -2096,6 +2096,18 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
 #endif
   if constexpr (PIPE) {
     if (P.pipe_mode & (PIPE_EXPORT | PIPE_FILLONLY)) {
+      // The table describes genotype generation memo_gen and is wiped lazily, when a structural step next looks at it.
+      // A chain that moved in the last structural step of this launch still carries the table of its previous genotype:
+      // it must not leave the kernel like that -- whoever loads it (the resuming launch, the table completion, the
+      // coasting kernel) takes every entry it finds for the current genotype's.
+      if (S.memo_stride != 0 && wave_any(c.alive && c.gen != c.memo_gen)) {
+        if (c.alive && c.gen != c.memo_gen) {
+          LDSP(double) all = S.memo_tot + gi * S.memo_stride;
+          for (int i = gl; i < S.memo_stride; i += G) all[i] = NAN;
+          c.memo_gen = c.gen;
+        }
+        lds_sync();
+      }
       // the interval memo of the current genotype, completed (both step types) -- unless a PIPE_FILLONLY launch will
       // do that with several wavefronts per chain -- then the hand-over record
       if ((fillonly || parts_eff <= 1) && !(P.flags & 32) && !(P.pipe_mode & PIPE_NOFILL)) {

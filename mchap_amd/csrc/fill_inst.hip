@@ -24,3 +24,12 @@ extern "C" __attribute__((visibility("hidden"))) int FILL_CAT(mchap_fill_launch_
   hipLaunchKernelGGL(ks, dim3(grid), dim3(64), lds, stream, *P);
   return (int)hipGetLastError();
 }
+
+#if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
+extern "C" __attribute__((visibility("hidden"))) int FILL_CAT(mchap_fill_stats_, FILL_K)(unsigned long long *out, int reset) {
+  unsigned long long z[mchap::N_STATS] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mchap::g_stats), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(mchap::g_stats), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif

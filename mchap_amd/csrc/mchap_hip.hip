@@ -14,8 +14,8 @@
 #include "denovo_kernel.hpp"
 #include "denovo_simt_kernel.hpp"
 #include "denovo_spec_kernel.hpp"
-#include "denovo_fill_kernel.hpp"
 #ifdef MCHAP_TEST_KERNELS
+#include "denovo_fill_kernel.hpp"
 #include "denovo_lane_kernel.hpp"
 #endif
 #include "exact_kernel.hpp"
@@ -52,12 +52,12 @@ SPEC_LIST(DECL_SPEC)
 SPECP_LIST(DECL_SPECP)
 SIMT_LIST(DECL_SIMT)
 extern "C" int mchap_coast_launch(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+#ifdef MCHAP_TEST_KERNELS
 #define FILL_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #define DECL_FILL(k)                                                \
   extern "C" int mchap_fill_init_##k(const double *, const double *); \
   extern "C" int mchap_fill_launch_##k(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 FILL_LIST(DECL_FILL)
-#ifdef MCHAP_TEST_KERNELS
 #define DECL_V1(r)                                                \
   extern "C" int mchap_v1_init_##r(const double *, const double *); \
   extern "C" int mchap_v1_launch_##r(const mchap::DenovoParams *, unsigned, unsigned, unsigned, size_t, hipStream_t);
@@ -157,9 +157,9 @@ int ensure_init() {
 #define ROW_V1_INIT(r) mchap_v1_init_##r,
 #define ROW_LANE_INIT(k) mchap_lane_init_##k,
 #define ROW_FILL_INIT(k) mchap_fill_init_##k,
-    const init_fn inits[] = {SIMT_LIST(ROW_SIMT_INIT) FILL_LIST(ROW_FILL_INIT)
+    const init_fn inits[] = {SIMT_LIST(ROW_SIMT_INIT)
 #ifdef MCHAP_TEST_KERNELS
-                                 V1_LIST(ROW_V1_INIT) LANE_LIST(ROW_LANE_INIT)
+                                 FILL_LIST(ROW_FILL_INIT) V1_LIST(ROW_V1_INIT) LANE_LIST(ROW_LANE_INIT)
 #endif
     };
     for (init_fn f : inits)
@@ -260,7 +260,7 @@ struct Tune {
   int cache_slots = 1024, flags = 0, spec_group = 0, pipe_first = 0, pipe_resume = 8, pipe_rounds = 2, pipe_max = 64, pipe_parts = 8;
   int pipe_group = 64;
   size_t prep_lds_limit = 8 * 1024;
-  bool pipe_stop = false;
+  int pipe_stop = 0;
 };
 Tune tune_of(const mchap_denovo_cfg *cfg) {
   Tune t;
@@ -275,7 +275,7 @@ Tune tune_of(const mchap_denovo_cfg *cfg) {
   if (u->pipe_max > 0) t.pipe_max = u->pipe_max;
   if (u->pipe_parts > 0 && u->pipe_parts <= 64) t.pipe_parts = u->pipe_parts;
   if (u->prep_lds_limit > 0) t.prep_lds_limit = (size_t)u->prep_lds_limit;
-  t.pipe_stop = u->pipe_stop != 0;
+  t.pipe_stop = u->pipe_stop;
 #ifdef MCHAP_TEST_KERNELS
   if (u->reserved[0] == 16 || u->reserved[0] == 32) t.pipe_group = u->reserved[0];  // narrower phased groups: test library only
 #endif
@@ -569,23 +569,30 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   HIP_TRY(hipMemsetAsync(counts, 0, (PIPE_MAX_ROUNDS + 2) * 4, stream));
   SamplerTimer tm(timer, stream);
   // every chain: first steps from scratch, complete tables, records
-  // Table completion: denovo_fill_kernel (one lane per request) after every exporting launch; shapes it does not take
-  // (and tuning flag 64) keep the completion inside the exporting launch, spread over several wavefronts per chain by a
-  // PIPE_FILLONLY launch when the chains are few
-  const bool lpr = mchap::fill_supported(K, P.max_pos, P.max_allele, P.d.rpad) && !(T.flags & 64);
-  const size_t lds_fill = lpr ? mchap::fill_lds_bytes(K, P.max_pos, P.max_allele, P.d.rpad) : 0;
-  const int export_mode = mchap::PIPE_EXPORT | (lpr ? mchap::PIPE_NOFILL : 0);
-  P.fill_lt = lpr ? mchap::fill_tile_lanes(K, P.max_pos, P.max_allele, P.d.rpad) : 0;
-  P.fill_kw = mchap::fill_key_words(K, P.max_pos, P.max_allele);
+  // Table completion: inside the exporting launch (spread over several wavefronts per chain by a PIPE_FILLONLY launch when
+  // the chains are few).  The parity suite's library also carries denovo_fill_kernel -- the same tables from one lane per
+  // request -- behind tuning flag 64: bit-identical (tests/test_gpu_fill.py), measured slower, not shipped.
+  bool lpr = false;
+  size_t lds_fill = 0;
+#ifdef MCHAP_TEST_KERNELS
+  if (T.flags & 64) {
+    P.fill_lt = mchap::fill_geometry(K, P.max_pos, P.max_allele, P.d.rpad, &lds_fill);
+    P.fill_kw = mchap::fill_key_words(K, P.max_pos, P.max_allele);
+    lpr = P.fill_lt > 0;
+  }
 #define ROW_FILL_LAUNCH(k) mchap_fill_launch_##k,
   const simt_launch_fn fill_launches[] = {FILL_LIST(ROW_FILL_LAUNCH)};
+#endif
+  const int export_mode = mchap::PIPE_EXPORT | (lpr ? mchap::PIPE_NOFILL : 0);
   P.pipe_list = nullptr;
   P.pipe_count = nullptr;
   P.pipe_iters = s0;
   P.pipe_mode = export_mode;
   int e = launch(&P, grid_s, lds, stream);
   auto fill_launch = [&]() {
+#ifdef MCHAP_TEST_KERNELS
     if (lpr) return fill_launches[K - 2](&P, (unsigned)n_chains, lds_fill, stream);
+#endif
     if (P.pipe_parts <= 1) return 0;  // (a no-op unless the chains of the list are few: pipe_parts_eff)
     mchap::SimtParams F = P;
     F.pipe_mode = mchap::PIPE_RESUME | mchap::PIPE_FILLONLY;
@@ -596,7 +603,7 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   P.pipe_out = lists;
   P.pipe_out_count = counts;
   if (e == 0) e = mchap_coast_launch(&P, grid_c, lds_c, stream);
-  for (int r = 0; r <= rounds && e == 0 && !T.pipe_stop; r++) {
+  for (int r = 0; r <= rounds && e == 0 && T.pipe_stop != 1; r++) {
     P.pipe_list = lists + (size_t)(r & 1) * list_stride;
     P.pipe_count = counts + r;
     const bool last = r == rounds;
@@ -608,7 +615,9 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
     if (e != 0) break;
     P.pipe_out = lists + (size_t)((r + 1) & 1) * list_stride;
     P.pipe_out_count = counts + r + 1;
+    if (T.pipe_stop == -(r + 2)) break;  // (debugging: stop before this round's coasting launch)
     e = mchap_coast_launch(&P, grid_c, lds_c, stream);
+    if (T.pipe_stop == r + 2) break;  // (measurement / debugging: stop after this round's coasting launch)
   }
   if (e != 0) return fail(MCHAP_ERR_HIP, "launch of the phased sampler <%d, %d>: %s", K, G, hipGetErrorString((hipError_t)e));
   return MCHAP_OK;
@@ -684,7 +693,24 @@ int mchap_debug_stats(unsigned long long *out, int reset) {
   }
   return MCHAP_OK;
 }
+/* counters of the table-completion kernel (denovo_fill_kernel.hpp FPH / FCNT) summed over its objects: ticks in
+ * [0] listing, [1] de-duplication, [2] staging, [3] evaluation, [4] probabilities + totals; [6] chunks, [7] distinct requests,
+ * [8] option slots, [9] stagings, [10] batch x tile evaluations, [11] chains */
 #ifdef MCHAP_TEST_KERNELS
+#define DECL_FILL_STATS(k) extern "C" int mchap_fill_stats_##k(unsigned long long *, int);
+FILL_LIST(DECL_FILL_STATS)
+extern "C" int mchap_debug_fill_stats(unsigned long long *out, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < mchap::N_STATS; i++) out[i] = 0;
+#define ROW_FILL_STATS(k) mchap_fill_stats_##k,
+  int (*fs[])(unsigned long long *, int) = {FILL_LIST(ROW_FILL_STATS)};
+  for (auto f : fs) {
+    unsigned long long t[mchap::N_STATS];
+    if (f(t, reset) != 0) return fail(MCHAP_ERR_HIP, "reading the counters of a table-completion object");
+    for (int i = 0; i < mchap::N_STATS; i++) out[i] += t[i];
+  }
+  return MCHAP_OK;
+}
 /* counters of the steady-state sampler's K = 4 object (its own layout: denovo_lane_kernel.hpp LPH / LCNT) */
 int mchap_debug_lane_stats(unsigned long long *out, int reset) {
   HIP_TRY(hipDeviceSynchronize());

@@ -184,10 +184,11 @@ def test_llk_cache_is_results_neutral():
         assert np.array_equal(a.genotypes, b.genotypes) and np.array_equal(a.llks, b.llks)
 
 
-def test_both_kernels_give_identical_traces():
+def test_both_kernels_give_identical_traces(monkeypatch):
     from mchap_amd import DenovoMCMC
     from mchap_amd.synth import synth_units
 
+    monkeypatch.setenv("MCHAP_HIP_TEST_KERNELS", "1")  # kernel 1 lives in the parity suite's library
     reads, _, _ = synth_units(70, ploidy=4, n_pos=8, n_reads=200, first_unit=500)  # > one wavefront of chains
     kw = dict(ploidy=4, n_alleles=[2] * 8, steps=120, chains=2, random_seed=99)
     a = DenovoMCMC(kernel=1, **kw).fit_batch(list(reads))

@@ -47,3 +47,9 @@ for nm, b, w in (("recombination", 12, 20), ("dosage (both kinds)", 16, 21)):
     n = max(out[b], 1)
     print("%s: wave-calls %d  groups executing per wave-call %.3f  groups needing rounds %.3f  wave-calls with rounds %.3f  rounds per wave-call %.3f" % (
         nm, out[b], out[b + 1] / n, out[b + 2] / n, out[w] / n, out[b + 3] / n))
+
+f = (C.c_ulonglong * 48)()
+if hasattr(L, "mchap_debug_fill_stats") and L.mchap_debug_fill_stats(f, 1) == 0 and f[11]:
+    n = f[11]
+    print("fill kernel per chain (%d chains): ticks list %.0f dedup %.0f stage %.0f eval %.0f totals %.0f | chunks %.2f uniques %.1f slots %.1f stagings %.2f batch-tiles %.2f" % (
+        n, f[0] / n, f[1] / n, f[2] / n, f[3] / n, f[4] / n, f[6] / n, f[7] / n, f[8] / n, f[9] / n, f[10] / n))
