@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip value_incl_h2d and the config4 / config5 lines")
     ap.add_argument("--config5-loci", type=int, default=256)  # 1024 chains: one wave per SIMD
     ap.add_argument("--config4-units", type=int, default=256)
+    ap.add_argument("--tempered", action="store_true",
+                    help="also run extra.config5_tempered (one chain x 4 temperatures at configs[4]'s shape): minutes of GPU time, "
+                         "so not part of the default line (profiles/ holds the measured run)")
     return ap.parse_args()
 
 
@@ -728,7 +731,9 @@ def main():
         if world == 1 and not args.no_extras:
             out["value_incl_h2d"] = incl_h2d(args, model)
             out["extra"] = {"config1": bench_config1(args), "config2_dedup": bench_config2_dedup(args), "moving": bench_moving(args),
-                            "config4": bench_config4(args), "config5": bench_config5(args), "config5_tempered": bench_config5_tempered(args)}
+                            "config4": bench_config4(args), "config5": bench_config5(args)}
+            if args.tempered:
+                out["extra"]["config5_tempered"] = bench_config5_tempered(args)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline leg runs at N = 1 only
             cores, quota = usable_cores()
             out["cpu_baseline"] = cpu_baseline(args, cores, quota)

@@ -50,12 +50,22 @@ def run(n_cases, seed, ploidies=(2, 3, 4, 5, 6, 8), read_depths=(1, 5, 30, 64, 7
             g, l = _oracle_trace(m0, reads[u], m0.n_alleles, None, u)
             ref.append((sort_haplotypes(g), l))
         res = []
-        for k in (1, 2, 3, 4, 5):
+        for k in (1, 2, 3, 4, 5, 6):
+            # kernels 1 and 4 live in the parity suite's library (MCHAP_HIP_TEST_KERNELS); "6" = the phased sampler with the
+            # lane-per-request table completion of that library (tuning flag 64)
+            test_lib = k in (1, 4, 6)
+            if test_lib:
+                os.environ["MCHAP_HIP_TEST_KERNELS"] = "1"
+            if k == 6:
+                os.environ["MCHAP_HIP_FLAGS"] = "64"
             try:
-                tr = DenovoMCMC(kernel=k, **kw).fit_batch(list(reads))
+                tr = DenovoMCMC(kernel=5 if k == 6 else k, **kw).fit_batch(list(reads))
             except NotImplementedError:
                 res.append("n/a")
                 continue
+            finally:
+                os.environ.pop("MCHAP_HIP_TEST_KERNELS", None)
+                os.environ.pop("MCHAP_HIP_FLAGS", None)
             ok = all(np.array_equal(tr[u].genotypes, ref[u][0]) and
                      np.allclose(tr[u].llks, ref[u][1], rtol=1e-10, atol=1e-9, equal_nan=True) for u in range(U))
             res.append("ok" if ok else "FAIL")

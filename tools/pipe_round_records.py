@@ -1,4 +1,5 @@
-import os, sys, ctypes as C
+"""Measurement / debugging aid: the phased sampler stopped after each round (MCHAP_HIP_PIPE_STOP): hand-over records, interval tables and
+trace rows of one docs/example unit against kernel 3.   python tools/pipe_round_records.py locus002 progeny015 [flags]"""
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
