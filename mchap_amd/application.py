@@ -29,19 +29,50 @@ class ReadSource:
         self.filter = dict(min_quality=mapping_quality, skip_duplicates=skip_duplicates, skip_qcfail=skip_qcfail,
                            skip_supplementary=skip_supplementary)
         paths = list(dict.fromkeys(p for pairs in self.pools.values() for _, p in pairs))
+        self.workers = int(workers)
+        self.id_field = read_group_field
+
+        def load(q):
+            # BAM: block-wise reader with columnar records (and region fetches through the .bai index for big files);
+            # SAM text: the record reader
+            with open(q, "rb") as f:
+                magic = f.read(2)
+            if magic == b"\x1f\x8b":
+                from .io import BamFile
+
+                return BamFile(q, read_group_field, workers=self.workers)
+            return read_alignments(q, read_group_field)
+
         if workers > 1 and len(paths) > 1:
-            # --cores: the files are inflated and parsed by a pool of threads (zlib releases the interpreter lock)
+            # --cores: the files are read by a pool of threads (zlib releases the interpreter lock)
             from concurrent.futures import ThreadPoolExecutor
 
             with ThreadPoolExecutor(max_workers=int(workers)) as ex:
-                loaded = list(ex.map(lambda q: read_alignments(q, read_group_field), paths))
+                loaded = list(ex.map(load, paths))
         else:
-            loaded = [read_alignments(q, read_group_field) for q in paths]
+            loaded = [load(q) for q in paths]
         self.bams = dict(zip(paths, loaded))
 
+    WHOLE_FILE_BYTES = 256 << 20  # smaller files are inflated once; bigger ones are fetched region by region (needs the .bai)
+
     def reads(self, locus, sample):
-        return sample_reads(locus, [(name, self.bams[path]) for name, path in self.pools[sample]], self.error_rate, self.use_phred,
-                            self.filter)
+        from .io import BamFile, extract_read_variants_columns
+
+        M = len(locus.positions)
+        parts = []
+        for name, path in self.pools[sample]:
+            bam = self.bams[path]
+            if isinstance(bam, BamFile):
+                region = bam.index is not None and len(bam.data) > self.WHOLE_FILE_BYTES
+                cols = bam.columns(locus.contig, locus.start, locus.stop) if region else bam.columns()
+                parts.append(extract_read_variants_columns(locus, cols, name, **self.filter))
+            else:
+                parts.append(extract_read_variants(locus, bam, name, **self.filter))
+        if parts:
+            chars, quals = np.concatenate([c for c, _ in parts]), np.concatenate([q for _, q in parts])
+        else:
+            chars, quals = np.empty((0, M), dtype="U1"), np.empty((0, M), dtype=np.int16)
+        return encode_reads(locus, chars, quals, self.error_rate, self.use_phred)
 
 
 class MatrixSource:

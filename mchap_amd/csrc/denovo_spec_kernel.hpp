@@ -722,7 +722,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
   S.cols = cols_tab;
   S.dict = dict_tab;
   S.bw = bw_tab;
-  const int nch = rpad / WAVE;
+  const int nch_batch = rpad / WAVE;
   double val = 0.0;
   // Reuse: a chain's proposals differ from its current genotype (the base words in bw_tab) in one or two haplotype
   // words; when a chain has several requests in this call, the products of the base haplotypes are formed once and a
@@ -742,6 +742,10 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
     if constexpr (LT) cw = lds_cw + lane;
     else cw = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;
     const int nrd = (int)nreads_tab[sg];
+    // read chunks of THIS unit: a batch is padded to its deepest unit, but the chunks beyond a unit's own reads hold
+    // padding only -- weight 0, terms +-0.0, which every sum absorbs exactly -- so they are not evaluated (a ragged
+    // batch of real pileups is mostly shallow units: docs/example has 2 to 534 read pairs per unit)
+    const int nch = max(1, min(nch_batch, (nrd + WAVE - 1) / WAVE));
     const int cstride = crow / WAVE;  // code bytes per lane and row
     if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && KT * Mh <= 2 * WAVE) {
       // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped.

@@ -42,3 +42,75 @@ def test_read_matrices_of_the_reference_test(ext):
     np.testing.assert_array_equal(sr["calls"], EXPECT_CALLS)
     np.testing.assert_array_equal(sr["depth"], (EXPECT_CHARS != "-").sum(axis=0))
     assert int(sr["counts"].sum()) == len(EXPECT_CHARS)
+
+
+def test_columnar_reader_and_vectorised_extraction_equal_the_record_reader():
+    """The block-wise BAM reader with columnar records (io.BamFile / AlignmentColumns) and the vectorised
+    extract_read_variants_columns give the matrices of the per-record reader -- which the test above pins to the reference's
+    -- on every locus and sample of the reference's test BAMs (shallow, deep, mixed mapping qualities and flags)."""
+    import glob
+
+    bed = io.read_bed4(os.path.join(HERE, "simple.bed"))
+    _, variants = io.read_vcf(os.path.join(HERE, "simple.vcf"))
+    n = 0
+    for path in sorted(glob.glob(os.path.join(HERE, "*.bam"))):
+        old = io.read_alignments(path)
+        cols = io.BamFile(path).columns()
+        assert cols.n == len(old[2])
+        for contig, start, stop, name in bed:
+            locus = io.DenovoLocus(contig, start, stop, name, variants, "A" * (stop - start))
+            for sample in dict.fromkeys(old[1].values()):
+                for kw in ({}, dict(min_quality=0, skip_duplicates=False, skip_qcfail=False, skip_supplementary=False), dict(min_quality=61)):
+                    a = io.extract_read_variants(locus, old, sample, **kw)
+                    b = io.extract_read_variants_columns(locus, cols, sample, **kw)
+                    np.testing.assert_array_equal(a[0], b[0])
+                    np.testing.assert_array_equal(a[1], b[1])
+                    n += 1
+    assert n >= 60
+    chars, quals = io.extract_read_variants_columns(_locus(), io.BamFile(os.path.join(HERE, "simple.sample1.bam")).columns(), "SAMPLE1")
+    np.testing.assert_array_equal(chars, EXPECT_CHARS)
+
+
+def test_bgzf_blocks_bai_index_and_region_fetch(tmp_path):
+    """A synthetic coordinate-sorted BAM written block by block with its .bai (mchap_amd.synth.write_bam): the BGZF walk finds
+    every block, the record reader (whole-file gzip inflate) and the block-wise reader see the same records, and a region
+    fetch through the index -- only the blocks that can hold overlapping records are inflated -- yields the same matrices as
+    the whole file, also for reads whose mates overlap the same SNV (agreeing: qualities added; disagreeing: 'N')."""
+    from mchap_amd import synth
+
+    job = synth.synth_assembly_inputs(str(tmp_path), n_loci=40, n_samples=1, reads_per_locus=30, gap=3000)  # 125 kb: 8 index bins
+    path = job["bams"][0]
+    data = open(path, "rb").read()
+    blocks = io.bgzf_blocks(data)
+    assert len(blocks) >= 3 and sum(b[1] for b in blocks) == len(data)
+    bf = io.BamFile(path, workers=2)
+    assert bf.index is not None and bf.refs[0][0] == "chrS" and bf.rg == {"rgS000": "S000"}
+    whole = bf.columns()
+    old = io.read_alignments(path)
+    assert whole.n == len(old[2]) == 40 * 30
+    _, variants = io.read_vcf(job["vcf"])
+    ref = io.Reference(job["fasta"])
+    fetched = 0
+    for contig, start, stop, name in io.read_bed4(job["bed"]):
+        locus = io.DenovoLocus(contig, start, stop, name, variants, ref.fetch(contig, start, stop))
+        a = io.extract_read_variants(locus, old, "S000")
+        region = bf.columns(contig, start, stop)
+        fetched += region.n
+        for cols in (whole, region):
+            b = io.extract_read_variants_columns(locus, cols, "S000")
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+        assert len(a[0]) >= 20
+    assert fetched < 0.8 * 40 * whole.n  # (a region is a block or two, not the file)
+    # overlapping mates: same query name, second record agrees at one SNV and disagrees at another
+    locus = io.DenovoLocus("chrS", 100, 160, "t", [dict(chrom="chrS", pos=111, id=".", ref="A", alts=("C",), info={}),
+                                                  dict(chrom="chrS", pos=121, id=".", ref="A", alts=("G",), info={})], "A" * 60)
+    recs = [dict(qname="p", flag=0, ref=0, pos=105, mapq=60, cigar=[(30, "M")], seq="A" * 5 + "C" + "A" * 9 + "G" + "A" * 14, qual=[30] * 30, rg="g"),
+            dict(qname="p", flag=0, ref=0, pos=108, mapq=60, cigar=[(2, "S"), (28, "M")], seq="TT" + "A" * 2 + "C" + "A" * 9 + "A" + "A" * 15, qual=[20] * 30, rg="g")]
+    p2 = str(tmp_path / "pair.bam")
+    synth.write_bam(p2, [("chrS", 1000)], {"g": "X"}, recs)
+    a = io.extract_read_variants(locus, io.read_alignments(p2), "X")
+    b = io.extract_read_variants_columns(locus, io.BamFile(p2).columns("chrS", 100, 160), "X")
+    assert a[0].tolist() == [["C", "N"]] and a[1].tolist() == [[50, 30]]
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
