@@ -278,7 +278,13 @@ def bench_config4(args):
     # (mchap_exact_workspace_bytes_cached, ExactDeviceBatch's default), twice otherwise
     cached = batch.ws_bytes > int(_lib_exact_ws(U, H, K))
     terms = (1.0 if cached else 2.0) * U * G * R
-    flop_per_term = 2 * K + 40  # K multiply-adds + one float64 log (about 20 fused multiply-adds in the device library)
+    # Measured, not assumed (profiles/r03h_config4_sq_counters.json, rocprofv3 --pmc on this workload, whole launch):
+    # SQ_INSTS_VALU 7.65e9 wavefront instructions for 1.085e8 wavefront-terms = 70.5 per term, of which float64
+    # FMA 11.2 + ADD 16.1 + MUL 17.1 (+ 1.0 reciprocal) = 55.6 flop per (genotype, read) term with an FMA as two;
+    # -ffp-contract=off keeps the K multiply-adds of a read's mean apart, as the reference's compiled loop has them.
+    flop_per_term = 55.6
+    valu_per_wave_term = 70.5
+    valu_issue_peak = 256 * 4 * 2.4e9 / 4.0  # wavefront instructions / s: 1024 SIMDs, 4 cycles per 64-lane instruction
     ms = res["streaming"]
     out = {
         "workload": "%d units: hexaploid, %d haplotypes x %d SNVs, %d reads, G = %d genotypes, prior (0.1, Dirichlet(1)); HBM resident" % (U, H, M, R, G),
@@ -286,7 +292,9 @@ def bench_config4(args):
         "arrays_value": U / (res["arrays"] * 1e-3), "arrays_kernel_ms": res["arrays"],
         "roofline": {"bound": "valu_fp64", "achieved": terms * flop_per_term / (ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                      "frac": terms * flop_per_term / (ms * 1e-3) / 1e12 / 78.6, "terms_per_s": terms / (ms * 1e-3),
-                     "assumed_flop_per_term": flop_per_term,
+                     "flop_per_term": flop_per_term, "valu_insts_per_wave_term": valu_per_wave_term,
+                     "valu_issue_frac": terms / 64.0 * valu_per_wave_term / (ms * 1e-3) / valu_issue_peak,
+                     "counters": "profiles/r03h_config4_sq_counters.json (SQ_INSTS_VALU* per launch)",
                      "second_pass": "from the joint log-probabilities kept in the workspace" if cached else "recomputed",
                      "note": "log-throughput bound: one float64 log per (genotype, read) term; 80 KB in, < 1 KB out per unit"},
     }
@@ -331,8 +339,15 @@ def bench_config5(args):
         "workload": "%d loci: octoploid, %d SNVs, %d reads, %d chains x %d steps, burn %d; HBM resident; one pass" % (U, M, R, C_, S, S // 2),
         "value": U / dt, "unit": "loci/s", "kernel": batch.sampler_name, "kernel_ms": kms, "pass_ms": dt * 1e3,
         "ok": bool((status <= 1).all()),
-        "roofline": {"bound": "issue", "achieved": substeps / (kms * 1e-3), "unit": "sub-steps/s",
-                     "note": "serial sub-step latency bound like configs[1]; 160 mutation sub-steps per chain step"},
+        # VALU issue: profiles/r03h_config5_sq_counters.json -- the sampler's launches issue 3.71e10 wavefront VALU
+        # instructions for this workload (256 loci: 3.34e8 sub-steps, 111 per sub-step); the chip issues at most
+        # 1024 SIMDs x 2.4 GHz / 4 cycles = 6.14e11 per second.  One pass is 1024 chains = one wavefront per SIMD.
+        "roofline": {"bound": "valu_issue", "achieved": 111.2 * substeps / (kms * 1e-3) / 1e9, "peak": 614.4, "unit": "G wavefront-instructions/s",
+                     "frac": 111.2 * substeps / (kms * 1e-3) / 614.4e9, "sub_steps_per_s": substeps / (kms * 1e-3),
+                     "valu_insts_per_sub_step": 111.2, "counters": "profiles/r03h_config5_sq_counters.json",
+                     "note": "serial sub-step latency bound like configs[1]; 160 mutation sub-steps per chain step; one pass "
+                             "holds one wavefront per SIMD, so the fraction of one pass alone cannot exceed the share of cycles "
+                             "a single wavefront issues in (SQ_WAIT_ANY 47 % of its cycles)"},
     }
     nfl = 2 * args.inflight if args.inflight > 1 else 1
     if nfl > 1:

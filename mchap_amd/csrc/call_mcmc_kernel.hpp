@@ -178,11 +178,21 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
   auto coop_llk = [&](int kk) -> double {
     const double invk = 1.0 / (double)kk;
     double s = 0.0;
-    for (int r = lane; r < R; r += WAVE) {
-      const double *row = E.ptab + (size_t)r * H;
-      double rp = 0.0;
-      for (int i = 0; i < kk; i++) rp += row[s_req[i]] * invk;
-      s += read_log(rp) * E.cnt[r];
+    if (EP.ptab_ext) {  // table in the workspace
+      for (int r = lane; r < R; r += WAVE) {
+        const double *row = E.ptab + (size_t)r * H;
+        double rp = 0.0;
+        for (int i = 0; i < kk; i++) rp += row[s_req[i]] * invk;
+        s += read_log(rp) * E.cnt[r];
+      }
+    } else {  // table in the LDS: ds_read instead of flat_load (exact_kernel.hpp lds_table), same values
+      lds_cdouble *ptab = lds_table(E.ptab), *cnt = lds_table(E.cnt);
+      for (int r = lane; r < R; r += WAVE) {
+        lds_cdouble *row = ptab + r * H;
+        double rp = 0.0;
+        for (int i = 0; i < kk; i++) rp += row[s_req[i]] * invk;
+        s += read_log(rp) * cnt[r];
+      }
     }
     return wave_sum(s);
   };
