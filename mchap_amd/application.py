@@ -65,13 +65,14 @@ class ReadSource:
             if isinstance(bam, BamFile):
                 region = bam.index is not None and len(bam.data) > self.WHOLE_FILE_BYTES
                 cols = bam.columns(locus.contig, locus.start, locus.stop) if region else bam.columns()
-                parts.append(extract_read_variants_columns(locus, cols, name, **self.filter))
+                parts.append(extract_read_variants_columns(locus, cols, name, as_codes=True, **self.filter))
             else:
-                parts.append(extract_read_variants(locus, bam, name, **self.filter))
+                c, q = extract_read_variants(locus, bam, name, **self.filter)
+                parts.append((_codes(c), q))
         if parts:
             chars, quals = np.concatenate([c for c, _ in parts]), np.concatenate([q for _, q in parts])
         else:
-            chars, quals = np.empty((0, M), dtype="U1"), np.empty((0, M), dtype=np.int16)
+            chars, quals = np.empty((0, M), dtype=np.uint8), np.empty((0, M), dtype=np.int16)
         return encode_reads(locus, chars, quals, self.error_rate, self.use_phred)
 
 
@@ -88,10 +89,7 @@ class MatrixSource:
 
     def reads(self, locus, sample):
         chars, quals = self.matrices[(locus.name, sample)]
-        chars = np.asarray(chars)
-        if chars.dtype == np.uint8:
-            chars = chars.view("S1").astype("U1").reshape(chars.shape)
-        return encode_reads(locus, chars, np.asarray(quals, dtype=np.int16), self.error_rate, self.use_phred)
+        return encode_reads(locus, np.asarray(chars), np.asarray(quals, dtype=np.int16), self.error_rate, self.use_phred)
 
 
 def load_matrices(path):
@@ -121,21 +119,35 @@ def sample_reads(locus, pairs, error_rate=0.0024, use_phred=False, read_filter=N
     if parts:
         chars, quals = np.concatenate([c for c, _ in parts]), np.concatenate([q for _, q in parts])
     else:
-        chars, quals = np.empty((0, M), dtype="U1"), np.empty((0, M), dtype=np.int16)
+        chars, quals = np.empty((0, M), dtype=np.uint8), np.empty((0, M), dtype=np.int16)
     return encode_reads(locus, chars, quals, error_rate, use_phred)
 
 
+def _codes(chars):
+    """A character matrix ('U1' strings, or uint8 ASCII codes already) as uint8 ASCII codes."""
+    chars = np.asarray(chars)
+    if chars.dtype == np.uint8:
+        return chars
+    return chars.astype("S1").view(np.uint8).reshape(chars.shape) if chars.size else np.empty(chars.shape, dtype=np.uint8)
+
+
 def encode_reads(locus, chars, quals, error_rate=0.0024, use_phred=False):
-    """Character matrix + qualities -> allele calls, probabilistic rows, de-duplicated rows with counts, depth
-    (application/baseclass.py:189-207)."""
+    """Character matrix (strings or ASCII codes) + qualities -> allele calls, probabilistic rows, de-duplicated rows with
+    counts, depth (application/baseclass.py:189-207)."""
     M = len(locus.positions)
+    chars = _codes(chars)
     calls = np.full(chars.shape, -1, dtype=np.int8)
-    for j in range(M):
-        for a, c in enumerate(locus.alleles[j]):
-            calls[chars[:, j] == c, j] = a
+    if M and chars.shape[0]:
+        # allele index of every character: one table look-up per SNV column
+        lut = np.full((M, 256), -1, dtype=np.int8)
+        for j in range(M):
+            for a, c in enumerate(locus.alleles[j]):
+                if lut[j, ord(c)] < 0:
+                    lut[j, ord(c)] = a
+        calls = lut[np.arange(M)[None, :], chars]
     dists = encoding.encode_read_distributions(locus.n_alleles, calls, quals if use_phred else None, error_rate=error_rate)
     uniq, counts = encoding.unique_counts(dists)
-    depth = (chars != "-").sum(axis=0) if M else np.array([])
+    depth = (chars != ord("-")).sum(axis=0) if M else np.array([])
     return dict(chars=chars, calls=calls, depth=depth, dists=uniq, counts=counts)
 
 
@@ -629,6 +641,29 @@ def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_t
                       ";".join(parts), ":".join(SAMPLE_FIELDS + tuple(fmt_opt))] + cols)
 
 
+def _variants_by_contig(variants):
+    """{contig: (positions ascending, the records in that order)}: the file order of equal positions is kept (stable sort),
+    as DenovoLocus merges the records of a position in the order it is given them."""
+    by = {}
+    for r in variants:
+        by.setdefault(r["chrom"], []).append(r)
+    out = {}
+    for contig, recs in by.items():
+        pos = np.fromiter((r["pos"] for r in recs), dtype=np.int64, count=len(recs))
+        o = np.argsort(pos, kind="stable")
+        out[contig] = (pos[o], [recs[i] for i in o])
+    return out
+
+
+def _variants_within(by_contig, contig, start, stop):
+    """The variant records of a target's interval, by bisection of the contig's sorted positions."""
+    if contig not in by_contig:
+        return ()
+    pos, recs = by_contig[contig]
+    lo, hi = np.searchsorted(pos, start + 1, side="left"), np.searchsorted(pos, stop + 1, side="left")  # (pos is 1-based)
+    return recs[int(lo):int(hi)]
+
+
 def assemble_targets(bed_path=None, region=None, region_id=None):
     """The target loci of `mchap assemble`: the lines of a BED4 file, or one --region (application/assemble.py:75-85)."""
     from .io import parse_region
@@ -685,9 +720,7 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
         targets = read_bed4(bed_path)
     targets = _shard(list(targets), shard)
     fetch = reference_sequences.fetch if isinstance(reference_sequences, Reference) else (lambda c, a, b: reference_sequences[c][a:b])
-    by_contig = {}
-    for r in variants:
-        by_contig.setdefault(r["chrom"], []).append(r)
+    by_contig = _variants_by_contig(variants)
     if units_per_block is None:
         # device bytes of one unit: its traces (chains x steps x (ploidy words + llk)), the per-chain likelihood cache and
         # tables of the workspace, a typical read tensor
@@ -695,7 +728,7 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
         units_per_block = device_unit_budget(chains * steps * (kmax + 1) * 8 + chains * 1024 * 16 * 2 + (256 << 10), fraction=0.4)
     loci_per_block = max(1, units_per_block // max(1, len(samples)))
     for block in _blocks(targets, loci_per_block):
-        loci = [DenovoLocus(contig, start, stop, name, by_contig.get(contig, ()), fetch(contig, start, stop))
+        loci = [DenovoLocus(contig, start, stop, name, _variants_within(by_contig, contig, start, stop), fetch(contig, start, stop))
                 for contig, start, stop, name in block]
         encoded = {}
         units, where = [], []

@@ -685,19 +685,33 @@ class AlignmentColumns:
         tag_off = self.qual_off + l_seq
         rec_end = offs + 4 + block
         self.buf = b
-        # query names -> integer ids (mates share a name); read groups from the RG:Z tag
-        names = [bytes(buf[int(a):int(a + l - 1)]) for a, l in zip(name_off, l_name)]
-        ids = {}
-        self.qname = np.fromiter((ids.setdefault(nm, len(ids)) for nm in names), dtype=np.int64, count=n)
+        # query names -> integer ids (mates share a name): the names as one fixed-width byte-string column
+        if n:
+            width = int(l_name.max())
+            k_ = np.arange(width)
+            nm = np.where(k_[None, :] < (l_name - 1)[:, None], b[np.minimum(name_off[:, None] + k_[None, :], len(b) - 1)], 0).astype(np.uint8)
+            self.qname = np.unique(np.ascontiguousarray(nm).view("S%d" % width).reshape(n), return_inverse=True)[1].astype(np.int64)
+        else:
+            self.qname = np.zeros(0, dtype=np.int64)
+        # read groups from the RG:Z tag: every "RGZ" in the buffer, kept when it lies in a record's tag bytes (the first one
+        # of a record), then its NUL-terminated value matched with the header's read-group ids
         rg_names = list(rg_table)
-        rg_index = {k.encode(): i for i, k in enumerate(rg_names)}
         self.rg_samples = [rg_table[k] if id_field == "SM" else k for k in rg_names]
         rgi = np.full(n, -1, dtype=np.int64)
-        for i in range(n):
-            t = bytes(buf[int(tag_off[i]):int(rec_end[i])])
-            k = t.find(b"RGZ")
-            if k >= 0:
-                rgi[i] = rg_index.get(t[k + 3:t.index(b"\0", k + 3)], -1)
+        if n and rg_names and len(b) >= 4:
+            at = np.flatnonzero((b[:-3] == ord("R")) & (b[1:-2] == ord("G")) & (b[2:-1] == ord("Z")))
+            ri = np.searchsorted(offs, at, side="right") - 1
+            keep = (ri >= 0)
+            keep[keep] &= (at[keep] >= tag_off[ri[keep]]) & (at[keep] + 3 < rec_end[ri[keep]])
+            at, ri = at[keep], ri[keep]
+            firsts = np.r_[True, ri[1:] != ri[:-1]] if len(ri) else np.zeros(0, bool)
+            at, ri = at[firsts], ri[firsts]
+            for gi, key in enumerate(rg_names):
+                kb = np.frombuffer(key.encode() + b"\0", dtype=np.uint8)
+                room = at + 3 + len(kb) <= rec_end[ri]
+                m = room.copy()
+                m[room] = (b[(at[room] + 3)[:, None] + np.arange(len(kb))] == kb).all(axis=1)
+                rgi[ri[m]] = gi
         self.rg = rgi
         # CIGAR operations, flattened: record, op, length, reference / read offset at the start of the op
         total = int(n_cig.sum())
@@ -716,6 +730,22 @@ class AlignmentColumns:
         self.c_ref0 = self.pos[rec].astype(np.int64) + (cref - base_ref).astype(np.int64)
         self.c_read0 = (cread - base_read).astype(np.int64)
         self.end = self.pos.astype(np.int64) + np.bincount(rec, ref_adv, n).astype(np.int64) if total else self.pos.astype(np.int64)
+        # coordinate-sorted files (the usual case, and what an index requires): the records that can overlap a region are
+        # a contiguous run found by bisection; the CIGAR operations of a run of records are a contiguous run as well
+        self.seg_first = np.r_[np.cumsum(n_cig) - n_cig, total].astype(np.int64)
+        rid = np.where(self.ref_id < 0, np.int64(1) << 30, self.ref_id.astype(np.int64))  # unplaced reads sort last
+        self.sort_key = (rid << 32) | self.pos.astype(np.int64).clip(0)
+        self.sorted = bool(n < 2 or (self.sort_key[1:] >= self.sort_key[:-1]).all())
+        self.max_span = int((self.end - self.pos).max()) if n else 0
+
+    def window(self, tid, start, stop):
+        """[lo, hi): the run of records that can overlap [start, stop) of reference `tid` (all records of an unsorted file)."""
+        if not self.sorted or tid < 0:
+            return 0, self.n
+        base = np.int64(tid) << 32
+        lo = int(np.searchsorted(self.sort_key, base | max(0, start - self.max_span), side="left"))
+        hi = int(np.searchsorted(self.sort_key, base | max(0, stop), side="left"))
+        return lo, hi
 
 
 class BamFile:
@@ -794,32 +824,44 @@ class BamFile:
 _NIB = np.frombuffer(SEQ_CODE.encode(), dtype=np.uint8)
 
 
-def extract_read_variants_columns(locus, cols, sample, min_quality=20, skip_duplicates=True, skip_qcfail=True, skip_supplementary=True):
+def extract_read_variants_columns(locus, cols, sample, min_quality=20, skip_duplicates=True, skip_qcfail=True, skip_supplementary=True,
+                                  as_codes=False):
     """extract_read_variants (io/bam.py:54-229) over AlignmentColumns, vectorised: same matrices as the per-read loop (rows in
     order of the first passing record of each query name; a position covered by both mates keeps the base when they agree,
-    with the qualities added, and becomes 'N' when they do not)."""
+    with the qualities added, and becomes 'N' when they do not).  Only the records of the locus's window are looked at
+    (AlignmentColumns.window).  as_codes: the characters as uint8 ASCII codes instead of a 'U1' array."""
     n_snv = len(locus.positions)
+
+    def result(chars, quals):
+        return (chars if as_codes else chars.view("S1").astype("U1").reshape(chars.shape)), quals.astype(np.int16)
+
     skip = 0x4 | (0x400 if skip_duplicates else 0) | (0x200 if skip_qcfail else 0) | (0x800 if skip_supplementary else 0)
-    tid = [n for n, _ in cols.refs].index(locus.contig) if cols.n else -1
+    names = [n for n, _ in cols.refs]
+    tid = names.index(locus.contig) if cols.n and locus.contig in names else -1
+    lo, hi = cols.window(tid, locus.start, locus.stop) if cols.n else (0, 0)
+    w = slice(lo, hi)
     want_rg = np.array([s == sample for s in cols.rg_samples] + [False])  # (index -1: no read group)
-    ok = (cols.ref_id == tid) & (cols.pos < locus.stop) & (cols.end > locus.start) & ((cols.flag & skip) == 0) & \
-        (cols.mapq >= min_quality) & want_rg[cols.rg] if cols.n else np.zeros(0, bool)
-    recs = np.flatnonzero(ok)
+    ok = (cols.ref_id[w] == tid) & (cols.pos[w] < locus.stop) & (cols.end[w] > locus.start) & ((cols.flag[w] & skip) == 0) & \
+        (cols.mapq[w] >= min_quality) & want_rg[cols.rg[w]]
+    recs = np.flatnonzero(ok)  # (relative to lo)
     if len(recs) == 0:
-        return np.empty((0, n_snv), dtype="U1"), np.empty((0, n_snv), dtype=np.int16)
-    first_of, row_of = np.unique(cols.qname[recs], return_index=True)[1], None
-    order = np.sort(first_of)                      # rows in order of first appearance
-    names_in_order = cols.qname[recs][order]
-    lut = {int(q): i for i, q in enumerate(names_in_order)}
-    row_of = np.fromiter((lut[int(q)] for q in cols.qname[recs]), dtype=np.int64, count=len(recs))
-    rec_row = np.full(cols.n, -1, dtype=np.int64)
-    rec_row[recs] = row_of
+        return result(np.empty((0, n_snv), dtype=np.uint8), np.empty((0, n_snv), dtype=np.int16))
+    # rows in order of the first passing record of each query name
+    _, first_of, inv = np.unique(cols.qname[w][recs], return_index=True, return_inverse=True)
+    order = np.argsort(first_of, kind="stable")
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    rec_row = np.full(hi - lo, -1, dtype=np.int64)
+    rec_row[recs] = rank[inv]
     chars = np.full((len(order), n_snv), ord("-"), dtype=np.uint8)
     quals = np.zeros((len(order), n_snv), dtype=np.int64)
     if n_snv:
-        seg = np.flatnonzero(ok[cols.c_rec] & np.isin(cols.c_op, (0, 7, 8)))
+        s0, s1 = int(cols.seg_first[lo]), int(cols.seg_first[hi])
+        c_rec, c_op = cols.c_rec[s0:s1], cols.c_op[s0:s1]
+        seg = np.flatnonzero(ok[c_rec - lo] & ((c_op == 0) | (c_op == 7) | (c_op == 8))) + s0
         P = np.asarray(locus.positions, dtype=np.int64)
-        hit = (cols.c_ref0[seg][:, None] <= P[None, :]) & (P[None, :] < (cols.c_ref0[seg] + cols.c_len[seg])[:, None])
+        r0 = cols.c_ref0[seg]
+        hit = (r0[:, None] <= P[None, :]) & (P[None, :] < (r0 + cols.c_len[seg])[:, None])
         si, pj = np.nonzero(hit)                   # (segment, SNV) pairs in record order, then position order
         s_ = seg[si]
         rec = cols.c_rec[s_]
@@ -827,20 +869,24 @@ def extract_read_variants_columns(locus, cols, sample, min_quality=20, skip_dupl
         byte = cols.buf[cols.seq_off[rec] + (ro >> 1)]
         base = _NIB[np.where(ro & 1, byte & 15, byte >> 4)]
         q = cols.buf[cols.qual_off[rec] + ro].astype(np.int64)
-        rows = rec_row[rec]
+        rows = rec_row[rec - lo]
         # a (row, SNV) cell hit more than once (overlapping mates): apply the hits in record order
         cell = rows * n_snv + pj
-        rank = np.zeros(len(cell), dtype=np.int64)
         o = np.argsort(cell, kind="stable")
         sc = cell[o]
-        startg = np.r_[True, sc[1:] != sc[:-1]]
-        rank[o] = np.arange(len(sc)) - np.maximum.accumulate(np.where(startg, np.arange(len(sc)), 0))
-        for k in range(int(rank.max(initial=-1)) + 1):
-            m = rank == k
-            r_, j_, b_, q_ = rows[m], pj[m], base[m], q[m]
-            cur = chars[r_, j_]
-            empty = cur == ord("-")
-            same = cur == b_
-            chars[r_, j_] = np.where(empty, b_, np.where(same, cur, ord("N")))
-            quals[r_, j_] = np.where(empty, q_, np.where(same, quals[r_, j_] + q_, quals[r_, j_]))
-    return chars.view("S1").astype("U1").reshape(chars.shape), quals.astype(np.int16)
+        if len(sc) and (sc[1:] != sc[:-1]).all():  # every cell hit once (no overlapping mates): one scatter
+            chars[rows, pj] = base
+            quals[rows, pj] = q
+        else:
+            rank_c = np.zeros(len(cell), dtype=np.int64)
+            startg = np.r_[True, sc[1:] != sc[:-1]]
+            rank_c[o] = np.arange(len(sc)) - np.maximum.accumulate(np.where(startg, np.arange(len(sc)), 0))
+            for k in range(int(rank_c.max(initial=-1)) + 1):
+                m = rank_c == k
+                r_, j_, b_, q_ = rows[m], pj[m], base[m], q[m]
+                cur = chars[r_, j_]
+                empty = cur == ord("-")
+                same = cur == b_
+                chars[r_, j_] = np.where(empty, b_, np.where(same, cur, ord("N")))
+                quals[r_, j_] = np.where(empty, q_, np.where(same, quals[r_, j_] + q_, quals[r_, j_]))
+    return result(chars, quals)

@@ -14,7 +14,8 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 cache = int(sys.argv[3]) if len(sys.argv) > 3 else 100  # llk_cache_threshold (-1: no cache)
 reads, _, _ = synth_units(U, n_reads=R, qual=(3, 20))
 out = {}
-for kernel in (3, 0):
+kernels = tuple(int(k) for k in os.environ.get("SWEEP_KERNELS", "3,0").split(","))
+for kernel in kernels:
     model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=1000, chains=2, random_seed=42, kernel=kernel, llk_cache_threshold=cache)
     b = DenovoDeviceBatch(model, reads)
     b.time_sampler(True)
@@ -29,4 +30,4 @@ for kernel in (3, 0):
     print("%d loci x %d reads  %-62s %s ms   chains moving after step 100: %.1f %%" % (
         U, R, b.sampler_name, " ".join("%.2f" % m for m in ms), 100 * moved), flush=True)
     del b
-print("same traces" if np.array_equal(out[3], out[0]) else "TRACES DIFFER")
+print("same traces" if all(np.array_equal(out[kernels[0]], out[k]) for k in kernels[1:]) else "TRACES DIFFER")
