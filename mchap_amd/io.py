@@ -299,31 +299,36 @@ def extract_read_variants(locus, bam, sample, min_quality=20, skip_duplicates=Tr
 
 
 def qual_of_prob(prob, precision=6):
-    """io/util.py:56-89"""
-    maximum = 1 - 0.1 ** precision
-    prob = min(prob, maximum)
-    prob = np.floor(prob * 10 ** precision) / 10 ** precision
-    return int(np.round(-10 * np.log10(1 - prob)))
+    """Phred-scaled quality of a probability of being right, as the VCF fields GQ / SQ want it (io/util.py:56-89): the
+    probability is cut off (not rounded) after `precision` decimals and capped one unit below 1, so the quality is finite."""
+    unit = 10 ** precision
+    kept = np.floor(min(prob, 1 - 0.1 ** precision) * unit) / unit
+    return int(np.round(-10 * np.log10(1 - kept)))
+
+
+def _number_text(x, precision, negative_zero):
+    """One float of a VCF field: rounded, without a trailing '.0', '.' for NaN."""
+    if np.isnan(x):
+        return "."
+    r = float(np.round(x, precision))
+    if np.isfinite(r) and r == int(r):
+        return "-0" if (negative_zero and r == 0 and np.signbit(r)) else str(int(r))
+    return repr(r)[:16]
 
 
 def vcfstr(obj, precision=3):
-    """io/vcf/util.py:4-42"""
-    if isinstance(obj, np.ndarray):
-        if len(obj) == 0:
-            return "."
-        if np.issubdtype(obj.dtype, np.floating):
-            obj = obj.round(precision)
-            string = ",".join(obj.astype("U16")).replace("nan", ".").replace(".0,", ",")
-            return string[:-2] if string[-2:] == ".0" else string
-        return ",".join(obj.astype("U16"))
+    """The text of a VCF value (io/vcf/util.py:4-42): None / NaN / an empty array -> '.', arrays comma-separated, floats rounded
+    to `precision` decimals and whole numbers written without a fraction."""
     if obj is None:
         return "."
-    if isinstance(obj, (float, np.floating)):
-        if np.isnan(obj):
+    if isinstance(obj, np.ndarray):
+        if obj.size == 0:
             return "."
-        obj = np.round(obj, precision)
-        i = int(obj)
-        return str(i) if i == obj else str(obj)
+        if np.issubdtype(obj.dtype, np.floating):
+            return ",".join(_number_text(x, precision, True) for x in obj.tolist())
+        return ",".join(str(x) for x in obj.tolist())
+    if isinstance(obj, (float, np.floating)):
+        return _number_text(float(obj), precision, False)
     return str(obj)
 
 
