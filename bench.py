@@ -614,7 +614,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist = None
-    if world > 1:
+    # (MCHAP_BENCH_DIST=1: join a process group even as a single rank -- the RCCL calls of the N > 1 path on a 1-GPU box)
+    if world > 1 or os.environ.get("MCHAP_BENCH_DIST") == "1":
         import torch.distributed as dist
 
         # RCCL over xGMI; MCHAP_BENCH_BACKEND=gloo lets the N > 1 path be exercised by several ranks on ONE GPU

@@ -1022,7 +1022,7 @@ template <int KT, int G, bool LT = false>
 __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, int mmax, int nmax, int rpad,
                                               int lane, int gi, int gl) {
   const int Mh = c.Mh;
-  const int n = KT * Mh;  // sub-steps; position p of the sequence is held by lane p % G, slot p / G (n <= 2 G)
+  const int n = KT * Mh;  // sub-steps; position p of the sequence is held by lane p % G, slot p / G (n <= NS G)
   const uint64_t ctr0 = c.ctr;
   // Fast path.  For an unchanged genotype the outcome of sub-step e depends only on its uniform: it stays iff
   // lo_e <= u < hi_e (the cumulative probabilities around the current allele).  With mlo = max lo_e and
@@ -1065,8 +1065,9 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
   LDSP(uint8_t) shift = S.shift + gi * mmax;
   LDSP(uint8_t) nal = S.nal + gi * mmax;
   LDSP(double) pt = S.prior + gi * (2 * KT + 5);
-  // sub-steps per lane ("slots"): two, three for octoploids with up to 3 G = 192 sub-steps (20 SNVs and more)
-  constexpr int NS = (KT == 8 && G == 64) ? 3 : 2;
+  // sub-steps per lane ("slots"): two; three with one chain per wavefront, i.e. up to 3 G = 192 sub-steps (octoploids with
+  // 20 SNVs and more, tetraploids with 33-48).  Only the slots in use are visited (nslots below).
+  constexpr int NS = (G == 64) ? 3 : 2;
   const bool two = wave_any(c.alive && n > G);  // second slot in use anywhere in the wave
   // (1) the 2n-1 draws of this compound step, staged through LDS; the Fisher-Yates shuffle is swap(i, k_i) for
   //     i = n-1 .. 1 with k_i = interval(i) from draw ctr0 + (n-1-i)

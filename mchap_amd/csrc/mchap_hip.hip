@@ -314,13 +314,14 @@ int batch_dims(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units
 }
 
 // lanes per chain for the speculative sampler: every option of an interval step (<= K(K-1)) and half the
-// sub-steps of a mutation step (K * n_pos) must fit; 0 if the shape is not supported by it
+// sub-steps of a mutation step (K * n_pos) must fit -- a third of them with one chain per wavefront; 0 if the
+// shape is not supported by it
 int spec_group(const Tune &T, int K, int max_pos) {
   if (K < 2 || K > 8) return 0;
   const int n = K * max_pos;
   int g = T.spec_group ? T.spec_group : 16;
   while (g < 64 && (g < K * (K - 1) || 2 * g < n)) g *= 2;
-  const int slots = (K == 8) ? 3 : 2;  // sub-steps per lane the instantiation supports (denovo_spec_kernel.hpp)
+  const int slots = (g == 64) ? 3 : 2;   // sub-steps per lane the instantiation supports (denovo_spec_kernel.hpp: NS)
   if (g < K * (K - 1) || slots * g < n) return 0;
   if ((K == 5 || K == 6) && g < 32) g = 32;  // instantiated group sizes: 2..4: 16/32/64, 5..6: 32/64, 7..8: 64
   if (K >= 7) g = 64;

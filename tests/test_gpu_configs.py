@@ -237,3 +237,49 @@ def test_config4_call_exact_arrays_batched_on_the_device():
         assert mode[0][u].tolist() == a.tolist()
         np.testing.assert_allclose([mode[1][u], mode[2][u], mode[3][u]], [ml, mp, sp], rtol=1e-9)
         np.testing.assert_allclose(mode[4][u], fq, rtol=1e-9, atol=1e-300)
+
+
+WIDE_SHAPES = [
+    # (ploidy, SNVs, reads, steps, first synthetic unit): ploidy x SNVs in 129..192 -- three sub-steps per lane of the
+    # one-chain-per-wavefront kernels (two cover 128; before round 3 only the octoploid instantiation had a third)
+    (4, 40, 120, 120, 500),
+    (4, 44, 60, 100, 510),
+    (6, 30, 150, 100, 520),
+    (5, 38, 100, 100, 530),
+    (3, 44, 90, 120, 540),
+]
+
+
+@pytest.mark.parametrize("shape", WIDE_SHAPES, ids=lambda s: "K%d-M%d" % (s[0], s[1]))
+def test_wide_loci_on_the_fast_samplers(shape, monkeypatch):
+    """Loci with many SNVs (33-44 at ploidy 3-6: 129-192 mutation sub-steps per step) run on the phased sampler and on the
+    speculative kernel -- not on the general lanes-over-chains kernel they fell to before -- and every step of every chain
+    equals the oracle's: a clean unit (settles: hand-over, table completion over 780-990 intervals, coasting) and a shallow
+    low-quality one (keeps moving: speculation windows over three slots per lane).  Reference: assemble/mcmc.py:268-426,
+    mutation.py:164-246 (no limit on the number of positions)."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.classes import sort_haplotypes
+    from mchap_amd.synth import synth_units
+    from tests.helpers import beta_break_table
+
+    K, M, R, steps, first = shape
+    clean, _, _ = synth_units(1, ploidy=K, n_pos=M, n_reads=R, window=(M // 3, M), first_unit=first)
+    noisy, _, _ = synth_units(1, ploidy=K, n_pos=M, n_reads=24, window=(M // 3, M), first_unit=first + 1, qual=(4, 14))
+    reads = [clean[0], noisy[0]]
+    ref = []
+    for u, rd in enumerate(reads):
+        cfg = orc.make_cfg(K, steps, 2, None, (1.0,), llk_cache_threshold=100, rng_kind=orc.RNG_PHILOX, seed=5, stream_id=u,
+                           break_table=beta_break_table(M, 1.0, 3.0))
+        g, l, code = orc.denovo_fit(cfg, rd, [2] * M)
+        assert code == 0
+        ref.append((sort_haplotypes(g), l))
+    assert (np.diff(ref[1][1], axis=1) != 0).sum() >= 10  # the noisy unit does move
+    for kernel, name in ((0, "phased"), (3, "denovo_spec_kernel<%d, 64>" % K), (2, "simt")):
+        monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
+        model = DenovoMCMC(ploidy=K, n_alleles=[2] * M, steps=steps, chains=2, random_seed=5)
+        traces = model.fit_batch(reads)
+        assert name in model.last_sampler, model.last_sampler
+        for u, tr in enumerate(traces):
+            assert tr.genotypes.shape == (2, steps, K, M)
+            assert np.array_equal(tr.genotypes, ref[u][0]), "kernel %d unit %d" % (kernel, u)
+            np.testing.assert_allclose(tr.llks, ref[u][1], rtol=1e-10)
