@@ -130,6 +130,8 @@ struct SpecLds {
   LDSP(uint64_t) bw;      // [NG][K] the chain's current genotype while its proposals are evaluated (base words)
   LDSP(double) bpc;       // [K][4][64] one chain per wave only (G = 64), else null: the haplotype products of ...
   LDSP(uint64_t) bpt;     // [K + 1] ... these base words (bpt[K] != 0: valid), kept from one evaluation call to the next
+  LDSP(const uint8_t) sct;  // [rows][64] code of read `lane` in every row of the table, for a shallow unit (<= 32 reads, <= 24
+                            // rows) of a one-chain-per-wave launch: kept in the product cache's unused chunk slots; else null
   LDSP(uint64_t) tbuf;    // [NG][SPEC_TB][K + 1] trace records (K sorted words + llk) waiting to be written as a line
   uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
   int key_words;          // words per entry of the wide-genotype key table (DenovoParams::cache_key_words)
@@ -715,7 +717,8 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
                                                 LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, LDSP(uint64_t) bw_tab,
                                                 bool reuse, int crow, int mmax, int Mh_lane, uint32_t amask_lane, int rpad,
                                                 int lane, LDSP(const uint8_t) lds_ct = nullptr, LDSP(const double) lds_cw = nullptr,
-                                                LDSP(double) bpc = nullptr, LDSP(uint64_t) bpt = nullptr) {
+                                                LDSP(double) bpc = nullptr, LDSP(uint64_t) bpt = nullptr,
+                                                LDSP(const uint8_t) sct = nullptr) {
   SpecLds S;
   S.pw = pwbuf;
   S.shift = shift_tab;
@@ -819,22 +822,70 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
               }
             }
             const int my_src = sub == 0 ? srcs[0] : (sub == 1 ? srcs[1] : (sub == 2 ? srcs[2] : srcs[3]));
-            double sv = 0.0;
+            // the product over the positions of one haplotype word for the lane's read, eight positions at a time: their
+            // code loads go out together, then the dictionary gathers, then the products in position order (a position
+            // beyond Mh multiplies by 1.0: exact) -- one memory round trip per eight positions instead of one per position
+            auto hap_product = [&](uint64_t wa) -> double {
+              double ph = 1.0;
+              for (int j0 = 0; j0 < Mh; j0 += 8) {
+                uint8_t cd[8];
+                uint32_t row[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                  const int j = min(j0 + t, Mh - 1);
+                  row[t] = (uint32_t)cols[j] + ((uint32_t)(wa >> shift[j]) & amask);
+                }
+                if (sct != nullptr) {  // (wave-uniform) the unit's codes are in LDS: no memory round trip at all
+#pragma unroll
+                  for (int t = 0; t < 8; t++) cd[t] = sct[row[t] * WAVE + r];
+                } else {
+#pragma unroll
+                  for (int t = 0; t < 8; t++) cd[t] = ctb[(size_t)(row[t] * WAVE + r) * cstride];
+                }
+                double f[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) f[t] = dict[cd[t]];
+#pragma unroll
+                for (int t = 0; t < 8; t++) ph *= (j0 + t < Mh) ? f[t] : 1.0;
+              }
+              return ph;
+            };
+            // Which haplotypes does the lane's request change?  Mutation proposals change one, and then the sub-groups
+            // -- each with a different changed haplotype -- form their product in ONE pass of the whole wavefront instead
+            // of one divergent pass per haplotype.  Same factors, same order of the sum over haplotypes: same values.
+            int hc = -1, nchg = 0;
+            uint64_t wac = 0;
             if (sub < nq) {
+#pragma unroll
+              for (int h = 0; h < KT; h++) {
+                const uint64_t wa = pwbuf[(size_t)h * WAVE + my_src];
+                if (wa != bw_tab[(size_t)sg * KT + h]) {
+                  if (nchg == 0) {
+                    hc = h;
+                    wac = wa;
+                  }
+                  nchg++;
+                }
+              }
+            }
+            double sv = 0.0;
+            if (!wave_any(nchg > 1)) {
+              const double pc = nchg == 1 ? hap_product(wac) : 1.0;
+              if (sub < nq) {
+                double acc = 0.0;
+#pragma unroll
+                for (int h = 0; h < KT; h++) {
+                  const double ph = (h == hc) ? pc : bpc[(h * 4) * WAVE + r];
+                  acc += ph * invK;
+                }
+                sv = read_log(acc) * cwr;
+              }
+            } else if (sub < nq) {
               double acc = 0.0;
 #pragma unroll
               for (int h = 0; h < KT; h++) {
                 const uint64_t wa = pwbuf[(size_t)h * WAVE + my_src], wb = bw_tab[(size_t)sg * KT + h];
-                double ph;
-                if (wa == wb) {
-                  ph = bpc[(h * 4) * WAVE + r];
-                } else {
-                  ph = 1.0;
-                  for (int j = 0; j < Mh; j++) {
-                    const uint32_t row = (uint32_t)cols[j] + ((uint32_t)(wa >> shift[j]) & amask);
-                    ph *= dict[ctb[(size_t)(row * WAVE + r) * cstride]];
-                  }
-                }
+                const double ph = (wa == wb) ? bpc[(h * 4) * WAVE + r] : hap_product(wa);
                 acc += ph * invK;
               }
               sv = read_log(acc) * cwr;
@@ -983,7 +1034,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
       for (int h = 0; h < KT; h++) S.bw[(size_t)(lane / G) * KT + h] = cg.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G, LT>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw, S.bpc, S.bpt);
+    const double v = spec_coop_all<KT, G, LT>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw, S.bpc, S.bpt, S.sct);
     if (miss) val = v;
     bool writer = miss && slot != nullptr;
     if (wave_any(writer && wide)) {
@@ -1832,6 +1883,19 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     const double *du = P.dict + (size_t)u * DICT_MAX;
     for (int i = gl; i < nd; i += G) S.dict[(size_t)gi * DICT_MAX + i] = du[i];
   }
+  S.sct = nullptr;
+  if constexpr (G == 64) {
+    // A shallow unit (one chunk of at most 32 reads: spec_coop_all evaluates its requests side by side) with a small table:
+    // every lane's code of every row goes into LDS once per launch -- into the chunk slots 1..3 of haplotype 0 of the
+    // product cache, which a one-chunk unit never uses -- and its evaluations then make no memory round trip.
+    const int rows = U.n_pos * A;
+    if (S.bpc != nullptr && c.alive && U.n_reads <= 32 && rows <= 24 && mi[META_I_NDICT] != 0 && !(P.flags & 4)) {
+      LDSP(uint8_t) t = (LDSP(uint8_t))(S.bpc + WAVE);
+      GLBP(const uint8_t) ct = (GLBP(const uint8_t))(P.codes + (size_t)u * P.max_ma * WAVE * P.cstride);
+      for (int r_ = 0; r_ < rows; r_++) t[r_ * WAVE + lane] = ct[(size_t)(r_ * WAVE + lane) * P.cstride];
+      S.sct = t;
+    }
+  }
   if (c.alive) {
     for (int j = gl; j < Mh; j += G) {
       S.cols[(size_t)gi * mmax + j] = (uint16_t)mi[META_I_COLS + j];
@@ -1936,7 +2000,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = g0.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, nullptr, nullptr, S.bpc, S.bpt);
+    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, nullptr, nullptr, S.bpc, S.bpt, S.sct);
     lds_sync();
     c.llk = __shfl(v, 0, G);
     if (c.alive && gl == 0) {

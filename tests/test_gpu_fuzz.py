@@ -31,3 +31,13 @@ def test_high_ploidy_single_temperature(seed):
     import fuzz_kernels
 
     assert fuzz_kernels.run(6, seed, ploidies=(6, 8), read_depths=(70, 200, 300), tempering=False, max_pos=12) == 0
+
+
+@pytest.mark.parametrize("seed", [41, 42, 43])
+def test_ragged_launches_match_oracle(seed):
+    """Ragged batches as `mchap assemble` builds them (units of different SNV counts, alleles per SNV, depths, qualities,
+    priors; 1 to 300 units per launch) through DenovoRaggedBatch's single launch: every unit's trace and device-side
+    posterior summary against the oracle (tests/fuzz_ragged.py)."""
+    import fuzz_ragged
+
+    assert fuzz_ragged.run(8, seed, verbose=True) == 0
