@@ -57,7 +57,8 @@ typedef struct mchap_denovo_tuning {
   int32_t cache_slots;   /* {tag, llk} entries per chain of the likelihood cache: a power of two in 64..65536 (default 1024) */
   int32_t flags;         /* 1: no mutation memo, 2: no interval memo, 4: no coded read table, 8: no product reuse,
                             16: no LDS base-product cache, 32: skip the phased sampler's table completion (timing only: with
-                            pipe_stop), 64 (libmchap_hip_test.so only): the tables completed by denovo_fill_kernel, one lane per request */
+                            pipe_stop), 64 (libmchap_hip_test.so only): the tables completed by denovo_fill_kernel, one lane per request,
+                            128: units without information (all gaps) are evaluated like any other */
   int32_t spec_group;    /* kernel 3: lanes per chain, 16 / 32 / 64 (default: the smallest the shape allows) */
   int32_t pipe_first;    /* kernel 5: MCMC steps before the first hand-over (default ploidy * n_pos / 10, clamped to 4..32) */
   int32_t pipe_resume;   /*           steps a handed-back chain runs before it is handed over again (default 8) */
@@ -192,6 +193,18 @@ int mchap_trace_posterior_batch_device(int n_units, const mchap_unit *units_dev,
                                        double *mode_stats, int32_t *mode_index, uint64_t *mode_words,
                                        int32_t *mode_count, void *stream);
 
+/* The same summary for the few units of a batch whose chains visited more distinct genotypes than the batch call keeps
+ * (post_n < 0: shallow or empty samples whose chains wander), with a table of `cap` states per unit instead of 512 --
+ * up to mchap_trace_posterior_max_states(ploidy_max), what 160 KB of LDS hold; cap >= chains * (steps - burn) can never
+ * overflow.  unit_list int32 [n_list] (device): the units; post_words uint64 [n_list][cap][ploidy_max] and post_counts
+ * int32 [n_list][cap] are indexed by list position, the per-unit outputs (post_n, mode_*) by unit, overwriting the batch
+ * call's values.  So the program never has to download a trace (assemble/classes.py:280-325 on the host). */
+int mchap_trace_posterior_max_states(int ploidy_max);
+int mchap_trace_posterior_listed_device(int n_list, const int32_t *unit_list_dev, const mchap_unit *units_dev, int steps, int chains,
+                                        int burn, const uint64_t *trace_words, int cap, int ploidy_max, uint64_t *post_words,
+                                        int32_t *post_counts, int32_t *post_n, double *mode_stats, int32_t *mode_index,
+                                        uint64_t *mode_words, int32_t *mode_count, void *stream);
+
 /* Exact caller: replaces calling.exact.genotype_likelihoods (calling/exact.py:266-292): llks_out float32 [G] as the
  * reference stores them and / or llks64_out float64 [G] (the unrounded values), G = C(n_haps + ploidy - 1, ploidy) genotypes in
  * VCF order; either may be NULL.  Host pointers, one unit. */
@@ -212,6 +225,12 @@ int mchap_exact_genotype_posteriors(const void *llks, int is_f32, int64_t n_geno
 int mchap_trace_incongruence_batch_device(int n_units, const mchap_unit *units_dev, int steps, int chains, int burn,
                                           const uint64_t *trace_words, int ploidy_max, double threshold, int32_t *mci,
                                           void *stream);
+
+/* ... and for a list of units with a table of `cap` states per chain (mci[u] == -1 after the batch call), as
+ * mchap_trace_posterior_listed_device; mci is indexed by unit. */
+int mchap_trace_incongruence_listed_device(int n_list, const int32_t *unit_list_dev, const mchap_unit *units_dev, int steps, int chains,
+                                           int burn, const uint64_t *trace_words, int cap, int ploidy_max, double threshold, int32_t *mci,
+                                           void *stream);
 
 /* Exact caller for a batch of units that share (n_reads, n_pos, max_allele, n_haps, ploidy), everything resident on the
  * device: what application/call_exact.py:126-179 asks of calling/exact.py per sample, for all samples of a chunk of

@@ -227,6 +227,9 @@ EXPORTS = [
     "mchap_denovo_fit_batch",
     "mchap_log_likelihood_batch",
     "mchap_trace_posterior_batch_device",
+    "mchap_trace_posterior_max_states",
+    "mchap_trace_posterior_listed_device",
+    "mchap_trace_incongruence_listed_device",
     "mchap_trace_incongruence_batch_device",
     "mchap_exact_genotype_likelihoods",
     "mchap_exact_genotype_posteriors",

@@ -48,12 +48,13 @@ def unpack_trace(words, fixed_alleles, max_allele):
     het = np.flatnonzero(fixed_alleles < 0)
     bits = allele_bits(max_allele)
     mh = len(het)
+    words = np.asarray(words)
     out = np.empty(words.shape + (len(fixed_alleles),), dtype=np.int8)
     out[...] = np.where(fixed_alleles < 0, 0, fixed_alleles).astype(np.int8)
-    mask = np.uint64((1 << bits) - 1)
-    for jj, j in enumerate(het):
-        shift = np.uint64(bits * (mh - 1 - jj))
-        out[..., j] = ((words >> shift) & mask).astype(np.int8)
+    if mh:
+        # every sampled position's field in one pass: position jj of the mh sampled ones sits bits * (mh - 1 - jj) bits up
+        shifts = (bits * (mh - 1 - np.arange(mh))).astype(np.uint64)
+        out[..., het] = ((words[..., None] >> shifts) & np.uint64((1 << bits) - 1)).astype(np.int8)
     return out
 
 

@@ -957,6 +957,7 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
     cu.Mh = __builtin_amdgcn_readlane(c.Mh, owner);
     cu.bits = __builtin_amdgcn_readlane(c.bits, owner);
     cu.alive = true;
+    cu.flat = false;  // (the shortcut of denovo_spec_kernel for all-gap units is not used by this kernel)
     cu.ctr = bcast_u64(c.ctr, owner);
     cu.doff = 0;
     cu.dcount = 0;

@@ -22,8 +22,11 @@ namespace mchap {
 constexpr int META_I_MH = 0;      // number of sampled (non-fixed) positions
 constexpr int META_I_STATUS = 1;  // MCHAP_UNIT_*
 constexpr int META_I_NDICT = 2;   // distinct values of the unit's table (0: more than DICT_MAX, no coded table)
-constexpr int META_I_COLS = 3;    // then [M]: column (j * A) of sampled position jj ; then [M]: n_alleles
-__host__ __device__ inline int meta_i_stride(int max_pos) { return 3 + 2 * max_pos; }
+constexpr int META_I_FLAT = 3;    // 1: every entry of the unit's table (existing alleles) is a gap -- a sample without reads
+                                  // at the locus, which the reference samples all the same (assemble/mcmc.py:132-137): the
+                                  // likelihood of every genotype is then the same number
+constexpr int META_I_COLS = 4;    // then [M]: column (j * A) of sampled position jj ; then [M]: n_alleles
+__host__ __device__ inline int meta_i_stride(int max_pos) { return 4 + 2 * max_pos; }
 // Coded read table (speculative sampler): a unit's table usually holds a few dozen distinct probabilities
 // (one per base quality, its error share, 1.0 for gaps), so it is also stored as uint8 codes into a per-unit
 // dictionary of float64 values: lossless, 8x smaller, and what the likelihood evaluation then streams stays in L2.
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
   int32_t *mi = P.meta_i + (size_t)u * meta_i_stride(P.max_pos);
   double *mf = P.meta_f + (size_t)u * meta_f_stride(P.max_ploidy, P.max_pos, P.max_allele);
 
+  bool all_gaps = true;  // every factor a likelihood can read is 1.0
   for (int r = lane; r < rpad; r += WAVE) {
     // eight entries of the read's row at a time: the loads are independent and issued together (the stores that
     // follow could alias them as far as the compiler knows)
@@ -154,9 +158,14 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
           const double x = isnan(v[k]) ? 1.0 : v[k];
           if (in_lds) rl[(size_t)q * rpad + r] = x;
           rt[(size_t)q * rpad + r] = x;
+          if (q % A < (int)nal0[q / A]) all_gaps = all_gaps && (x == 1.0);
         }
       }
     }
+  }
+  {
+    const bool flat = __ballot(!all_gaps) == 0ull;
+    if (lane == 0) mi[META_I_FLAT] = flat ? 1 : 0;
   }
   double cnt[RPL];
 #pragma unroll

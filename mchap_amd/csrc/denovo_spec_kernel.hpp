@@ -386,6 +386,7 @@ template <int KT>
 struct Grp {
   int Mh, bits;
   bool alive;
+  bool flat;     // the unit's table holds gaps only (META_I_FLAT): every genotype has the chain's current likelihood
   uint64_t ctr;  // next draw of the current stream (Philox words of the stream: SpecLds::gstream)
   int doff, dcount;  // staged window of the group's draw table: entry doff holds draw ctr, dcount entries are valid
   double llk;
@@ -965,6 +966,13 @@ template <int KT, int G, bool LT = false>
 __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, const Grp<KT> &c, const SpecLds &S, int mmax,
                                             int rpad, int lane) {
   double val = 0.0;
+  // A unit without information (a sample with no reads at the locus: one all-gap row, every factor 1.0) gives every
+  // genotype the same likelihood -- the same arithmetic on the same values --, which the chain already holds: no
+  // probe, no evaluation.  (Such chains move at every other sub-step; they used to be the slowest of a launch.)
+  if (c.flat) {
+    val = c.llk;
+    need = false;
+  }
   bool miss = need;
   uint64_t tag = 0;
   ulonglong2 *slot = nullptr;
@@ -1838,6 +1846,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
   const int A = U.max_allele;
   c.Mh = c.alive ? mi[META_I_MH] : 1;
   c.bits = allele_bits(A);
+  c.flat = c.alive && mi[META_I_FLAT] != 0 && !(P.flags & 128);
   if (gl == 0) {
     S.gval[gi * GV_N + GV_INB] = U.inbreeding;
     S.gval[gi * GV_N + GV_MLO] = 0.0;

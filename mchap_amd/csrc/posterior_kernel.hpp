@@ -15,13 +15,16 @@
 
 namespace mchap {
 
-constexpr int POST_CAP = 512;  // distinct states kept per unit; more -> overflow flag (post_n = -n)
+constexpr int POST_CAP = 512;  // distinct states kept per unit by the batch launches; more -> overflow flag (post_n = -n), and the
+                               // few units that overflow are summarised again by a listed launch with a larger table (cap)
 
 struct PosteriorParams {
   const mchap_unit *units;
   const uint64_t *trace;
   int steps, chains, burn;
   int max_states, ploidy_max;
+  int cap;                   // distinct states the LDS table holds (POST_CAP for a whole batch; up to posterior_max_cap for a list)
+  const int32_t *unit_list;  // null: workgroup b summarises unit b; else unit unit_list[b], its states written to row b
   uint64_t *post_words;
   int32_t *post_counts;
   int32_t *post_n;
@@ -39,12 +42,12 @@ struct PostSummary {
 };
 
 __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, const mchap_unit &U, int S, int burn, int ch_lo,
-                                                      int ch_hi, uint64_t *uw, int *ucount, int *order, int *label) {
+                                                      int ch_hi, uint64_t *uw, int *ucount, int *order, int *label, const int CAP) {
   const int K = U.ploidy;
   const int lane = threadIdx.x;
   const int per_chain = S - burn;
   const int N = (ch_hi - ch_lo) * per_chain;
-  for (int i = lane; i < POST_CAP; i += WAVE) ucount[i] = 0;
+  for (int i = lane; i < CAP; i += WAVE) ucount[i] = 0;
   __syncthreads();
 
   int n_u = 0;        // wave-uniform
@@ -81,16 +84,16 @@ __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, con
         if (h < K) {
           const uint64_t lw = __shfl(st[h], leader, WAVE);
           eq = eq && (lw == st[h]);
-          if (lane == leader && n_u < POST_CAP) uw[(size_t)n_u * K + h] = lw;
+          if (lane == leader && n_u < CAP) uw[(size_t)n_u * K + h] = lw;
         }
       }
-      if (active && found < 0 && eq) found = n_u < POST_CAP ? n_u : POST_CAP;
-      if (n_u < POST_CAP) n_u++;
+      if (active && found < 0 && eq) found = n_u < CAP ? n_u : CAP;
+      if (n_u < CAP) n_u++;
       else overflow++;
       pending = __ballot(active && found < 0);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
-    if (active && found >= 0 && found < POST_CAP) atomicAdd(&ucount[found], 1);
+    if (active && found >= 0 && found < CAP) atomicAdd(&ucount[found], 1);
     __syncthreads();
   }
 
@@ -175,54 +178,57 @@ __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, con
 
 __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const mchap_unit U = P.units[blockIdx.x];
+  const int row = blockIdx.x;                                   // row of the per-state outputs
+  const int unit = P.unit_list ? P.unit_list[row] : row;        // index of the per-unit outputs
+  const mchap_unit U = P.units[unit];
   const int K = U.ploidy;
   const int lane = threadIdx.x;
   const int N = P.chains * (P.steps - P.burn);
+  const int CAP = P.cap;
   if (K > P.ploidy_max || K < 1) {  // the LDS tables are sized for ploidy_max: refuse instead of overrunning them
     if (lane == 0) {
-      P.post_n[blockIdx.x] = INT_MIN;
-      P.mode_stats[2 * (size_t)blockIdx.x + 0] = NAN;
-      P.mode_stats[2 * (size_t)blockIdx.x + 1] = NAN;
-      P.mode_index[blockIdx.x] = -1;
-      if (P.mode_count) P.mode_count[blockIdx.x] = 0;
+      P.post_n[unit] = INT_MIN;
+      P.mode_stats[2 * (size_t)unit + 0] = NAN;
+      P.mode_stats[2 * (size_t)unit + 1] = NAN;
+      P.mode_index[unit] = -1;
+      if (P.mode_count) P.mode_count[unit] = 0;
     }
     return;
   }
-  uint64_t *uw = reinterpret_cast<uint64_t *>(smem);                  // [POST_CAP][K]
-  int *ucount = reinterpret_cast<int *>(smem + (size_t)POST_CAP * K * 8);  // [POST_CAP]
-  int *order = ucount + POST_CAP;                                     // [POST_CAP] rank -> unique index
-  int *label = order + POST_CAP;                                      // [POST_CAP] support label by rank
-  const PostSummary R = post_summarise(P.trace, U, P.steps, P.burn, 0, P.chains, uw, ucount, order, label);
+  uint64_t *uw = reinterpret_cast<uint64_t *>(smem);                  // [CAP][K]
+  int *ucount = reinterpret_cast<int *>(smem + (size_t)CAP * K * 8);  // [CAP]
+  int *order = ucount + CAP;                                          // [CAP] rank -> unique index
+  int *label = order + CAP;                                           // [CAP] support label by rank
+  const PostSummary R = post_summarise(P.trace, U, P.steps, P.burn, 0, P.chains, uw, ucount, order, label, CAP);
   const int n_u = R.n_u;
   for (int r = lane; r < n_u; r += WAVE) {
     if (r < P.max_states) {
       const int e = order[r];
-      uint64_t *dst = P.post_words + ((size_t)blockIdx.x * P.max_states + r) * P.ploidy_max;
+      uint64_t *dst = P.post_words + ((size_t)row * P.max_states + r) * P.ploidy_max;
       for (int h = 0; h < P.ploidy_max; h++) dst[h] = h < K ? uw[(size_t)e * K + h] : 0ull;
-      P.post_counts[(size_t)blockIdx.x * P.max_states + r] = ucount[e];
+      P.post_counts[(size_t)row * P.max_states + r] = ucount[e];
     }
   }
   for (int r = n_u + lane; r < P.max_states; r += WAVE) {
-    uint64_t *dst = P.post_words + ((size_t)blockIdx.x * P.max_states + r) * P.ploidy_max;
+    uint64_t *dst = P.post_words + ((size_t)row * P.max_states + r) * P.ploidy_max;
     for (int h = 0; h < P.ploidy_max; h++) dst[h] = 0ull;
-    P.post_counts[(size_t)blockIdx.x * P.max_states + r] = 0;
+    P.post_counts[(size_t)row * P.max_states + r] = 0;
   }
   if (lane == 0) {
-    P.post_n[blockIdx.x] = R.overflow ? -(n_u + R.overflow) : n_u;
+    P.post_n[unit] = R.overflow ? -(n_u + R.overflow) : n_u;
     if (n_u > 0) {
-      P.mode_stats[2 * (size_t)blockIdx.x + 0] = R.best;                                            // SPM
-      P.mode_stats[2 * (size_t)blockIdx.x + 1] = (double)ucount[order[R.best_r]] / (double)N;       // GPM
-      P.mode_index[blockIdx.x] = R.best_r;
+      P.mode_stats[2 * (size_t)unit + 0] = R.best;                                            // SPM
+      P.mode_stats[2 * (size_t)unit + 1] = (double)ucount[order[R.best_r]] / (double)N;       // GPM
+      P.mode_index[unit] = R.best_r;
       if (P.mode_words)
         for (int h = 0; h < P.ploidy_max; h++)
-          P.mode_words[(size_t)blockIdx.x * P.ploidy_max + h] = h < K ? uw[(size_t)order[R.best_r] * K + h] : 0ull;
-      if (P.mode_count) P.mode_count[blockIdx.x] = ucount[order[R.best_r]];
+          P.mode_words[(size_t)unit * P.ploidy_max + h] = h < K ? uw[(size_t)order[R.best_r] * K + h] : 0ull;
+      if (P.mode_count) P.mode_count[unit] = ucount[order[R.best_r]];
     } else {
-      if (P.mode_count) P.mode_count[blockIdx.x] = 0;
-      P.mode_stats[2 * (size_t)blockIdx.x + 0] = NAN;
-      P.mode_stats[2 * (size_t)blockIdx.x + 1] = NAN;
-      P.mode_index[blockIdx.x] = -1;
+      if (P.mode_count) P.mode_count[unit] = 0;
+      P.mode_stats[2 * (size_t)unit + 0] = NAN;
+      P.mode_stats[2 * (size_t)unit + 1] = NAN;
+      P.mode_index[unit] = -1;
     }
   }
 }
@@ -238,27 +244,31 @@ struct IncongruenceParams {
   int steps, chains, burn;
   double threshold;
   int ploidy_max;
+  int cap;                   // as PosteriorParams::cap
+  const int32_t *unit_list;  // null, or the units to summarise (mci is indexed by unit)
   int32_t *mci;
 };
 
 __global__ __launch_bounds__(64) void trace_incongruence_kernel(const IncongruenceParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const mchap_unit U = P.units[blockIdx.x];
+  const int unit = P.unit_list ? P.unit_list[blockIdx.x] : (int)blockIdx.x;
+  const mchap_unit U = P.units[unit];
   const int K = U.ploidy;
   const int lane = threadIdx.x;
+  const int CAP = P.cap;
   if (K > P.ploidy_max || K < 1) {
-    if (lane == 0) P.mci[blockIdx.x] = -1;
+    if (lane == 0) P.mci[unit] = -1;
     return;
   }
   uint64_t *uw = reinterpret_cast<uint64_t *>(smem);
-  int *ucount = reinterpret_cast<int *>(smem + (size_t)POST_CAP * K * 8);
-  int *order = ucount + POST_CAP;
-  int *label = order + POST_CAP;
-  uint64_t *sets = reinterpret_cast<uint64_t *>(label + POST_CAP);  // [chains][K] distinct words of the chain's mode support
+  int *ucount = reinterpret_cast<int *>(smem + (size_t)CAP * K * 8);
+  int *order = ucount + CAP;
+  int *label = order + CAP;
+  uint64_t *sets = reinterpret_cast<uint64_t *>(smem + (((size_t)CAP * K * 8 + (size_t)CAP * 12 + 7) & ~(size_t)7));  // [chains][K] distinct words of the chain's mode support
   int *nset = reinterpret_cast<int *>(sets + (size_t)POST_MAX_CHAINS * MCHAP_MAX_PLOIDY);  // [chains] size, 0 = below threshold
   int bad = 0;
   for (int ch = 0; ch < P.chains; ch++) {
-    const PostSummary R = post_summarise(P.trace, U, P.steps, P.burn, ch, ch + 1, uw, ucount, order, label);
+    const PostSummary R = post_summarise(P.trace, U, P.steps, P.burn, ch, ch + 1, uw, ucount, order, label, CAP);
     if (R.overflow) bad = 1;
     if (lane == 0) {
       int n = 0;
@@ -303,13 +313,18 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
       // (assemble/classes.py:371-375: `ploidy = len(alleles[0])`)
       if (total > nset[first]) out = 2;
     }
-    P.mci[blockIdx.x] = bad ? -1 : out;
+    P.mci[unit] = bad ? -1 : out;
   }
 }
 
-inline size_t posterior_lds_bytes(int K) { return (size_t)POST_CAP * K * 8 + (size_t)POST_CAP * 4 * 3; }
-inline size_t incongruence_lds_bytes(int K) {
-  return posterior_lds_bytes(K) + (size_t)POST_MAX_CHAINS * MCHAP_MAX_PLOIDY * 8 + (size_t)POST_MAX_CHAINS * 4;
+inline size_t posterior_lds_bytes(int K, int cap = POST_CAP) { return (((size_t)cap * K * 8 + (size_t)cap * 4 * 3) + 7) & ~(size_t)7; }
+inline size_t incongruence_lds_bytes(int K, int cap = POST_CAP) {
+  return posterior_lds_bytes(K, cap) + (size_t)POST_MAX_CHAINS * MCHAP_MAX_PLOIDY * 8 + (size_t)POST_MAX_CHAINS * 4;
+}
+// the largest table (distinct states) a workgroup's 160 KB of LDS holds at this ploidy, beside the incongruence kernel's sets
+inline int posterior_max_cap(int K) {
+  const size_t fixed = (size_t)POST_MAX_CHAINS * MCHAP_MAX_PLOIDY * 8 + (size_t)POST_MAX_CHAINS * 4 + 64;
+  return (int)((160 * 1024 - fixed) / ((size_t)K * 8 + 12));
 }
 
 }  // namespace mchap

@@ -450,8 +450,8 @@ class DenovoRaggedBatch:
 
     def results(self):
         """Per unit: dict(genotypes int8 [n, K, M] distinct states (probability descending), probabilities [n], spm, gpm,
-        mode_genotype int8 [K, M], mci, status).  Units with more distinct states than the kernel keeps are summarised
-        from their downloaded trace by the host classes."""
+        mode_genotype int8 [K, M], mci, status).  Units with more distinct states than the batch kernels keep (512) are
+        summarised by a second, listed launch with a table of chains x (steps - burn) states (as many as the LDS holds)."""
         from .classes import GenotypeMultiTrace
 
         U, K, ms = self.n_units, self.Kmax, self.max_states
@@ -464,6 +464,33 @@ class DenovoRaggedBatch:
         status = self.d_status.cpu().numpy()
         fixed = self.d_fixed.cpu().numpy()
         total = self.Cn * (self.S - self.burn)
+        # Units whose chains visited more distinct genotypes than the batch kernels keep (samples with few or no reads:
+        # their chains wander): summarised again on the device with a table that cannot overflow, a list launch over
+        # those units only -- no trace is downloaded, no posterior formed on the host
+        over = np.flatnonzero((status >= 0) & ((n < 0) | (n > ms) | (mci < 0))).astype(np.int32)
+        over_row = {}
+        if len(over):
+            torch = self.torch
+            L = _lib.lib()
+            cap = min(total, int(L.mchap_trace_posterior_max_states(K)))
+            stream = torch.cuda.current_stream().cuda_stream
+            d_list = torch.from_numpy(over).to(self.device)
+            o_words = torch.empty(len(over) * cap * K, dtype=torch.int64, device=self.device)
+            o_counts = torch.empty(len(over) * cap, dtype=torch.int32, device=self.device)
+            _lib.check(L.mchap_trace_posterior_listed_device(
+                len(over), self._p(d_list), self._p(self.d_units), self.S, self.Cn, self.burn, self._p(self.d_trace), cap, K,
+                self._p(o_words), self._p(o_counts), self._p(self.p_n), self._p(self.p_stats), self._p(self.p_mode),
+                self._p(self.p_mode_words), self._p(self.p_mode_count), C.c_void_p(stream)))
+            _lib.check(L.mchap_trace_incongruence_listed_device(
+                len(over), self._p(d_list), self._p(self.d_units), self.S, self.Cn, self.burn, self._p(self.d_trace),
+                min(self.S - self.burn, cap), K, C.c_double(self.incongruence_threshold), self._p(self.p_mci), C.c_void_p(stream)))
+            n = self.p_n.cpu().numpy()
+            stats = self.p_stats.cpu().numpy().reshape(U, 2)
+            mode_words = self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K)
+            mci = self.p_mci.cpu().numpy()
+            ow = o_words.cpu().numpy().view(np.uint64).reshape(len(over), cap, K)
+            oc = o_counts.cpu().numpy().reshape(len(over), cap)
+            over_row = {int(u): (ow[i], oc[i], cap) for i, u in enumerate(over)}
         out = []
         trace = llks = None
         for u in range(U):
@@ -477,8 +504,14 @@ class DenovoRaggedBatch:
                 raise ValueError("breaks must be smaller then n")
             if st < 0:
                 raise NotImplementedError("mchap_hip: unit %d exceeds the packed haplotype width" % u)
+            if u in over_row and 0 <= n[u] <= over_row[u][2] and mci[u] >= 0:
+                w_, c_, _ = over_row[u]
+                k = int(n[u])
+                out.append(dict(genotypes=unpack_trace(w_[:k, :Ku], fx, A), probabilities=c_[:k] / total, spm=float(stats[u, 0]),
+                                gpm=float(stats[u, 1]), mode_genotype=unpack_trace(mode_words[u, :Ku], fx, A), mci=int(mci[u]), status=st))
+                continue
             if n[u] < 0 or n[u] > ms or mci[u] < 0:
-                # more distinct states than the device summary keeps: the host classes on the trace
+                # (more distinct states than even the LDS holds -- tens of thousands of steps: the host classes on the trace)
                 if trace is None:
                     trace = self.d_trace.cpu().numpy().view(np.uint64)
                     llks = self.d_llks.cpu().numpy()

@@ -85,3 +85,49 @@ def test_seed_reproducibility_and_difference():
     np.testing.assert_array_equal(a.genotypes, b.genotypes)
     np.testing.assert_array_equal(a.llks, b.llks)
     assert not np.array_equal(a.genotypes, c.genotypes)
+
+
+@pytest.mark.parametrize("shape", [(4, 13, 2, None), (4, 23, 2, None), (2, 9, 2, 0.2), (6, 10, 2, None), (3, 7, 3, 0.1), (8, 12, 2, None)],
+                         ids=lambda s: "K%d-M%d-A%d-F%s" % s)
+def test_samples_without_reads_equal_the_oracle_on_every_kernel(shape, monkeypatch):
+    """A sample without reads at a locus is sampled like any other (one all-gap read: assemble/mcmc.py:132-137), and so is one
+    whose reads are gaps at every SNV.  Every genotype then has the same likelihood, which the fast samplers use (no cache probe, no
+    evaluation: denovo_spec_kernel's spec_eval) -- these chains move at every other sub-step and were the slowest of a launch.
+    Traces against the oracle, step for step, on the default dispatch, the speculative kernel and the lanes-over-chains kernel
+    (which has no shortcut), with the shortcut switched off (tuning flag 128) as well; a unit WITH reads shares the launch."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.classes import sort_haplotypes
+    from mchap_amd.synth import synth_units
+    from oracle import binding as orc
+    from tests.helpers import beta_break_table
+
+    K, M, A, F = shape
+    steps = 150
+    n_alleles = [A] * M
+    if A > 2:
+        n_alleles[1] = 2  # a biallelic position in a triallelic unit: its third row is 0.0 and never read
+    gaps1 = np.full((1, M, A), np.nan)
+    gaps5 = np.full((5, M, A), np.nan)
+    for rd in (gaps1, gaps5):
+        for j, n in enumerate(n_alleles):
+            rd[:, j, n:] = 0.0
+    real, _, _ = synth_units(1, ploidy=K, n_pos=M, n_reads=40, n_alleles=A, first_unit=900, window=(max(1, M // 2), M))
+    for j, n in enumerate(n_alleles):
+        real[0][:, j, n:] = 0.0
+    reads = [gaps1, real[0], gaps5]
+    ref = []
+    for u, rd in enumerate(reads):
+        cfg = orc.make_cfg(K, steps, 2, F, (1.0,), llk_cache_threshold=100, rng_kind=orc.RNG_PHILOX, seed=3, stream_id=u,
+                           break_table=beta_break_table(M, 1.0, 3.0))
+        g, l, code = orc.denovo_fit(cfg, rd, n_alleles)
+        assert code == 0
+        ref.append((sort_haplotypes(g), l))
+    assert (np.diff(ref[0][1], axis=1) == 0).all() and (np.diff(ref[0][0], axis=1) != 0).any()  # constant llk, moving chain
+    for kernel, flags in ((0, 0), (0, 128), (3, 0), (2, 0)):
+        monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
+        monkeypatch.setenv("MCHAP_HIP_FLAGS", str(flags))
+        model = DenovoMCMC(ploidy=K, n_alleles=n_alleles, inbreeding=F, steps=steps, chains=2, random_seed=3)
+        traces = model.fit_batch(reads)
+        for u, tr in enumerate(traces):
+            assert np.array_equal(tr.genotypes, ref[u][0]), "kernel %d flags %d unit %d" % (kernel, flags, u)
+            np.testing.assert_allclose(tr.llks, ref[u][1], rtol=1e-10, atol=1e-12)
