@@ -178,3 +178,89 @@ def test_device_incongruence_matches_host_classes():
     torch.cuda.synchronize()
     assert d_mci.cpu().tolist() == [x[2] for x in cases]
     assert 0 in seen and (1 in seen or 2 in seen)
+
+
+@pytest.mark.parametrize("K,M,steps,chains", [(4, 12, 1400, 2), (2, 16, 900, 3), (8, 6, 700, 2)])
+def test_listed_launch_summarises_wandering_chains_like_the_host_classes(K, M, steps, chains):
+    """Chains that visit more than 512 distinct genotypes (samples with few or no reads) overflow the batch kernels' table:
+    post_n < 0 and mci = -1.  mchap_trace_posterior_listed_device / mchap_trace_incongruence_listed_device summarise those
+    units with a table of chains x (steps - burn) states: distinct genotypes in the reference's order with their counts,
+    SPM / GPM, mode genotype and the incongruence code equal to the host classes' on the same trace (GenotypeMultiTrace,
+    assemble/classes.py:265-376, pinned to reference vectors in tests/test_classes.py); units that did not overflow keep the batch
+    call's values."""
+    import torch
+    from mchap_amd import GenotypeMultiTrace, _lib
+    from mchap_amd.classes import sort_haplotypes
+
+    rng = np.random.default_rng(K * 100 + M)
+    burn = steps // 4
+    U = 4
+    traces = []
+    for u in range(U):
+        if u == 2:  # a settled unit: two genotypes only -- stays with the batch call
+            base = rng.integers(0, 2, size=(2, K, M)).astype(np.int8)
+            g = base[rng.integers(0, 2, size=(chains, steps))]
+        else:       # a random walk: one allele flips per step (as a wandering chain's trace looks), with revisits
+            g = np.empty((chains, steps, K, M), dtype=np.int8)
+            for c in range(chains):
+                cur = rng.integers(0, 2, size=(K, M)).astype(np.int8)
+                for s_ in range(steps):
+                    if rng.random() < (0.9 if u != 3 else 0.5):
+                        cur = cur.copy()
+                        cur[rng.integers(0, K), rng.integers(0, M)] ^= 1
+                    g[c, s_] = cur
+        traces.append(sort_haplotypes(g))
+    words = np.concatenate([_pack(t).reshape(-1) for t in traces])
+    units = np.zeros(U, dtype=_lib.UNIT_DTYPE)
+    for u in range(U):
+        units[u]["ploidy"], units[u]["trace_off"] = K, u * chains * steps * K
+    L = _lib.lib()
+    L.mchap_trace_posterior_max_states.restype = C.c_int
+    total = chains * (steps - burn)
+    cap = min(total, int(L.mchap_trace_posterior_max_states(K)))
+    assert cap == total  # (the LDS holds every state of these runs)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+    d_units = torch.from_numpy(units.view(np.uint8).reshape(-1)).cuda()
+    d_trace = torch.from_numpy(words.view(np.int64)).cuda()
+    ms = 512
+    d_words = torch.empty(U * ms * K, dtype=torch.int64, device="cuda")
+    d_counts = torch.empty(U * ms, dtype=torch.int32, device="cuda")
+    d_n = torch.empty(U, dtype=torch.int32, device="cuda")
+    d_stats = torch.empty(U * 2, dtype=torch.float64, device="cuda")
+    d_mode = torch.empty(U, dtype=torch.int32, device="cuda")
+    d_mw = torch.empty(U * K, dtype=torch.int64, device="cuda")
+    d_mc = torch.empty(U, dtype=torch.int32, device="cuda")
+    d_mci = torch.empty(U, dtype=torch.int32, device="cuda")
+    _lib.check(L.mchap_trace_posterior_batch_device(U, p(d_units), steps, chains, burn, p(d_trace), ms, K, p(d_words), p(d_counts), p(d_n),
+                                                    p(d_stats), p(d_mode), p(d_mw), p(d_mc), None))
+    _lib.check(L.mchap_trace_incongruence_batch_device(U, p(d_units), steps, chains, burn, p(d_trace), K, C.c_double(0.6), p(d_mci), None))
+    torch.cuda.synchronize()
+    n0, mci0 = d_n.cpu().numpy().copy(), d_mci.cpu().numpy().copy()
+    over = np.flatnonzero((n0 < 0) | (mci0 < 0)).astype(np.int32)
+    assert set(over.tolist()) >= {0, 1} and 2 not in over and n0[2] == len(np.unique(_pack(traces[2])[:, burn:].reshape(-1, K), axis=0))
+    batch_stats2 = d_stats.cpu().numpy().reshape(U, 2)[2].copy()
+    d_list = torch.from_numpy(over).cuda()
+    o_words = torch.empty(len(over) * cap * K, dtype=torch.int64, device="cuda")
+    o_counts = torch.empty(len(over) * cap, dtype=torch.int32, device="cuda")
+    _lib.check(L.mchap_trace_posterior_listed_device(len(over), p(d_list), p(d_units), steps, chains, burn, p(d_trace), cap, K, p(o_words),
+                                                     p(o_counts), p(d_n), p(d_stats), p(d_mode), p(d_mw), p(d_mc), None))
+    _lib.check(L.mchap_trace_incongruence_listed_device(len(over), p(d_list), p(d_units), steps, chains, burn, p(d_trace),
+                                                        min(steps - burn, cap), K, C.c_double(0.6), p(d_mci), None))
+    torch.cuda.synchronize()
+    n, stats, mci = d_n.cpu().numpy(), d_stats.cpu().numpy().reshape(U, 2), d_mci.cpu().numpy()
+    ow = o_words.cpu().numpy().view(np.uint64).reshape(len(over), cap, K)
+    oc = o_counts.cpu().numpy().reshape(len(over), cap)
+    mw = d_mw.cpu().numpy().view(np.uint64).reshape(U, K)
+    assert np.array_equal(stats[2], batch_stats2) and n[2] == n0[2] and mci[2] == mci0[2]
+    assert (n[over] > 0).all() and (n[over] > 512).any()
+    for i, u in enumerate(over):
+        tr = GenotypeMultiTrace._from_sorted(traces[u], np.zeros((chains, steps))).burn(burn)
+        post = tr.posterior()
+        k = int(n[u])
+        assert k == len(post.probabilities)
+        assert_same_posterior(_unpack(ow[i, :k], M), oc[i, :k] / total, post.genotypes, post.probabilities)
+        sup = post.mode_genotype_support()
+        mg, gp = sup.mode_genotype()
+        assert abs(stats[u, 0] - sup.probabilities.sum()) < 1e-12 and abs(stats[u, 1] - gp) < 1e-15
+        assert np.array_equal(_unpack(mw[u], M), mg)
+        assert int(mci[u]) == int(tr.replicate_incongruence(0.6))
