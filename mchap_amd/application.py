@@ -145,8 +145,15 @@ def encode_reads(locus, chars, quals, error_rate=0.0024, use_phred=False):
                 if lut[j, ord(c)] < 0:
                     lut[j, ord(c)] = a
         calls = lut[np.arange(M)[None, :], chars]
-    dists = encoding.encode_read_distributions(locus.n_alleles, calls, quals if use_phred else None, error_rate=error_rate)
-    uniq, counts = encoding.unique_counts(dists)
+    if use_phred or M == 0 or calls.shape[0] == 0:
+        dists = encoding.encode_read_distributions(locus.n_alleles, calls, quals if use_phred else None, error_rate=error_rate)
+        uniq, counts = encoding.unique_counts(dists)
+    else:
+        # qualities ignored: a row of distributions is a function of its row of calls, so the distinct rows (in order of first
+        # appearance, with their counts: mset.unique_counts at application/baseclass.py:207) are found on the int8 calls and
+        # only those are turned into distributions
+        ucalls, counts = encoding.unique_counts(np.ascontiguousarray(calls))
+        uniq = encoding.encode_read_distributions(locus.n_alleles, ucalls, None, error_rate=error_rate)
     depth = (chars != ord("-")).sum(axis=0) if M else np.array([])
     return dict(chars=chars, calls=calls, depth=depth, dists=uniq, counts=counts)
 

@@ -44,6 +44,13 @@
 #ifndef MCHAP_SPEC_CG
 #define MCHAP_SPEC_CG 4  // pairs whose dictionary gathers are in flight together in spec_coop_coded (ploidy > 4)
 #endif
+// MCHAP_SPEC_SBS = 1 (the "side by side" objects: spec_inst.hip with -DSPEC_SBS) compiles in the evaluation of several requests
+// of a unit of at most 64 reads in one pass of the wavefront (spec_coop_all).  It is its own instantiation because its
+// registers cost the evaluation of deep units 1-2 % (spills in the kernel's hot region): a batch whose units all have more
+// than 64 reads runs the plain instantiation, which does not carry that code at all.  Same traces either way.
+#ifndef MCHAP_SPEC_SBS
+#define MCHAP_SPEC_SBS 0
+#endif
 #ifndef MCHAP_SPEC_WIN0
 #define MCHAP_SPEC_WIN0 4     // mutation sub-steps a chain's first compound step speculates over per round
 #endif
@@ -797,6 +804,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
       // A lane forms the same factors in the same order for its (request, read); the sum over the reads is the
       // wavefront butterfly restricted to the sub-group -- the other lanes of a full-width evaluation hold padding
       // reads with weight 0, whose terms are +0.0 -- so the values are those of the one-request path, bit for bit.
+#if MCHAP_SPEC_SBS
       if constexpr (BPL) {
         if (use_base && nch == 1 && nrd <= 32) {
           const int RS = nrd <= 16 ? 16 : 32, NQ = WAVE / RS;
@@ -900,7 +908,152 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
           }
           continue;  // next chain
         }
+        // 33 to 64 reads, several requests (a side-by-side pass costs more than one plain evaluation -- three or four reads
+        // per lane --, so a lone request takes the plain path below)
+        if (use_base && nch == 1 && (reqs & (reqs - 1ull)) != 0ull) {
+          // Units of one chunk (at most 64 reads): FOUR requests are evaluated side by side, a sub-group of 16 lanes each,
+          // lane r of a sub-group taking the reads r, r + 16, r + 32, r + 48 of the unit (RK = 1..4 of them exist).  A
+          // lane forms the same factors in the same order for its (request, read) as the plain path; the sum over the
+          // reads is the wavefront butterfly (wave_sum: partners at distance 32, 16, 8, ... 1): the lane adds its reads
+          // r and r + 32, and r + 16 and r + 48 (the step at distance 32), then those two sums (distance 16), and the
+          // distances 8 .. 1 stay inside the sub-group.  Reads beyond the unit's are padding -- weight 0, a term of
+          // +-0.0, which every sum absorbs exactly -- and are left out.  Bit for bit the values of the one-request path.
+          const int RK = (nrd + 15) >> 4;
+          const int sub = lane >> 4, r = lane & 15;
+          LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
+          LDSP(const uint8_t) shift = shift_tab + (size_t)sg * mmax;
+          LDSP(const uint16_t) cols = cols_tab + (size_t)sg * mmax;
+          GLBP(const uint8_t) ctb = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT];
+          GLBP(const double) cwg = (GLBP(const double))(uintptr_t)gp[GP_CW];
+          double cwr[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) cwr[k] = k < RK ? cwg[r + 16 * k] : 0.0;
+          const double invK = 1.0 / (double)KT;
+          // the products over the positions of one haplotype word for the lane's reads, four positions at a time: the code
+          // loads of all reads go out together, then the dictionary gathers, then the products in position order (a
+          // position beyond Mh multiplies by 1.0: exact) -- one memory round trip per four positions, not one per factor
+          auto hap_products = [&](uint64_t wa, double (&ph)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) ph[k] = 1.0;
+            for (int j0 = 0; j0 < Mh; j0 += 4) {
+              uint32_t row[4];
+#pragma unroll
+              for (int t = 0; t < 4; t++) {
+                const int j = min(j0 + t, Mh - 1);
+                row[t] = (uint32_t)cols[j] + ((uint32_t)(wa >> shift[j]) & amask);
+              }
+              uint8_t cd[4][4];
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                if (k < RK) {  // (wave-uniform)
+                  if (sct != nullptr) {  // the unit's codes are in LDS: no memory round trip at all
+#pragma unroll
+                    for (int t = 0; t < 4; t++) cd[k][t] = sct[row[t] * WAVE + r + 16 * k];
+                  } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) cd[k][t] = ctb[(size_t)(row[t] * WAVE + r + 16 * k) * cstride];
+                  }
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                if (k < RK) {
+                  double f[4];
+#pragma unroll
+                  for (int t = 0; t < 4; t++) f[t] = dict[cd[k][t]];
+#pragma unroll
+                  for (int t = 0; t < 4; t++) ph[k] *= (j0 + t < Mh) ? f[t] : 1.0;
+                }
+              }
+            }
+          };
+          while (reqs) {
+            int srcs[4] = {0, 0, 0, 0};
+            unsigned long long dupm[4] = {0ull, 0ull, 0ull, 0ull};
+            int nq = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              if (reqs) {
+                const int src = __ffsll((long long)reqs) - 1;
+                const unsigned long long dups = spec_same_request<KT>(pwbuf, reqs, src, lane);
+                reqs &= ~dups;
+                srcs[k] = src;
+                dupm[k] = dups;
+                nq = k + 1;
+              }
+            }
+            const int my_src = sub == 0 ? srcs[0] : (sub == 1 ? srcs[1] : (sub == 2 ? srcs[2] : srcs[3]));
+            // Which haplotypes does the lane's request change?  Mutation proposals change one, and then the sub-groups
+            // -- each with a different changed haplotype -- form their products in ONE pass of the whole wavefront instead
+            // of one divergent pass per haplotype.  Same factors, same order of the sum over haplotypes: same values.
+            int hc = -1, nchg = 0;
+            uint64_t wac = 0;
+            if (sub < nq) {
+#pragma unroll
+              for (int h = 0; h < KT; h++) {
+                const uint64_t wa = pwbuf[(size_t)h * WAVE + my_src];
+                if (wa != bw_tab[(size_t)sg * KT + h]) {
+                  if (nchg == 0) {
+                    hc = h;
+                    wac = wa;
+                  }
+                  nchg++;
+                }
+              }
+            }
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
+            if (!wave_any(nchg > 1)) {
+              double pc[4] = {1.0, 1.0, 1.0, 1.0};
+              if (nchg == 1) hap_products(wac, pc);
+              if (sub < nq) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  if (k < RK) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int h = 0; h < KT; h++) {
+                      const double ph = (h == hc) ? pc[k] : bpc[(h * 4) * WAVE + r + 16 * k];
+                      acc += ph * invK;
+                    }
+                    v[k] = read_log(acc) * cwr[k];
+                  }
+                }
+              }
+            } else if (sub < nq) {
+              double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int h = 0; h < KT; h++) {
+                const uint64_t wa = pwbuf[(size_t)h * WAVE + my_src], wb = bw_tab[(size_t)sg * KT + h];
+                double ph[4];
+                if (wa == wb) {
+#pragma unroll
+                  for (int k = 0; k < 4; k++) ph[k] = k < RK ? bpc[(h * 4) * WAVE + r + 16 * k] : 0.0;
+                } else {
+                  hap_products(wa, ph);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[k] += ph[k] * invK;
+              }
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                if (k < RK) v[k] = read_log(acc[k]) * cwr[k];
+            }
+            // distance 32: reads r | r + 32 and r + 16 | r + 48; distance 16: the two sums; then inside the sub-group
+            const double a0 = RK > 2 ? v[0] + v[2] : v[0];
+            const double a1 = RK > 3 ? v[1] + v[3] : v[1];
+            double sv = RK > 1 ? a0 + a1 : a0;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) sv += __shfl_xor(sv, o, WAVE);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const double vk = __shfl(sv, 16 * k, WAVE);
+              if (k < nq && ((dupm[k] >> lane) & 1ull)) val = vk;
+            }
+          }
+          continue;  // next chain
+        }
       }
+#endif
       while (reqs) {
         const int src = __ffsll((long long)reqs) - 1;
         // requests for the same genotype (options of different intervals often coincide) are evaluated once
@@ -1185,8 +1338,12 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
   // every round ends at an accepted move and whatever was evaluated behind it is thrown away, so the window halves
   // after a round with a move and doubles after one without (Grp::mwin carries it to the next compound step; a
   // settled chain evaluates all n sub-steps in one round).  Results do not depend on it.
+  // (a unit of at most 16 or of 33-64 reads gets four requests evaluated in one pass of the wavefront -- spec_coop_all --, so a
+  // window of fewer than four sub-steps would leave that pass partly empty; 17-32 reads: two)
+  const int nrd_ = (int)S.nreads[gi];
+  const int wmin = (MCHAP_SPEC_SBS != 0 && G == 64 && S.bpc != nullptr && (nrd_ <= 16 || (nrd_ > 32 && nrd_ <= 64))) ? 4 : MCHAP_SPEC_WIN_MIN;
   int start = 0;
-  int win = c.mwin;
+  int win = max(c.mwin, wmin);
   bool done = !run;
   bool any_move = false;
   double my_lo = 0.0, my_hi = 2.0;  // this lane's sub-steps: max lo_e, min hi_e
@@ -1286,7 +1443,7 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
     if (!done) {
       if (found) {
         any_move = true;
-        win = max(MCHAP_SPEC_WIN_MIN, win >> 1);
+        win = max(wmin, win >> 1);
       } else {
         start = wstop;  // the window's sub-steps all stay
         win = min(2 * win, 4 * G);
@@ -1731,7 +1888,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
 // PIPE: the phased form (kernel 5).  A launch runs the chains of P.pipe_list for P.pipe_iters compound steps each,
 // starting from scratch or (PIPE_RESUME) from their PipeState records, and (PIPE_EXPORT) leaves records + complete
 // interval memos behind for denovo_coast_kernel.  Single temperature only.
-template <int KT, int G, bool PIPE = false>
+template <int KT, int G, bool PIPE = false, int VAR = MCHAP_SPEC_SBS>  // (VAR only names the object: the code is selected by the macro)
 __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const SimtParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NG = 64 / G;
@@ -1893,12 +2050,12 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     for (int i = gl; i < nd; i += G) S.dict[(size_t)gi * DICT_MAX + i] = du[i];
   }
   S.sct = nullptr;
-  if constexpr (G == 64) {
-    // A shallow unit (one chunk of at most 32 reads: spec_coop_all evaluates its requests side by side) with a small table:
+  if constexpr (G == 64 && MCHAP_SPEC_SBS != 0) {
+    // A unit of one chunk (at most 64 reads: spec_coop_all evaluates its requests side by side) with a small table:
     // every lane's code of every row goes into LDS once per launch -- into the chunk slots 1..3 of haplotype 0 of the
     // product cache, which a one-chunk unit never uses -- and its evaluations then make no memory round trip.
     const int rows = U.n_pos * A;
-    if (S.bpc != nullptr && c.alive && U.n_reads <= 32 && rows <= 24 && mi[META_I_NDICT] != 0 && !(P.flags & 4)) {
+    if (S.bpc != nullptr && c.alive && U.n_reads <= 64 && rows <= 24 && mi[META_I_NDICT] != 0 && !(P.flags & 4)) {
       LDSP(uint8_t) t = (LDSP(uint8_t))(S.bpc + WAVE);
       GLBP(const uint8_t) ct = (GLBP(const uint8_t))(P.codes + (size_t)u * P.max_ma * WAVE * P.cstride);
       for (int r_ = 0; r_ < rows; r_++) t[r_ * WAVE + lane] = ct[(size_t)(r_ * WAVE + lane) * P.cstride];

@@ -33,6 +33,8 @@
 #else
 #define SPECP_LIST(X) X(2, 64) X(3, 64) X(4, 64) X(5, 64) X(6, 64) X(7, 64) X(8, 64)
 #endif
+// the phased form with the side-by-side evaluation of shallow units compiled in (MCHAP_SPEC_SBS, denovo_spec_kernel.hpp)
+#define SPECS_LIST(X) X(2, 64) X(3, 64) X(4, 64) X(5, 64) X(6, 64) X(7, 64) X(8, 64)
 #define SIMT_LIST(X) X(0) X(2) X(4) X(6) X(8)
 #define V1_LIST(X) X(1) X(2) X(4) X(8) X(16)
 #define LANE_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
@@ -48,8 +50,12 @@ typedef int (*simt_launch_fn)(const mchap::SimtParams *, unsigned, size_t, hipSt
 #define DECL_SIMT(k)                                                \
   extern "C" int mchap_simt_init_##k(const double *, const double *); \
   extern "C" int mchap_simt_launch_##k(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+#define DECL_SPECS(k, g)                                                    \
+  extern "C" int mchap_specs_init_##k##_##g(const double *, const double *); \
+  extern "C" int mchap_specs_launch_##k##_##g(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 SPEC_LIST(DECL_SPEC)
 SPECP_LIST(DECL_SPECP)
+SPECS_LIST(DECL_SPECS)
 SIMT_LIST(DECL_SIMT)
 extern "C" int mchap_coast_launch(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 #ifdef MCHAP_TEST_KERNELS
@@ -70,8 +76,10 @@ LANE_LIST(DECL_LANE)
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
 #define DECL_SPEC_STATS(k, g) extern "C" int mchap_spec_stats_##k##_##g(unsigned long long *, int);
 #define DECL_SPECP_STATS(k, g) extern "C" int mchap_specp_stats_##k##_##g(unsigned long long *, int);
+#define DECL_SPECS_STATS(k, g) extern "C" int mchap_specs_stats_##k##_##g(unsigned long long *, int);
 SPEC_LIST(DECL_SPEC_STATS)
 SPECP_LIST(DECL_SPECP_STATS)
+SPECS_LIST(DECL_SPECS_STATS)
 #ifdef MCHAP_TEST_KERNELS
 extern "C" int mchap_lane_stats_4(unsigned long long *, int);
 #endif
@@ -125,6 +133,8 @@ struct SpecInst {
 #define ROW_SPECP(k, g) {k, g, mchap_specp_init_##k##_##g, mchap_specp_launch_##k##_##g},
 const SpecInst SPEC_INSTS[] = {SPEC_LIST(ROW_SPEC)};
 const SpecInst SPECP_INSTS[] = {SPECP_LIST(ROW_SPECP)};
+#define ROW_SPECS(k, g) {k, g, mchap_specs_init_##k##_##g, mchap_specs_launch_##k##_##g},
+const SpecInst SPECS_INSTS[] = {SPECS_LIST(ROW_SPECS)};
 const SpecInst *find_inst(const SpecInst *tab, size_t n, int K, int G) {
   for (size_t i = 0; i < n; i++)
     if (tab[i].K == K && tab[i].G == G) return &tab[i];
@@ -132,6 +142,7 @@ const SpecInst *find_inst(const SpecInst *tab, size_t n, int K, int G) {
 }
 #define FIND_SPEC(K, G) find_inst(SPEC_INSTS, sizeof(SPEC_INSTS) / sizeof(SPEC_INSTS[0]), K, G)
 #define FIND_SPECP(K, G) find_inst(SPECP_INSTS, sizeof(SPECP_INSTS) / sizeof(SPECP_INSTS[0]), K, G)
+#define FIND_SPECS(K, G) find_inst(SPECS_INSTS, sizeof(SPECS_INSTS) / sizeof(SPECS_INSTS[0]), K, G)
 
 int ensure_init() {
   int dev = 0;
@@ -152,6 +163,8 @@ int ensure_init() {
     if (i.init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the speculative sampler <%d, %d>", i.K, i.G);
   for (const SpecInst &i : SPECP_INSTS)
     if (i.init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the phased sampler <%d, %d>", i.K, i.G);
+  for (const SpecInst &i : SPECS_INSTS)
+    if (i.init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the phased sampler <%d, %d> (side by side)", i.K, i.G);
   {
 #define ROW_SIMT_INIT(k) mchap_simt_init_##k,
 #define ROW_V1_INIT(r) mchap_v1_init_##r,
@@ -291,6 +304,7 @@ size_t break_table_bytes(const mchap_denovo_cfg *cfg) {
 
 struct BatchDims {
   int max_reads = 1, max_pos = 1, max_allele = 1, max_ploidy = 1, max_ma = 1, max_ugens = 1;
+  int min_reads = 1 << 30;  // the shallowest unit (units of at most 64 reads select the side-by-side instantiation)
   int uniform_ploidy = -1;  // the ploidy shared by all units, 0 if mixed
 };
 
@@ -303,6 +317,7 @@ int batch_dims(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units
     if (U.n_pos < 1 || U.n_pos > 62) return fail(MCHAP_ERR_LIMIT, "unit %d: n_pos %d not in 1..62", u, U.n_pos);
     if (cfg->n_intervals == 0 && U.n_pos > cfg->max_pos) return fail(MCHAP_ERR_BAD_ARG, "unit %d: n_pos exceeds break_table", u);
     B.max_reads = std::max(B.max_reads, U.n_reads);
+    B.min_reads = std::min(B.min_reads, U.n_reads);
     B.max_pos = std::max(B.max_pos, U.n_pos);
     B.max_allele = std::max(B.max_allele, U.max_allele);
     B.max_ploidy = std::max(B.max_ploidy, U.ploidy);
@@ -545,8 +560,10 @@ int launch_lane(const Tune &T, int K, const mchap::SimtParams &P, int n_units, i
 // The phased sampler (kernel 5): denovo_spec_kernel<K, G, true> for the first steps, denovo_coast_kernel for the
 // chains' long no-move stretches, denovo_spec_kernel again for the chains handed back.
 int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, int chains, int32_t *lists, int32_t *counts, void *timer,
-                hipStream_t stream) {
-  const SpecInst *inst = FIND_SPECP(K, G);
+                hipStream_t stream, bool shallow_units) {
+  // a batch with a unit of at most 64 reads runs the instantiation that evaluates such a unit's requests side by side
+  const SpecInst *inst = (shallow_units && G == 64 && !(T.flags & 256)) ? FIND_SPECS(K, G) : nullptr;
+  if (!inst) inst = FIND_SPECP(K, G);
   if (!inst) return fail(MCHAP_ERR_LIMIT, "phased sampler: no instantiation for ploidy %d with %d lanes per chain", K, G);
   simt_launch_fn launch = inst->launch;
   size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, 1, G);
@@ -686,7 +703,8 @@ int mchap_debug_stats(unsigned long long *out, int reset) {
   // plus the copies of the speculative sampler's object files
 #define ROW_SPEC_STATS(k, g) mchap_spec_stats_##k##_##g,
 #define ROW_SPECP_STATS(k, g) mchap_specp_stats_##k##_##g,
-  int (*fs[])(unsigned long long *, int) = {SPEC_LIST(ROW_SPEC_STATS) SPECP_LIST(ROW_SPECP_STATS)};
+#define ROW_SPECS_STATS(k, g) mchap_specs_stats_##k##_##g,
+  int (*fs[])(unsigned long long *, int) = {SPEC_LIST(ROW_SPEC_STATS) SPECP_LIST(ROW_SPECP_STATS) SPECS_LIST(ROW_SPECS_STATS)};
   for (auto f : fs) {
     unsigned long long t[mchap::N_STATS];
     if (f(t, reset) != 0) return fail(MCHAP_ERR_HIP, "reading the counters of a sampler object");
@@ -925,7 +943,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.max_ploidy = B.max_ploidy;
     SP.max_ma = B.max_ma;
     SP.cstride = code_stride(rpl);
-    SP.flags = T.flags & (63 | 128);
+    SP.flags = T.flags & (63 | 128);  // (256: host only -- never the side-by-side instantiation)
     // the prepare pass keeps the transposed table in LDS when it fits, else it re-reads its own global copy
     SP.max_ugens_pad = (B.max_ugens + 8) & ~7;
     const size_t lds_dict = (size_t)mchap::DICT_HASH * (8 + 2) + 64;  // hash set of the dictionary pass
@@ -965,7 +983,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
 #endif
       case SAMPLER_PIPE:
         return launch_pipe(T, pl.K, pl.G, SP, n_units, cfg->chains, reinterpret_cast<int32_t *>(ws + cv.pipe_lists),
-                           reinterpret_cast<int32_t *>(ws + cv.pipe_counts), cfg->timer, stream);
+                           reinterpret_cast<int32_t *>(ws + cv.pipe_counts), cfg->timer, stream, B.min_reads <= 64);
       case SAMPLER_SPEC: return launch_spec(T, pl.K, pl.G, SP, n_units, cfg->chains, cfg->n_temps, cfg->timer, stream);
       default: return launch_simt(pl.K, SP, n_units, cfg->chains, lds_simt, cfg->timer, stream);  // lanes over chains
     }

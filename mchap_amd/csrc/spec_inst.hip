@@ -10,7 +10,13 @@
 #define SPEC_CAT(a, k, g) SPEC_CAT_(a, k, g)
 
 #ifdef SPEC_PIPE
-// the phased form (kernel 5) of this instantiation: its own object file, its own copy of the constant tables
+// the phased form (kernel 5) of this instantiation: its own object file, its own copy of the constant tables; with
+// -DSPEC_SBS (and -DMCHAP_SPEC_SBS=1) the variant that evaluates the requests of shallow units side by side ("specs" objects)
+#ifdef SPEC_SBS
+#define mchap_specp_init_ mchap_specs_init_
+#define mchap_specp_launch_ mchap_specs_launch_
+#define mchap_specp_stats_ mchap_specs_stats_
+#endif
 extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_specp_init_, SPEC_K, SPEC_G)(const double *ln,
                                                                                                  const double *ln_inv) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(mchap::c_ln), ln, sizeof(double) * 260) != hipSuccess) return 1;

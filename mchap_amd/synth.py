@@ -72,7 +72,7 @@ def dedup_unit(reads):
         n = len(reads)
         return reads[: min(n, 1)], np.full(min(n, 1), n, dtype=np.int64)
     flat = np.ascontiguousarray(reads).reshape(len(reads), -1)
-    keys = flat.view("V%d" % (flat.shape[1] * 8)).reshape(-1)
+    keys = flat.view("V%d" % (flat.shape[1] * flat.dtype.itemsize)).reshape(-1)  # (rows of any item type: float64 tensors, int8 calls)
     _, first, inv = np.unique(keys, return_index=True, return_inverse=True)
     order = np.argsort(first, kind="stable")
     rank = np.empty(len(order), dtype=np.int64)

@@ -123,7 +123,7 @@ def test_samples_without_reads_equal_the_oracle_on_every_kernel(shape, monkeypat
         assert code == 0
         ref.append((sort_haplotypes(g), l))
     assert (np.diff(ref[0][1], axis=1) == 0).all() and (np.diff(ref[0][0], axis=1) != 0).any()  # constant llk, moving chain
-    for kernel, flags in ((0, 0), (0, 128), (3, 0), (2, 0)):
+    for kernel, flags in ((0, 0), (0, 128), (0, 256), (3, 0), (2, 0)):  # (256: the instantiation without side-by-side evaluation)
         monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
         monkeypatch.setenv("MCHAP_HIP_FLAGS", str(flags))
         model = DenovoMCMC(ploidy=K, n_alleles=n_alleles, inbreeding=F, steps=steps, chains=2, random_seed=3)
