@@ -59,7 +59,8 @@ typedef struct mchap_denovo_tuning {
                             16: no LDS base-product cache, 32: skip the phased sampler's table completion (timing only: with
                             pipe_stop), 64 (libmchap_hip_test.so only): the tables completed by denovo_fill_kernel, one lane per request,
                             128: units without information (all gaps) are evaluated like any other,
-                            256: never the instantiation that evaluates the requests of shallow units (<= 64 reads) side by side */
+                            256: never the instantiation that evaluates the requests of shallow units (<= 64 reads) side by side,
+                            512: no haplotype-product rows in the workspace for deep units (> 256 reads) */
   int32_t spec_group;    /* kernel 3: lanes per chain, 16 / 32 / 64 (default: the smallest the shape allows) */
   int32_t pipe_first;    /* kernel 5: MCMC steps before the first hand-over (default ploidy * n_pos / 10, clamped to 4..32) */
   int32_t pipe_resume;   /*           steps a handed-back chain runs before it is handed over again (default 8) */

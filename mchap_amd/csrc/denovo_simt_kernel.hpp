@@ -46,6 +46,7 @@ struct SimtParams {
   double *cntw;      // [U][rpad]
   uint8_t *codes;    // [U][max_ma][64][cstride]: code of read lane + 64 i at byte i of the lane's group
   double *dict;      // [U][DICT_MAX]
+  double *gbp;       // [U * chains][max_ploidy][rpad] haplotype products of the chains' current genotypes for read chunks >= 4, or null
   int32_t *meta_i;   // [U][meta_i_stride]
   double *meta_f;    // [U][meta_f_stride]
   int n_units;

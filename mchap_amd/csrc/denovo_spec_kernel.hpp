@@ -105,7 +105,7 @@ struct TabPtr<true> {
   static __device__ __forceinline__ CT ld(u8 p) { return *reinterpret_cast<LDSP(const CT)>(p); }
 };
 
-enum { GP_RT = 0, GP_CW, GP_CT, GP_CACHE, GP_CKEYS, GP_TRACE, GP_LLK, GP_N };
+enum { GP_RT = 0, GP_CW, GP_CT, GP_CACHE, GP_CKEYS, GP_TRACE, GP_LLK, GP_GBP, GP_N };
 enum { GV_INB = 0, GV_MLO, GV_MHI, GV_N };
 struct SpecLds {
   LDSP(uint64_t) pw;      // [K][64] request words of missing lanes (lane strided)
@@ -137,6 +137,7 @@ struct SpecLds {
   LDSP(uint64_t) bw;      // [NG][K] the chain's current genotype while its proposals are evaluated (base words)
   LDSP(double) bpc;       // [K][4][64] one chain per wave only (G = 64), else null: the haplotype products of ...
   LDSP(uint64_t) bpt;     // [K + 1] ... these base words (bpt[K] != 0: valid), kept from one evaluation call to the next
+  LDSP(uint64_t) gbt;     // [NG][K + 1] the words whose products the chain's rows of SimtParams::gbp hold (deep units), [K] != 0: valid
   LDSP(const uint8_t) sct;  // [rows][64] code of read `lane` in every row of the table, for a shallow unit (<= 32 reads, <= 24
                             // rows) of a one-chain-per-wave launch: kept in the product cache's unused chunk slots; else null
   LDSP(uint64_t) tbuf;    // [NG][SPEC_TB][K + 1] trace records (K sorted words + llk) waiting to be written as a line
@@ -203,6 +204,7 @@ __host__ __device__ inline size_t spec_lds_bytes(int K, int Mmax, int Amax, int 
   b = (b + 15) & ~(size_t)15;
   b += (size_t)16 * NG;                  // gstream
   b += (size_t)8 * NG * K;               // bw
+  b += (size_t)8 * NG * (K + 1);         // gbt
   b += (size_t)8 * NG * SPEC_TB * (K + 1);   // tbuf
   b = (b + 15) & ~(size_t)15;
   b += (size_t)8 * NG * spec_draws(K, Mmax);
@@ -585,30 +587,37 @@ __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int
 
 // ---- coded evaluation, one haplotype at a time ----
 // Row of pair p = h * Mh + j of the genotype whose words are words[h] (an LDS array), for the lane's pairs
-// p = lane and p = lane + 64 (K * Mh <= 128).
+// p = lane, lane + 64 and lane + 128 (K * Mh <= 192).
+struct PairRows {
+  int r0, r1, r2;
+};
 template <int KT>
-__device__ __forceinline__ void spec_pair_rows(LDSP(const uint64_t) words, int wstride, int widx, const SpecLds &S, int sg, int mmax,
-                                               int Mh, uint32_t amask, int lane, int &row0, int &row1) {
+__device__ __forceinline__ PairRows spec_pair_rows(LDSP(const uint64_t) words, int wstride, int widx, const SpecLds &S, int sg, int mmax,
+                                                   int Mh, uint32_t amask, int lane) {
   const int n_pairs = KT * Mh;
-  row0 = 0;
-  row1 = 0;
+  PairRows R;
+  R.r0 = 0;
+  R.r1 = 0;
+  R.r2 = 0;
 #pragma unroll
-  for (int t = 0; t < 2; t++) {
+  for (int t = 0; t < 3; t++) {
     const int p = lane + WAVE * t;
-    if (p < n_pairs) {
+    if (p < n_pairs) {  // (t = 2: octoploids with more than 16 sampled positions only)
       const int h = p / Mh, j = p - h * Mh;
       const uint64_t wh = words[(size_t)h * wstride + widx];
       const uint32_t a = (uint32_t)(wh >> S.shift[(size_t)sg * mmax + j]) & amask;
       const int r = (int)S.cols[(size_t)sg * mmax + j] + (int)a;
-      if (t == 0) row0 = r;
-      else row1 = r;
+      if (t == 0) R.r0 = r;
+      else if (t == 1) R.r1 = r;
+      else R.r2 = r;
     }
   }
+  return R;
 }
-// prod[i] = product over the Mh positions of haplotype h (pairs h*Mh .. h*Mh+Mh-1, rows in row0/row1), reads of
+// prod[i] = product over the Mh positions of haplotype h (pairs h*Mh .. h*Mh+Mh-1, rows in `rows`), reads of
 // chunk i, in position order: the factors and their order are those of spec_coop_coded
 template <int RPL, class CT, bool LT = false>
-__device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int row1, int p0, int Mh, typename TabPtr<LT>::u8 ct,
+__device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, const PairRows rows, int p0, int Mh, typename TabPtr<LT>::u8 ct,
                                               int crow, double (&prod)[RPL]) {
   constexpr int UNR = 8;  // code loads in flight
   constexpr int GB = 2;   // positions whose dictionary gathers are in flight together
@@ -619,7 +628,8 @@ __device__ __forceinline__ void spec_hap_prod(LDSP(double) dict, int row0, int r
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
       const int p = __builtin_amdgcn_readfirstlane(p0 + min(j0 + u, Mh - 1));
-      const int row = p < WAVE ? __builtin_amdgcn_readlane(row0, p & (WAVE - 1)) : __builtin_amdgcn_readlane(row1, p & (WAVE - 1));
+      const int row = p < WAVE ? __builtin_amdgcn_readlane(rows.r0, p & (WAVE - 1))
+                               : (p < 2 * WAVE ? __builtin_amdgcn_readlane(rows.r1, p & (WAVE - 1)) : __builtin_amdgcn_readlane(rows.r2, p & (WAVE - 1)));
       cd[u] = TabPtr<LT>::template ld<CT>(ct + (size_t)row * crow);
     }
     // No branch between the positions: the gathers of GB positions are issued together (a branch per position made
@@ -660,6 +670,15 @@ struct BaseProducts<KT, true> {
   __device__ __forceinline__ double get(int h, int i, int lane) const { return p[(h * 4 + i) * WAVE + lane]; }
   __device__ __forceinline__ void set(int h, int i, int lane, double x) { p[(h * 4 + i) * WAVE + lane] = x; }
 };
+// ... and for the read chunks beyond the first four (deep units: 257 reads and more), in the chain's rows of the
+// workspace (SimtParams::gbp, [chain][K][rpad]): each lane its own column again, so a lane only ever reads what it wrote.
+template <int KT>
+struct BaseProductsG {
+  GLBP(double) p;  // the chain's [K][rpad] rows
+  int rpad, cb;    // first chunk of the block the products belong to
+  __device__ __forceinline__ double get(int h, int i, int lane) const { return p[(size_t)h * rpad + (cb + i) * WAVE + lane]; }
+  __device__ __forceinline__ void set(int h, int i, int lane, double x) { p[(size_t)h * rpad + (cb + i) * WAVE + lane] = x; }
+};
 // One request with reuse: haplotypes whose word equals the base word take the base product bp[h].
 template <int KT, int RPL, class CT, bool LT = false, class BP>
 __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
@@ -667,8 +686,7 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
                                                   const BP &bp, bool use_base) {
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   const double invK = 1.0 / (double)KT;
-  int row0, row1;
-  spec_pair_rows<KT>(S.pw, WAVE, src, S, sg, mmax, Mh, amask, lane, row0, row1);
+  const PairRows rows = spec_pair_rows<KT>(S.pw, WAVE, src, S, sg, mmax, Mh, amask, lane);
   double acc[RPL];
 #pragma unroll
   for (int i = 0; i < RPL; i++) acc[i] = 0.0;
@@ -681,7 +699,7 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
 #pragma unroll
       for (int i = 0; i < RPL; i++) ph[i] = bp.get(h, i, lane);
     } else {
-      spec_hap_prod<RPL, CT, LT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
+      spec_hap_prod<RPL, CT, LT>(dict, rows, h * Mh, Mh, ct, crow, ph);
     }
 #pragma unroll
     for (int i = 0; i < RPL; i++) acc[i] += ph[i] * invK;
@@ -695,15 +713,25 @@ template <int KT, int RPL, class CT, bool LT = false, class BP>
 __device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int mmax, int Mh, uint32_t amask,
                                                    typename TabPtr<LT>::u8 ct, int crow, int lane, BP &bp) {
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
-  int row0, row1;
-  spec_pair_rows<KT>(S.bw + (size_t)sg * KT, 1, 0, S, sg, mmax, Mh, amask, lane, row0, row1);
+  const PairRows rows = spec_pair_rows<KT>(S.bw + (size_t)sg * KT, 1, 0, S, sg, mmax, Mh, amask, lane);
 #pragma unroll
   for (int h = 0; h < KT; h++) {
     double ph[RPL];
-    spec_hap_prod<RPL, CT, LT>(dict, row0, row1, h * Mh, Mh, ct, crow, ph);
+    spec_hap_prod<RPL, CT, LT>(dict, rows, h * Mh, Mh, ct, crow, ph);
 #pragma unroll
     for (int i = 0; i < RPL; i++) bp.set(h, i, lane, ph[i]);
   }
+}
+// The same for ONE haplotype h of the current genotype (the rows of the deep chunks are refreshed haplotype by haplotype:
+// a move changes one or two words)
+template <int KT, int RPL, class CT, bool LT = false, class BP>
+__device__ __forceinline__ void spec_base_products_of(const SpecLds &S, const PairRows rows, int sg, int h, int Mh,
+                                                      typename TabPtr<LT>::u8 ct, int crow, int lane, BP &bp) {
+  LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
+  double ph[RPL];
+  spec_hap_prod<RPL, CT, LT>(dict, rows, h * Mh, Mh, ct, crow, ph);
+#pragma unroll
+  for (int i = 0; i < RPL; i++) bp.set(h, i, lane, ph[i]);
 }
 
 // lanes of `reqs` whose request words equal those of lane `src` (src included)
@@ -726,7 +754,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
                                                 bool reuse, int crow, int mmax, int Mh_lane, uint32_t amask_lane, int rpad,
                                                 int lane, LDSP(const uint8_t) lds_ct = nullptr, LDSP(const double) lds_cw = nullptr,
                                                 LDSP(double) bpc = nullptr, LDSP(uint64_t) bpt = nullptr,
-                                                LDSP(const uint8_t) sct = nullptr) {
+                                                LDSP(const uint8_t) sct = nullptr, LDSP(uint64_t) gbt = nullptr) {
   SpecLds S;
   S.pw = pwbuf;
   S.shift = shift_tab;
@@ -758,7 +786,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
     // batch of real pileups is mostly shallow units: docs/example has 2 to 534 read pairs per unit)
     const int nch = max(1, min(nch_batch, (nrd + WAVE - 1) / WAVE));
     const int cstride = crow / WAVE;  // code bytes per lane and row
-    if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && KT * Mh <= 2 * WAVE) {
+    if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && KT * Mh <= 3 * WAVE) {
       // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped.
       // The base products cover the first block of (up to) 4 chunks; deeper reads add their other blocks in full.
       const int nb0 = nch < 4 ? nch : 4;
@@ -795,6 +823,48 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
 #pragma unroll
             for (int h = 0; h < KT; h++) bpt[h] = bw_tab[(size_t)sg * KT + h];
             bpt[KT] = 1ull;
+          }
+          lds_sync();
+        }
+      }
+      // Deep units: the products of the current genotype's haplotypes for the chunks beyond the first four are kept in the
+      // chain's rows of the workspace, refreshed haplotype by haplotype when a word differs from the one they were formed
+      // for -- a request then forms the products of the words it changed only, in every chunk, instead of all K x Mh
+      // factors of every read of twelve chunks (config #5: 2 560 gathers per lane and request -> 320 + 112 loads).
+      GLBP(double) gbp = (GLBP(double))(uintptr_t)gp[GP_GBP];
+      const bool deep = use_base && nch > 4 && gbp != nullptr && gbt != nullptr;
+      if (deep) {
+        LDSP(uint64_t) gt = gbt + (size_t)sg * (KT + 1);
+        const bool any_valid = gt[KT] != 0ull;
+        bool have_rows = false, wrote = false;
+        PairRows rows;
+        rows.r0 = rows.r1 = rows.r2 = 0;
+        for (int h = 0; h < KT; h++) {
+          const bool ok = any_valid && gt[h] == bw_tab[(size_t)sg * KT + h];
+          if (__builtin_amdgcn_readfirstlane((int)ok) != 0) continue;
+          if (!have_rows) {
+            rows = spec_pair_rows<KT>(bw_tab + (size_t)sg * KT, 1, 0, S, sg, mmax, Mh, amask, lane);
+            have_rows = true;
+          }
+          for (int cb = 4; cb < nch; cb += 4) {
+            const int rem = nch - cb;
+            BaseProductsG<KT> bg;
+            bg.p = gbp;
+            bg.rpad = rpad;
+            bg.cb = cb;
+            if (rem >= 4) spec_base_products_of<KT, 4, uint32_t, LT>(S, rows, sg, h, Mh, ct + cb, crow, lane, bg);
+            else if (rem == 3) spec_base_products_of<KT, 3, uint32_t, LT>(S, rows, sg, h, Mh, ct + cb, crow, lane, bg);
+            else if (rem == 2) spec_base_products_of<KT, 2, uint16_t, LT>(S, rows, sg, h, Mh, ct + cb, crow, lane, bg);
+            else spec_base_products_of<KT, 1, uint8_t, LT>(S, rows, sg, h, Mh, ct + cb, crow, lane, bg);
+          }
+          wrote = true;
+        }
+        if (wrote) {
+          lds_sync();
+          if (lane == 0) {
+#pragma unroll
+            for (int h = 0; h < KT; h++) gt[h] = bw_tab[(size_t)sg * KT + h];
+            gt[KT] = 1ull;
           }
           lds_sync();
         }
@@ -1067,10 +1137,21 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
         for (int cb = 4; cb < nch; cb += 4) {
           const int rem = nch - cb;
           typename TabPtr<LT>::f64 cwb = cw + cb * WAVE;
-          if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-          else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-          else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-          else s += spec_coop_coded<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          if (deep) {  // (wave-uniform) unchanged haplotypes: their products from the chain's rows
+            BaseProductsG<KT> bg;
+            bg.p = gbp;
+            bg.rpad = rpad;
+            bg.cb = cb;
+            if (rem >= 4) s += spec_coop_reuse<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, true);
+            else if (rem == 3) s += spec_coop_reuse<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, true);
+            else if (rem == 2) s += spec_coop_reuse<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, true);
+            else s += spec_coop_reuse<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, true);
+          } else {
+            if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            else s += spec_coop_coded<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+          }
         }
         s = wave_sum(s);
         if ((dups >> lane) & 1ull) val = s;
@@ -1195,7 +1276,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
       for (int h = 0; h < KT; h++) S.bw[(size_t)(lane / G) * KT + h] = cg.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G, LT>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw, S.bpc, S.bpt, S.sct);
+    const double v = spec_coop_all<KT, G, LT>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw, S.bpc, S.bpt, S.sct, S.gbt);
     if (miss) val = v;
     bool writer = miss && slot != nullptr;
     if (wave_any(writer && wide)) {
@@ -1960,6 +2041,8 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.gstream = lds_cast<uint32_t>(p); p += (size_t)16 * NG;
     S.bw = lds_cast<uint64_t>(p); p += (size_t)8 * NG * KT;
+    S.gbt = lds_cast<uint64_t>(p); p += (size_t)8 * NG * (KT + 1);
+    for (int i = lane; i < NG * (KT + 1); i += WAVE) S.gbt[i] = 0ull;  // nothing in the chain's product rows yet
     S.tbuf = lds_cast<uint64_t>(p); p += (size_t)8 * NG * SPEC_TB * (KT + 1);
     p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
     S.ndraws = spec_draws(KT, mmax);
@@ -2029,6 +2112,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     gp[GP_CKEYS] = (S.cache_on && D.cache_keys) ? (uint64_t)(uintptr_t)(D.cache_keys + (size_t)q * (size_t)D.cache_slots * D.cache_key_words) : 0ull;
     gp[GP_TRACE] = (uint64_t)(uintptr_t)(D.trace + U.trace_off + (size_t)chain * D.steps * KT);
     gp[GP_LLK] = (uint64_t)(uintptr_t)(D.llks + U.llk_off + (size_t)chain * D.steps);
+    gp[GP_GBP] = P.gbp ? (uint64_t)(uintptr_t)(P.gbp + (size_t)q * P.max_ploidy * rpad) : 0ull;
   }
   c.ctr = 0;
   c.doff = 0;
@@ -2166,7 +2250,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       for (int h = 0; h < KT; h++) S.pw[h * WAVE + lane] = g0.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, nullptr, nullptr, S.bpc, S.bpt, S.sct);
+    const double v = spec_coop_all<KT, G>(__ballot(req), S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, nullptr, nullptr, S.bpc, S.bpt, S.sct, S.gbt);
     lds_sync();
     c.llk = __shfl(v, 0, G);
     if (c.alive && gl == 0) {

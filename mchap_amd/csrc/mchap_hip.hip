@@ -430,6 +430,8 @@ struct SimtCarve {
   size_t cache = 0, ckeys = 0, rt = 0, cntw = 0, codes = 0, dict = 0, meta_i = 0, meta_f = 0, lane_state = 0, lane_memo = 0, total = 0;
   size_t pipe_state = 0, pipe_memo = 0, pipe_lists = 0, pipe_counts = 0;
   int key_words = 0;
+  size_t gbp = 0;
+  bool has_gbp = false;
 };
 constexpr int PIPE_MAX_ROUNDS = 6;  // resume rounds of the phased sampler (counters in the workspace)
 
@@ -455,6 +457,12 @@ SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, c
     c.lane_memo = o; o += up256(nc * 2 * mchap::spec_memo_entries(B.max_pos) * 4);
   }
 #endif
+  // deep units (more than four chunks of 64 reads): the haplotype products of every chain's current genotype for the
+  // chunks beyond the fourth (denovo_spec_kernel.hpp BaseProductsG), [chain][ploidy][rpad] doubles
+  if ((pl.kind == SAMPLER_PIPE || pl.kind == SAMPLER_SPEC) && rpad > 4 * 64) {
+    c.gbp = o; o += up256(nc * (size_t)B.max_ploidy * rpad * 8);
+    c.has_gbp = true;
+  }
   if (pl.kind == SAMPLER_PIPE) {  // hand-over records of the phased sampler
     c.pipe_state = o; o += up256(nc * sizeof(mchap::PipeState));
     c.pipe_memo = o; o += up256(nc * 2 * mchap::spec_memo_entries(B.max_pos) * 8);
@@ -931,6 +939,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.cntw = reinterpret_cast<double *>(ws + cv.cntw);
     SP.codes = ws + cv.codes;
     SP.dict = reinterpret_cast<double *>(ws + cv.dict);
+    SP.gbp = (cv.has_gbp && !(T.flags & 512)) ? reinterpret_cast<double *>(ws + cv.gbp) : nullptr;
     SP.meta_i = reinterpret_cast<int32_t *>(ws + cv.meta_i);
     SP.meta_f = reinterpret_cast<double *>(ws + cv.meta_f);
     SP.lane_state = ws + cv.lane_state;
@@ -943,7 +952,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.max_ploidy = B.max_ploidy;
     SP.max_ma = B.max_ma;
     SP.cstride = code_stride(rpl);
-    SP.flags = T.flags & (63 | 128);  // (256: host only -- never the side-by-side instantiation)
+    SP.flags = T.flags & (63 | 128);  // (256, 512: host only -- never the side-by-side instantiation / no deep-chunk product rows)
     // the prepare pass keeps the transposed table in LDS when it fits, else it re-reads its own global copy
     SP.max_ugens_pad = (B.max_ugens + 8) & ~7;
     const size_t lds_dict = (size_t)mchap::DICT_HASH * (8 + 2) + 64;  // hash set of the dictionary pass
