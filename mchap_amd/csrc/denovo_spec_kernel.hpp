@@ -44,13 +44,20 @@
 #ifndef MCHAP_SPEC_CG
 #define MCHAP_SPEC_CG 4  // pairs whose dictionary gathers are in flight together in spec_coop_coded (ploidy > 4)
 #endif
-// MCHAP_SPEC_SBS = 1 (the "side by side" objects: spec_inst.hip with -DSPEC_SBS) compiles in the evaluation of several requests
-// of a unit of at most 64 reads in one pass of the wavefront (spec_coop_all).  It is its own instantiation because its
-// registers cost the evaluation of deep units 1-2 % (spills in the kernel's hot region): a batch whose units all have more
-// than 64 reads runs the plain instantiation, which does not carry that code at all.  Same traces either way.
-#ifndef MCHAP_SPEC_SBS
-#define MCHAP_SPEC_SBS 0
+// Instantiation variants (MCHAP_SPEC_VAR, set per object by spec_inst.hip; the kernel's last template argument names them):
+//   0 plain: what a batch of units with 65 to 256 reads needs (configs[1]) and nothing else;
+//   1 "side by side" (MCHAP_SPEC_SBS): several requests of a unit of at most 64 reads evaluated in one pass of the wavefront
+//     (spec_coop_all) -- for batches that hold such a unit;
+//   2 "deep" (MCHAP_SPEC_DEEP): haplotype products of the current genotype kept in the workspace for the read chunks beyond
+//     the first four, and product reuse for up to 192 (haplotype, position) pairs -- for batches with more than 256 reads per
+//     unit or more than 128 pairs (configs[4]).
+// They are separate instantiations because the extra paths cost registers: compiled into one kernel they took 1-4 % off the
+// evaluation of configs[1] (spills in the kernel's hot region: 48 -> 88-97 spilled VGPRs).  Same traces whichever runs.
+#ifndef MCHAP_SPEC_VAR
+#define MCHAP_SPEC_VAR 0
 #endif
+#define MCHAP_SPEC_SBS (MCHAP_SPEC_VAR == 1)
+#define MCHAP_SPEC_DEEP (MCHAP_SPEC_VAR == 2)
 #ifndef MCHAP_SPEC_WIN0
 #define MCHAP_SPEC_WIN0 4     // mutation sub-steps a chain's first compound step speculates over per round
 #endif
@@ -600,9 +607,9 @@ __device__ __forceinline__ PairRows spec_pair_rows(LDSP(const uint64_t) words, i
   R.r1 = 0;
   R.r2 = 0;
 #pragma unroll
-  for (int t = 0; t < 3; t++) {
+  for (int t = 0; t < (MCHAP_SPEC_DEEP ? 3 : 2); t++) {
     const int p = lane + WAVE * t;
-    if (p < n_pairs) {  // (t = 2: octoploids with more than 16 sampled positions only)
+    if (p < n_pairs) {  // (t = 2, the "deep" instantiation: octoploids with more than 16 sampled positions)
       const int h = p / Mh, j = p - h * Mh;
       const uint64_t wh = words[(size_t)h * wstride + widx];
       const uint32_t a = (uint32_t)(wh >> S.shift[(size_t)sg * mmax + j]) & amask;
@@ -709,6 +716,44 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
   for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
   return s;
 }
+// The same for a block of deep chunks, whose base products come from the workspace: the K x RPL loads of a block go out
+// together, ahead of everything else (behind the per-haplotype branches each would be a memory round trip of its own:
+// measured 54 000 ticks per evaluation at config #5, of which 32 dependent round trips).  A changed haplotype's row is loaded
+// too and not used.
+template <int KT, int RPL, class CT, bool LT = false>
+__device__ __forceinline__ double spec_coop_reuse_g(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
+                                                    typename TabPtr<LT>::u8 ct, typename TabPtr<LT>::f64 cw, int crow, int lane,
+                                                    const BaseProductsG<KT> &bg) {
+  double bpv[KT][RPL];
+#pragma unroll
+  for (int h = 0; h < KT; h++)
+#pragma unroll
+    for (int i = 0; i < RPL; i++) bpv[h][i] = bg.get(h, i, lane);
+  LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
+  const double invK = 1.0 / (double)KT;
+  const PairRows rows = spec_pair_rows<KT>(S.pw, WAVE, src, S, sg, mmax, Mh, amask, lane);
+  double acc[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; i++) acc[i] = 0.0;
+#pragma unroll
+  for (int h = 0; h < KT; h++) {
+    const uint64_t a = S.pw[(size_t)h * WAVE + src], b = S.bw[(size_t)sg * KT + h];
+    const bool same = __builtin_amdgcn_readfirstlane((int)(a == b)) != 0;
+    double ph[RPL];
+    if (same) {
+#pragma unroll
+      for (int i = 0; i < RPL; i++) ph[i] = bpv[h][i];
+    } else {
+      spec_hap_prod<RPL, CT, LT>(dict, rows, h * Mh, Mh, ct, crow, ph);
+    }
+#pragma unroll
+    for (int i = 0; i < RPL; i++) acc[i] += ph[i] * invK;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
+  return s;
+}
 template <int KT, int RPL, class CT, bool LT = false, class BP>
 __device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int mmax, int Mh, uint32_t amask,
                                                    typename TabPtr<LT>::u8 ct, int crow, int lane, BP &bp) {
@@ -786,7 +831,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
     // batch of real pileups is mostly shallow units: docs/example has 2 to 534 read pairs per unit)
     const int nch = max(1, min(nch_batch, (nrd + WAVE - 1) / WAVE));
     const int cstride = crow / WAVE;  // code bytes per lane and row
-    if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && KT * Mh <= 3 * WAVE) {
+    if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && KT * Mh <= (MCHAP_SPEC_DEEP ? 3 : 2) * WAVE) {
       // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped.
       // The base products cover the first block of (up to) 4 chunks; deeper reads add their other blocks in full.
       const int nb0 = nch < 4 ? nch : 4;
@@ -832,7 +877,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
       // for -- a request then forms the products of the words it changed only, in every chunk, instead of all K x Mh
       // factors of every read of twelve chunks (config #5: 2 560 gathers per lane and request -> 320 + 112 loads).
       GLBP(double) gbp = (GLBP(double))(uintptr_t)gp[GP_GBP];
-      const bool deep = use_base && nch > 4 && gbp != nullptr && gbt != nullptr;
+      const bool deep = MCHAP_SPEC_DEEP && use_base && nch > 4 && gbp != nullptr && gbt != nullptr;
       if (deep) {
         LDSP(uint64_t) gt = gbt + (size_t)sg * (KT + 1);
         const bool any_valid = gt[KT] != 0ull;
@@ -1142,10 +1187,10 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
             bg.p = gbp;
             bg.rpad = rpad;
             bg.cb = cb;
-            if (rem >= 4) s += spec_coop_reuse<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, true);
-            else if (rem == 3) s += spec_coop_reuse<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, true);
-            else if (rem == 2) s += spec_coop_reuse<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, true);
-            else s += spec_coop_reuse<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, true);
+            if (rem >= 4) s += spec_coop_reuse_g<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg);
+            else if (rem == 3) s += spec_coop_reuse_g<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg);
+            else if (rem == 2) s += spec_coop_reuse_g<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg);
+            else s += spec_coop_reuse_g<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg);
           } else {
             if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
             else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
@@ -1969,7 +2014,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
 // PIPE: the phased form (kernel 5).  A launch runs the chains of P.pipe_list for P.pipe_iters compound steps each,
 // starting from scratch or (PIPE_RESUME) from their PipeState records, and (PIPE_EXPORT) leaves records + complete
 // interval memos behind for denovo_coast_kernel.  Single temperature only.
-template <int KT, int G, bool PIPE = false, int VAR = MCHAP_SPEC_SBS>  // (VAR only names the object: the code is selected by the macro)
+template <int KT, int G, bool PIPE = false, int VAR = MCHAP_SPEC_VAR>  // (VAR only names the object: the code is selected by the macro)
 __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const SimtParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NG = 64 / G;

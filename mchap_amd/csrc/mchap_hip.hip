@@ -52,7 +52,9 @@ typedef int (*simt_launch_fn)(const mchap::SimtParams *, unsigned, size_t, hipSt
   extern "C" int mchap_simt_launch_##k(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 #define DECL_SPECS(k, g)                                                    \
   extern "C" int mchap_specs_init_##k##_##g(const double *, const double *); \
-  extern "C" int mchap_specs_launch_##k##_##g(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+  extern "C" int mchap_specs_launch_##k##_##g(const mchap::SimtParams *, unsigned, size_t, hipStream_t); \
+  extern "C" int mchap_specd_init_##k##_##g(const double *, const double *); \
+  extern "C" int mchap_specd_launch_##k##_##g(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 SPEC_LIST(DECL_SPEC)
 SPECP_LIST(DECL_SPECP)
 SPECS_LIST(DECL_SPECS)
@@ -76,7 +78,7 @@ LANE_LIST(DECL_LANE)
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
 #define DECL_SPEC_STATS(k, g) extern "C" int mchap_spec_stats_##k##_##g(unsigned long long *, int);
 #define DECL_SPECP_STATS(k, g) extern "C" int mchap_specp_stats_##k##_##g(unsigned long long *, int);
-#define DECL_SPECS_STATS(k, g) extern "C" int mchap_specs_stats_##k##_##g(unsigned long long *, int);
+#define DECL_SPECS_STATS(k, g) extern "C" int mchap_specs_stats_##k##_##g(unsigned long long *, int); extern "C" int mchap_specd_stats_##k##_##g(unsigned long long *, int);
 SPEC_LIST(DECL_SPEC_STATS)
 SPECP_LIST(DECL_SPECP_STATS)
 SPECS_LIST(DECL_SPECS_STATS)
@@ -135,6 +137,8 @@ const SpecInst SPEC_INSTS[] = {SPEC_LIST(ROW_SPEC)};
 const SpecInst SPECP_INSTS[] = {SPECP_LIST(ROW_SPECP)};
 #define ROW_SPECS(k, g) {k, g, mchap_specs_init_##k##_##g, mchap_specs_launch_##k##_##g},
 const SpecInst SPECS_INSTS[] = {SPECS_LIST(ROW_SPECS)};
+#define ROW_SPECD(k, g) {k, g, mchap_specd_init_##k##_##g, mchap_specd_launch_##k##_##g},
+const SpecInst SPECD_INSTS[] = {SPECS_LIST(ROW_SPECD)};
 const SpecInst *find_inst(const SpecInst *tab, size_t n, int K, int G) {
   for (size_t i = 0; i < n; i++)
     if (tab[i].K == K && tab[i].G == G) return &tab[i];
@@ -143,6 +147,7 @@ const SpecInst *find_inst(const SpecInst *tab, size_t n, int K, int G) {
 #define FIND_SPEC(K, G) find_inst(SPEC_INSTS, sizeof(SPEC_INSTS) / sizeof(SPEC_INSTS[0]), K, G)
 #define FIND_SPECP(K, G) find_inst(SPECP_INSTS, sizeof(SPECP_INSTS) / sizeof(SPECP_INSTS[0]), K, G)
 #define FIND_SPECS(K, G) find_inst(SPECS_INSTS, sizeof(SPECS_INSTS) / sizeof(SPECS_INSTS[0]), K, G)
+#define FIND_SPECD(K, G) find_inst(SPECD_INSTS, sizeof(SPECD_INSTS) / sizeof(SPECD_INSTS[0]), K, G)
 
 int ensure_init() {
   int dev = 0;
@@ -165,6 +170,8 @@ int ensure_init() {
     if (i.init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the phased sampler <%d, %d>", i.K, i.G);
   for (const SpecInst &i : SPECS_INSTS)
     if (i.init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the phased sampler <%d, %d> (side by side)", i.K, i.G);
+  for (const SpecInst &i : SPECD_INSTS)
+    if (i.init(ln, ln_inv) != 0) return fail(MCHAP_ERR_HIP, "constant tables of the phased sampler <%d, %d> (deep)", i.K, i.G);
   {
 #define ROW_SIMT_INIT(k) mchap_simt_init_##k,
 #define ROW_V1_INIT(r) mchap_v1_init_##r,
@@ -569,8 +576,11 @@ int launch_lane(const Tune &T, int K, const mchap::SimtParams &P, int n_units, i
 // chains' long no-move stretches, denovo_spec_kernel again for the chains handed back.
 int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, int chains, int32_t *lists, int32_t *counts, void *timer,
                 hipStream_t stream, bool shallow_units) {
-  // a batch with a unit of at most 64 reads runs the instantiation that evaluates such a unit's requests side by side
-  const SpecInst *inst = (shallow_units && G == 64 && !(T.flags & 256)) ? FIND_SPECS(K, G) : nullptr;
+  // deep units (product rows in the workspace) or more than 128 (haplotype, position) pairs: the "deep" instantiation; else a
+  // batch with a unit of at most 64 reads: the one that evaluates such a unit's requests side by side; else the plain one
+  const SpecInst *inst = nullptr;
+  if (G == 64 && (P.gbp != nullptr || (K * P.max_pos > 128 && !(T.flags & 512)))) inst = FIND_SPECD(K, G);
+  else if (shallow_units && G == 64 && !(T.flags & 256)) inst = FIND_SPECS(K, G);
   if (!inst) inst = FIND_SPECP(K, G);
   if (!inst) return fail(MCHAP_ERR_LIMIT, "phased sampler: no instantiation for ploidy %d with %d lanes per chain", K, G);
   simt_launch_fn launch = inst->launch;
@@ -711,7 +721,7 @@ int mchap_debug_stats(unsigned long long *out, int reset) {
   // plus the copies of the speculative sampler's object files
 #define ROW_SPEC_STATS(k, g) mchap_spec_stats_##k##_##g,
 #define ROW_SPECP_STATS(k, g) mchap_specp_stats_##k##_##g,
-#define ROW_SPECS_STATS(k, g) mchap_specs_stats_##k##_##g,
+#define ROW_SPECS_STATS(k, g) mchap_specs_stats_##k##_##g, mchap_specd_stats_##k##_##g,
   int (*fs[])(unsigned long long *, int) = {SPEC_LIST(ROW_SPEC_STATS) SPECP_LIST(ROW_SPECP_STATS) SPECS_LIST(ROW_SPECS_STATS)};
   for (auto f : fs) {
     unsigned long long t[mchap::N_STATS];

@@ -11,11 +11,15 @@
 
 #ifdef SPEC_PIPE
 // the phased form (kernel 5) of this instantiation: its own object file, its own copy of the constant tables; with
-// -DSPEC_SBS (and -DMCHAP_SPEC_SBS=1) the variant that evaluates the requests of shallow units side by side ("specs" objects)
-#ifdef SPEC_SBS
+// -DMCHAP_SPEC_VAR=1 / 2 the "side by side" / "deep" variants (denovo_spec_kernel.hpp; "specs" / "specd" objects)
+#if MCHAP_SPEC_VAR == 1
 #define mchap_specp_init_ mchap_specs_init_
 #define mchap_specp_launch_ mchap_specs_launch_
 #define mchap_specp_stats_ mchap_specs_stats_
+#elif MCHAP_SPEC_VAR == 2
+#define mchap_specp_init_ mchap_specd_init_
+#define mchap_specp_launch_ mchap_specd_launch_
+#define mchap_specp_stats_ mchap_specd_stats_
 #endif
 extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_specp_init_, SPEC_K, SPEC_G)(const double *ln,
                                                                                                  const double *ln_inv) {
