@@ -339,15 +339,14 @@ def bench_config5(args):
         "workload": "%d loci: octoploid, %d SNVs, %d reads, %d chains x %d steps, burn %d; HBM resident; one pass" % (U, M, R, C_, S, S // 2),
         "value": U / dt, "unit": "loci/s", "kernel": batch.sampler_name, "kernel_ms": kms, "pass_ms": dt * 1e3,
         "ok": bool((status <= 1).all()),
-        # VALU issue: profiles/r03h_config5_sq_counters.json -- the sampler's launches issue 3.71e10 wavefront VALU
-        # instructions for this workload (256 loci: 3.34e8 sub-steps, 111 per sub-step); the chip issues at most
-        # 1024 SIMDs x 2.4 GHz / 4 cycles = 6.14e11 per second.  One pass is 1024 chains = one wavefront per SIMD.
-        "roofline": {"bound": "valu_issue", "achieved": 111.2 * substeps / (kms * 1e-3) / 1e9, "peak": 614.4, "unit": "G wavefront-instructions/s",
-                     "frac": 111.2 * substeps / (kms * 1e-3) / 614.4e9, "sub_steps_per_s": substeps / (kms * 1e-3),
-                     "valu_insts_per_sub_step": 111.2, "counters": "profiles/r03h_config5_sq_counters.json",
-                     "note": "serial sub-step latency bound like configs[1]; 160 mutation sub-steps per chain step; one pass "
-                             "holds one wavefront per SIMD, so the fraction of one pass alone cannot exceed the share of cycles "
-                             "a single wavefront issues in (SQ_WAIT_ANY 47 % of its cycles)"},
+        # VALU issue: profiles/r03ab_config5_sq_counters.json -- the sampler's launches issue 1.49e10 wavefront VALU
+        # instructions for this workload (256 loci: 3.34e8 sub-steps, 44.7 per sub-step; 111 before the deep units' product rows
+        # lived in the workspace: r03h); the chip issues at most 1024 SIMDs x 2.4 GHz / 4 cycles = 6.14e11 per second.
+        "roofline": {"bound": "valu_issue", "achieved": 44.7 * substeps / (kms * 1e-3) / 1e9, "peak": 614.4, "unit": "G wavefront-instructions/s",
+                     "frac": 44.7 * substeps / (kms * 1e-3) / 614.4e9, "sub_steps_per_s": substeps / (kms * 1e-3),
+                     "valu_insts_per_sub_step": 44.7, "counters": "profiles/r03ab_config5_sq_counters.json",
+                     "note": "one pass alone holds one wavefront per SIMD and waits on memory 45 % of its cycles (SQ_WAIT_ANY: the product "
+                             "rows and code rows of deep units come from L2 / HBM); batches in flight fill the rest (value)"},
     }
     nfl = 2 * args.inflight if args.inflight > 1 else 1
     if nfl > 1:

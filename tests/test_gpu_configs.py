@@ -132,8 +132,11 @@ def test_config5_full_shape_four_chains_300_steps(monkeypatch):
     moves = [int((np.diff(ref[u][1], axis=1) != 0).sum()) for u in range(2)]
     late = int(max(np.flatnonzero(np.diff(ref[1][1], axis=1).any(axis=0))))
     assert moves[1] >= 12 and late > 150, (moves, late)  # the noisy unit does exercise the hand-back path
-    for kernel in (0, 5, 3):
+    # (tuning flag 512: without the product rows of deep units in the workspace -- the plain instantiation, every factor of
+    # every read formed for every request, as before round 3)
+    for kernel, flags in ((0, 0), (5, 0), (3, 0), (0, 512)):
         monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
+        monkeypatch.setenv("MCHAP_HIP_FLAGS", str(flags))
         model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=300, random_seed=11, **kw)
         traces = model.fit_batch(reads)
         assert ("phased" in model.last_sampler) == (kernel != 3), model.last_sampler
