@@ -859,17 +859,32 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
           for (int i = 0; i < 4; i++) bp.v[h][i] = 0.0;
       }
       if (use_base && !cached) {
-        if (nb0 == 1) spec_base_products<KT, 1, uint8_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
-        else if (nb0 == 2) spec_base_products<KT, 2, uint16_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
-        else if (nb0 == 3) spec_base_products<KT, 3, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
-        else spec_base_products<KT, 4, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
         if constexpr (BPL) {
+          // Only the haplotypes whose word changed since their products were formed: an accepted mutation changes one word,
+          // and in a chain that keeps moving nearly every round follows a move -- re-forming all K products each time was
+          // half of such a round (phase timers, 16-read units: 12 000 ticks per round, 6 000 of them here).
+          const bool any_valid = bpt[KT] != 0ull;
+          const PairRows rows = spec_pair_rows<KT>(bw_tab + (size_t)sg * KT, 1, 0, S, sg, mmax, Mh, amask, lane);
+          for (int h = 0; h < KT; h++) {
+            const bool ok = any_valid && bpt[h] == bw_tab[(size_t)sg * KT + h];
+            if (__builtin_amdgcn_readfirstlane((int)ok) != 0) continue;
+            if (nb0 == 1) spec_base_products_of<KT, 1, uint8_t, LT>(S, rows, sg, h, Mh, ct, crow, lane, bp);
+            else if (nb0 == 2) spec_base_products_of<KT, 2, uint16_t, LT>(S, rows, sg, h, Mh, ct, crow, lane, bp);
+            else if (nb0 == 3) spec_base_products_of<KT, 3, uint32_t, LT>(S, rows, sg, h, Mh, ct, crow, lane, bp);
+            else spec_base_products_of<KT, 4, uint32_t, LT>(S, rows, sg, h, Mh, ct, crow, lane, bp);
+          }
+          lds_sync();
           if (lane == 0) {
 #pragma unroll
             for (int h = 0; h < KT; h++) bpt[h] = bw_tab[(size_t)sg * KT + h];
             bpt[KT] = 1ull;
           }
           lds_sync();
+        } else {
+          if (nb0 == 1) spec_base_products<KT, 1, uint8_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+          else if (nb0 == 2) spec_base_products<KT, 2, uint16_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+          else if (nb0 == 3) spec_base_products<KT, 3, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
+          else spec_base_products<KT, 4, uint32_t, LT>(S, sg, mmax, Mh, amask, ct, crow, lane, bp);
         }
       }
       // Deep units: the products of the current genotype's haplotypes for the chunks beyond the first four are kept in the
