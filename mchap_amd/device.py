@@ -60,7 +60,27 @@ class PassesInFlight:
             cur.wait_stream(s)
 
 
-class DenovoDeviceBatch:
+class _OwnBuffers:
+    """A device batch owns its buffers (inputs, workspace, traces, summaries): two passes over it must not overlap, whatever
+    streams they are issued on.  Every enqueueing method waits for the event the previous one left behind and leaves its
+    own -- passes of ONE batch are serialised on the device, passes of different batches still run side by side
+    (PassesInFlight)."""
+
+    _last_use = None
+
+    def _begin(self):
+        s = self.torch.cuda.current_stream()
+        if self._last_use is not None:
+            s.wait_event(self._last_use)
+        return s
+
+    def _end(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream())
+        self._last_use = ev
+
+
+class DenovoDeviceBatch(_OwnBuffers):
     """A batch of uniformly shaped units resident on one GPU.
 
     reads : float64 [U, R, M, A] (numpy, copied once) ; read_counts : int64 [U, R] or None."""
@@ -150,7 +170,7 @@ class DenovoDeviceBatch:
     def run(self):
         """Enqueue the sampler on torch's current stream (no synchronisation)."""
         L = _lib.lib()
-        stream = self.torch.cuda.current_stream().cuda_stream
+        stream = self._begin().cuda_stream
         if self.d_reads is None:
             rc = L.mchap_denovo_fit_batch_calls_device(
                 C.byref(self.cfg), self.shape[0], self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_calls),
@@ -158,12 +178,14 @@ class DenovoDeviceBatch:
                 self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks), self._p(self.d_fixed),
                 self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream))
             _lib.check(rc)
+            self._end()
             return
         rc = L.mchap_denovo_fit_batch_device(
             C.byref(self.cfg), self.shape[0], self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_reads),
             self._p(self.d_counts), self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks),
             self._p(self.d_fixed), self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream))
         _lib.check(rc)
+        self._end()
 
     def posterior(self, burn, max_states=32):
         """Enqueue the posterior summary of the traces written by run()."""
@@ -182,12 +204,13 @@ class DenovoDeviceBatch:
                 mode_count=torch.empty(U, dtype=torch.int32, device=dev),
             )
         P = self.post
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = self._begin().cuda_stream
         rc = _lib.lib().mchap_trace_posterior_batch_device(
             U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), int(max_states), self.K,
             self._p(P["words"]), self._p(P["counts"]), self._p(P["n"]), self._p(P["stats"]), self._p(P["mode"]),
             self._p(P["mode_words"]), self._p(P["mode_count"]), C.c_void_p(stream))
         _lib.check(rc)
+        self._end()
 
     def incongruence(self, burn, threshold=0.6):
         """Enqueue the replicate-incongruence code (MCI) of every unit's chains; returns the int32 device tensor
@@ -196,11 +219,12 @@ class DenovoDeviceBatch:
         U = self.shape[0]
         if getattr(self, "d_mci", None) is None:
             self.d_mci = torch.empty(U, dtype=torch.int32, device=self.device)
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = self._begin().cuda_stream
         rc = _lib.lib().mchap_trace_incongruence_batch_device(
             U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), self.K, C.c_double(float(threshold)),
             self._p(self.d_mci), C.c_void_p(stream))
         _lib.check(rc)
+        self._end()
         return self.d_mci
 
     # ---- results back on the host ----
@@ -342,7 +366,7 @@ class ExactDeviceBatch:
         return res
 
 
-class DenovoRaggedBatch:
+class DenovoRaggedBatch(_OwnBuffers):
     """Units of different shapes (loci with different numbers of SNVs and alleles, samples with different read depths,
     per-sample ploidy / inbreeding) in ONE sampler launch, with the posterior summary and the replicate incongruence
     taken on the device: what `mchap assemble` needs per (locus x sample) comes back as a few hundred bytes per unit.
@@ -422,7 +446,7 @@ class DenovoRaggedBatch:
         torch = self.torch
         dev = self.device
         U, K = self.n_units, self.Kmax
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = self._begin().cuda_stream
         L = _lib.lib()
         type(self).n_runs += 1
         _lib.check(L.mchap_denovo_fit_batch_device(
@@ -447,6 +471,7 @@ class DenovoRaggedBatch:
             self._p(self.p_mci), C.c_void_p(stream)))
         self.burn = int(burn)
         self.incongruence_threshold = float(incongruence_threshold)
+        self._end()
 
     def results(self):
         """Per unit: dict(genotypes int8 [n, K, M] distinct states (probability descending), probabilities [n], spm, gpm,
@@ -455,6 +480,7 @@ class DenovoRaggedBatch:
         from .classes import GenotypeMultiTrace
 
         U, K, ms = self.n_units, self.Kmax, self.max_states
+        self._begin()  # (the pass may have been issued on another stream)
         words = self.p_words.cpu().numpy().view(np.uint64).reshape(U, ms, K)
         counts = self.p_counts.cpu().numpy().reshape(U, ms)
         n = self.p_n.cpu().numpy()
