@@ -1,7 +1,9 @@
+# Run ON THE GPU BOX via gpurun: kernel traces of the bench command (default and --inflight 1), PMC traffic passes with calibration,
+# SQ counter passes for configs[1] and configs[4]; tools/pmc_traffic.py <tag> ... and tools/pmc_sq.py turn them into profiles/<tag>_*.
 cd /root/repo
 export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out
-TAG=r03ab
+TAG=${1:-r03ab}
 [ -f /root/repo/tools/libpmc_calib.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o /root/repo/tools/libpmc_calib.so /root/repo/tools/pmc_calib.hip
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 /root/repo/bench.py --no-cpu-baseline --no-extras > $OUT/${TAG}_trace.log 2>&1
