@@ -7,6 +7,8 @@ Parity: the reference's RNG-free `call-exact` golden VCFs are reproduced line fo
 """
 import numpy as np
 
+from contextlib import nullcontext as _nullcontext
+
 from . import encoding
 from .io import DenovoLocus, Locus, extract_read_variants, qual_of_prob, read_alignments, read_bam, read_bed4, read_vcf, vcfstr  # noqa: F401
 
@@ -730,11 +732,15 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
     by_contig = _variants_by_contig(variants)
     if units_per_block is None:
         # device bytes of one unit: its traces (chains x steps x (ploidy words + llk)), the per-chain likelihood cache and
-        # tables of the workspace, a typical read tensor
+        # tables of the workspace, a typical read tensor; two blocks are resident at a time (below).  A block is at most
+        # 32 768 units: large enough that its launch is set by the average chain and not by its slowest, small enough that
+        # a big job is several blocks whose host and device work overlap
         kmax = max(int(ploidy_of(s_)) for s_ in samples)
-        units_per_block = device_unit_budget(chains * steps * (kmax + 1) * 8 + chains * 1024 * 16 * 2 + (256 << 10), fraction=0.4)
+        units_per_block = min(32768, device_unit_budget(chains * steps * (kmax + 1) * 8 + chains * 1024 * 16 * 2 + (256 << 10), fraction=0.2))
     loci_per_block = max(1, units_per_block // max(1, len(samples)))
-    for block in _blocks(targets, loci_per_block):
+
+    def start_block(block, stream):
+        """Stage 1 of a block: loci, read encoding (host), the sampler launches enqueued on `stream` (not waited for)."""
         loci = [DenovoLocus(contig, start, stop, name, _variants_within(by_contig, contig, start, stop), fetch(contig, start, stop))
                 for contig, start, stop, name in block]
         encoded = {}
@@ -753,37 +759,51 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
                 units.append(dict(reads=dists, counts=counts, n_alleles=locus.n_alleles, ploidy=int(ploidy_of(sample)),
                                   inbreeding=inbreeding_of(sample), stream_id=0, temps=tuple(temps_of(sample))))
                 where.append((li, sample))
-        summaries = {}
         t1_ = _time.perf_counter()
         timings["encode_s"] += t1_ - t0_
         timings["units"] += len(units)
+        state = dict(loci=loci, encoded=encoded, units=units, where=where, summaries={}, pending=[], stream=stream)
         if units and sampler is not None:
             settings = dict(steps=steps, chains=chains, seed=seed, burn=burn, incongruence_threshold=incongruence_threshold, **mcmc_kw)
             for w_, res in zip(where, sampler(units, settings)):
-                summaries[w_] = res
+                state["summaries"][w_] = res
         elif units:
+            import torch
+
             # one launch per (ploidy, temperature ladder) present (usually one): the library's fast samplers take one ploidy
             # per launch (mixed ploidies would run on the general lanes-over-chains kernel), and a ladder is a launch setting
             groups = {}
             for i, u in enumerate(units):
                 groups.setdefault((u["ploidy"], u["temps"]), []).append(i)
-            # (several groups: their launches go out on separate HIP streams and fill each other's thin phases)
-            flight = PassesInFlight(min(4, len(groups))) if len(groups) > 1 else None
-            pending = []
-            for (K, temps), idx in groups.items():
-                model = DenovoMCMC(ploidy=K, n_alleles=[2], inbreeding=None, steps=steps, chains=chains, random_seed=seed,
-                                   temperatures=temps, **mcmc_kw)
-                batch = DenovoRaggedBatch(model, [units[i] for i in idx])
+            with torch.cuda.stream(stream) if stream is not None else _nullcontext():
+                # (several groups: their launches go out on separate HIP streams and fill each other's thin phases)
+                flight = PassesInFlight(min(4, len(groups))) if len(groups) > 1 else None
+                for (K, temps), idx in groups.items():
+                    model = DenovoMCMC(ploidy=K, n_alleles=[2], inbreeding=None, steps=steps, chains=chains, random_seed=seed,
+                                       temperatures=temps, **mcmc_kw)
+                    batch = DenovoRaggedBatch(model, [units[i] for i in idx])
+                    if flight is not None:
+                        flight.submit(lambda b=batch: b.run(burn, incongruence_threshold=incongruence_threshold))
+                    else:
+                        batch.run(burn, incongruence_threshold=incongruence_threshold)
+                    state["pending"].append((idx, batch))
                 if flight is not None:
-                    flight.submit(lambda b=batch: b.run(burn, incongruence_threshold=incongruence_threshold))
-                else:
-                    batch.run(burn, incongruence_threshold=incongruence_threshold)
-                pending.append((idx, batch))
-            if flight is not None:
-                flight.join()
-            for idx, batch in pending:
-                for i, res in zip(idx, batch.results()):
-                    summaries[where[i]] = res
+                    flight.join()
+        timings["sampler_s"] += _time.perf_counter() - t1_
+        return state
+
+    def finish_block(state):
+        """Stage 2: the block's results on the host (waits for its launches only), its records formatted and yielded."""
+        t1_ = _time.perf_counter()
+        loci, encoded, where, summaries = state["loci"], state["encoded"], state["where"], state["summaries"]
+        if state["pending"]:
+            import torch
+
+            with torch.cuda.stream(state["stream"]) if state["stream"] is not None else _nullcontext():
+                for idx, batch in state["pending"]:
+                    for i, res in zip(idx, batch.results()):
+                        summaries[where[i]] = res
+            state["pending"] = []  # (the block's device buffers go back to the allocator)
         t2_ = _time.perf_counter()
         timings["sampler_s"] += t2_ - t1_
         for li, locus in enumerate(loci):
@@ -809,6 +829,24 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
             timings["format_s"] += _time.perf_counter() - t2_
             yield line
             t2_ = _time.perf_counter()
+
+    # Two blocks in flight: while the device samples block i the host encodes block i + 1, and while it samples block i + 1
+    # the host formats block i.  Each block's launches go to one of two side streams (a block's results are read on its own
+    # stream, so fetching them does not wait for the next block's launches); a job of one block runs on the current stream.
+    blocks = list(_blocks(targets, loci_per_block))
+    streams = [None, None]
+    if len(blocks) > 1 and sampler is None:
+        import torch
+
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    prev = None
+    for bi, block in enumerate(blocks):
+        cur = start_block(block, streams[bi % 2])
+        if prev is not None:
+            yield from finish_block(prev)
+        prev = cur
+    if prev is not None:
+        yield from finish_block(prev)
 
 
 # ---------------------------------------------------------------------------------------------------------

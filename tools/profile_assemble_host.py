@@ -13,19 +13,20 @@ class NSeq:
         return "N" * (sl.stop - sl.start)
 
 
-def once(rep, tm):
+def once(rep, tm, upb=None):
     source = application.MatrixSource(samples, matrices)
     return list(application.assemble(None, variants, {c: NSeq() for c, _ in contigs}, source, ploidy=4, steps=2000, burn=1000, chains=2,
-                                     seed=42, targets=list(targets) * rep, timings=tm))
+                                     seed=42, targets=list(targets) * rep, timings=tm, units_per_block=upb))
 
 
 once(1, {})
 rep = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+upb = int(sys.argv[2]) if len(sys.argv) > 2 else None  # units per block (several blocks: host and device work overlap)
 tm = {}
 pr = cProfile.Profile()
 t = time.perf_counter()
 pr.enable()
-lines = once(rep, tm)
+lines = once(rep, tm, upb)
 pr.disable()
 print("wall %.2f s" % (time.perf_counter() - t), {k: round(v, 3) for k, v in tm.items()})
 pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
