@@ -175,6 +175,24 @@ def pmc_traffic(args):
     return None
 
 
+def pmc_valu_insts(args):
+    """Wavefront VALU instructions per sampler call from the same profile summaries (SQ_INSTS_VALU of the SQ counter passes),
+    or None."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("loci") == args.loci and t.get("mcmc_steps") == args.mcmc_steps and t.get("chains") == args.chains:
+                v = t.get("sq_counters_per_launch", {}).get("SQ_INSTS_VALU")
+                if v:
+                    return float(v), os.path.basename(path)
+        except Exception:
+            pass
+    return None
+
+
 def incl_h2d(args, model):
     """The same pass as the caller sees it from host memory: compact input (int8 allele calls + int16 base qualities,
     4.8 KB per locus at the default shape) uploaded, prepare + sampler + posterior summary, the posterior records
@@ -759,6 +777,11 @@ def main():
         bytes_out = args.chains * args.mcmc_steps * (args.ploidy * 8 + 8)
         bytes_per_launch = U * (bytes_in + bytes_out)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        # the bound that binds: VALU issue (wavefront VALU instructions of a sampler call, from the SQ counter passes, against
+        # 1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane instruction), reported beside the HBM fraction the contract asks for
+        pv = pmc_valu_insts(args)
+        valu_insts, valu_src = (pv if pv else (None, None))
+        valu_frac = (valu_insts / (kern_ms * 1e-3) / (1024 * 2.4e9 / 4.0)) if valu_insts else None
         out = {
             "metric": "loci/sec (whole node) for 1000-step MCMC, tetraploid 8-SNV loci, 1/2/4/8 GPUs",
             "value": value,
@@ -786,6 +809,7 @@ def main():
                 "bound": "hbm", "kernel": kern_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
                 "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": kern_ms, "sampler_span_ms": span_ms,
+                "valu_issue_frac": valu_frac, "valu_insts_per_launch": valu_insts, "valu_counters": valu_src,
                 "note": "a sampler call is several launches (phased sampler: speculative kernel phases + coasting kernel, "
                         "DESIGN.md 4.1c); kernel_ms is the span of HIP events around all of them, measured with ONE pass in "
                         "flight in %d passes right after the timed region (in the timed region passes overlap on separate "
