@@ -98,3 +98,9 @@ def test_assemble_is_one_sampler_launch_per_vcf():
     for ln in mixed:
         cols = ln.split("\t")
         assert len(cols[10].split(":")[0].split("/")) == 2 and len(cols[9].split(":")[0].split("/")) == 4
+    # the same job in blocks of one target (three units: two launches per block, blocks pipelined on two side streams,
+    # a block's results fetched while the next one runs): the same records
+    blocked = list(application.assemble(os.path.join(HERE, "simple.bed"), os.path.join(HERE, "simple.vcf"), ref, bams,
+                                        ploidy={"SAMPLE1": 4, "SAMPLE2": 2, "SAMPLE3": 4}, inbreeding={"SAMPLE1": 0.0, "SAMPLE2": 0.1, "SAMPLE3": 0.0},
+                                        steps=200, burn=50, chains=2, seed=11, units_per_block=3))
+    assert blocked == mixed
