@@ -650,6 +650,9 @@ def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_t
                       ";".join(parts), ":".join(SAMPLE_FIELDS + tuple(fmt_opt))] + cols)
 
 
+MAX_SNVS_PER_LOCUS = 62  # what mchap_denovo_fit_batch takes per unit (include/mchap_hip.h)
+
+
 def _variants_by_contig(variants):
     """{contig: (positions ascending, the records in that order)}: the file order of equal positions is kept (stable sort),
     as DenovoLocus merges the records of a position in the order it is given them."""
@@ -746,8 +749,14 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
         encoded = {}
         units, where = [], []
         t0_ = _time.perf_counter()
+        skipped = {}
         for li, locus in enumerate(loci):
             M = len(locus.positions)
+            if M > MAX_SNVS_PER_LOCUS:
+                # beyond what the library takes (the reference has no limit): the target is left out of the output with a
+                # warning instead of ending a run of many targets
+                skipped[li] = "%d SNVs (at most %d per target)" % (M, MAX_SNVS_PER_LOCUS)
+                continue
             for sample in samples:
                 sr = source.reads(locus, sample)
                 encoded[(li, sample)] = sr
@@ -762,7 +771,7 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
         t1_ = _time.perf_counter()
         timings["encode_s"] += t1_ - t0_
         timings["units"] += len(units)
-        state = dict(loci=loci, encoded=encoded, units=units, where=where, summaries={}, pending=[], stream=stream)
+        state = dict(loci=loci, encoded=encoded, units=units, where=where, summaries={}, pending=[], stream=stream, skipped=skipped)
         if units and sampler is not None:
             settings = dict(steps=steps, chains=chains, seed=seed, burn=burn, incongruence_threshold=incongruence_threshold, **mcmc_kw)
             for w_, res in zip(where, sampler(units, settings)):
@@ -801,13 +810,21 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
 
             with torch.cuda.stream(state["stream"]) if state["stream"] is not None else _nullcontext():
                 for idx, batch in state["pending"]:
-                    for i, res in zip(idx, batch.results()):
+                    for i, res in zip(idx, batch.results(raise_on_limit=False)):
                         summaries[where[i]] = res
+                        if res.get("limit"):
+                            state["skipped"].setdefault(where[i][0], "sample %s: %s" % (where[i][1], res["limit"]))
             state["pending"] = []  # (the block's device buffers go back to the allocator)
         t2_ = _time.perf_counter()
         timings["sampler_s"] += t2_ - t1_
         for li, locus in enumerate(loci):
             M = len(locus.positions)
+            if li in state["skipped"]:
+                import sys
+
+                sys.stderr.write("mchap_amd assemble: target %s (%s:%d-%d) left out: %s\n" % (
+                    locus.name, locus.contig, locus.start + 1, locus.stop, state["skipped"][li]))
+                continue
             per, posteriors = {}, []
             for sample in samples:
                 sr = encoded[(li, sample)]

@@ -473,10 +473,12 @@ class DenovoRaggedBatch(_OwnBuffers):
         self.incongruence_threshold = float(incongruence_threshold)
         self._end()
 
-    def results(self):
+    def results(self, raise_on_limit=True):
         """Per unit: dict(genotypes int8 [n, K, M] distinct states (probability descending), probabilities [n], spm, gpm,
         mode_genotype int8 [K, M], mci, status).  Units with more distinct states than the batch kernels keep (512) are
-        summarised by a second, listed launch with a table of chains x (steps - burn) states (as many as the LDS holds)."""
+        summarised by a second, listed launch with a table of chains x (steps - burn) states (as many as the LDS holds).
+        A unit beyond the library's packed haplotype width raises NotImplementedError, or with raise_on_limit=False comes
+        back as dict(status, limit=reason)."""
         from .classes import GenotypeMultiTrace
 
         U, K, ms = self.n_units, self.Kmax, self.max_states
@@ -529,7 +531,11 @@ class DenovoRaggedBatch(_OwnBuffers):
             if st == _lib.UNIT_BREAKS:
                 raise ValueError("breaks must be smaller then n")
             if st < 0:
-                raise NotImplementedError("mchap_hip: unit %d exceeds the packed haplotype width" % u)
+                if raise_on_limit:
+                    raise NotImplementedError("mchap_hip: unit %d exceeds the packed haplotype width" % u)
+                out.append(dict(status=st, limit="more than 64 bits of sampled alleles per haplotype (one bit per biallelic, two per "
+                                                 "tri- / tetra-allelic SNV that is not fixed as homozygous)"))
+                continue
             if u in over_row and 0 <= n[u] <= over_row[u][2] and mci[u] >= 0:
                 w_, c_, _ = over_row[u]
                 k = int(n[u])
