@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--config5-loci", type=int, default=256)  # 1024 chains: one wave per SIMD
     ap.add_argument("--config4-units", type=int, default=256)
     ap.add_argument("--e2e-loci", type=int, default=1000)
+    ap.add_argument("--call-units", type=int, default=4096, help="units of the `mchap call` sampler's extra (extra.call_mcmc)")
     ap.add_argument("--tempered", action="store_true",
                     help="also run extra.config5_tempered (one chain x 4 temperatures at configs[4]'s shape): minutes of GPU time, "
                          "so not part of the default line (profiles/ holds the measured run)")
@@ -399,6 +400,76 @@ def bench_config5(args):
         dc = time.perf_counter() - t
         out["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": min(cores, n_cpu), "kind": "port",
                                "sample": "%d loci of the same workload, oracle with llk cache, one locus per thread, %.1f s wall" % (n_cpu, dc)}
+    return out
+
+
+def bench_call_mcmc(args):
+    """`mchap call`: the Gibbs sampler over the genotypes of KNOWN haplotypes (calling/mcmc.py:15-453) for a batch of
+    tetraploid units -- 16 known haplotypes over 8 SNVs, 200 reads, the program's defaults of 2000 steps (burn 1000) x 2 chains,
+    Dirichlet-multinomial prior with inbreeding 0.1 -- resident in HBM, mchap_call_mcmc_batch_device on torch's stream; the
+    oracle on the same Philox streams beside it (and the first units' traces compared with it)."""
+    import ctypes as C
+
+    import torch
+    from mchap_amd import _lib
+    from mchap_amd.synth import synth_units
+
+    U, K, H, M, R, S, Cn = args.call_units, 4, 16, 8, 200, 2000, 2
+    rng = np.random.default_rng(9)
+    reads, _, truth = synth_units(U, ploidy=K, n_pos=M, n_reads=R, first_unit=700)
+    haps = np.zeros((U, H, M), np.int8)
+    for u in range(U):
+        pool = np.unique(np.concatenate([truth[u], rng.integers(0, 2, size=(8 * H, M)).astype(np.int8)]), axis=0)
+        rng.shuffle(pool)
+        tr = np.unique(truth[u], axis=0)
+        rest = [p_ for p_ in pool if not any(np.array_equal(p_, t) for t in tr)][: H - len(tr)]
+        hs = np.concatenate([tr, np.array(rest, np.int8)])
+        rng.shuffle(hs)
+        haps[u] = hs
+    F = np.full(U, 0.1)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+    d_reads, d_haps, d_F = d(reads), d(haps), d(F)
+    d_sid = d(np.arange(U, dtype=np.int64))
+    d_g = torch.empty(U * Cn * S * K, dtype=torch.int64, device=dev)
+    d_l = torch.empty(U * Cn * S, dtype=torch.float64, device=dev)
+    d_st = torch.empty(U, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    ws = int(L.mchap_call_mcmc_workspace_bytes_for(U, R, H, K, S, Cn))
+    d_ws = torch.empty(max(ws, 16), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def once():
+        _lib.check(L.mchap_call_mcmc_batch_device(U, p(d_reads), R, M, 2, None, p(d_haps), H, K, 1, p(d_F), None, None, p(d_sid), S, Cn, 0,
+                                                  C.c_uint64(42), p(d_g), p(d_l), p(d_st), p(d_ws), C.c_int64(ws), C.c_void_p(stream)))
+
+    once()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 3
+    for _ in range(n):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    assert (d_st.cpu().numpy() == 0).all()
+    out = {"workload": "%d units: tetraploid, %d known haplotypes x %d SNVs, %d reads, Gibbs steps, %d steps x %d chains, prior (0.1, flat); HBM resident" % (U, H, M, R, S, Cn),
+           "value": U / (ms * 1e-3), "unit": "units/s", "kernel": "call_mcmc_kernel", "kernel_ms": ms,
+           "allele_steps_per_s": U * Cn * S * K / (ms * 1e-3)}
+    if not args.no_cpu_baseline:
+        from oracle import binding as orc
+
+        g = d_g.cpu().numpy().reshape(U, Cn, S, K)
+        n_cpu = 16
+        t = time.perf_counter()
+        for u in range(n_cpu):
+            go, lo = orc.call_mcmc(reads[u], haps[u], K, steps=S, chains=Cn, step_type=0, prior=(0.1, None), rng_kind=orc.RNG_PHILOX, seed=42, stream_id=u)
+            assert np.array_equal(go, g[u]), "call sampler trace of unit %d differs from the oracle's" % u
+        dc = (time.perf_counter() - t) / n_cpu
+        out["cpu_baseline"] = {"value": 1.0 / dc, "unit": "units/s", "cores": 1, "kind": "port",
+                               "sample": "%d units through oracle/mchap_oracle.c call_mcmc, one thread; traces equal the GPU's" % n_cpu}
     return out
 
 
@@ -829,6 +900,7 @@ def main():
             out["extra"] = {"config1": bench_config1(args), "config2_dedup": bench_config2_dedup(args), "moving": bench_moving(args),
                             "config4": bench_config4(args), "config5": bench_config5(args)}
             out["extra"]["program_e2e"] = bench_program_e2e(args)
+            out["extra"]["call_mcmc"] = bench_call_mcmc(args)
             if args.tempered:
                 out["extra"]["config5_tempered"] = bench_config5_tempered(args)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline leg runs at N = 1 only

@@ -60,9 +60,22 @@ struct CallParams {
   int32_t *status;           // [U]: 0 ok, MCHAP_ERR_LIMIT if a table filled up
 };
 
+// Memo of Gibbs sub-steps (round 3): the option probabilities of a sub-step are a function of the OTHER K - 1 alleles of the
+// genotype alone -- the likelihood table never forgets or changes an entry, the priors are tables -- and normalising them is
+// a chain of H - 1 dependent add_log_prob (an exp and a log1p each: calling/mcmc.py via jitutils.py:30-74) that only one
+// lane can run: measured 36 us of a 37 us sub-step.  A converged chain meets the same few contexts step after step, so the
+// last CALL_MEMO contexts keep their probabilities and likelihoods in LDS ([entries][2 H] doubles + keys); a hit goes straight
+// to the draw.  Same values by construction.
+constexpr int CALL_MEMO = 8;
+__host__ __device__ inline int call_memo_entries(int H) {
+  const int per = 2 * H * 8;  // bytes of an entry's probabilities and likelihoods
+  const int n = 16384 / per;
+  return n > CALL_MEMO ? CALL_MEMO : n;
+}
 inline size_t call_lds_bytes(int R, int H, int K) {
-  // ptab, cnt, lgd, lgf, lfreq (exact_setup) + rtab [H][K] + 3 arrays [H] + request words
-  return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)H * K + 4 * (size_t)CALL_MAX_HAPS + 64) * 8;
+  // ptab, cnt, lgd, lgf, lfreq (exact_setup) + rtab [H][K] + 3 arrays [H] + request words + the Gibbs memo
+  return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)H * K + 4 * (size_t)CALL_MAX_HAPS + 64 +
+          (size_t)CALL_MEMO + (size_t)call_memo_entries(H) * 2 * H) * 8;
 }
 
 // calling/prior.py:116-179 on the alleles in ARRAY order (allelic dosage at first occurrence, calling/utils.py:7-35)
@@ -139,6 +152,13 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
   double *o_lpr = o_llk + CALL_MAX_HAPS;
   double *o_prob = o_lpr + CALL_MAX_HAPS;
   double *o_aux = o_prob + CALL_MAX_HAPS;   // proposal ratios (Metropolis-Hastings)
+  // Gibbs memo (call_memo_entries): keys (context rank + 1, 0 = empty), then per entry H probabilities and H likelihoods
+  const int n_memo = (P.step_type == 0) ? call_memo_entries(H) : 0;
+  long long *memo_key = reinterpret_cast<long long *>(o_aux + CALL_MAX_HAPS + 64);
+  double *memo_val = reinterpret_cast<double *>(memo_key + CALL_MEMO);
+  for (int i = lane; i < CALL_MEMO; i += WAVE) memo_key[i] = 0;
+  int memo_next = 0;                        // (wave-uniform) the entry the next miss replaces
+  __shared__ double s_acc, s_choice_llk;
   __shared__ int s_g[MCHAP_MAX_PLOIDY];     // the chain's genotype (array order)
   __shared__ int s_req[MCHAP_MAX_PLOIDY];   // alleles of the request being evaluated
   __shared__ double s_left;                 // Gibbs prior: lgamma(sum_alpha) - lgamma(1 + sum_alpha)
@@ -404,6 +424,23 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
         }
         cur_llk = __shfl(val, 0, WAVE);
       }
+      // Gibbs: has this context (the other K - 1 alleles) been normalised before?
+      const double *use_prob = o_prob, *use_llk = o_llk;
+      long long ctx = 0;
+      int memo_hit = -1;
+      if (n_memo > 0) {
+        int o[MCHAP_MAX_PLOIDY];
+        int n_o = 0;
+        for (int i = 0; i < K; i++)
+          if (i != k) o[n_o++] = s_g[i];
+        ctx = (K > 1 ? call_key(o, K - 1) : 0) + 1;
+        const unsigned long long m = __ballot(lane < n_memo && memo_key[lane] == ctx);
+        memo_hit = m ? __ffsll((long long)m) - 1 : -1;
+      }
+      if (memo_hit >= 0) {
+        use_prob = memo_val + (size_t)memo_hit * 2 * H;
+        use_llk = use_prob + H;
+      } else {
       for (int a0 = 0; a0 < H; a0 += WAVE) option_llks(k, a0);
       // priors (and proposal ratios) of the options
       for (int a = lane; a < H; a += WAVE) {
@@ -430,12 +467,32 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
         }
       }
       __syncthreads();
-      if (lane == 0) {
-        if (P.step_type == 0) {
-          // normalise_log_probs(llks + lpriors): sequential add_log_prob in allele order (jitutils.py:30-74)
+      if (P.step_type == 0) {
+        // normalise_log_probs(llks + lpriors): sequential add_log_prob in allele order (jitutils.py:30-74) -- one lane --,
+        // then the H exponentials, one lane each (the same function of the same arguments as the sequential loop)
+        if (lane == 0) {
           double acc = o_llk[0] + o_lpr[0];
           for (int a = 1; a < H; a++) acc = add_log_prob(acc, o_llk[a] + o_lpr[a]);
-          for (int a = 0; a < H; a++) o_prob[a] = exp((o_llk[a] + o_lpr[a]) - acc);
+          s_acc = acc;
+        }
+        __syncthreads();
+        const double acc = s_acc;
+        for (int a = lane; a < H; a += WAVE) o_prob[a] = exp((o_llk[a] + o_lpr[a]) - acc);
+        __syncthreads();
+        if (n_memo > 0) {  // remember the context
+          double *mv = memo_val + (size_t)memo_next * 2 * H;
+          for (int a = lane; a < H; a += WAVE) {
+            mv[a] = o_prob[a];
+            mv[H + a] = o_llk[a];
+          }
+          if (lane == 0) memo_key[memo_next] = ctx;
+          memo_next = memo_next + 1 == n_memo ? 0 : memo_next + 1;
+          __syncthreads();
+        }
+      }
+      }  // (memo miss)
+      if (lane == 0) {
+        if (P.step_type == 0) {
         } else {
           double sum = 0.0;
           for (int a = 0; a < H; a++) {
@@ -452,7 +509,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
         double cacc = 0.0;
         int ch = H;
         for (int a = 0; a < H; a++) {
-          cacc += o_prob[a];
+          cacc += use_prob[a];
           if (cacc > u) {
             ch = a;
             break;
@@ -460,6 +517,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
         }
         if (ch >= H) ch = H - 1;  // u beyond the last cumulative value (probability ~1e-16)
         s_choice = ch;
+        s_choice_llk = use_llk[ch];
         s_g[k] = ch;
       }
       ctr++;
@@ -477,7 +535,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
         }
         s_g[b + 1] = v;
       }
-      lout[step] = o_llk[choice];
+      lout[step] = s_choice_llk;
     }
     __syncthreads();
     if (lane < K) gout[(size_t)step * K + lane] = s_g[lane];
