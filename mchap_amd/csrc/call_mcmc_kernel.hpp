@@ -430,22 +430,21 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
       int memo_hit = -1;
       if (n_memo > 0) {
         // key of the context: the other alleles sorted, eight bits each (H <= 256, K - 1 <= 7) -- any one-to-one function of
-        // the multiset does; the genotype's rank would cost a chain of 64-bit divisions per sub-step
-        int o[MCHAP_MAX_PLOIDY];
-        int n_o = 0;
-        for (int i = 0; i < K; i++)
-          if (i != k) o[n_o++] = s_g[i];
-        for (int a = 1; a < n_o; a++) {  // insertion sort
-          const int v = o[a];
-          int b = a - 1;
-          while (b >= 0 && o[b] > v) {
-            o[b + 1] = o[b];
-            b--;
-          }
-          o[b + 1] = v;
-        }
+        // the multiset does; the genotype's rank would cost a chain of 64-bit divisions per sub-step.  Sorted by counting
+        // (the place of an allele is the number of alleles before it in the order), all loops of constant extent: no
+        // register array is indexed by a run-time value
+        int v[MCHAP_MAX_PLOIDY];
+#pragma unroll
+        for (int i = 0; i < MCHAP_MAX_PLOIDY; i++) v[i] = i < K ? s_g[i] : 0;
         unsigned long long packed = 0ull;
-        for (int i = 0; i < n_o; i++) packed = (packed << 8) | (unsigned long long)(o[i] & 255);
+#pragma unroll
+        for (int i = 0; i < MCHAP_MAX_PLOIDY; i++) {
+          int place = 0;
+#pragma unroll
+          for (int j = 0; j < MCHAP_MAX_PLOIDY; j++)
+            place += (j < K && j != k && j != i && (v[j] < v[i] || (v[j] == v[i] && j < i))) ? 1 : 0;
+          if (i < K && i != k) packed |= (unsigned long long)(v[i] & 255) << (8 * place);
+        }
         ctx = (long long)((packed << 1) | 1ull);  // (never 0: 0 marks an empty entry)
         const unsigned long long m = __ballot(lane < n_memo && memo_key[lane] == ctx);
         memo_hit = m ? __ffsll((long long)m) - 1 : -1;
