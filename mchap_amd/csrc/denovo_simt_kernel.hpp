@@ -31,7 +31,7 @@ __host__ __device__ inline int meta_i_stride(int max_pos) { return 4 + 2 * max_p
 // (one per base quality, its error share, 1.0 for gaps), so it is also stored as uint8 codes into a per-unit
 // dictionary of float64 values: lossless, 8x smaller, and what the likelihood evaluation then streams stays in L2.
 constexpr int DICT_MAX = 128;  // entries kept per unit (LDS of the sampler: 1 KB per chain)
-constexpr int DICT_HASH = 1024;  // open-addressing slots of the prepare pass's LDS set
+constexpr int DICT_HASH = 512;   // open-addressing slots of the prepare pass's LDS set (at most DICT_MAX = 128 are taken)
 // doubles: [0] luh, [1..] prior table (2K+5), then dist [M*A]
 __host__ __device__ inline int meta_f_prior(int) { return 1; }
 __host__ __device__ inline int meta_f_dist(int max_ploidy) { return 1 + 2 * max_ploidy + 5; }
