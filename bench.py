@@ -52,7 +52,9 @@ def passes_in_flight(n):
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU).  Without WORLD_SIZE in the environment and N > 1 this process starts N fresh rank "
+                         "processes (python -m torch.distributed.run) before anything touches the GPU and relays rank 0's line")
     ap.add_argument("--steps", type=int, default=50)   # 0.7 s of timed passes at the default workload
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--loci", type=int, default=10000, help="loci per GPU")
@@ -159,39 +161,53 @@ def cpu_baseline(args, cores, quota=None):
     }
 
 
-def pmc_traffic(args):
-    """HBM bytes per sampler launch from the rocprofv3 PMC passes (profiles/*_pmc_traffic.json, produced by
-    tools/profile_round.sh + tools/pmc_traffic.py: FETCH_SIZE / WRITE_SIZE converted with factors calibrated in the
-    sampler's access width, MI355X_MICROARCH.md "HBM"); the newest summary that matches this workload, else None."""
+def _profile_order(path):
+    """profiles/ are named r<round><tag>_...: order by round, then by the tag as a spreadsheet column (a..z, aa, ab, ...), so that
+    r03ab (end of round 3) ranks above r03h (mid round) -- a plain string sort put 'h' above 'ab'."""
+    import re
+
+    m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+    return (int(m.group(1)), len(m.group(2)), m.group(2)) if m else (-1, 0, "")
+
+
+def pmc_profile(args):
+    """The newest committed PMC summary that matches this workload (profiles/*_pmc_traffic.json, produced by
+    tools/profile_round.sh + tools/pmc_traffic.py in separate rocprofv3 --pmc passes: FETCH_SIZE / WRITE_SIZE converted with
+    factors calibrated in the sampler's access width, MI355X_MICROARCH.md "HBM"; SQ counters).  These are STATIC figures of an
+    earlier profiling run of the same command, not measurements of this run: the line names the file they come from."""
     import glob
 
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=_profile_order, reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
             if t.get("loci") == args.loci and t.get("mcmc_steps") == args.mcmc_steps and t.get("chains") == args.chains:
-                return t["hbm_bytes_per_launch"]
+                return t, "profiles/" + os.path.basename(path)
         except Exception:
             pass
-    return None
+    return None, None
 
 
-def pmc_valu_insts(args):
-    """Wavefront VALU instructions per sampler call from the same profile summaries (SQ_INSTS_VALU of the SQ counter passes),
-    or None."""
-    import glob
+# Issue cycles of one wavefront instruction on a SIMD (MI355X_MICROARCH.md "Wave scheduling" / "Per-instruction cycle constants":
+# a wave64 32-bit VALU op issues over 2 cycles once the SIMD has a second wave to interleave; float64 runs at half that rate
+# (78.6 against 157.3 TFLOP/s) = 4 cycles, 64-bit integer ops are priced the same, transcendentals 8)
+SIMD_CYCLES_PER_S = 1024 * 2.4e9  # 256 CUs x 4 SIMDs x 2.4 GHz
+VALU_CYCLES = {"f64": 4.0, "int64": 4.0, "trans": 8.0, "other": 2.0}
 
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-        try:
-            with open(path) as f:
-                t = json.load(f)
-            if t.get("loci") == args.loci and t.get("mcmc_steps") == args.mcmc_steps and t.get("chains") == args.chains:
-                v = t.get("sq_counters_per_launch", {}).get("SQ_INSTS_VALU")
-                if v:
-                    return float(v), os.path.basename(path)
-        except Exception:
-            pass
-    return None
+
+def valu_issue_cycles(sq):
+    """Issue cycles of a launch's wavefront VALU instructions, weighted per class from the SQ counters (None when the per-class
+    counters are not in the summary)."""
+    if not sq or "SQ_INSTS_VALU" not in sq:
+        return None
+    tot = float(sq["SQ_INSTS_VALU"])
+    f64 = sum(float(sq.get(k, 0.0)) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+    i64 = float(sq.get("SQ_INSTS_VALU_INT64", 0.0))
+    trans = sum(float(sq.get(k, 0.0)) for k in ("SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_TRANS_F16"))
+    have = all(k in sq for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+    other = max(0.0, tot - f64 - i64 - trans)
+    cyc = f64 * VALU_CYCLES["f64"] + i64 * VALU_CYCLES["int64"] + trans * VALU_CYCLES["trans"] + other * VALU_CYCLES["other"]
+    return {"cycles": cyc, "f64": f64, "int64": i64, "trans": trans, "other": other, "per_class_complete": have}
 
 
 def incl_h2d(args, model):
@@ -303,7 +319,10 @@ def bench_config4(args):
     # -ffp-contract=off keeps the K multiply-adds of a read's mean apart, as the reference's compiled loop has them.
     flop_per_term = 55.6
     valu_per_wave_term = 70.5
-    valu_issue_peak = 256 * 4 * 2.4e9 / 4.0  # wavefront instructions / s: 1024 SIMDs, 4 cycles per 64-lane instruction
+    # issue cycles per wavefront-term, weighted per class (r03h_config4_sq_counters.json): float64 FMA 11.2 + ADD 16.1 + MUL 17.1 at 4
+    # cycles, one float64 reciprocal at 8, 6.3 64-bit integer ops at 4, the other 18.8 (moves, compares, selects, 32-bit integer) at 2
+    cyc_per_wave_term = (11.2 + 16.1 + 17.1) * VALU_CYCLES["f64"] + 1.0 * VALU_CYCLES["trans"] + 6.3 * VALU_CYCLES["int64"] \
+        + (valu_per_wave_term - 11.2 - 16.1 - 17.1 - 1.0 - 6.3) * VALU_CYCLES["other"]
     ms = res["streaming"]
     out = {
         "workload": "%d units: hexaploid, %d haplotypes x %d SNVs, %d reads, G = %d genotypes, prior (0.1, Dirichlet(1)); HBM resident" % (U, H, M, R, G),
@@ -312,7 +331,10 @@ def bench_config4(args):
         "roofline": {"bound": "valu_fp64", "achieved": terms * flop_per_term / (ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                      "frac": terms * flop_per_term / (ms * 1e-3) / 1e12 / 78.6, "terms_per_s": terms / (ms * 1e-3),
                      "flop_per_term": flop_per_term, "valu_insts_per_wave_term": valu_per_wave_term,
-                     "valu_issue_frac": terms / 64.0 * valu_per_wave_term / (ms * 1e-3) / valu_issue_peak,
+                     "valu_issue_frac": terms / 64.0 * cyc_per_wave_term / (ms * 1e-3) / SIMD_CYCLES_PER_S,
+                     "valu_issue_cycles_per_wave_term": cyc_per_wave_term,
+                     "valu_issue_note": "issue cycles weighted per instruction class (float64 and 64-bit integer 4, transcendental 8, other 2 "
+                                        "cycles per wavefront instruction) over 1024 SIMDs x 2.4 GHz; round 3 priced every instruction at 4",
                      "counters": "profiles/r03h_config4_sq_counters.json (SQ_INSTS_VALU* per launch)",
                      "second_pass": "from the joint log-probabilities kept in the workspace" if cached else "recomputed",
                      "note": "log-throughput bound: one float64 log per (genotype, read) term; 80 KB in, < 1 KB out per unit"},
@@ -330,6 +352,41 @@ def bench_config4(args):
         out["cpu_baseline"] = {"value": 1.0 / dc, "unit": "units/s", "cores": 1, "kind": "port",
                                "sample": "%d units through oracle/mchap_oracle.c posterior_mode, one thread; mode and GPM equal the GPU's" % n_cpu}
     return out
+
+
+def sq_counters_of(pattern, kernel_prefix):
+    """Per-kernel SQ counter sums of the newest profiles/<pattern> summary (tools/pmc_sq.py output: {kernel: {counter: sum}})."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=_profile_order, reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            for name, c in t.items():
+                if name.startswith(kernel_prefix) and "SQ_INSTS_VALU" in c:
+                    return c, "profiles/" + os.path.basename(path), name
+        except Exception:
+            pass
+    return None, None, None
+
+
+def config5_roofline(U, substeps, kms):
+    """VALU issue at configs[4]: wavefront VALU instructions of the sampler's launches from the committed SQ counter passes of this
+    workload at 256 loci (static figures of an earlier profiling run, scaled per sub-step), priced per class in issue cycles."""
+    c, src, kname = sq_counters_of("*_config5_sq_counters.json", "denovo_spec_kernel<8")
+    if c is None:
+        return None
+    ref_substeps = 256.0 * 4 * 2000 * (8 * 20 + 3)
+    per = float(c["SQ_INSTS_VALU"]) / ref_substeps
+    w = valu_issue_cycles(c)
+    cyc = w["cycles"] / ref_substeps
+    return {"bound": "valu_issue", "achieved": cyc * substeps / (kms * 1e-3) / 1e9, "peak": SIMD_CYCLES_PER_S / 1e9,
+            "unit": "G SIMD issue cycles/s", "frac": cyc * substeps / (kms * 1e-3) / SIMD_CYCLES_PER_S,
+            "sub_steps_per_s": substeps / (kms * 1e-3), "valu_insts_per_sub_step": per, "issue_cycles_per_sub_step": cyc,
+            "per_class_complete": w["per_class_complete"], "counters": "%s (%s; static: an earlier rocprofv3 --pmc run)" % (src, kname),
+            "note": "issue cycles weighted per class (float64 / 64-bit integer 4, transcendental 8, other 2; when the summary lacks the "
+                    "float64 ADD / MUL counters they are priced at 2 and the fraction is a lower bound).  One pass alone holds one "
+                    "wavefront per SIMD and waits on memory (SQ_WAIT_ANY); batches in flight fill the rest (value)"}
 
 
 def bench_config5(args):
@@ -358,14 +415,7 @@ def bench_config5(args):
         "workload": "%d loci: octoploid, %d SNVs, %d reads, %d chains x %d steps, burn %d; HBM resident; one pass" % (U, M, R, C_, S, S // 2),
         "value": U / dt, "unit": "loci/s", "kernel": batch.sampler_name, "kernel_ms": kms, "pass_ms": dt * 1e3,
         "ok": bool((status <= 1).all()),
-        # VALU issue: profiles/r03ab_config5_sq_counters.json -- the sampler's launches issue 1.49e10 wavefront VALU
-        # instructions for this workload (256 loci: 3.34e8 sub-steps, 44.7 per sub-step; 111 before the deep units' product rows
-        # lived in the workspace: r03h); the chip issues at most 1024 SIMDs x 2.4 GHz / 4 cycles = 6.14e11 per second.
-        "roofline": {"bound": "valu_issue", "achieved": 44.7 * substeps / (kms * 1e-3) / 1e9, "peak": 614.4, "unit": "G wavefront-instructions/s",
-                     "frac": 44.7 * substeps / (kms * 1e-3) / 614.4e9, "sub_steps_per_s": substeps / (kms * 1e-3),
-                     "valu_insts_per_sub_step": 44.7, "counters": "profiles/r03ab_config5_sq_counters.json",
-                     "note": "one pass alone holds one wavefront per SIMD and waits on memory 45 % of its cycles (SQ_WAIT_ANY: the product "
-                             "rows and code rows of deep units come from L2 / HBM); batches in flight fill the rest (value)"},
+        "roofline": config5_roofline(U, substeps, kms),
     }
     nfl = 2 * args.inflight if args.inflight > 1 else 1
     if nfl > 1:
@@ -691,24 +741,51 @@ def bench_program_e2e(args):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it (the reference deals its loci to a pool of worker processes the same
+    way: application/baseclass.py:360-388): start N fresh rank processes -- this parent has not imported torch nor made any HIP
+    call, so nothing that has initialised the GPU is ever re-executed --, relay what they print (rank 0 prints the one JSON line)
+    and return their exit status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus is not None and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is None:
+        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     import torch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % n_dev)
     dist = None
+    backend = None
     # (MCHAP_BENCH_DIST=1: join a process group even as a single rank -- the RCCL calls of the N > 1 path on a 1-GPU box)
     if world > 1 or os.environ.get("MCHAP_BENCH_DIST") == "1":
         import torch.distributed as dist
 
-        # RCCL over xGMI; MCHAP_BENCH_BACKEND=gloo lets the N > 1 path be exercised by several ranks on ONE GPU
-        # (RCCL refuses two ranks on the same device), which is how it is tested on the 1-GPU boxes
-        dist.init_process_group(backend=os.environ.get("MCHAP_BENCH_BACKEND", "nccl"))
+        # RCCL over xGMI when every rank has a GPU of its own.  With fewer GPUs than ranks (the 1-GPU test boxes) the ranks share
+        # devices and RCCL refuses two ranks on one device: gloo then carries the records (MCHAP_BENCH_BACKEND overrides)
+        backend = os.environ.get("MCHAP_BENCH_BACKEND", "nccl" if n_dev >= world else "gloo")
+        dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from mchap_amd import DenovoMCMC
     from mchap_amd.device import DenovoDeviceBatch
@@ -850,9 +927,11 @@ def main():
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         # the bound that binds: VALU issue (wavefront VALU instructions of a sampler call, from the SQ counter passes, against
         # 1024 SIMDs x 2.4 GHz / 4 cycles per 64-lane instruction), reported beside the HBM fraction the contract asks for
-        pv = pmc_valu_insts(args)
-        valu_insts, valu_src = (pv if pv else (None, None))
-        valu_frac = (valu_insts / (kern_ms * 1e-3) / (1024 * 2.4e9 / 4.0)) if valu_insts else None
+        prof, prof_src = pmc_profile(args)
+        sq = (prof or {}).get("sq_counters_per_launch")
+        w = valu_issue_cycles(sq)
+        valu_insts = float(sq["SQ_INSTS_VALU"]) if w else None
+        valu_frac = (w["cycles"] / (kern_ms * 1e-3) / SIMD_CYCLES_PER_S) if w else None
         out = {
             "metric": "loci/sec (whole node) for 1000-step MCMC, tetraploid 8-SNV loci, 1/2/4/8 GPUs",
             "value": value,
@@ -874,13 +953,20 @@ def main():
                 "mcmc_steps": args.mcmc_steps, "chains": args.chains, "burn": args.burn,
                 "llk_cache": not args.no_cache, "passes_in_flight": nfl,
                 "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                "parallelism": "loci sharded contiguously over %d rank(s); posterior records all-gathered every pass" % world,
+                "parallelism": "loci sharded contiguously over %d rank(s) on %d device(s); posterior records all-gathered every pass%s"
+                               % (world, min(world, n_dev), "" if backend is None else " (%s)" % ("RCCL" if backend == "nccl" else backend)),
+                "world_size": world, "devices": min(world, n_dev), "backend": backend,
             },
             "roofline": {
                 "bound": "hbm", "kernel": kern_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": (prof or {}).get("hbm_bytes_per_launch"),
+                "traffic_source": None if prof is None else "%s: rocprofv3 --pmc passes of an EARLIER run of this command (static figure, "
+                                                             "not measured in this run)" % prof_src,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": kern_ms, "sampler_span_ms": span_ms,
-                "valu_issue_frac": valu_frac, "valu_insts_per_launch": valu_insts, "valu_counters": valu_src,
+                "valu_issue_frac": valu_frac, "valu_insts_per_launch": valu_insts, "valu_issue_cycles_per_launch": w["cycles"] if w else None,
+                "valu_classes": None if not w else {k: w[k] for k in ("f64", "int64", "trans", "other", "per_class_complete")},
+                "valu_counters": None if not w else "%s (static, as traffic); issue cycles = float64 x 4 + 64-bit integer x 4 + "
+                                                    "transcendental x 8 + other x 2 over 1024 SIMDs x 2.4 GHz" % prof_src,
                 "note": "a sampler call is several launches (phased sampler: speculative kernel phases + coasting kernel, "
                         "DESIGN.md 4.1c); kernel_ms is the span of HIP events around all of them, measured with ONE pass in "
                         "flight in %d passes right after the timed region (in the timed region passes overlap on separate "

@@ -58,7 +58,9 @@ def build_parser(program):
     p = argparse.ArgumentParser("mchap_amd " + program)
     if program == "assemble":
         _sample_args(p, 1)
-        p.add_argument("--reference", type=str, nargs=1, default=[None], help="reference FASTA (or one known by its .fai index)")
+        p.add_argument("--reference", type=str, nargs=1, default=[None], help="reference FASTA")
+        p.add_argument("--reference-index-only", action="store_true",
+                       help="(not a reference flag) accept a --reference of which only the .fai index exists: N for unknown bases")
         p.add_argument("--region", type=str, nargs=1, default=[None], help="a single target contig:start-stop (not with --targets)")
         p.add_argument("--region-id", type=str, nargs=1, default=[None])
         p.add_argument("--targets", type=str, nargs=1, default=[None], help="BED4 file of target loci")
@@ -142,7 +144,7 @@ def run(argv, out=None):
             raise ValueError("--variants and --reference are required")
         seed = args.mcmc_seed[0]
         inbreeding = io.sample_values(args.use_dirmul_prior[0], samples, float)
-        reference = io.Reference(args.reference[0])
+        reference = io.Reference(args.reference[0], allow_index_only=args.reference_index_only)
         contigs = reference.contigs
         targets = application.assemble_targets(args.targets[0], args.region[0], args.region_id[0])
         records = application.assemble(

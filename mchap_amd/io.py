@@ -334,7 +334,9 @@ def vcfstr(obj, precision=3):
 
 # ---- de novo assembly loci (mchap assemble): targets from a BED file, SNVs from a VCF (io/loci.py:94-135) ----
 class DenovoLocus:
-    def __init__(self, contig, start, stop, name, variant_records, sequence):
+    def __init__(self, contig, start, stop, name, variant_records, sequence, sequence_known=True):
+        """sequence_known=False: `sequence` came from a reference known by its index only (io.Reference without the FASTA: all
+        'N'); the variants' REF alleles are then written at their positions.  A real FASTA's own N bases are never touched."""
         self.contig, self.start, self.stop, self.name, self.sequence = contig, start, stop, name, sequence
         snps = {}
         for r in variant_records:
@@ -350,8 +352,7 @@ class DenovoLocus:
         self.positions = list(snps)
         self.alleles = [snps[p] for p in self.positions]
         self.n_alleles = [len(a) for a in self.alleles]
-        if self.sequence is not None and "N" in self.sequence:
-            # a reference known by its index only (io.Reference): the variants' REF alleles at their positions
+        if self.sequence is not None and not sequence_known:
             chars = list(self.sequence)
             for p, tup in zip(self.positions, self.alleles):
                 if chars[p - start] == "N":
@@ -538,7 +539,9 @@ class Reference:
     (plain or gzip / bgzip compressed); or, when only its `.fai` index is at hand, the contig lengths with every base
     unknown (`N`): the assembled haplotypes then carry the variants' own alleles at the SNV positions and N elsewhere."""
 
-    def __init__(self, path):
+    def __init__(self, path, allow_index_only=False):
+        """allow_index_only: accept a FASTA of which only the `.fai` index exists (contig lengths for the header, 'N' for every
+        base that is not an SNV).  Off by default: a mistyped path must not silently produce records with N sequences."""
         import os
 
         self.path = path
@@ -550,6 +553,9 @@ class Reference:
             fai = path + ".fai"
             if not os.path.isfile(fai):
                 raise IOError("reference '%s' not found (nor its index '%s')" % (path, fai))
+            if not allow_index_only:
+                raise IOError("reference '%s' not found; only its index '%s' exists (pass --reference-index-only to write N for the "
+                              "unknown reference bases)" % (path, fai))
             self.seqs = None
             self.contigs = [(f[0], int(f[1])) for f in (line.split("\t") for line in open(fai)) if len(f) >= 2]
             self.lengths = dict(self.contigs)
@@ -594,11 +600,12 @@ def sample_values(arg, samples, cast, default=None):
 # one (zlib releases the interpreter lock: a thread pool inflates in parallel), the `.bai` index for region fetches, records
 # kept as columns (numpy), and extract_read_variants vectorised over a locus's records instead of one Python loop per read.
 # ---------------------------------------------------------------------------------------------------------------
-def bgzf_blocks(data):
-    """[(offset, compressed size)] of the BGZF blocks of a byte string (SAM/BAM specification 4.1: a gzip member whose extra
-    field carries its own size: BSIZE)."""
-    out, o, n = [], 0, len(data)
-    while o + 18 <= n:
+def bgzf_blocks(data, first=0, count=None, last=None):
+    """[(offset, compressed size, header size)] of the BGZF blocks of a byte string or mapped file (SAM/BAM specification 4.1: a
+    gzip member whose extra field carries its own size: BSIZE), from the block at file offset `first`; at most `count` blocks, and
+    none that starts beyond file offset `last`."""
+    out, o, n = [], first, len(data)
+    while o + 18 <= n and (count is None or len(out) < count) and (last is None or o <= last):
         if data[o:o + 4] != b"\x1f\x8b\x08\x04":
             raise IOError("not a BGZF block at offset %d" % o)
         (xlen,) = struct.unpack_from("<H", data, o + 10)
@@ -664,6 +671,32 @@ def read_bai(path):
     return refs
 
 
+_AUX_SIZE = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
+
+
+def _aux_rg(buf, o, end):
+    """The value of a record's RG:Z tag found by walking its aux fields (SAM specification 4.2.4), or None."""
+    while o + 3 <= end:
+        tag, typ = bytes(buf[o:o + 2]), chr(buf[o + 2])
+        o += 3
+        if typ in ("Z", "H"):
+            z = o
+            while z < end and buf[z] != 0:
+                z += 1
+            if tag == b"RG" and typ == "Z":
+                return bytes(buf[o:z]).decode()
+            o = z + 1
+        elif typ == "B":
+            sub = chr(buf[o])
+            (cnt,) = struct.unpack_from("<i", buf, o + 1)
+            o += 5 + cnt * _AUX_SIZE.get(sub, 1)
+        elif typ in _AUX_SIZE:
+            o += _AUX_SIZE[typ]
+        else:
+            return None
+    return None
+
+
 class AlignmentColumns:
     """The records of (a region of) a BAM file as columns: ref_id, pos, end, mapq, flag, read-group index, query-name id,
     and the flattened CIGAR operations / packed sequences / qualities they index into."""
@@ -710,6 +743,7 @@ class AlignmentColumns:
             keep[keep] &= (at[keep] >= tag_off[ri[keep]]) & (at[keep] + 3 < rec_end[ri[keep]])
             at, ri = at[keep], ri[keep]
             firsts = np.r_[True, ri[1:] != ri[:-1]] if len(ri) else np.zeros(0, bool)
+            n_cand = np.bincount(ri, minlength=n)
             at, ri = at[firsts], ri[firsts]
             for gi, key in enumerate(rg_names):
                 kb = np.frombuffer(key.encode() + b"\0", dtype=np.uint8)
@@ -717,6 +751,13 @@ class AlignmentColumns:
                 m = room.copy()
                 m[room] = (b[(at[room] + 3)[:, None] + np.arange(len(kb))] == kb).all(axis=1)
                 rgi[ri[m]] = gi
+            # "RGZ" can also occur inside another tag's payload (a Z / H string, a B array, integer bytes): records with more than
+            # one candidate, or whose first candidate named no header read group, are settled by walking their aux fields
+            # (what pysam's read.get_tag("RG") does)
+            index_of = {k: i for i, k in enumerate(rg_names)}
+            for r in np.flatnonzero((n_cand > 1) | ((n_cand == 1) & (rgi < 0))):
+                v = _aux_rg(buf, int(tag_off[r]), int(rec_end[r]))
+                rgi[r] = index_of.get(v, -1)
         self.rg = rgi
         # CIGAR operations, flattened: record, op, length, reference / read offset at the start of the op
         total = int(n_cig.sum())
@@ -760,21 +801,35 @@ class BamFile:
     def __init__(self, path, id_field="SM", workers=1):
         import os
 
+        import mmap
+
         self.path, self.id_field, self.workers = path, id_field, workers
-        self.data = open(path, "rb").read()
-        self.blocks = bgzf_blocks(self.data)
-        self.block_at = {o: i for i, (o, _, _) in enumerate(self.blocks)}
-        head = b"".join(bgzf_inflate(self.data, self.blocks[:1]))
-        i = 1
+        # the file is mapped, not read: a region fetch touches only the pages of the blocks it inflates, so N samples of
+        # multi-GB files cost N x (a few blocks) of resident memory, as pysam's fetch does
+        with open(path, "rb") as f:
+            self.data = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if os.fstat(f.fileno()).st_size else b""
+        self._blocks = None
+        first = bgzf_blocks(self.data, 0, 1)
+        head = b"".join(bgzf_inflate(self.data, first))
+        nxt = first[0][0] + first[0][1]
         while True:  # the header may span blocks
             try:
                 self._parse_header(head)
                 break
             except (struct.error, IndexError):
-                head += bgzf_inflate(self.data, self.blocks[i:i + 1])[0]
-                i += 1
+                blk = bgzf_blocks(self.data, nxt, 1)
+                head += bgzf_inflate(self.data, blk)[0]
+                nxt = blk[0][0] + blk[0][1]
         self.index = read_bai(path + ".bai") if os.path.isfile(path + ".bai") else None
         self._all = None
+        self._last = (None, None)  # the columns of the last region fetched: all samples of a locus share one inflate + parse
+
+    @property
+    def blocks(self):
+        """Every block of the file (walks all block headers: only the whole-file path needs it)."""
+        if self._blocks is None:
+            self._blocks = bgzf_blocks(self.data)
+        return self._blocks
 
     def _parse_header(self, d):
         assert d[:4] == b"BAM\1"
@@ -821,9 +876,12 @@ class BamFile:
             return AlignmentColumns(self.refs, self.rg, b"", [], self.id_field)
         lo = min(int(c[0]) for c in chunks)
         hi = max(int(c[1]) for c in chunks)
-        b0, b1 = self.block_at[lo >> 16], self.block_at[hi >> 16]
-        payload = b"".join(bgzf_inflate(self.data, self.blocks[b0:b1 + 1], self.workers))
-        return self._columns_of(payload, lo & 0xFFFF)
+        key = (lo, hi)
+        if self._last[0] != key:
+            # (virtual offsets are block file offsets << 16: the region's blocks are walked from the first one, nothing else is touched)
+            payload = b"".join(bgzf_inflate(self.data, bgzf_blocks(self.data, lo >> 16, last=hi >> 16), self.workers))
+            self._last = (key, self._columns_of(payload, lo & 0xFFFF))
+        return self._last[1]
 
 
 _NIB = np.frombuffer(SEQ_CODE.encode(), dtype=np.uint8)

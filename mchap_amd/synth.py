@@ -93,7 +93,7 @@ def _reg2bin(beg, end):
 def write_bam(path, contigs, read_groups, records, index=True):
     """Write a coordinate-sorted BAM file (BGZF) and, with index=True, its `.bai`.
     contigs: [(name, length)]; read_groups: {id: sample}; records: iterable of dicts with qname, flag, ref (contig index),
-    pos (0-based), mapq, cigar [(length, op char)], seq (str), qual (sequence of ints), rg (id).  Every record lies in one
+    pos (0-based), mapq, cigar [(length, op char)], seq (str), qual (sequence of ints), rg (id), optionally tags_before (raw aux bytes).  Every record lies in one
     BGZF block (a new block starts when the next record would not fit), so its virtual offsets are (block << 16 | offset)."""
     import struct
     import zlib
@@ -131,7 +131,7 @@ def write_bam(path, contigs, read_groups, records, index=True):
         packed = bytearray((len(seq) + 1) // 2)
         for i, c in enumerate(seq):
             packed[i >> 1] |= seq_code[c] << (4 if i % 2 == 0 else 0)
-        tags = b"RGZ" + r["rg"].encode() + b"\0"
+        tags = r.get("tags_before", b"") + b"RGZ" + r["rg"].encode() + b"\0"  # (tags_before: raw aux bytes ahead of RG, for tests)
         end = r["pos"] + max(ref_len, 1)
         b = _reg2bin(r["pos"], end)
         body = struct.pack("<iiBBHHHiiii", r["ref"], r["pos"], len(name), r["mapq"], b, len(r["cigar"]), r["flag"], len(seq), -1, -1, 0) + \

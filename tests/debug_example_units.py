@@ -11,7 +11,7 @@ samples, targets, variants, matrices, contigs = application.load_matrices("tests
 source = application.MatrixSource(samples, matrices)
 by = {}
 for contig, start, stop, name in targets:
-    locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start))
+    locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start), sequence_known=False)
     for s in samples:
         sr = source.reads(locus, s)
         if len(sr["dists"]):

@@ -29,13 +29,13 @@ samples = list(table)
 bams = {s: io.read_alignments(p) for s, p in table.items()}
 targets = io.read_bed4(os.path.join(EX, "input/bed/targets20.bed"))
 _, variants = io.read_vcf(os.path.join(EX, "input/vcf/snvs.vcf.gz"))
-ref = io.Reference(os.path.join(EX, "input/fasta/chr1.fa.gz"))
+ref = io.Reference(os.path.join(EX, "input/fasta/chr1.fa.gz"), allow_index_only=True)
 out = dict(samples=np.array(samples), contigs=np.array([c for c, _ in ref.contigs]), contig_lengths=np.array([n for _, n in ref.contigs]),
            target_contig=np.array([t[0] for t in targets]), target_start=np.array([t[1] for t in targets]),
            target_stop=np.array([t[2] for t in targets]), target_name=np.array([t[3] for t in targets]))
 n_reads = 0
 for li, (contig, start, stop, name) in enumerate(targets):
-    locus = io.DenovoLocus(contig, start, stop, name, variants, ref.fetch(contig, start, stop))
+    locus = io.DenovoLocus(contig, start, stop, name, variants, ref.fetch(contig, start, stop), sequence_known=ref.known)
     out["pos_%d" % li] = np.array(locus.positions, dtype=np.int64)
     out["alleles_%d" % li] = np.array(["".join(a) for a in locus.alleles])  # e.g. "AC": REF then ALTs, one character each
     for si, s in enumerate(samples):

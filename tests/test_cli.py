@@ -142,10 +142,13 @@ def test_pools_temperatures_region_and_reference_index(tmp_path):
     # a reference known by its index only: lengths for the header, N for the unknown bases, REF alleles of the variants kept
     fa = tmp_path / "ref.fa"
     (tmp_path / "ref.fa.fai").write_text("chrZ\t1000\t6\t60\t61\n")
-    ref = io.Reference(str(fa))
+    with pytest.raises(IOError):
+        io.Reference(str(fa))  # index-only references are opt-in
+    ref = io.Reference(str(fa), allow_index_only=True)
     assert ref.contigs == [("chrZ", 1000)] and ref.fetch("chrZ", 10, 16) == "NNNNNN"
     recs = [dict(chrom="chrZ", pos=12, id=".", ref="A", alts=("C",), info={}), dict(chrom="chrZ", pos=15, id=".", ref="G", alts=("T", "A"), info={})]
-    locus = io.DenovoLocus("chrZ", 10, 16, "t", recs, ref.fetch("chrZ", 10, 16))
+    locus = io.DenovoLocus("chrZ", 10, 16, "t", recs, ref.fetch("chrZ", 10, 16), sequence_known=ref.known)
+    assert io.DenovoLocus("chrZ", 10, 16, "t", recs, "NNNNNN").sequence == "NNNNNN"  # a real FASTA's N bases stay
     assert locus.sequence == "NANNGN" and locus.format_haplotype([1, 2]) == "NCNNAN" and locus.n_alleles == [2, 3]
     with pytest.raises(IOError):
         io.Reference(str(tmp_path / "other.fa"))

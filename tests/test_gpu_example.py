@@ -97,7 +97,7 @@ def test_every_unit_trace_equals_the_oracle(example):
     source = application.MatrixSource(samples, matrices)
     by_m = {}
     for contig, start, stop, name in targets:
-        locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start))
+        locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start), sequence_known=False)
         for s in samples:
             sr = source.reads(locus, s)
             if len(sr["dists"]):

@@ -72,3 +72,24 @@ def test_bench_strong_scaling_uneven_shards():
     assert d["scaling"] == "strong" and d["n_gpus"] == 2
     assert abs(d["value"] - 777 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["gather_checked_units"] == 8
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two fresh rank processes before anything touches
+    the GPU and relays rank 0's line (round 3's flag was parsed and ignored: one rank, n_gpus 1).  On a box with fewer GPUs than
+    ranks the ranks share the device and gloo carries the gather; with a GPU each it is RCCL -- the line says which."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MCHAP_BENCH_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--loci", "512", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] in ("nccl", "gloo")
+    assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["gather_checked_units"] == 8
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silent single-rank run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0", "--loci", "64",
+                          "--no-cpu-baseline", "--no-extras"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert bad.returncode != 0 and "--gpus 4" in bad.stderr

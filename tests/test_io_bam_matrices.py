@@ -114,3 +114,29 @@ def test_bgzf_blocks_bai_index_and_region_fetch(tmp_path):
     assert a[0].tolist() == [["C", "N"]] and a[1].tolist() == [[50, 30]]
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_read_group_behind_a_decoy_tag(tmp_path):
+    """A record whose aux bytes hold the literal 'RGZ' inside ANOTHER tag's payload ahead of the real RG:Z tag (a Z string, a B
+    array, integer bytes) still belongs to its read group: the reference asks pysam for read.get_tag('RG') (io/bam.py:100-118)."""
+    import struct
+
+    from mchap_amd.synth import write_bam
+
+    decoys = [b"XSZ" + b"aRGZs1\0",                                    # a Z string containing "RGZ" + a real group's id
+              b"XBBC" + struct.pack("<i", 5) + b"RGZs1",                # a byte array
+              b"XIi" + b"RGZ\0",                                        # integer bytes
+              b"COZ" + b"xRGZnobody\0"]                                 # names no group at all
+    recs = []
+    for i, d in enumerate(decoys + [b""]):
+        recs.append(dict(qname="q%d" % i, flag=0, ref=0, pos=100 + i, mapq=60, cigar=[(20, "M")], seq="ACGTACGTACGTACGTACGT",
+                         qual=[30] * 20, rg="s2", tags_before=d))
+    recs.append(dict(qname="q9", flag=0, ref=0, pos=106, mapq=60, cigar=[(20, "M")], seq="ACGTACGTACGTACGTACGT", qual=[30] * 20, rg="s1"))
+    path = str(tmp_path / "decoy.bam")
+    write_bam(path, [("chrD", 1000)], {"s1": "S1", "s2": "S2"}, recs)
+    cols = io.BamFile(path).columns()
+    assert [cols.rg_samples[i] for i in cols.rg] == ["S2"] * 5 + ["S1"]
+    assert [r["rg"] for r in io.read_bam(path)[2]] == ["s2"] * 5 + ["s1"]
+    # region fetches of one file share the last region's columns (one inflate + parse per locus, not per sample)
+    bf = io.BamFile(path)
+    assert bf.columns("chrD", 100, 130) is bf.columns("chrD", 100, 130)
