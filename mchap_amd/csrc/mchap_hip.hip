@@ -14,6 +14,7 @@
 #include "denovo_kernel.hpp"
 #include "denovo_simt_kernel.hpp"
 #include "denovo_spec_kernel.hpp"
+#include "denovo_fillw_kernel.hpp"
 #ifdef MCHAP_TEST_KERNELS
 #include "denovo_fill_kernel.hpp"
 #include "denovo_lane_kernel.hpp"
@@ -60,6 +61,12 @@ SPECP_LIST(DECL_SPECP)
 SPECS_LIST(DECL_SPECS)
 SIMT_LIST(DECL_SIMT)
 extern "C" int mchap_coast_launch(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+// table completion of the phased sampler, one workgroup per chain and one wavefront per request (denovo_fillw_kernel.hpp): shipped
+#define FILLW_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#define DECL_FILLW(k)                                                    \
+  extern "C" int mchap_fillw_init_##k(const double *, const double *); \
+  extern "C" int mchap_fillw_launch_##k(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+FILLW_LIST(DECL_FILLW)
 #ifdef MCHAP_TEST_KERNELS
 #define FILL_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #define DECL_FILL(k)                                                \
@@ -177,7 +184,8 @@ int ensure_init() {
 #define ROW_V1_INIT(r) mchap_v1_init_##r,
 #define ROW_LANE_INIT(k) mchap_lane_init_##k,
 #define ROW_FILL_INIT(k) mchap_fill_init_##k,
-    const init_fn inits[] = {SIMT_LIST(ROW_SIMT_INIT)
+#define ROW_FILLW_INIT(k) mchap_fillw_init_##k,
+    const init_fn inits[] = {SIMT_LIST(ROW_SIMT_INIT) FILLW_LIST(ROW_FILLW_INIT)
 #ifdef MCHAP_TEST_KERNELS
                                  FILL_LIST(ROW_FILL_INIT) V1_LIST(ROW_V1_INIT) LANE_LIST(ROW_LANE_INIT)
 #endif
@@ -610,6 +618,15 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   // request -- behind tuning flag 64: bit-identical (tests/test_gpu_fill.py), measured slower, not shipped.
   bool lpr = false;
   size_t lds_fill = 0;
+  // The shipped completion (round 4): denovo_fillw_kernel -- its own launch after every exporting launch, a workgroup of four
+  // wavefronts per chain, one wavefront per distinct request, 128 VGPRs -- for genotypes that pack into 64 bits (tuning flag 1024:
+  // the in-kernel completion instead; the tables are the same bit for bit: tests/test_gpu_fillw.py)
+  const bool fillw = G == 64 && !(T.flags & (64 | 1024 | 32)) && mchap::fillw_takes(K, P.max_pos, P.max_allele);
+  const int fillw_rows = mchap::fillw_tab_rows(P.max_pos, P.max_allele, P.d.rpad);
+  const size_t lds_fillw = mchap::fillw_lds_bytes(K, P.max_pos, fillw_rows, P.d.rpad);
+  if (fillw) P.fill_lt = fillw_rows;
+#define ROW_FILLW_LAUNCH(k) mchap_fillw_launch_##k,
+  const simt_launch_fn fillw_launches[] = {FILLW_LIST(ROW_FILLW_LAUNCH)};
 #ifdef MCHAP_TEST_KERNELS
   if (T.flags & 64) {
     P.fill_lt = mchap::fill_geometry(K, P.max_pos, P.max_allele, P.d.rpad, &lds_fill);
@@ -619,7 +636,7 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
 #define ROW_FILL_LAUNCH(k) mchap_fill_launch_##k,
   const simt_launch_fn fill_launches[] = {FILL_LIST(ROW_FILL_LAUNCH)};
 #endif
-  const int export_mode = mchap::PIPE_EXPORT | (lpr ? mchap::PIPE_NOFILL : 0);
+  const int export_mode = mchap::PIPE_EXPORT | ((lpr || fillw) ? mchap::PIPE_NOFILL : 0);
   P.pipe_list = nullptr;
   P.pipe_count = nullptr;
   P.pipe_iters = s0;
@@ -629,6 +646,7 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
 #ifdef MCHAP_TEST_KERNELS
     if (lpr) return fill_launches[K - 2](&P, (unsigned)n_chains, lds_fill, stream);
 #endif
+    if (fillw) return fillw_launches[K - 2](&P, (unsigned)n_chains, lds_fillw, stream);
     if (P.pipe_parts <= 1) return 0;  // (a no-op unless the chains of the list are few: pipe_parts_eff)
     mchap::SimtParams F = P;
     F.pipe_mode = mchap::PIPE_RESUME | mchap::PIPE_FILLONLY;
@@ -962,7 +980,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.max_ploidy = B.max_ploidy;
     SP.max_ma = B.max_ma;
     SP.cstride = code_stride(rpl);
-    SP.flags = T.flags & (63 | 128);  // (256, 512: host only -- never the side-by-side instantiation / no deep-chunk product rows)
+    SP.flags = T.flags & (63 | 128 | 2048 | 4096);  // (2048 / 4096: denovo_fillw_kernel without the cache probe / the LDS table)  // (256, 512: host only -- never the side-by-side instantiation / no deep-chunk product rows)
     // the prepare pass keeps the transposed table in LDS when it fits, else it re-reads its own global copy
     SP.max_ugens_pad = (B.max_ugens + 8) & ~7;
     const size_t lds_dict = (size_t)mchap::DICT_HASH * (8 + 2) + 64;  // hash set of the dictionary pass

@@ -1,0 +1,138 @@
+"""GPU parity of denovo_fillw_kernel (round 4: the phased sampler's table completion as its own launch -- one workgroup per
+chain, one wavefront per distinct request, 128 VGPRs) against the completion inside the exporting launch it replaced (the code of
+a visit: structural.py:433-673 through denovo_spec_kernel's spec_structural; tuning flag 1024 selects it).
+
+The tables hold the total move probability of every interval step of a settled chain's genotype; the coasting kernel compares
+uniforms with them, so a difference of one unit in the last place would hardly ever show in a trace.  The TABLES are therefore
+compared entry for entry, bit for bit (NaN = not evaluated and -1 = no options included) -- and then whole traces of full runs,
+hand-back rounds included, with the oracle as the third party on one case."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(reads, flags, **kw):
+    """First phase of the phased sampler (steps, table completion, first coasting launch) -> the chains' interval tables."""
+    import torch
+
+    from mchap_amd import DenovoMCMC, _lib
+    from mchap_amd.device import DenovoDeviceBatch
+
+    os.environ["MCHAP_HIP_TEST_KERNELS"] = "1"  # mchap_debug_pipe_memo lives in the parity suite's library
+    os.environ["MCHAP_HIP_PIPE_STOP"] = "1"
+    os.environ["MCHAP_HIP_FLAGS"] = str(flags)
+    try:
+        model = DenovoMCMC(random_seed=42, kernel=5, **kw)
+        b = DenovoDeviceBatch(model, reads)
+        assert "phased" in b.sampler_name
+        b.run()
+        torch.cuda.synchronize()
+        U, M = reads.shape[0], reads.shape[2]
+        E = M * (M + 1) // 2
+        memo = np.zeros((U * model.chains, 2, E), dtype=np.float64)
+        f = _lib.lib().mchap_debug_pipe_memo
+        f.restype = C.c_int
+        rc = f(C.byref(b.cfg), U, _lib.ptr(b.units_host), C.c_void_p(b.d_ws.data_ptr()), _lib.ptr(memo))
+        assert rc == 0, _lib.last_error()
+        return memo
+    finally:
+        for k in ("MCHAP_HIP_TEST_KERNELS", "MCHAP_HIP_PIPE_STOP", "MCHAP_HIP_FLAGS"):
+            os.environ.pop(k, None)
+
+
+CASES = {
+    # name: (units, ploidy, n_pos, n_reads, n_alleles, inbreeding, synth kwargs)
+    "config2": (48, 4, 8, 200, 2, None, {}),
+    "config2-inbred": (16, 4, 8, 200, 2, 0.1, {}),
+    "diploid-20-snvs": (16, 2, 20, 90, 2, None, dict(window=(4, 12))),      # several chunks of entries (420 per table pair)
+    "triploid-odd-reads": (16, 3, 7, 131, 2, None, dict(window=(3, 7))),
+    "hexaploid": (12, 6, 8, 200, 2, None, {}),                               # 30 + 30 options per interval: several chunks of slots
+    "octoploid": (6, 8, 8, 300, 2, None, {}),                                # five read chunks: the block beyond the base products
+    "triallelic": (12, 4, 7, 150, 3, None, dict(window=(4, 7))),             # two bits per allele: 56-bit genotypes
+    "tetraploid-16-snvs": (8, 4, 16, 200, 2, None, dict(window=(6, 16))),    # the widest packed key: 64 bits
+    "shallow": (24, 4, 8, 20, 2, None, dict(qual=(25, 40))),
+    "deep-2600-reads": (3, 4, 6, 2600, 2, None, dict(window=(2, 6), qual=(10, 40))),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_tables_equal_the_in_kernel_completion(case):
+    from mchap_amd.synth import synth_units
+
+    U, K, M, R, A, F, skw = CASES[case]
+    reads, _, _ = synth_units(U, ploidy=K, n_pos=M, n_reads=R, n_alleles=A, first_unit=11, **skw)
+    kw = dict(ploidy=K, n_alleles=[A] * M, steps=60, chains=2, inbreeding=F)
+    new = _tables(reads, 0, **kw)       # the shipped path: denovo_fillw_kernel after the exporting launch
+    old = _tables(reads, 1024, **kw)    # tuning flag 1024: the completion inside the exporting launch
+    assert new.shape == old.shape
+    done = ~np.isnan(old)
+    # (entries beyond the unit's non-fixed positions stay NaN; most chains of these batches settle and get complete tables)
+    assert done.any(axis=(1, 2)).mean() > 0.5
+    assert np.array_equal(np.isnan(new), np.isnan(old))
+    assert np.array_equal(new[done].view(np.uint64), old[done].view(np.uint64)), \
+        "max |diff| %.3e" % np.nanmax(np.abs(new - old))
+    assert (old[done] >= 0).any() and (old[done] == -1.0).any()  # both kinds of entries occur
+    # ... and without the probe of the chain's likelihood cache (2048) / without the unit's table in LDS (4096): the same tables
+    for flags in (2048, 4096, 2048 | 4096):
+        alt = _tables(reads, flags, **kw)
+        assert np.array_equal(np.isnan(alt), np.isnan(old)) and np.array_equal(alt[done].view(np.uint64), old[done].view(np.uint64)), flags
+
+
+def _run(reads, flags, **kw):
+    import torch
+
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.device import DenovoDeviceBatch
+
+    os.environ["MCHAP_HIP_FLAGS"] = str(flags)
+    try:
+        b = DenovoDeviceBatch(DenovoMCMC(random_seed=7, kernel=5, **kw), reads)
+        b.run()
+        torch.cuda.synchronize()
+        return b.traces()
+    finally:
+        os.environ.pop("MCHAP_HIP_FLAGS", None)
+
+
+@pytest.mark.parametrize("case", ["config2", "shallow", "triallelic", "hexaploid"])
+def test_whole_traces_do_not_depend_on_the_completion_kernel(case):
+    """Full runs (hand-back rounds included: their lists go through the same kernel): words, fixed alleles, llks and status."""
+    from mchap_amd.synth import synth_units
+
+    U, K, M, R, A, F, skw = CASES[case]
+    reads, _, _ = synth_units(U, ploidy=K, n_pos=M, n_reads=R, n_alleles=A, first_unit=3, **skw)
+    kw = dict(ploidy=K, n_alleles=[A] * M, steps=400, chains=2, inbreeding=F)
+    a, b = _run(reads, 0, **kw), _run(reads, 1024, **kw)
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))
+
+
+def test_against_the_oracle_step_for_step():
+    from oracle import binding as orc
+
+    from mchap_amd.assemble import break_table
+    from mchap_amd.classes import sort_haplotypes
+    from mchap_amd.device import DenovoDeviceBatch
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+    import torch
+
+    reads, _, _ = synth_units(6, ploidy=4, n_pos=8, n_reads=200, first_unit=500)
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=300, chains=2, random_seed=11, kernel=5)
+    b = DenovoDeviceBatch(model, reads)
+    assert "phased" in b.sampler_name
+    b.run()
+    torch.cuda.synchronize()
+    words, fixed, llks, status = b.traces()
+    assert (status == 0).all()
+    for u in range(len(reads)):
+        cfg = orc.make_cfg(4, 300, 2, None, (1.0,), llk_cache_threshold=-1, rng_kind=orc.RNG_PHILOX, seed=11, stream_id=u,
+                           break_table=break_table(8, 1.0, 3.0))
+        g, l, code = orc.denovo_fit(cfg, reads[u], [2] * 8)
+        assert code == 0
+        assert np.array_equal(b.genotypes(u, words, fixed), sort_haplotypes(g))
+        np.testing.assert_allclose(llks[u], l, rtol=1e-10)
