@@ -535,6 +535,8 @@ def bench_config1(args):
     samples, targets, variants, matrices, contigs = application.load_matrices(path)
 
     class NSeq:
+        known = False  # (application.assemble: the variants' REF alleles are written at their positions)
+
         def __getitem__(self, sl):
             return "N" * (sl.stop - sl.start)
 
@@ -579,7 +581,7 @@ def bench_config1(args):
         source = application.MatrixSource(samples, matrices)
         n_cpu, t = 0, time.perf_counter()
         for contig, start, stop, name in targets[:4]:
-            locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start))
+            locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start), sequence_known=False)
             M = len(locus.positions)
             for s_ in samples:
                 sr = source.reads(locus, s_)

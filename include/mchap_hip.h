@@ -175,6 +175,9 @@ int mchap_log_likelihood_batch(const double *reads, int n_reads, int n_pos, int 
 /* Test hook: the logarithm the likelihood kernels take of their per-read terms (csrc/read_log.hpp: < 1 ulp; 0 -> -inf,
  * negative or NaN -> NaN), for n arguments.  Host pointers. */
 int mchap_read_log_batch(const double *x, int64_t n, double *out);
+/* Test hook: the 64-lane sum every likelihood goes through (csrc/denovo_kernel.hpp wave_sum: the XOR butterfly's tree, its last
+ * four steps through DPP row rotations): out[w] = sum of x[64 w .. 64 w + 63].  Host pointers. */
+int mchap_wave_sum_batch(const double *x, int64_t n_waves, double *out);
 
 /* Posterior summary of a batch of traces: replaces GenotypeMultiTrace.burn(n).posterior() and the
  * mode/support statistics the assemble program reads from it (assemble/classes.py:280-325,87-128,194-205;

@@ -253,6 +253,7 @@ EXPORTS = [
     "mchap_timer_destroy",
     "mchap_denovo_sampler_name",
     "mchap_read_log_batch",
+    "mchap_wave_sum_batch",
 ]
 
 

@@ -732,7 +732,13 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
         targets = read_bed4(bed_path)
     targets = _shard(list(targets), shard)
     fetch = reference_sequences.fetch if isinstance(reference_sequences, Reference) else (lambda c, a, b: reference_sequences[c][a:b])
-    seq_known = reference_sequences.known if isinstance(reference_sequences, Reference) else True
+
+    def seq_known(contig):
+        """False for a reference known by its index only (io.Reference without the FASTA), or a {contig: sequence} mapping whose
+        sequence object says so itself (attribute `known`: the tests' stand-in for such a reference)."""
+        if isinstance(reference_sequences, Reference):
+            return reference_sequences.known
+        return bool(getattr(reference_sequences[contig], "known", True))
     by_contig = _variants_by_contig(variants)
     if units_per_block is None:
         # device bytes of one unit: its traces (chains x steps x (ploidy words + llk)), the per-chain likelihood cache and
@@ -746,7 +752,7 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
     def start_block(block, stream):
         """Stage 1 of a block: loci, read encoding (host), the sampler launches enqueued on `stream` (not waited for)."""
         loci = [DenovoLocus(contig, start, stop, name, _variants_within(by_contig, contig, start, stop), fetch(contig, start, stop),
-                            sequence_known=seq_known)
+                            sequence_known=seq_known(contig))
                 for contig, start, stop, name in block]
         encoded = {}
         units, where = [], []

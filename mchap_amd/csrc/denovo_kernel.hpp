@@ -110,10 +110,38 @@ __host__ __device__ inline WaveLayout wave_layout(int K, int M, int A, int T) {
 __host__ __device__ inline int allele_bits(int A) { return A <= 2 ? 1 : (A <= 4 ? 2 : 3); }
 
 // ---- small device helpers ------------------------------------------------------------------
+// Sum over the 64 lanes, in every lane, associated as the XOR butterfly 32, 16, 8, 4, 2, 1 associates it (every likelihood of
+// every kernel goes through this tree: the bits of a value must not depend on which kernel formed it).  The two steps across rows of
+// 16 lanes are ds_bpermute round trips; inside a row the partners come through DPP row rotations (round 4: ~10 instead of ~100
+// cycles of latency per step).  row_ror:8 reads lane (i + 8) mod 16 = i ^ 8 of the row; after that step the row's values have period
+// 8, so row_ror:4 reads a lane holding exactly the value of lane i ^ 4 -- and so on: the same operands in every addition (a + b
+// is b + a bit for bit), hence the same bits as the plain butterfly (tests/test_gpu_read_log.py::test_wave_sum_tree).
+template <int CTRL>
+__device__ __forceinline__ double wave_dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
 __device__ __forceinline__ double wave_sum(double v) {
+#ifdef MCHAP_PLAIN_BUTTERFLY
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
+#else
+  v += __shfl_xor(v, 32, WAVE);
+  v += __shfl_xor(v, 16, WAVE);
+  v += wave_dpp_f64<0x128>(v);  // row_ror:8
+  v += wave_dpp_f64<0x124>(v);  // row_ror:4
+  v += wave_dpp_f64<0x122>(v);  // row_ror:2
+  v += wave_dpp_f64<0x121>(v);  // row_ror:1
+#endif
   return v;
+}
+// test hook (mchap_wave_sum_batch): one wavefront per 64 values; every lane must hold the same sum
+static __global__ void wave_sum_kernel(const double *x, double *out) {
+  const double s = wave_sum(x[(size_t)blockIdx.x * WAVE + threadIdx.x]);
+  const bool same = __ballot(__double_as_longlong(s) == __double_as_longlong(__shfl(s, 0, WAVE))) == ~0ull;
+  if (threadIdx.x == 0) out[blockIdx.x] = same ? s : __longlong_as_double(0x7ff8dead00000000ll);
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll

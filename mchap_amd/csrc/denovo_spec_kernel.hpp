@@ -148,6 +148,8 @@ struct SpecLds {
   LDSP(const uint8_t) sct;  // [rows][64] code of read `lane` in every row of the table, for a shallow unit (<= 32 reads, <= 24
                             // rows) of a one-chain-per-wave launch: kept in the product cache's unused chunk slots; else null
   LDSP(uint64_t) tbuf;    // [NG][SPEC_TB][K + 1] trace records (K sorted words + llk) waiting to be written as a line
+  LDSP(uint64_t) lc;      // [lc_mask + 1][2] {tag, value bits}: the chain's likelihood cache IN LDS (one chain per wave), or lc_mask == 0
+  uint32_t lc_mask;       // entries - 1 of that front cache (0: none -- the cache in the workspace is probed instead)
   uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
   int key_words;          // words per entry of the wide-genotype key table (DenovoParams::cache_key_words)
   bool cache_on;
@@ -173,6 +175,8 @@ __host__ __device__ inline size_t spec_memo_bytes(int Mmax, int T, int G) {
   return per_group * (64 / G);
 }
 
+constexpr int SPEC_LC_ENTRIES = 256;  // entries of the LDS front cache of a chain's likelihoods (16 bytes each)
+__host__ __device__ inline size_t spec_lc_bytes() { return (size_t)16 * SPEC_LC_ENTRIES + 16; }
 // LDS of the base-product cache (SpecLds::bpc / bpt) of a one-chain-per-wave launch
 __host__ __device__ inline size_t spec_bp_cache_bytes(int K) { return (size_t)8 * K * 4 * 64 + (size_t)8 * (K + 1); }
 
@@ -1275,6 +1279,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
   // beside the entry (SimtParams::d.cache_keys) -- a hit is always the genotype itself, never a colliding one.
   const bool wide = C_KEYBITS(c) * KT > 63;
   uint64_t *kslot = nullptr;
+  LDSP(uint64_t) lslot = S.lc;  // (only used where lc_mask != 0)
   if (need && S.cache_on) {
     // 8-way sets (one 128-byte line).  The lanes of a group probe and fill the chain's table concurrently, so the
     // policy must not depend on read-modify-write sequences: hits never move entries, a miss goes to the first
@@ -1292,6 +1297,20 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
     const size_t set_i = (size_t)((hsh >> 12) & S.cache_mask);
     ulonglong2 *set = reinterpret_cast<ulonglong2 *>((uintptr_t)S.gptr[(lane / G) * GP_N + GP_CACHE]) + 8 * set_i;
     int way = (int)((hsh >> 24) & 7u);
+    if (S.lc_mask != 0u && !wide) {
+      // Front cache in LDS (round 4; one chain per wave, exact tags): a probe of the table in the workspace is a memory round
+      // trip of ~1.2 us in EVERY speculation round, about as long as the round's evaluations.  The LDS table is authoritative
+      // for the chain's own steps -- a miss is evaluated, which is results-neutral like every miss --; what is evaluated still
+      // goes to the table in the workspace (a blind store to the way the key picks: nothing waits for it), where the table
+      // completion's launch (denovo_fillw_kernel.hpp) looks it up.
+      LDSP(uint64_t) le = S.lc + 2 * (size_t)((hsh >> 3) & S.lc_mask);
+      const uint64_t t = le[0], v = le[1];
+      if (t == tag) {
+        val = __longlong_as_double((long long)v);
+        miss = false;
+      }
+      lslot = le;
+    } else {
     int hit_way = -1;
 #pragma unroll
     for (int w = 7; w >= 0; w--) {
@@ -1316,6 +1335,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
         }
       }
       kslot = kset + (size_t)way * S.key_words;
+    }
     }
     slot = set + way;
   }
@@ -1359,6 +1379,13 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
         for (int h = 0; h < KT; h++) kslot[h] = pw.w[h];
       }
       *slot = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(val));
+    }
+    if (S.lc_mask != 0u && !wide) {
+      // the front cache: lanes with different keys may pick the same entry in one round -- every lane writes its tag, the one
+      // whose tag stayed writes the value, so an entry's value always belongs to its tag
+      if (writer) lslot[0] = tag;
+      lds_sync();
+      if (writer && lslot[0] == tag) lslot[1] = (uint64_t)__double_as_longlong(val);
     }
     lds_sync();
     GSUB(c, 10);
@@ -2112,12 +2139,20 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     for (int i = lane; i < NG * S.memo_stride; i += WAVE) S.memo_tot[i] = NAN;  // nothing evaluated yet
     S.bpc = nullptr;
     S.bpt = nullptr;
+    S.lc = lds_cast<uint64_t>(p);
+    S.lc_mask = 0u;
     if (G == 64 && P.bp_cache) {
       p += spec_memo_bytes(mmax, T, G);
       p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
       S.bpc = lds_cast<double>(p); p += (size_t)8 * KT * 4 * 64;
-      S.bpt = lds_cast<uint64_t>(p);
+      S.bpt = lds_cast<uint64_t>(p); p += (size_t)8 * (KT + 1);
       if (lane == 0) S.bpt[KT] = 0ull;
+      if (P.bp_cache & 2) {  // the chain's likelihood cache in LDS (spec_eval), carved behind the product cache
+        p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
+        S.lc = lds_cast<uint64_t>(p);
+        S.lc_mask = (uint32_t)SPEC_LC_ENTRIES - 1u;
+        for (int i = lane; i < 2 * SPEC_LC_ENTRIES; i += WAVE) S.lc[i] = 0ull;  // (a tag is never 0: tag_of)
+      }
     }
   }
   for (int i = lane; i < SPEC_LN; i += WAVE) {

@@ -596,6 +596,17 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   if (lds > 160 * 1024) return fail(MCHAP_ERR_LIMIT, "speculative sampler needs %zu bytes of LDS", lds);
   P.bp_cache = bp_cache_fits(T, G, lds, K);
   if (P.bp_cache) lds = ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K);
+  // The chain's likelihood cache in LDS (denovo_spec_kernel.hpp spec_eval): exact tags only (packed genotype of at most 63
+  // bits), and only where its 4 KB do not cost the launch a resident wavefront per CU (two per SIMD: eight per CU at most).
+  // Tuning flag 8192: never (the table in the workspace is probed, as before round 4: same traces).
+  if (P.bp_cache && P.d.cache_slots > 0 && !(T.flags & 8192) && K * mchap::allele_bits(P.max_allele) * P.max_pos <= 63) {
+    const size_t with = ((lds + 15) & ~(size_t)15) + mchap::spec_lc_bytes();
+    auto per_cu = [](size_t b) { const size_t w = (160 * 1024) / b; return w > 8 ? (size_t)8 : w; };
+    if (with <= 160 * 1024 && per_cu(with) >= per_cu(lds)) {
+      P.bp_cache |= 2;
+      lds = with;
+    }
+  }
   const long long n_chains = (long long)n_units * chains;
   // steps before the first hand-over: a chain handed over before it has settled comes back and has its tables
   // completed a second time, which costs more the more sub-steps and intervals a step has (config #2: 32 sub-steps,
@@ -997,22 +1008,25 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     const size_t lds_simt = mchap::simt_lds_bytes(B.max_ploidy, B.max_pos, cfg->n_temps);
     if (lds_prep > 160 * 1024 || lds_simt > 160 * 1024)
       return fail(MCHAP_ERR_LIMIT, "a unit needs %zu / %zu bytes of LDS (> 160 KiB)", lds_prep, lds_simt);
-    switch (rpl) {
-      case 1: rc = launch_prepare<1>(SP, n_units, lds_prep, stream); break;
-      case 2: rc = launch_prepare<2>(SP, n_units, lds_prep, stream); break;
-      case 3: rc = launch_prepare<3>(SP, n_units, lds_prep, stream); break;
-      case 4: rc = launch_prepare<4>(SP, n_units, lds_prep, stream); break;
-      case 5: rc = launch_prepare<5>(SP, n_units, lds_prep, stream); break;
-      case 6: rc = launch_prepare<6>(SP, n_units, lds_prep, stream); break;
-      case 7: rc = launch_prepare<7>(SP, n_units, lds_prep, stream); break;
-      case 8: rc = launch_prepare<8>(SP, n_units, lds_prep, stream); break;
-      case 12: rc = launch_prepare<12>(SP, n_units, lds_prep, stream); break;
-      case 16: rc = launch_prepare<16>(SP, n_units, lds_prep, stream); break;
-      case 24: rc = launch_prepare<24>(SP, n_units, lds_prep, stream); break;
-      case 32: rc = launch_prepare<32>(SP, n_units, lds_prep, stream); break;
-      case 48: rc = launch_prepare<48>(SP, n_units, lds_prep, stream); break;
-      default: rc = launch_prepare<64>(SP, n_units, lds_prep, stream); break;
-    }
+    auto prepare = [&](const mchap::SimtParams &Q, int n, hipStream_t st) {
+      switch (rpl) {
+        case 1: return launch_prepare<1>(Q, n, lds_prep, st);
+        case 2: return launch_prepare<2>(Q, n, lds_prep, st);
+        case 3: return launch_prepare<3>(Q, n, lds_prep, st);
+        case 4: return launch_prepare<4>(Q, n, lds_prep, st);
+        case 5: return launch_prepare<5>(Q, n, lds_prep, st);
+        case 6: return launch_prepare<6>(Q, n, lds_prep, st);
+        case 7: return launch_prepare<7>(Q, n, lds_prep, st);
+        case 8: return launch_prepare<8>(Q, n, lds_prep, st);
+        case 12: return launch_prepare<12>(Q, n, lds_prep, st);
+        case 16: return launch_prepare<16>(Q, n, lds_prep, st);
+        case 24: return launch_prepare<24>(Q, n, lds_prep, st);
+        case 32: return launch_prepare<32>(Q, n, lds_prep, st);
+        case 48: return launch_prepare<48>(Q, n, lds_prep, st);
+        default: return launch_prepare<64>(Q, n, lds_prep, st);
+      }
+    };
+    rc = prepare(SP, n_units, stream);
     if (rc) return rc;
     switch (pl.kind) {
 #ifdef MCHAP_TEST_KERNELS
@@ -1166,6 +1180,25 @@ int mchap_read_log_batch(const double *x, int64_t n, double *out) {
                      d_x.as<double>(), (long long)n, d_o.as<double>());
   HIP_TRY(hipGetLastError());
   MCHAP_TRY(hc.down(out, d_o.p, (size_t)n * 8));
+  return hc.sync();
+}
+
+/* Test hook: wave_sum (csrc/denovo_kernel.hpp), the 64-lane sum every likelihood goes through, for n_waves x 64 values: out[w] =
+ * the sum of x[64 w .. 64 w + 63] as lane 0 holds it.  Host pointers. */
+int mchap_wave_sum_batch(const double *x, int64_t n_waves, double *out) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (n_waves <= 0) return MCHAP_OK;
+  if (!x || !out) return fail(MCHAP_ERR_BAD_ARG, "NULL buffer");
+  DevBuf d_x, d_o;
+  HostCall hc;
+  MCHAP_TRY(hc.open());
+  HIP_TRY(hipMalloc(&d_x.p, (size_t)n_waves * 64 * 8));
+  HIP_TRY(hipMalloc(&d_o.p, (size_t)n_waves * 8));
+  MCHAP_TRY(hc.up(d_x.p, x, (size_t)n_waves * 64 * 8));
+  hipLaunchKernelGGL(mchap::wave_sum_kernel, dim3((unsigned)n_waves), dim3(64), 0, hc.stream, d_x.as<double>(), d_o.as<double>());
+  HIP_TRY(hipGetLastError());
+  MCHAP_TRY(hc.down(out, d_o.p, (size_t)n_waves * 8));
   return hc.sync();
 }
 

@@ -69,6 +69,9 @@ def _run(example, sampler=None, report=("AFP", "GP"), **kw):
 class _NSeq:
     """a reference sequence known by its length only (io.Reference's behaviour without the FASTA file)"""
 
+    known = False  # (application.assemble: the variants' REF alleles are written at their positions)
+
+
     def __getitem__(self, sl):
         return "N" * (sl.stop - sl.start)
 

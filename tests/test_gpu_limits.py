@@ -8,6 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 class _NSeq:
+    known = False  # (application.assemble: the variants' REF alleles are written at their positions)
+
     def __getitem__(self, sl):
         return "N" * (sl.stop - sl.start)
 

@@ -62,3 +62,27 @@ def test_read_log_special_values():
     assert got[0] == -np.inf and got[1] == -np.inf      # log(0) = -inf: a read no haplotype explains
     assert np.isnan(got[2:6]).all()
     assert got[6] == 0.0
+
+
+def test_wave_sum_tree():
+    """wave_sum (csrc/denovo_kernel.hpp): the sum over the 64 lanes of a wavefront is the XOR butterfly's tree -- offsets 32, 16,
+    8, 4, 2, 1 -- whatever instructions carry it (round 4: DPP row rotations for the last four steps).  Emulated here in float64
+    with numpy, operand for operand; the device value must have the same bits, in every lane."""
+    from mchap_amd import _lib
+
+    rng = np.random.default_rng(11)
+    n = 4096
+    x = np.concatenate([
+        rng.standard_normal((n // 4, 64)) * np.exp(rng.uniform(-30, 30, (n // 4, 64))),   # wildly different magnitudes: every rounding shows
+        -rng.random((n // 4, 64)) * 700.0,                                               # what a likelihood adds: c * log(p) <= 0
+        np.where(rng.random((n // 4, 64)) < 0.3, 0.0, -rng.random((n // 4, 64))),        # padding lanes: +0.0 terms
+        rng.integers(-3, 4, (n // 4, 64)).astype(np.float64) * 2.0 ** rng.integers(-40, 40, (n // 4, 64)),
+    ])
+    out = np.empty(n, dtype=np.float64)
+    _lib.check(_lib.lib().mchap_wave_sum_batch(_lib.ptr(np.ascontiguousarray(x)), C.c_int64(n), _lib.ptr(out)))
+    v = x.copy()
+    lanes = np.arange(64)
+    for o in (32, 16, 8, 4, 2, 1):
+        v = v + v[:, lanes ^ o]
+    assert not np.isnan(out).any()  # (NaN: the lanes of a wavefront disagreed)
+    assert np.array_equal(out.view(np.uint64), v[:, 0].view(np.uint64))

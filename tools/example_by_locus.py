@@ -13,7 +13,7 @@ source = application.MatrixSource(samples, matrices)
 model = DenovoMCMC(ploidy=4, n_alleles=[2], steps=2000, chains=2, random_seed=42)
 allu = []
 for contig, start, stop, name in targets:
-    locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start))
+    locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start), sequence_known=False)
     M = len(locus.positions)
     units = []
     for s in samples:

@@ -10,7 +10,7 @@ samples, targets, variants, matrices, contigs = application.load_matrices("tests
 source = application.MatrixSource(samples, matrices)
 name, sample = sys.argv[1], sys.argv[2]
 t = [x for x in targets if x[3] == name][0]
-locus = io.DenovoLocus(t[0], t[1], t[2], t[3], variants, "N" * (t[2] - t[1]))
+locus = io.DenovoLocus(t[0], t[1], t[2], t[3], variants, "N" * (t[2] - t[1]), sequence_known=False)
 sr = source.reads(locus, sample)
 M = len(locus.positions)
 STEPS = 600

@@ -9,6 +9,8 @@ samples, targets, variants, matrices, contigs = application.load_matrices(os.pat
 
 
 class NSeq:
+    known = False  # (application.assemble: the variants' REF alleles are written at their positions)
+
     def __getitem__(self, sl):
         return "N" * (sl.stop - sl.start)
 
