@@ -105,6 +105,62 @@ def usable_cores():
     return n, quota
 
 
+def cpu_rates(unit_fn, n_one, n_all, unit="units/s", what="", cores=None):
+    """The oracle (a C port of the reference's algorithm: kind "port") timed on ONE thread and on all usable threads, one unit per
+    thread: unit_fn(i) runs unit i through oracle/mchap_oracle.c (ctypes releases the interpreter lock, so a thread pool of
+    plain calls is real parallelism).  Every `extra` reports both rates, so that speed-ups are quoted against the same thing."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    if cores is None:
+        cores, _ = usable_cores()
+    t = time.perf_counter()
+    for i in range(n_one):
+        unit_fn(i)
+    d1 = time.perf_counter() - t
+    n_all = max(n_all, cores)
+    t = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(unit_fn, range(n_all)))
+    dn = time.perf_counter() - t
+    return {"value": n_all / dn, "unit": unit, "cores": cores, "kind": "port", "value_1_thread": n_one / d1,
+            "sample": "%s: %d units on one thread (%.1f s), %d units on %d threads, one unit per thread (%.1f s)" % (what, n_one, d1, n_all, cores, dn)}
+
+
+def reference_postprocessing(args, batch, n=16):
+    """BASELINE.md section 4's separate line: what the reference does to every unit's trace IN PYTHON, whatever ran the sampler --
+    GenotypeMultiTrace.__post_init__ sorts the haplotypes of every recorded step with one np.lexsort call per (chain, step)
+    (assemble/classes.py:265-278 through encoding/integer/sequence.py:78-110), and posterior() counts distinct genotypes after
+    the burn-in (classes.py:307-325).  Restated here with the same numpy calls (a port, not the reference's file) and timed on
+    one host thread over the raw traces of the first n units of the timed batch.  The build's counterpart is fused into the
+    sampler's trace write plus trace_posterior_kernel (inside `value`)."""
+    from mchap_amd.assemble import unpack_trace
+
+    n = min(n, args.loci)
+    words, fixed, _, _ = batch.traces()
+    units = [unpack_trace(words[u], fixed[u], 2) for u in range(n)]  # int8 [chains, steps, ploidy, snvs]
+    t = time.perf_counter()
+    for g in units:
+        g = g.copy()
+        for c in range(g.shape[0]):
+            for i in range(g.shape[1]):
+                a = g[c, i]
+                g[c, i] = a[np.lexsort(np.flip(a, axis=-1).transpose((-1, -2)))]
+    d_sort = (time.perf_counter() - t) / n
+    t = time.perf_counter()
+    for g in units:
+        m = np.ascontiguousarray(g[:, args.burn:]).reshape(-1, g.shape[2] * g.shape[3])
+        _, counts = np.unique(m.view([("", m.dtype)] * m.shape[1]), return_counts=True)
+        probs = counts / counts.sum()
+        np.flip(np.argsort(probs))
+    d_post = (time.perf_counter() - t) / n
+    return {"kind": "port", "cores": 1, "units": n, "lexsort_ms_per_unit": d_sort * 1e3, "posterior_ms_per_unit": d_post * 1e3,
+            "implied_ceiling_loci_per_s_per_core": 1.0 / (d_sort + d_post),
+            "note": "the reference's Python-side trace post-processing per unit (one np.lexsort per chain and step, then the histogram of "
+                    "distinct genotypes), restated with the same numpy calls and timed on one host thread: with it a reference run "
+                    "cannot exceed this rate per core however fast its numba sampler is; it is NOT part of cpu_baseline.value "
+                    "(oracle: sampler only)"}
+
+
 def call_concordance(args, batch, n=64):
     """Checker leg (rank 0, after the timed region): the first n loci of the batch through the oracle on the same
     Philox streams (llk cache off); the posterior mode genotype and its probability must be those the device-side
@@ -343,14 +399,12 @@ def bench_config4(args):
         from oracle import binding as orc
 
         mode = batch.mode_results()
-        t = time.perf_counter()
-        n_cpu = 3
-        for u in range(n_cpu):
-            a, ml, mp, sp, fq, oc = orc.posterior_mode(reads[u], K, haps, None, prior)
-            assert a.tolist() == mode[0][u].tolist() and abs(mp - mode[2][u]) < 1e-9
-        dc = (time.perf_counter() - t) / n_cpu
-        out["cpu_baseline"] = {"value": 1.0 / dc, "unit": "units/s", "cores": 1, "kind": "port",
-                               "sample": "%d units through oracle/mchap_oracle.c posterior_mode, one thread; mode and GPM equal the GPU's" % n_cpu}
+
+        def one(u):
+            a, ml, mp, sp, fq, oc = orc.posterior_mode(reads[u % U], K, haps, None, prior)
+            assert a.tolist() == mode[0][u % U].tolist() and abs(mp - mode[2][u % U]) < 1e-9
+
+        out["cpu_baseline"] = cpu_rates(one, 2, 0, "units/s", "oracle/mchap_oracle.c posterior_mode; mode and GPM equal the GPU's")
     return out
 
 
@@ -446,25 +500,25 @@ def bench_config5(args):
         cores, _ = usable_cores()
         n_cpu = max(1, min(U, cores))
         t = time.perf_counter()
+        orc.denovo_fit_batch(cfg, reads[:1], [2] * M, n_threads=1, keep_traces=False)
+        d1 = time.perf_counter() - t
+        t = time.perf_counter()
         orc.denovo_fit_batch(cfg, reads[:n_cpu], [2] * M, n_threads=cores, keep_traces=False)
         dc = time.perf_counter() - t
-        out["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": min(cores, n_cpu), "kind": "port",
-                               "sample": "%d loci of the same workload, oracle with llk cache, one locus per thread, %.1f s wall" % (n_cpu, dc)}
+        out["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": min(cores, n_cpu), "kind": "port", "value_1_thread": 1.0 / d1,
+                               "sample": "oracle with llk cache: 1 locus on one thread (%.1f s), %d loci of the same workload one locus per "
+                                         "thread (%.1f s wall)" % (d1, n_cpu, dc)}
     return out
 
 
-def bench_call_mcmc(args):
-    """`mchap call` (SURVEY 8 f1): the Gibbs sampler over the genotypes of KNOWN haplotypes (calling/mcmc.py:15-453) for a batch of
-    tetraploid units -- 16 known haplotypes over 8 SNVs, 200 reads, the program's defaults of 2000 steps (burn 1000) x 2 chains,
-    Dirichlet-multinomial prior with inbreeding 0.1 -- resident in HBM, mchap_call_mcmc_batch_device on torch's stream; the
-    oracle on the same Philox streams beside it (and the first units' traces compared with it)."""
+def call_mcmc_workload(U):
+    """The extra.call_mcmc workload resident in HBM (also what tools/call_once.py profiles): -> (once, shapes, arrays)."""
     import ctypes as C
-
     import torch
     from mchap_amd import _lib
     from mchap_amd.synth import synth_units
 
-    U, K, H, M, R, S, Cn = args.call_units, 4, 16, 8, 200, 2000, 2
+    K, H, M, R, S, Cn = 4, 16, 8, 200, 2000, 2
     rng = np.random.default_rng(9)
     reads, _, truth = synth_units(U, ploidy=K, n_pos=M, n_reads=R, first_unit=700)
     haps = np.zeros((U, H, M), np.int8)
@@ -489,11 +543,47 @@ def bench_call_mcmc(args):
     ws = int(L.mchap_call_mcmc_workspace_bytes_for(U, R, H, K, S, Cn))
     d_ws = torch.empty(max(ws, 16), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    keep = (d_reads, d_haps, d_F, d_sid, d_l, d_ws)
 
     def once():
         _lib.check(L.mchap_call_mcmc_batch_device(U, p(d_reads), R, M, 2, None, p(d_haps), H, K, 1, p(d_F), None, None, p(d_sid), S, Cn, 0,
                                                   C.c_uint64(42), p(d_g), p(d_l), p(d_st), p(d_ws), C.c_int64(ws), C.c_void_p(stream)))
 
+    return once, (K, H, M, R, S, Cn), dict(reads=reads, haps=haps, d_g=d_g, d_st=d_st, keep=keep)
+
+
+def call_mcmc_roofline(U, S, Cn, K, ms):
+    """VALU issue of call_mcmc_kernel from the committed SQ counter passes of this workload at 4096 units (static figures of an
+    earlier rocprofv3 --pmc run, scaled per allele sub-step), priced per instruction class; None while no such profile exists."""
+    c, src, kname = sq_counters_of("*_call_sq_counters.json", "call_mcmc_kernel")
+    if c is None:
+        return None
+    ref = 4096.0 * 2 * 2000 * 4
+    w = valu_issue_cycles(c)
+    sub = float(U) * Cn * S * K
+    cyc = w["cycles"] / ref
+    out = {"bound": "valu_issue", "achieved": cyc * sub / (ms * 1e-3) / 1e9, "peak": SIMD_CYCLES_PER_S / 1e9, "unit": "G SIMD issue cycles/s",
+           "frac": cyc * sub / (ms * 1e-3) / SIMD_CYCLES_PER_S, "valu_insts_per_allele_sub_step": float(c["SQ_INSTS_VALU"]) / ref,
+           "issue_cycles_per_allele_sub_step": cyc, "per_class_complete": w["per_class_complete"],
+           "counters": "%s (%s; static: an earlier rocprofv3 --pmc run)" % (src, kname),
+           "note": "one wavefront per (unit, chain): a sub-step is bookkeeping on a handful of lanes (a categorical draw over 16 options from "
+                   "remembered likelihoods), so the issue slots it uses are a small fraction of the chip's; what bounds it is the dependent "
+                   "latency of that bookkeeping at the occupancy 8 192 wavefronts give"}
+    if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
+        out["wait_any_frac_of_wave_cycles"] = float(c["SQ_WAIT_ANY"]) / float(c["SQ_WAVE_CYCLES"])
+    return out
+
+
+def bench_call_mcmc(args):
+    """`mchap call` (SURVEY 8 f1): the Gibbs sampler over the genotypes of KNOWN haplotypes (calling/mcmc.py:15-453) for a batch of
+    tetraploid units -- 16 known haplotypes over 8 SNVs, 200 reads, the program's defaults of 2000 steps (burn 1000) x 2 chains,
+    Dirichlet-multinomial prior with inbreeding 0.1 -- resident in HBM, mchap_call_mcmc_batch_device on torch's stream; the
+    oracle on the same Philox streams beside it (and the first units' traces compared with it)."""
+    import torch
+
+    U = args.call_units
+    once, (K, H, M, R, S, Cn), A_ = call_mcmc_workload(U)
+    reads, haps, d_g, d_st = A_["reads"], A_["haps"], A_["d_g"], A_["d_st"]
     once()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -507,19 +597,17 @@ def bench_call_mcmc(args):
     assert (d_st.cpu().numpy() == 0).all()
     out = {"workload": "%d units: tetraploid, %d known haplotypes x %d SNVs, %d reads, Gibbs steps, %d steps x %d chains, prior (0.1, flat); HBM resident" % (U, H, M, R, S, Cn),
            "value": U / (ms * 1e-3), "unit": "units/s", "kernel": "call_mcmc_kernel", "kernel_ms": ms,
-           "allele_steps_per_s": U * Cn * S * K / (ms * 1e-3)}
+           "allele_steps_per_s": U * Cn * S * K / (ms * 1e-3), "roofline": call_mcmc_roofline(U, S, Cn, K, ms)}
     if not args.no_cpu_baseline:
         from oracle import binding as orc
 
         g = d_g.cpu().numpy().reshape(U, Cn, S, K)
-        n_cpu = 16
-        t = time.perf_counter()
-        for u in range(n_cpu):
+
+        def one(u):
             go, lo = orc.call_mcmc(reads[u], haps[u], K, steps=S, chains=Cn, step_type=0, prior=(0.1, None), rng_kind=orc.RNG_PHILOX, seed=42, stream_id=u)
             assert np.array_equal(go, g[u]), "call sampler trace of unit %d differs from the oracle's" % u
-        dc = (time.perf_counter() - t) / n_cpu
-        out["cpu_baseline"] = {"value": 1.0 / dc, "unit": "units/s", "cores": 1, "kind": "port",
-                               "sample": "%d units through oracle/mchap_oracle.c call_mcmc, one thread; traces equal the GPU's" % n_cpu}
+
+        out["cpu_baseline"] = cpu_rates(one, 8, 64, "units/s", "oracle/mchap_oracle.c call_mcmc; traces equal the GPU's")
     return out
 
 
@@ -579,21 +667,24 @@ def bench_config1(args):
         from mchap_amd.assemble import break_table
 
         source = application.MatrixSource(samples, matrices)
-        n_cpu, t = 0, time.perf_counter()
-        for contig, start, stop, name in targets[:4]:
+        todo = []
+        for contig, start, stop, name in targets:
             locus = io.DenovoLocus(contig, start, stop, name, variants, "N" * (stop - start), sequence_known=False)
             M = len(locus.positions)
             for s_ in samples:
                 sr = source.reads(locus, s_)
-                if M == 0 or len(sr["dists"]) == 0:
-                    continue
-                cfg = orc.make_cfg(4, 2000, 2, None, (1.0,), llk_cache_threshold=100, seed=42, rng_kind=orc.RNG_PHILOX, stream_id=0,
-                                   break_table=break_table(M, 1.0, 3.0))
-                assert orc.denovo_fit(cfg, sr["dists"], [2] * M, sr["counts"])[2] == 0
-                n_cpu += 1
-        dc = time.perf_counter() - t
-        out["cpu_baseline"] = {"value": n_cpu / dc, "unit": "units/s", "cores": 1, "kind": "port",
-                               "sample": "the %d units of the first 4 targets through oracle/mchap_oracle.c (sampler only), one thread, %.1f s" % (n_cpu, dc)}
+                if M and len(sr["dists"]):
+                    todo.append((M, sr))
+
+        def one(i):
+            M, sr = todo[i % len(todo)]
+            cfg = orc.make_cfg(4, 2000, 2, None, (1.0,), llk_cache_threshold=100, seed=42, rng_kind=orc.RNG_PHILOX, stream_id=0,
+                               break_table=break_table(M, 1.0, 3.0))
+            assert orc.denovo_fit(cfg, sr["dists"], [2] * M, sr["counts"])[2] == 0
+
+        n4 = sum(1 for _ in range(4 * len(samples)))
+        # one thread: the units of the first 4 targets; all threads: EVERY unit of the example (the same job the GPU ran)
+        out["cpu_baseline"] = cpu_rates(one, min(n4, len(todo)), len(todo), "units/s", "oracle/mchap_oracle.c, sampler only")
     return out
 
 
@@ -638,12 +729,10 @@ def bench_config2_dedup(args):
 
         cfg = orc.make_cfg(args.ploidy, args.mcmc_steps, args.chains, None, (1.0,), llk_cache_threshold=100, seed=42, rng_kind=orc.RNG_PHILOX,
                            break_table=break_table(args.snvs, 1.0, 3.0))
-        n_cpu = 64
-        t = time.perf_counter()
-        for i in range(n_cpu):
-            assert orc.denovo_fit(cfg, pairs[i][0], [2] * args.snvs, pairs[i][1])[2] == 0
-        dc = time.perf_counter() - t
-        out["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": 1, "kind": "port", "sample": "%d loci, oracle, one thread" % n_cpu}
+        def one(i):
+            assert orc.denovo_fit(cfg, pairs[i % len(pairs)][0], [2] * args.snvs, pairs[i % len(pairs)][1])[2] == 0
+
+        out["cpu_baseline"] = cpu_rates(one, 64, 1024, "loci/s", "oracle with llk cache")
     return out
 
 
@@ -673,7 +762,12 @@ def bench_moving(args):
             _, _, code, _ = orc.denovo_fit_batch(cfg, reads[:n_cpu], [2] * args.snvs, n_threads=cores, keep_traces=False)
             dc = time.perf_counter() - t
             assert code == 0
-            row["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": cores, "kind": "port", "sample": "%d loci, oracle with llk cache" % n_cpu}
+            n1 = 16
+            t = time.perf_counter()
+            orc.denovo_fit_batch(cfg, reads[:n1], [2] * args.snvs, n_threads=1, keep_traces=False)
+            d1 = time.perf_counter() - t
+            row["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": cores, "kind": "port", "value_1_thread": n1 / d1,
+                                   "sample": "oracle with llk cache: %d loci on %d threads, %d loci on one thread" % (n_cpu, cores, n1)}
         out["reads_%d" % R] = row
     return out
 
@@ -998,6 +1092,7 @@ def main():
                 conc, dgpm = call_concordance(args, batch)
                 out["cpu_baseline"]["mode_call_concordance"] = conc
                 out["cpu_baseline"]["max_abs_delta_gpm"] = dgpm
+            out["cpu_baseline"]["reference_python_postprocessing"] = reference_postprocessing(args, batch)
         print(json.dumps(out))
     if dist is not None:
         barrier()

@@ -146,7 +146,8 @@ int mchap_denovo_fit_batch_device(const mchap_denovo_cfg *cfg, int n_units, cons
  * reference does (qual_prob[0] = 1 - error_rate is used for every call when quals == NULL; qualities beyond the
  * table use its last entry).  The probability tensor is formed on the device by the prepare pass: the called
  * allele gets p, the others (1 - p) / 3, a gap NaN, alleles >= n_alleles[j] zero.  5x fewer input bytes than the
- * float64 tensor; same traces.  Kernels 2 and 3 only. */
+ * float64 tensor; same traces.  Every shipped sampler takes it (kernels 2, 3 and the phased sampler 5: they share the prepare
+ * pass); kernel 1 of the parity suite does not. */
 int mchap_denovo_fit_batch_calls_device(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
                                         const mchap_unit *units_host, const int8_t *calls, const int16_t *quals,
                                         const double *qual_prob, int qual_prob_len, const int64_t *read_counts,

@@ -544,6 +544,24 @@ def _genotype_posterior_array(post, labels, ploidy):
     return out
 
 
+def _limit_record_line(locus, samples, report=(), ploidy_of=None):
+    """The record of a target the library could not sample (beyond its shape limits: the reference has none, so this is a gap
+    of this build, made visible): REF, no ALT, FILTER = LIMIT, the INFO fields that do not depend on the sampler, and null
+    genotypes of each sample's ploidy -- never an omitted record (an incomplete file is worse than a flagged one)."""
+    from .vcfheader import report_fields
+
+    _, fmt_opt = report_fields(report)
+    M = len(locus.positions)
+    info = "AN=0;UAN=0;AC=.;NS=0;MCI=0;DP=.;RCOUNT=.;END=%d;NVAR=%d;SNVPOS=%s" % (
+        locus.stop, M, vcfstr(np.array(locus.positions, int) - locus.start + 1))
+    cols = []
+    for sample in samples:
+        K = int(ploidy_of(sample)) if ploidy_of is not None else 2
+        cols.append(":".join(["/".join(["."] * K)] + ["."] * (len(SAMPLE_FIELDS) - 1 + len(fmt_opt))))
+    return "\t".join([locus.contig, str(locus.start + 1), locus.name, locus.sequence, ".", ".", "LIMIT", info,
+                      ":".join(SAMPLE_FIELDS + tuple(fmt_opt))] + cols)
+
+
 def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_threshold, report=(), ploidy_of=None, encoded=None):
     """The VCF record line of `mchap assemble` from the per-sample summaries (application/assemble.py:144-252,
     baseclass.py:220-302).  per[sample]: genotype [K, M], gprob, sprob, mec, mecp, mci, rcount, rcalls, dp, depth;
@@ -830,8 +848,10 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
             if li in state["skipped"]:
                 import sys
 
-                sys.stderr.write("mchap_amd assemble: target %s (%s:%d-%d) left out: %s\n" % (
+                sys.stderr.write("mchap_amd assemble: target %s (%s:%d-%d) not assembled (record written with FILTER=LIMIT): %s\n" % (
                     locus.name, locus.contig, locus.start + 1, locus.stop, state["skipped"][li]))
+                timings["limit_records"] = timings.get("limit_records", 0) + 1
+                yield _limit_record_line(locus, samples, report, ploidy_of)
                 continue
             per, posteriors = {}, []
             for sample in samples:

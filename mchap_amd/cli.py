@@ -184,9 +184,12 @@ def run(argv, out=None):
     for line in vcfheader.header_lines(program, ["mchap_amd"] + list(argv[1:]), samples, contigs, report=report, random_seed=seed):
         out.write(line + "\n")
     n = 0
+    run.limit_records = 0
     for line in lines:
         out.write(line + "\n")
         n += 1
+        if program == "assemble" and line.split("\t", 7)[6] == "LIMIT":
+            run.limit_records += 1  # (a target beyond the build's shape limits: written with null genotypes, and main() says so)
     return n
 
 
@@ -200,6 +203,9 @@ def main(argv=None):
         return 0
     parser.parse_args(argv[1:2])
     run(argv)
+    if getattr(run, "limit_records", 0):
+        sys.stderr.write("mchap_amd: %d target(s) were not assembled (FILTER=LIMIT): exit status 3\n" % run.limit_records)
+        return 3
     return 0
 
 

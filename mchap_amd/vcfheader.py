@@ -12,6 +12,10 @@ FILTERS = [
     ("AF0", "All alleles have prior allele frequency of zero"),
 ]
 
+# `assemble` only, not a reference filter: a target beyond the library's shape limits (README: SNVs per target, bits of sampled
+# alleles per haplotype) is written with null genotypes and this filter instead of being left out of the file
+LIMIT_FILTER = ("LIMIT", "Target not assembled: beyond the shape limits of this build (record kept with null genotypes)")
+
 # (id, Number, Type, Description); the order is the order of the header and of the INFO column
 INFO_FIELDS = [
     ("AN", "1", "Integer", "Total number of alleles in called genotypes"),
@@ -83,7 +87,7 @@ def header_lines(program, command, samples, contigs, report=(), random_seed=None
            "##source=mchap_amd v%s (%s)" % (version or __version__, program), "##phasing=None", "##commandline=%s" % cmd,
            "##randomseed=%s" % random_seed]
     out += ["##contig=<ID=%s,length=%d>" % (n, l) for n, l in contigs]
-    out += ['##FILTER=<ID=%s,Description="%s">' % f for f in FILTERS]
+    out += ['##FILTER=<ID=%s,Description="%s">' % f for f in FILTERS + ([LIMIT_FILTER] if program == "assemble" else [])]
     info_opt, fmt_opt = report_fields(report)
     for fid, num, typ, descr in INFO_FIELDS:
         out.append('##INFO=<ID=%s,Number=%s,Type=%s,Description="%s">' % (fid, num, typ, descr))

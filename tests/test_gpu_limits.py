@@ -1,6 +1,7 @@
-"""GPU: targets beyond the library's limits do not end a run.  The reference has no limit on the SNVs of a target; this build
-takes 62 SNVs per target and 64 bits of sampled alleles per haplotype (one bit per biallelic SNV, two per tri- / tetra-allelic
-one).  `application.assemble` leaves such a target out of the output with a warning on stderr and carries on with the others."""
+"""GPU: targets beyond the library's limits neither end a run nor vanish from its output.  The reference has no limit on the SNVs
+of a target; this build takes 62 SNVs per target and 64 bits of sampled alleles per haplotype (one bit per biallelic SNV, two per
+tri- / tetra-allelic one).  `application.assemble` writes such a target's record with null genotypes and FILTER=LIMIT (declared
+in the header), warns on stderr, and the command line exits with status 3; the other targets are not affected."""
 import numpy as np
 import pytest
 
@@ -26,7 +27,7 @@ def _target(name, start, n_snv, alleles, rng, n_reads=30, ploidy=4):
     return ("c1", start, start + 3 * n_snv, name), variants, (chars, quals)
 
 
-def test_targets_beyond_the_limits_are_left_out_with_a_warning(capsys):
+def test_targets_beyond_the_limits_are_written_with_a_filter(capsys):
     from mchap_amd import application
 
     rng = np.random.default_rng(5)
@@ -40,11 +41,23 @@ def test_targets_beyond_the_limits_are_left_out_with_a_warning(capsys):
     source = application.MatrixSource(["S1"], matrices)
     lines = list(application.assemble(None, variants, {"c1": _NSeq()}, source, ploidy=4, steps=120, burn=60, chains=2, seed=3, targets=targets))
     names = [ln.split("\t")[2] for ln in lines]
-    assert names == ["ok1", "ok2", "wide_ok"]   # (44 biallelic SNVs: 176 sub-steps per step, the phased sampler's widest shape)
+    assert names == ["ok1", "toomany", "toowide", "ok2", "wide_ok"]   # every target has its record, in target order
+    by = {ln.split("\t")[2]: ln.split("\t") for ln in lines}
+    for nm in ("ok1", "ok2", "wide_ok"):  # (44 biallelic SNVs: 176 sub-steps per step, the phased sampler's widest shape)
+        assert by[nm][6] in ("PASS", "NOA") and "." not in by[nm][9].split(":")[0]
+    for nm, n_snv in (("toomany", 70), ("toowide", 40)):
+        f = by[nm]
+        assert f[4] == "." and f[6] == "LIMIT" and "NVAR=%d;" % n_snv in f[7] and f[7].startswith("AN=0;UAN=0;AC=.;NS=0")
+        assert f[8].split(":")[0] == "GT" and f[9].split(":")[0] == "./././." and len(f[9].split(":")) == len(f[8].split(":"))
+        assert len(f[3]) == 3 * n_snv  # the reference sequence of the target
     err = capsys.readouterr().err
     assert "target toomany" in err and "70 SNVs" in err
     assert "target toowide" in err and "64 bits" in err
     # the records of the targets that ran do not depend on their neighbours
     alone = list(application.assemble(None, variants, {"c1": _NSeq()}, source, ploidy=4, steps=120, burn=60, chains=2, seed=3,
                                       targets=[targets[0], targets[3], targets[4]]))
-    assert alone == lines
+    assert alone == [lines[0], lines[3], lines[4]]
+    from mchap_amd import vcfheader
+
+    assert any(ln.startswith("##FILTER=<ID=LIMIT,") for ln in vcfheader.header_lines("assemble", "x", ["S1"], [("c1", 9000)]))
+    assert not any("LIMIT" in ln for ln in vcfheader.header_lines("call-exact", "x", ["S1"], [("c1", 9000)]))

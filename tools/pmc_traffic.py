@@ -14,7 +14,7 @@ import json
 import sys
 
 tag, loci, steps, chains = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-SAMPLERS = ("denovo_spec", "denovo_coast", "denovo_simt_kernel", "denovo_mcmc")
+SAMPLERS = ("denovo_spec", "denovo_coast", "denovo_fillw", "denovo_simt_kernel", "denovo_mcmc")
 
 
 def per_launch(dirname, match):
@@ -59,7 +59,7 @@ out = {
     "launches_averaged": [nf.get("FETCH_SIZE", 0), nw.get("WRITE_SIZE", 0)],
 }
 sq = {}
-for d in ("pmc_sq1", "pmc_sq2"):
+for d in ("pmc_sq1", "pmc_sq2", "pmc_sq3"):
     v, _ = per_launch(d, SAMPLERS)
     sq.update(v)
 out["sq_counters_per_launch"] = sq

@@ -18,15 +18,19 @@ SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTI
 SQ3="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32"
 rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_sq1 -- python3 /root/repo/tools/prof_run.py full 10000 > $OUT/${TAG}_pmc_sq1.log 2>&1
 rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_sq2 -- python3 /root/repo/tools/prof_run.py full 10000 > $OUT/${TAG}_pmc_sq2.log 2>&1
-# the K = 8 sampler (configs[4]) and the exact caller's first pass (configs[3])
+rocprofv3 --pmc $SQ3 --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_sq3 -- python3 /root/repo/tools/prof_run.py full 10000 > $OUT/${TAG}_pmc_sq3.log 2>&1
+# the K = 8 sampler (configs[4]), the exact caller's first pass (configs[3]) and the `mchap call` sampler (extra.call_mcmc)
 for G in 1 2 3; do
   eval C=\$SQ$G
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_call_sq$G -- python3 /root/repo/tools/call_once.py 4096 1 > $OUT/${TAG}_call_sq$G.log 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_c5_sq$G -- python3 /root/repo/tools/config5_once.py 256 1 > $OUT/${TAG}_c5_sq$G.log 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_c4_sq$G -- python3 /root/repo/tools/exact_once.py 256 streaming > $OUT/${TAG}_c4_sq$G.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_c5_trace -- python3 /root/repo/tools/config5_once.py 256 1 > $OUT/${TAG}_c5_trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_c4_trace -- python3 /root/repo/tools/exact_once.py 256 streaming > $OUT/${TAG}_c4_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_call_trace -- python3 /root/repo/tools/call_once.py 4096 3 > $OUT/${TAG}_call_trace.log 2>&1
+python3 /root/repo/tools/pmc_sq.py $OUT/${TAG}_call_sq1 $OUT/${TAG}_call_sq2 $OUT/${TAG}_call_sq3 > $OUT/${TAG}_call_sq.json 2>> $OUT/${TAG}_call_sq1.log
 python3 /root/repo/tools/pmc_sq.py $OUT/${TAG}_c5_sq1 $OUT/${TAG}_c5_sq2 $OUT/${TAG}_c5_sq3 > $OUT/${TAG}_c5_sq.json 2>> $OUT/${TAG}_c5_sq1.log
 python3 /root/repo/tools/pmc_sq.py $OUT/${TAG}_c4_sq1 $OUT/${TAG}_c4_sq2 $OUT/${TAG}_c4_sq3 > $OUT/${TAG}_c4_sq.json 2>> $OUT/${TAG}_c4_sq1.log
-python3 /root/repo/tools/pmc_sq.py $OUT/${TAG}_pmc_sq1 $OUT/${TAG}_pmc_sq2 > $OUT/${TAG}_c2_sq.json 2>> $OUT/${TAG}_pmc_sq1.log
+python3 /root/repo/tools/pmc_sq.py $OUT/${TAG}_pmc_sq1 $OUT/${TAG}_pmc_sq2 $OUT/${TAG}_pmc_sq3 > $OUT/${TAG}_c2_sq.json 2>> $OUT/${TAG}_pmc_sq1.log
 ls $OUT | grep $TAG
