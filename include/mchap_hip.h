@@ -28,6 +28,10 @@ extern "C" {
 
 #define MCHAP_MAX_TEMPS 16
 #define MCHAP_MAX_PLOIDY 8   /* nibble-packed labels; reference has no limit */
+#define MCHAP_MAX_POS 126    /* SNVs per unit.  Up to 62 SNVs and 64 bits of sampled alleles per haplotype (1 bit per biallelic, 2 per
+                                tri- / tetra-allelic, 3 beyond) the fast samplers run; wider units -- up to 126 SNVs and 128 bits -- run on
+                                the lanes-over-chains sampler with 128-bit haplotype words and their traces hold TWO uint64 words per
+                                haplotype (mchap_denovo_trace_words_per_haplotype).  The reference has no limit. */
 #define MCHAP_MAX_ALLELE 8
 #define MCHAP_MAX_READS 4096 /* rows per unit after de-duplication (kernels 3 and 5; kernels 1 and 2: 1024) */
 
@@ -128,6 +132,9 @@ typedef struct mchap_unit {
  *                packed over the NON-fixed positions (position 0 most significant, `bits` bits per allele,
  *                bits = 1/2/3 for max_allele <= 2/4/8) and sorted ascending -- i.e. already in the
  *                canonical order GenotypeMultiTrace.__post_init__ produces (assemble/classes.py:265-278).
+ *                A batch with a unit wider than the fast samplers take (MCHAP_MAX_POS above) holds W = 2 words per haplotype,
+ *                uint64 [chains][steps][ploidy][2], most significant word first (W for a batch:
+ *                mchap_denovo_trace_words_per_haplotype; the caller sizes trace_words and its trace_off by it).
  *   llks         float64 [chains][steps]  (assemble/mcmc.py:418-425)
  *   fixed_alleles int8 [n_pos]: -1 for sampled positions, else the allele fixed as homozygous
  *                (assemble/mcmc.py:168-182,251-265); together with trace_words this is the full trace.
@@ -325,6 +332,9 @@ int mchap_call_mcmc_batch(int n_units, const double *reads, int n_reads, int n_p
 int mchap_timer_create(void **timer);
 double mchap_timer_ms(void *timer);
 int mchap_timer_destroy(void *timer);
+/* uint64 words per haplotype of this batch's trace_words: 1, or 2 when the batch holds a unit of more than 62 SNVs or more than
+ * 64 bits of alleles per haplotype (a pure function of cfg and the units' shapes; < 0: the shapes are beyond the limits) */
+int mchap_denovo_trace_words_per_haplotype(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host);
 /* name of the sampler kernel(s) a fit of this batch dispatches to (a pure function of cfg and the units' shapes) */
 int mchap_denovo_sampler_name(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host, char *out, int out_len);
 

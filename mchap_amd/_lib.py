@@ -254,6 +254,7 @@ EXPORTS = [
     "mchap_denovo_sampler_name",
     "mchap_read_log_batch",
     "mchap_wave_sum_batch",
+    "mchap_denovo_trace_words_per_haplotype",
 ]
 
 

@@ -668,7 +668,7 @@ def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_t
                       ";".join(parts), ":".join(SAMPLE_FIELDS + tuple(fmt_opt))] + cols)
 
 
-MAX_SNVS_PER_LOCUS = 62  # what mchap_denovo_fit_batch takes per unit (include/mchap_hip.h)
+MAX_SNVS_PER_LOCUS = 126  # what mchap_denovo_fit_batch takes per unit (include/mchap_hip.h MCHAP_MAX_POS)
 
 
 def _variants_by_contig(variants):
@@ -807,13 +807,17 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
 
             # one launch per (ploidy, temperature ladder) present (usually one): the library's fast samplers take one ploidy
             # per launch (mixed ploidies would run on the general lanes-over-chains kernel), and a ladder is a launch setting
+            # ... and units wider than the fast samplers take (more than 62 SNVs or 64 bits of alleles per haplotype) go to a launch
+            # of their own: they run on the general sampler with 128-bit haplotype words, which must not slow the others down
             groups = {}
             for i, u in enumerate(units):
-                groups.setdefault((u["ploidy"], u["temps"]), []).append(i)
+                M_, A_ = u["reads"].shape[1], u["reads"].shape[2]
+                wide = M_ > 62 or M_ * (1 if A_ <= 2 else 2 if A_ <= 4 else 3) > 64
+                groups.setdefault((u["ploidy"], u["temps"], wide), []).append(i)
             with torch.cuda.stream(stream) if stream is not None else _nullcontext():
                 # (several groups: their launches go out on separate HIP streams and fill each other's thin phases)
                 flight = PassesInFlight(min(4, len(groups))) if len(groups) > 1 else None
-                for (K, temps), idx in groups.items():
+                for (K, temps, _wide), idx in groups.items():
                     model = DenovoMCMC(ploidy=K, n_alleles=[2], inbreeding=None, steps=steps, chains=chains, random_seed=seed,
                                        temperatures=temps, **mcmc_kw)
                     batch = DenovoRaggedBatch(model, [units[i] for i in idx])

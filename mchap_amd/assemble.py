@@ -41,20 +41,33 @@ def allele_bits(max_allele):
     return 1 if max_allele <= 2 else (2 if max_allele <= 4 else 3)
 
 
-def unpack_trace(words, fixed_alleles, max_allele):
+def unpack_trace(words, fixed_alleles, max_allele, words_per_haplotype=1):
     """Packed, sorted haplotype words [..., K] + fixed-allele template [M0] -> int8 genotypes [..., K, M0]
-    (re-inserts the columns fixed as homozygous, reference assemble/mcmc.py:251-265)."""
+    (re-inserts the columns fixed as homozygous, reference assemble/mcmc.py:251-265).  words_per_haplotype = 2: the traces of
+    a batch with a unit wider than 64 bits, [..., K, 2] with the most significant word first (include/mchap_hip.h)."""
     fixed_alleles = np.asarray(fixed_alleles)
     het = np.flatnonzero(fixed_alleles < 0)
     bits = allele_bits(max_allele)
     mh = len(het)
     words = np.asarray(words)
-    out = np.empty(words.shape + (len(fixed_alleles),), dtype=np.int8)
+    lead = words.shape if words_per_haplotype == 1 else words.shape[:-1]
+    out = np.empty(lead + (len(fixed_alleles),), dtype=np.int8)
     out[...] = np.where(fixed_alleles < 0, 0, fixed_alleles).astype(np.int8)
     if mh:
         # every sampled position's field in one pass: position jj of the mh sampled ones sits bits * (mh - 1 - jj) bits up
-        shifts = (bits * (mh - 1 - np.arange(mh))).astype(np.uint64)
-        out[..., het] = ((words[..., None] >> shifts) & np.uint64((1 << bits) - 1)).astype(np.int8)
+        sh = bits * (mh - 1 - np.arange(mh))
+        mask = np.uint64((1 << bits) - 1)
+        if words_per_haplotype == 1:
+            out[..., het] = ((words[..., None] >> sh.astype(np.uint64)) & mask).astype(np.int8)
+        else:
+            assert words.shape[-1] == 2
+            hi, lo = words[..., 0, None], words[..., 1, None]
+            low = sh < 64
+            s_lo = np.where(low, sh, 0).astype(np.uint64)                  # field starts in the low word
+            up = np.where(low & (sh > 0), 64 - sh, 0).astype(np.uint64)    # ... and may run into the high one
+            v_low = (lo >> s_lo) | np.where(low & (sh > 0), hi << up, np.uint64(0))
+            v_high = hi >> np.where(low, 0, sh - 64).astype(np.uint64)
+            out[..., het] = (np.where(low, v_low, v_high) & mask).astype(np.int8)
     return out
 
 
@@ -190,7 +203,7 @@ class DenovoMCMC(Assembler):
                 i_off += ini.size
             else:
                 U["initial_off"] = -1
-            U["trace_off"] = t_off
+            U["trace_off"] = t_off  # (in haplotypes here; scaled by the batch's words per haplotype below)
             t_off += self.chains * self.steps * K
             U["llk_off"] = l_off
             l_off += self.chains * self.steps
@@ -202,6 +215,13 @@ class DenovoMCMC(Assembler):
             U["stream_id"] = u if stream_ids is None else int(stream_ids[u])
             shapes.append((n_pos, max_allele, K, None if initial[u] is None else ini.shape))
         cfg = self._cfg(len(n_alleles))
+        # uint64 words per haplotype of the traces: 1, or 2 for a batch with a unit of more than 62 SNVs / 64 bits per haplotype
+        wph = int(_lib.lib().mchap_denovo_trace_words_per_haplotype(C.byref(cfg), n_units, _lib.ptr(units)))
+        if wph < 1:
+            _lib.check(_lib.lib().mchap_denovo_sampler_name(C.byref(cfg), n_units, _lib.ptr(units), C.create_string_buffer(8), 8))
+            raise NotImplementedError("mchap_hip: unsupported unit shape")
+        units["trace_off"] *= wph
+        t_off *= wph
         reads_flat = np.concatenate(r_parts)
         counts_flat = np.concatenate(c_parts) if c_parts else None
         init_flat = np.concatenate(i_parts) if i_parts else None
@@ -232,8 +252,9 @@ class DenovoMCMC(Assembler):
             n_pos, max_allele, K, ini_shape = shapes[u]
             U = units[u]
             fx = fixed[U["fixed_off"]: U["fixed_off"] + n_pos]
-            w = trace[U["trace_off"]: U["trace_off"] + self.chains * self.steps * K].reshape(self.chains, self.steps, K)
-            g = unpack_trace(w, fx, max_allele)
+            w = trace[U["trace_off"]: U["trace_off"] + self.chains * self.steps * K * wph]
+            w = w.reshape((self.chains, self.steps, K) + ((wph,) if wph > 1 else ()))
+            g = unpack_trace(w, fx, max_allele, wph)
             lk = llks[U["llk_off"]: U["llk_off"] + self.chains * self.steps].reshape(self.chains, self.steps).copy()
             out.append(GenotypeMultiTrace._from_sorted(g, lk))
         return out

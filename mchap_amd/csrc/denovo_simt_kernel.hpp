@@ -72,6 +72,7 @@ struct SimtParams {
   int pipe_parts;             // wavefronts a short list of chains may spread the completion of one chain's tables over
   int bp_cache;               // speculative sampler with one chain per wave: base-product cache carved after its LDS
   int fill_lt, fill_kw;       // denovo_fill_kernel: lanes per tile of the read table, words kept per distinct request
+  int word_bits;              // bits of a packed haplotype word of this launch's sampler: 0 / 64, or 128 (denovo_simt_kernel<0, u128>)
 };
 constexpr int PIPE_RESUME = 1;  // start from the chains' PipeState records
 constexpr int PIPE_EXPORT = 2;  // at the end: complete the interval memo of the current genotype, write the records
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
   const int bits = allele_bits(A);
   int status = MCHAP_UNIT_OK;
   if (Mh == 0) status = MCHAP_UNIT_ALL_FIXED;
-  else if (Mh * bits > 64) status = MCHAP_ERR_LIMIT;
+  else if (Mh * bits > (P.word_bits ? P.word_bits : 64)) status = MCHAP_ERR_LIMIT;
   else if (U.initial_off >= 0 && U.initial_n_het != Mh) status = MCHAP_UNIT_BAD_INITIAL;  // assemble/mcmc.py:207
   if (lane == 0) {
     mi[META_I_MH] = Mh;
@@ -449,9 +450,28 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
 // ---------------------------------------------------------------------------------------------------------
 // sampler: one lane per chain
 // ---------------------------------------------------------------------------------------------------------
-struct SimtLds {
-  uint64_t *w;      // [T*Kmax][64]
-  uint64_t *pw;     // [Kmax][64]
+// W: the type of a packed haplotype word -- uint64_t (every shape of rounds 1-3: at most 64 bits of sampled alleles per haplotype),
+// or unsigned __int128 (round 4: up to 128 bits, i.e. 126 biallelic / 64 tri- or tetra-allelic SNVs; `denovo_simt_kernel<0, u128>`,
+// the general fallback for targets wider than the fast samplers take).  The code is the same; only the word's type differs.
+typedef unsigned __int128 u128;
+template <class W> struct WordBits { static constexpr int value = 8 * (int)sizeof(W); };
+__device__ __forceinline__ int word_popc(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ int word_popc(u128 x) { return __popcll((uint64_t)x) + __popcll((uint64_t)(x >> 64)); }
+__device__ __forceinline__ int word_ffs(uint64_t x) { return __ffsll((long long)x); }  // 1-based, 0 if none
+__device__ __forceinline__ int word_ffs(u128 x) {
+  const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+  return lo ? __ffsll((long long)lo) : (hi ? 64 + __ffsll((long long)hi) : 0);
+}
+__device__ __forceinline__ uint64_t word_mix(uint64_t t, uint64_t x) { return mix64(t ^ x) + 0x9E3779B97F4A7C15ull; }
+__device__ __forceinline__ uint64_t word_mix(uint64_t t, u128 x) {
+  t = mix64(t ^ (uint64_t)(x >> 64)) + 0x9E3779B97F4A7C15ull;
+  return mix64(t ^ (uint64_t)x) + 0x9E3779B97F4A7C15ull;
+}
+
+template <class W>
+struct SimtLdsT {
+  W *w;             // [T*Kmax][64]
+  W *pw;            // [Kmax][64]
   double *llk_t;    // [T][64]
   uint64_t *rngn;   // [T][64]
   double *prior;    // [2Kmax+5][64]
@@ -461,11 +481,12 @@ struct SimtLds {
   uint8_t *shift;   // [Mmax][64]
   uint8_t *nal;     // [Mmax][64]
 };
+typedef SimtLdsT<uint64_t> SimtLds;
 
-__host__ __device__ inline size_t simt_lds_bytes(int Kmax, int Mmax, int T) {
+__host__ __device__ inline size_t simt_lds_bytes(int Kmax, int Mmax, int T, int word_bytes = 8) {
   size_t b = 0;
-  b += (size_t)8 * T * Kmax * 64;
-  b += (size_t)8 * Kmax * 64;
+  b += (size_t)word_bytes * T * Kmax * 64;
+  b += (size_t)word_bytes * Kmax * 64;
   b += (size_t)8 * T * 64 * 2;
   b += (size_t)8 * (2 * Kmax + 5) * 64;
   b += (size_t)4 * Kmax * Kmax * 64;
@@ -499,12 +520,12 @@ __device__ __forceinline__ int wave_max_i(int v) {
 
 // per-lane helpers on the lane's haplotype words (row `base` .. base+K-1 of an LDS [..][64] array)
 // KT > 0: compile-time ploidy shared by every chain of the launch (loops unroll to exactly K); KT == 0: per-lane K
-template <int KT>
-__device__ __forceinline__ uint32_t lane_dosage_of_words(const uint64_t *arr, int base, int K, int lane) {
+template <int KT, class W>
+__device__ __forceinline__ uint32_t lane_dosage_of_words(const W *arr, int base, int K, int lane) {
   constexpr int KM = KT ? KT : MCHAP_MAX_PLOIDY;
-  uint64_t x[KM];
+  W x[KM];
 #pragma unroll
-  for (int h = 0; h < KM; h++) x[h] = h < K ? L_(arr, base + h) : 0ull;
+  for (int h = 0; h < KM; h++) x[h] = h < K ? L_(arr, base + h) : (W)0;
   uint32_t d = 0;
 #pragma unroll
   for (int h = 0; h < KM; h++)
@@ -524,10 +545,10 @@ __device__ __forceinline__ uint32_t lane_dosage_of_words(const uint64_t *arr, in
   return d;
 }
 
-template <int KT>
-__device__ __forceinline__ int lane_count_copies(const uint64_t *arr, int base, int K, int h, int lane) {
+template <int KT, class W>
+__device__ __forceinline__ int lane_count_copies(const W *arr, int base, int K, int h, int lane) {
   constexpr int KM = KT ? KT : MCHAP_MAX_PLOIDY;
-  const uint64_t x = L_(arr, base + h);
+  const W x = L_(arr, base + h);
   int n = 0;
 #pragma unroll
   for (int i = 0; i < KM; i++)
@@ -535,7 +556,8 @@ __device__ __forceinline__ int lane_count_copies(const uint64_t *arr, int base, 
   return n;
 }
 
-__device__ inline double lane_prior_of_dosage(const SimtLds &S, const Lane &c, uint32_t d, int lane) {
+template <class W>
+__device__ inline double lane_prior_of_dosage(const SimtLdsT<W> &S, const Lane &c, uint32_t d, int lane) {
   const int K = c.K;
   if (c.inbreeding == 0.0) {
     double den = 0.0;
@@ -550,18 +572,18 @@ __device__ inline double lane_prior_of_dosage(const SimtLds &S, const Lane &c, u
   return L_(S.prior, 2 * K + 2) + prod;
 }
 
-template <int KT>
-__device__ __forceinline__ double lane_words_prior(const SimtLds &S, const Lane &c, const uint64_t *arr, int base, int lane) {
+template <int KT, class W>
+__device__ __forceinline__ double lane_words_prior(const SimtLdsT<W> &S, const Lane &c, const W *arr, int base, int lane) {
   if (isnan(c.inbreeding)) return 0.0;
-  return lane_prior_of_dosage(S, c, lane_dosage_of_words<KT>(arr, base, KT ? KT : c.K, lane), lane);
+  return lane_prior_of_dosage(S, c, lane_dosage_of_words<KT, W>(arr, base, KT ? KT : c.K, lane), lane);
 }
 
-template <int KT>
-__device__ __forceinline__ uint32_t lane_segment_labels(const uint64_t *arr, int base, int K, uint64_t mask, int lane) {
+template <int KT, class W>
+__device__ __forceinline__ uint32_t lane_segment_labels(const W *arr, int base, int K, W mask, int lane) {
   constexpr int KM = KT ? KT : MCHAP_MAX_PLOIDY;
-  uint64_t x[KM];
+  W x[KM];
 #pragma unroll
-  for (int h = 0; h < KM; h++) x[h] = h < K ? (L_(arr, base + h) & mask) : 0ull;
+  for (int h = 0; h < KM; h++) x[h] = h < K ? (L_(arr, base + h) & mask) : (W)0;
   uint32_t lab = 0;
 #pragma unroll
   for (int h = 1; h < KM; h++) {
@@ -575,11 +597,13 @@ __device__ __forceinline__ uint32_t lane_segment_labels(const uint64_t *arr, int
   return lab;
 }
 
-__device__ __forceinline__ uint64_t lane_interval_mask(const Lane &c, int start, int stop) {
+template <class W>
+__device__ __forceinline__ W lane_interval_mask(const Lane &c, int start, int stop) {
+  constexpr int WB = WordBits<W>::value;
   const int nb = c.bits * (stop - start);
-  const uint64_t ones = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+  const W ones = nb >= WB ? ~(W)0 : (((W)1 << nb) - (W)1);
   const int sh = c.bits * (c.Mh - stop);
-  return sh >= 64 ? 0ull : ones << sh;
+  return sh >= WB ? (W)0 : ones << sh;
 }
 
 // Co-operative likelihood evaluation of the proposals S.pw[.][src] of every lane `src` with need set:
@@ -589,8 +613,8 @@ __device__ __forceinline__ uint64_t lane_interval_mask(const Lane &c, int start,
 // instead of one per position).
 // one request: RPL chunks of 64 reads per lane; the pair loop is unrolled so that UNR * RPL row loads are in
 // flight before the first multiply (one exposed memory latency per UNR pairs, not per pair)
-template <int RPL>
-__device__ __forceinline__ double coop_body(const SimtLds &S, int src, int K, int Mh, uint32_t amask, double invK,
+template <int RPL, class W>
+__device__ __forceinline__ double coop_body(const SimtLdsT<W> &S, int src, int K, int Mh, uint32_t amask, double invK,
                                             const double *rt, const double *cw, int rpad, int lane) {
   constexpr int UNR = RPL <= 4 ? 8 : (RPL == 8 ? 4 : 2);
   const int n_pairs = K * Mh;
@@ -606,7 +630,7 @@ __device__ __forceinline__ double coop_body(const SimtLds &S, int src, int K, in
       const int p = base + lane;
       if (p < n_pairs) {
         const int h = p / Mh, j = p - h * Mh;
-        const uint64_t wh = S.pw[(size_t)h * WAVE + src];
+        const W wh = S.pw[(size_t)h * WAVE + src];
         const uint32_t a = (uint32_t)(wh >> S.shift[(size_t)j * WAVE + src]) & amask;
         myrow = (int)S.cols[(size_t)j * WAVE + src] + (int)a;
       }
@@ -650,7 +674,8 @@ __device__ __forceinline__ double coop_body(const SimtLds &S, int src, int K, in
 // lanes over reads, coalesced 512-byte row reads of the unit's transposed tensor, wave butterfly sum.
 // The K*Mh row indices of a request are first computed one per lane and then broadcast with readlane, so the
 // global loads depend on nothing but registers.
-__device__ inline double coop_eval(bool need, const SimtLds &S, const Lane &c, int rpad, int lane) {
+template <class W>
+__device__ inline double coop_eval(bool need, const SimtLdsT<W> &S, const Lane &c, int rpad, int lane) {
   double result = 0.0;
   const int nch = rpad / WAVE;  // wave-uniform number of 64-read chunks
   unsigned long long todo = __ballot(need);
@@ -666,22 +691,23 @@ __device__ inline double coop_eval(bool need, const SimtLds &S, const Lane &c, i
     const double *rt = reinterpret_cast<const double *>((uintptr_t)rtb) + lane;
     const double *cw = reinterpret_cast<const double *>((uintptr_t)cwb) + lane;
     double s;
-    if (nch == 4) s = coop_body<4>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
-    else if (nch == 1) s = coop_body<1>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
-    else if (nch == 2) s = coop_body<2>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
-    else if (nch == 8) s = coop_body<8>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
-    else s = coop_body<16>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    if (nch == 4) s = coop_body<4, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    else if (nch == 1) s = coop_body<1, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    else if (nch == 2) s = coop_body<2, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    else if (nch == 8) s = coop_body<8, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    else s = coop_body<16, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
     if (lane == src) result = s;
   }
   return result;
 }
 
-__device__ __forceinline__ uint64_t lane_genotype_tag(const SimtLds &S, const Lane &c, int lane) {
+template <class W>
+__device__ __forceinline__ uint64_t lane_genotype_tag(const SimtLdsT<W> &S, const Lane &c, int lane) {
   uint64_t t = 0;
   if (c.key_bits * c.K <= 63) {
-    for (int h = 0; h < c.K; h++) t = (t << c.key_bits) | L_(S.pw, h);
+    for (int h = 0; h < c.K; h++) t = (t << c.key_bits) | (uint64_t)L_(S.pw, h);
   } else {
-    for (int h = 0; h < c.K; h++) t = mix64(t ^ L_(S.pw, h)) + 0x9E3779B97F4A7C15ull;
+    for (int h = 0; h < c.K; h++) t = word_mix(t, L_(S.pw, h));
   }
   return (t << 1) | 1ull;
 }
@@ -713,8 +739,8 @@ static __device__ unsigned long long g_stats[N_STATS];
 // The per-chain table is 4-way set associative (one 64-byte line per set): a hit in way k > 0 moves the entry one
 // way towards the front, a miss inserts into the last way, so the ~40 neighbours a converged chain proposes every
 // step stay resident however their keys collide.
-template <int KT>
-__device__ inline double lane_eval_cached(bool need, const SimtLds &S, const Lane &c, int rpad, int lane) {
+template <int KT, class W>
+__device__ inline double lane_eval_cached(bool need, const SimtLdsT<W> &S, const Lane &c, int rpad, int lane) {
   double val = 0.0;
   bool miss = need;
   uint64_t tag = 0;
@@ -759,7 +785,7 @@ __device__ inline double lane_eval_cached(bool need, const SimtLds &S, const Lan
       if (e.x == 0ull) wway = w;
     }
     if (hit >= 0) {
-      const uint64_t *kw = c.ckeys + (4 * si + hit) * c.key_words;
+      const W *kw = reinterpret_cast<const W *>(c.ckeys + (4 * si + hit) * c.key_words);  // (key_words = K words of W)
       bool same = true;
       for (int h = 0; h < c.K; h++) same = same && (kw[h] == L_(S.pw, h));
       if (same) {
@@ -778,7 +804,7 @@ __device__ inline double lane_eval_cached(bool need, const SimtLds &S, const Lan
     val = v;
     if (set) {
       if (wide) {
-        uint64_t *kw = c.ckeys + ((size_t)(set - c.cache) + wway) * c.key_words;
+        W *kw = reinterpret_cast<W *>(c.ckeys + ((size_t)(set - c.cache) + wway) * c.key_words);
         for (int h = 0; h < c.K; h++) kw[h] = L_(S.pw, h);
       }
       set[wide ? wway : 3] = make_ulonglong2(tag, (unsigned long long)__double_as_longlong(v));
@@ -788,20 +814,20 @@ __device__ inline double lane_eval_cached(bool need, const SimtLds &S, const Lan
 }
 
 // mutation.py:14-161 for every lane with act set; all lanes must call (co-operative evaluation inside)
-template <int KT>
-__device__ inline double simt_base_step(bool act, const SimtLds &S, Lane &c, int wb, double llk, int h, int j, double temp,
+template <int KT, class W>
+__device__ inline double simt_base_step(bool act, const SimtLdsT<W> &S, Lane &c, int wb, double llk, int h, int j, double temp,
                                         int amax, int rpad, int lane) {
   const int K = KT ? KT : c.K;
   int n_alleles = 0, sh = 0, current = 0;
   double lhapcount = 0.0, lprior = 0.0;
-  uint64_t wh = 0;
+  W wh = 0;
   if (act) {
     n_alleles = L_(S.nal, j);
     sh = L_(S.shift, j);
-    lhapcount = c_ln[lane_count_copies<KT>(S.w, wb, K, h, lane)];
-    lprior = lane_words_prior<KT>(S, c, S.w, wb, lane);
+    lhapcount = c_ln[lane_count_copies<KT, W>(S.w, wb, K, h, lane)];
+    lprior = lane_words_prior<KT, W>(S, c, S.w, wb, lane);
     wh = L_(S.w, wb + h);
-    current = (int)((wh >> sh) & c.amask);
+    current = (int)((uint32_t)(wh >> sh) & c.amask);
     for (int i = 0; i < K; i++) L_(S.pw, i) = L_(S.w, wb + i);
   }
   double la[MCHAP_MAX_ALLELE], lk[MCHAP_MAX_ALLELE];
@@ -814,15 +840,15 @@ __device__ inline double simt_base_step(bool act, const SimtLds &S, Lane &c, int
     const bool prop = act && i < n_alleles && i != current;
     if (prop) {
       n_options += 1;
-      L_(S.pw, h) = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)i << sh);
+      L_(S.pw, h) = (wh & ~((W)c.amask << sh)) | ((W)i << sh);
     }
-    const double llk_i = lane_eval_cached<KT>(prop, S, c, rpad, lane);
+    const double llk_i = lane_eval_cached<KT, W>(prop, S, c, rpad, lane);
     if (prop) {
       lk[i] = llk_i;
       const double llk_ratio = llk_i - llk;
       double lprior_ratio = 0.0;
-      if (!isnan(c.inbreeding)) lprior_ratio = lane_words_prior<KT>(S, c, S.pw, 0, lane) - lprior;
-      const double lproposal_ratio = c_ln[lane_count_copies<KT>(S.pw, 0, K, h, lane)] - lhapcount;
+      if (!isnan(c.inbreeding)) lprior_ratio = lane_words_prior<KT, W>(S, c, S.pw, 0, lane) - lprior;
+      const double lproposal_ratio = c_ln[lane_count_copies<KT, W>(S.pw, 0, K, h, lane)] - lhapcount;
       const double mh = (llk_ratio + lprior_ratio) * temp + lproposal_ratio;
       la[i] = fmin(0.0, mh);
     }
@@ -858,24 +884,24 @@ __device__ inline double simt_base_step(bool act, const SimtLds &S, Lane &c, int
     for (int i = 0; i < MCHAP_MAX_ALLELE; i++)
       if (i == choice) llk_new = lk[i];
   }
-  L_(S.w, wb + h) = (wh & ~((uint64_t)c.amask << sh)) | ((uint64_t)choice << sh);
+  L_(S.w, wb + h) = (wh & ~((W)c.amask << sh)) | ((W)choice << sh);
   return llk_new;
 }
 
 // structural.py:433-587 for every lane with act set
-template <int KT>
-__device__ inline double simt_interval_step(bool act, const SimtLds &S, Lane &c, int wb, double llk, int start, int stop,
+template <int KT, class W>
+__device__ inline double simt_interval_step(bool act, const SimtLdsT<W> &S, Lane &c, int wb, double llk, int start, int stop,
                                             int step_type, double temp, int rpad, int lane) {
   const int K = KT ? KT : c.K;
-  uint64_t min_ = 0;
+  W min_ = 0;
   uint32_t lout = 0;
   int n_options = 0;
   double lprior = 0.0, log_proposal_prob = 0.0, ln_opt = 0.0, u = 2.0;
   if (act) {
-    const uint64_t full = lane_interval_mask(c, 0, c.Mh);
-    min_ = lane_interval_mask(c, start, stop);
-    const uint32_t lin = lane_segment_labels<KT>(S.w, wb, K, min_, lane);
-    lout = lane_segment_labels<KT>(S.w, wb, K, full & ~min_, lane);
+    const W full = lane_interval_mask<W>(c, 0, c.Mh);
+    min_ = lane_interval_mask<W>(c, start, stop);
+    const uint32_t lin = lane_segment_labels<KT, W>(S.w, wb, K, min_, lane);
+    lout = lane_segment_labels<KT, W>(S.w, wb, K, full & ~min_, lane);
     // enumerate straight into the lane's LDS column
     {
       const uint32_t hd = dosage_of_labels(lin, lout, K, true);
@@ -908,7 +934,7 @@ __device__ inline double simt_interval_step(bool act, const SimtLds &S, Lane &c,
     if (n_options > 0) {
       log_proposal_prob = c_ln_inv[n_options];
       ln_opt = c_ln[n_options];
-      if (!isnan(c.inbreeding)) lprior = lane_words_prior<KT>(S, c, S.w, wb, lane);
+      if (!isnan(c.inbreeding)) lprior = lane_words_prior<KT, W>(S, c, S.w, wb, lane);
       u = rng_double(c.rng);  // the only draw of this step; the evaluations below consume none
     }
   }
@@ -923,7 +949,7 @@ __device__ inline double simt_interval_step(bool act, const SimtLds &S, Lane &c,
       oin = L_(S.optin, i);
       for (int h = 0; h < K; h++) L_(S.pw, h) = (L_(S.w, wb + h) & ~min_) | (L_(S.w, wb + nib(oin, h)) & min_);
     }
-    const double llk_i = lane_eval_cached<KT>(prop, S, c, rpad, lane);
+    const double llk_i = lane_eval_cached<KT, W>(prop, S, c, rpad, lane);
     if (prop) {
       const double llk_ratio = llk_i - llk;
       double lprior_ratio = 0.0;
@@ -948,32 +974,32 @@ __device__ inline double simt_interval_step(bool act, const SimtLds &S, Lane &c,
 }
 
 // structural.py:22-71 + 590-673 for every lane with act set.  Returns false for lanes that hit the ValueError.
-template <int KT>
-__device__ inline bool simt_structural_compound(bool act, const SimtLds &S, Lane &c, int wb, double &llk, int n_breaks,
+template <int KT, class W>
+__device__ inline bool simt_structural_compound(bool act, const SimtLdsT<W> &S, Lane &c, int wb, double &llk, int n_breaks,
                                                 bool whole, int step_type, double temp, int rpad, int lane) {
   bool ok = true;
-  uint64_t zeros = 0;  // bit i set = interval end point i
+  W zeros = 0;  // bit i set = interval end point i (n + 1 <= bits of W - 1: 62 / 126 positions)
   int n_int = 0;
   if (act) {
     const int n = c.Mh;
     if (whole) {
-      zeros = 1ull | (1ull << n);
+      zeros = (W)1 | ((W)1 << n);
       n_int = 1;
     } else if (n_breaks >= n) {
       ok = false;
       act = false;
     } else {
-      uint64_t ind = 0;
-      for (int i = 1; i < n; i++) ind |= 1ull << i;
+      W ind = 0;
+      for (int i = 1; i < n; i++) ind |= (W)1 << i;
       for (int b = 0; b < n_breaks; b++) {
-        const int no = __popcll(ind);
+        const int no = word_popc(ind);
         if (no == 0) break;
         int k = (int)rng_interval(c.rng, (uint32_t)(no - 1));
-        uint64_t t = ind;
+        W t = ind;
         while (k-- > 0) t &= t - 1;
         ind &= ~(t & (~t + 1));
       }
-      zeros = ~ind & ((1ull << (n + 1)) - 1ull);
+      zeros = ~ind & (((W)1 << (n + 1)) - (W)1);
       n_int = n_breaks + 1;
     }
     if (act) {
@@ -993,19 +1019,20 @@ __device__ inline bool simt_structural_compound(bool act, const SimtLds &S, Lane
     if (a2) {
       const int iv = L_(S.sub, i);
       // end points iv and iv+1 = the (iv)-th and (iv+1)-th set bits of zeros
-      uint64_t z = zeros;
+      W z = zeros;
       for (int q = 0; q < iv; q++) z &= z - 1;
-      start = __ffsll((long long)z) - 1;
+      start = word_ffs(z) - 1;
       z &= z - 1;
-      stop = __ffsll((long long)z) - 1;
+      stop = word_ffs(z) - 1;
     }
-    llk = simt_interval_step<KT>(a2, S, c, wb, llk, start, stop, step_type, temp, rpad, lane);
+    llk = simt_interval_step<KT, W>(a2, S, c, wb, llk, start, stop, step_type, temp, rpad, lane);
   }
   return ok;
 }
 
-template <int KT>
+template <int KT, class W = uint64_t>
 __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
+  constexpr int NW = (int)sizeof(W) / 8;  // uint64 words of the trace per haplotype (most significant first)
   extern __shared__ __align__(16) unsigned char smem[];
   const DenovoParams &D = P.d;
   const int lane = threadIdx.x;
@@ -1013,11 +1040,11 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
   const int Kmax = P.max_ploidy, Mmax = P.max_pos;
   const int rpad = D.rpad;
   // LDS carve (lane-strided arrays)
-  SimtLds S;
+  SimtLdsT<W> S;
   {
     unsigned char *p = smem;
-    S.w = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * T * Kmax * 64;
-    S.pw = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * Kmax * 64;
+    S.w = reinterpret_cast<W *>(p); p += sizeof(W) * T * Kmax * 64;
+    S.pw = reinterpret_cast<W *>(p); p += sizeof(W) * Kmax * 64;
     S.llk_t = reinterpret_cast<double *>(p); p += (size_t)8 * T * 64;
     S.rngn = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * T * 64;
     S.prior = reinterpret_cast<double *>(p); p += (size_t)8 * (2 * Kmax + 5) * 64;
@@ -1072,15 +1099,15 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
     if (U.initial_off >= 0) {
       const int8_t *ini = D.initial + U.initial_off + (size_t)chain * K * Mh;
       for (int h = 0; h < K; h++) {
-        uint64_t x = 0;
-        for (int j = 0; j < Mh; j++) x |= (uint64_t)(uint8_t)ini[h * Mh + j] << L_(S.shift, j);
+        W x = 0;
+        for (int j = 0; j < Mh; j++) x |= (W)(uint8_t)ini[h * Mh + j] << L_(S.shift, j);
         L_(S.w, h) = x;
       }
     } else {
       const double *dist = mf + meta_f_dist(P.max_ploidy);
       rng_open(c.rng, D.seed, U.stream_id, (uint32_t)chain, SLOT_INIT, 0);
       for (int h = 0; h < K; h++) {
-        uint64_t x = 0;
+        W x = 0;
         for (int j = 0; j < Mh; j++) {
           double s = 0.0;
           for (int a = 0; a < A; a++) s += dist[j * A + a];
@@ -1095,7 +1122,7 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
             }
           }
           if (ch >= A) ch = A - 1;
-          x |= (uint64_t)ch << L_(S.shift, j);
+          x |= (W)ch << L_(S.shift, j);
         }
         L_(S.w, h) = x;
       }
@@ -1114,7 +1141,7 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
   }
   const double *break_dist = D.break_table + (size_t)Mh * D.max_pos;
   const int n_break_dist = D.n_intervals > 0 ? D.n_intervals : Mh;
-  const size_t trace_base = U.trace_off + (size_t)chain * Sn * K;
+  const size_t trace_base = U.trace_off + (size_t)chain * Sn * K * NW;
   const size_t llk_base = U.llk_off + (size_t)chain * Sn;
   int status = MCHAP_UNIT_OK;
   const int nsub = K * Mh;
@@ -1153,7 +1180,7 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
           h = s >> 8;
           j = s & 255;
         }
-        llk = simt_base_step<KT>(act, S, c, wb, llk, h, j, temp, amax, rpad, lane);
+        llk = simt_base_step<KT, W>(act, S, c, wb, llk, h, j, temp, amax, rpad, lane);
       }
       for (int kind = 0; kind < 3; kind++) {
         bool act = false;
@@ -1170,7 +1197,7 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
             }
           }
         }
-        const bool ok = simt_structural_compound<KT>(act, S, c, wb, llk, nb, kind == 2, kind == 2 ? 1 : kind, temp, rpad, lane);
+        const bool ok = simt_structural_compound<KT, W>(act, S, c, wb, llk, nb, kind == 2, kind == 2 ? 1 : kind, temp, rpad, lane);
         if (!ok) {
           status = MCHAP_UNIT_BREAKS;
           c.alive = false;
@@ -1181,15 +1208,15 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
           // tempering.py:61-151
           const int wj = (t - 1) * Kmax;
           double llk_j = L_(S.llk_t, t - 1);
-          const double prior_i = lane_words_prior<KT>(S, c, S.w, wb, lane);
-          const double prior_j = lane_words_prior<KT>(S, c, S.w, wj, lane);
+          const double prior_i = lane_words_prior<KT, W>(S, c, S.w, wb, lane);
+          const double prior_j = lane_words_prior<KT, W>(S, c, S.w, wj, lane);
           const double ui = llk + prior_i, uj = llk_j + prior_j;
           double acc = exp((uj - ui) * temp + (ui - uj) * D.temps[t - 1]);
           if (acc > 1.0) acc = 1.0;
           const double val = rng_double(c.rng);
           if (acc >= val) {
             for (int h = 0; h < K; h++) {
-              const uint64_t x = L_(S.w, wb + h);
+              const W x = L_(S.w, wb + h);
               L_(S.w, wb + h) = L_(S.w, wj + h);
               L_(S.w, wj + h) = x;
             }
@@ -1207,13 +1234,18 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
       // record the cold chain with its haplotypes in canonical order (assemble/classes.py:265-278)
       const int wb = (T - 1) * Kmax;
       for (int h = 0; h < K; h++) {
-        const uint64_t x = L_(S.w, wb + h);
+        const W x = L_(S.w, wb + h);
         int rank = 0;
         for (int g = 0; g < K; g++) {
-          const uint64_t y = L_(S.w, wb + g);
+          const W y = L_(S.w, wb + g);
           rank += (y < x || (y == x && g < h)) ? 1 : 0;
         }
-        D.trace[trace_base + (size_t)step * K + rank] = x;
+        if (NW == 1) {
+          D.trace[trace_base + (size_t)step * K + rank] = (uint64_t)x;
+        } else {
+          D.trace[trace_base + ((size_t)step * K + rank) * 2] = (uint64_t)((u128)x >> 64);
+          D.trace[trace_base + ((size_t)step * K + rank) * 2 + 1] = (uint64_t)x;
+        }
       }
       D.llks[llk_base + step] = L_(S.llk_t, T - 1);
     }

@@ -60,6 +60,9 @@ SPEC_LIST(DECL_SPEC)
 SPECP_LIST(DECL_SPECP)
 SPECS_LIST(DECL_SPECS)
 SIMT_LIST(DECL_SIMT)
+// ... and its instantiation with 128-bit haplotype words (simt_inst.hip -DSIMT_WIDE): the general fallback for wide targets
+extern "C" int mchap_simt_init_w(const double *, const double *);
+extern "C" int mchap_simt_launch_w(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 extern "C" int mchap_coast_launch(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
 // table completion of the phased sampler, one workgroup per chain and one wavefront per request (denovo_fillw_kernel.hpp): shipped
 #define FILLW_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
@@ -185,7 +188,7 @@ int ensure_init() {
 #define ROW_LANE_INIT(k) mchap_lane_init_##k,
 #define ROW_FILL_INIT(k) mchap_fill_init_##k,
 #define ROW_FILLW_INIT(k) mchap_fillw_init_##k,
-    const init_fn inits[] = {SIMT_LIST(ROW_SIMT_INIT) FILLW_LIST(ROW_FILLW_INIT)
+    const init_fn inits[] = {SIMT_LIST(ROW_SIMT_INIT) mchap_simt_init_w, FILLW_LIST(ROW_FILLW_INIT)
 #ifdef MCHAP_TEST_KERNELS
                                  FILL_LIST(ROW_FILL_INIT) V1_LIST(ROW_V1_INIT) LANE_LIST(ROW_LANE_INIT)
 #endif
@@ -329,7 +332,7 @@ int batch_dims(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units
     if (U.ploidy < 1 || U.ploidy > MCHAP_MAX_PLOIDY) return fail(MCHAP_ERR_LIMIT, "unit %d: ploidy %d not in 1..%d", u, U.ploidy, MCHAP_MAX_PLOIDY);
     if (U.max_allele < 1 || U.max_allele > MCHAP_MAX_ALLELE) return fail(MCHAP_ERR_LIMIT, "unit %d: max_allele %d not in 1..%d", u, U.max_allele, MCHAP_MAX_ALLELE);
     if (U.n_reads < 1 || U.n_reads > MCHAP_MAX_READS) return fail(MCHAP_ERR_LIMIT, "unit %d: n_reads %d not in 1..%d (zero reads are mocked by the caller as one NaN read)", u, U.n_reads, MCHAP_MAX_READS);
-    if (U.n_pos < 1 || U.n_pos > 62) return fail(MCHAP_ERR_LIMIT, "unit %d: n_pos %d not in 1..62", u, U.n_pos);
+    if (U.n_pos < 1 || U.n_pos > MCHAP_MAX_POS) return fail(MCHAP_ERR_LIMIT, "unit %d: n_pos %d not in 1..%d", u, U.n_pos, MCHAP_MAX_POS);
     if (cfg->n_intervals == 0 && U.n_pos > cfg->max_pos) return fail(MCHAP_ERR_BAD_ARG, "unit %d: n_pos exceeds break_table", u);
     B.max_reads = std::max(B.max_reads, U.n_reads);
     B.min_reads = std::min(B.min_reads, U.n_reads);
@@ -408,9 +411,21 @@ bool use_simt(const mchap_denovo_cfg *cfg) { return cfg->kernel != 1; }
 enum SamplerKind { SAMPLER_V1 = 1, SAMPLER_SIMT = 2, SAMPLER_SPEC = 3, SAMPLER_LANE = 4, SAMPLER_PIPE = 5 };
 struct Plan {
   int kind = 0, K = 0, G = 0, rpl = 0;
+  bool wide = false;  // 128-bit haplotype words: denovo_simt_kernel<0, u128>
 };
+// A batch whose units may need more than 64 bits of sampled alleles per haplotype, or hold more than 62 SNVs (the 64-bit
+// samplers keep a unit's interval end points in one word): the lanes-over-chains sampler with 128-bit words takes it.
+bool wide_batch(const BatchDims &B) { return mchap::allele_bits(B.max_allele) * B.max_pos > 64 || B.max_pos > 62; }
 int plan_sampler(const mchap_denovo_cfg *cfg, const Tune &T, const BatchDims &B, Plan &pl) {
   pl.K = B.uniform_ploidy;
+  if (use_simt(cfg) && wide_batch(B)) {
+    pl.rpl = rpl_for(B.max_reads);
+    if (pl.rpl < 0) return fail(MCHAP_ERR_LIMIT, "n_reads %d: the sampler for targets wider than 64 bits takes 1..1024 reads", B.max_reads);
+    pl.kind = SAMPLER_SIMT;
+    pl.K = 0;
+    pl.wide = true;
+    return MCHAP_OK;
+  }
   pl.rpl = use_simt(cfg) ? simt_rpl(cfg, T, B.uniform_ploidy, B.max_pos, B.max_reads) : rpl_for(B.max_reads);
   if (pl.rpl < 0)
     return fail(MCHAP_ERR_LIMIT, "n_reads %d: the sampler kernel for this batch takes 1..%d reads", B.max_reads,
@@ -434,7 +449,10 @@ int plan_sampler(const mchap_denovo_cfg *cfg, const Tune &T, const BatchDims &B,
 void plan_name(const Plan &pl, char *out, size_t n) {
   switch (pl.kind) {
     case SAMPLER_V1: snprintf(out, n, "denovo_mcmc_kernel<%d>", pl.rpl); break;
-    case SAMPLER_SIMT: snprintf(out, n, "denovo_simt_kernel<%d>", pl.K); break;
+    case SAMPLER_SIMT:
+      if (pl.wide) snprintf(out, n, "denovo_simt_kernel<0, u128>");
+      else snprintf(out, n, "denovo_simt_kernel<%d>", pl.K);
+      break;
     case SAMPLER_SPEC: snprintf(out, n, "denovo_spec_kernel<%d, %d>", pl.K, pl.G); break;
     case SAMPLER_LANE: snprintf(out, n, "denovo_settle_kernel<%d> + denovo_steady_kernel<%d>", pl.K, pl.K); break;
     default: snprintf(out, n, "denovo_spec_kernel<%d, %d, phased> + denovo_coast_kernel", pl.K, pl.G); break;
@@ -457,7 +475,7 @@ SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, c
   c.cache = o; o += up256(nc * cache_slots * 16);
   // genotypes of more than 63 bits: their words beside the (hashed) tags, so that a cache hit is always exact
   if (cache_slots > 0 && B.max_ploidy * mchap::allele_bits(B.max_allele) * B.max_pos > 63) {
-    c.key_words = B.max_ploidy;
+    c.key_words = B.max_ploidy * (pl.wide ? 2 : 1);  // (uint64 words per entry: K haplotype words of 64 or 128 bits)
     c.ckeys = o; o += up256(nc * cache_slots * c.key_words * 8);
   }
   c.rt = o; o += up256((size_t)n_units * B.max_ma * rpad * 8);
@@ -498,8 +516,9 @@ int launch_prepare(const mchap::SimtParams &P, int n_units, size_t lds_prep, hip
   return MCHAP_OK;
 }
 
-int launch_simt(int KT, const mchap::SimtParams &P, int n_units, int chains, size_t lds_simt, void *timer, hipStream_t stream) {
-  simt_launch_fn launch =
+int launch_simt(int KT, const mchap::SimtParams &P, int n_units, int chains, size_t lds_simt, void *timer, hipStream_t stream,
+                bool wide = false) {
+  simt_launch_fn launch = wide ? mchap_simt_launch_w :
       KT == 2 ? mchap_simt_launch_2 : KT == 4 ? mchap_simt_launch_4 : KT == 6 ? mchap_simt_launch_6 : KT == 8 ? mchap_simt_launch_8 : mchap_simt_launch_0;
   const long long n_chains = (long long)n_units * chains;
   SamplerTimer tm(timer, stream);
@@ -738,6 +757,15 @@ int mchap_denovo_sampler_name(const mchap_denovo_cfg *cfg, int n_units, const mc
   if (rc) return rc;
   plan_name(pl, out, (size_t)out_len);
   return MCHAP_OK;
+}
+
+int mchap_denovo_trace_words_per_haplotype(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host) {
+  if (validate_cfg(cfg) || !units_host || n_units < 1) return -1;
+  BatchDims B;
+  if (batch_dims(cfg, n_units, units_host, B)) return -1;
+  Plan pl;
+  if (plan_sampler(cfg, tune_of(cfg), B, pl)) return -1;
+  return pl.wide ? 2 : 1;
 }
 
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
@@ -1005,7 +1033,8 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
       lds_prep += (size_t)B.max_allele * rpad * 8;
       SP.flags |= mchap::SIMT_FLAG_PREP_GLOBAL;
     }
-    const size_t lds_simt = mchap::simt_lds_bytes(B.max_ploidy, B.max_pos, cfg->n_temps);
+    const size_t lds_simt = mchap::simt_lds_bytes(B.max_ploidy, B.max_pos, cfg->n_temps, pl.wide ? 16 : 8);
+    SP.word_bits = pl.wide ? 128 : 64;
     if (lds_prep > 160 * 1024 || lds_simt > 160 * 1024)
       return fail(MCHAP_ERR_LIMIT, "a unit needs %zu / %zu bytes of LDS (> 160 KiB)", lds_prep, lds_simt);
     auto prepare = [&](const mchap::SimtParams &Q, int n, hipStream_t st) {
@@ -1036,7 +1065,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
         return launch_pipe(T, pl.K, pl.G, SP, n_units, cfg->chains, reinterpret_cast<int32_t *>(ws + cv.pipe_lists),
                            reinterpret_cast<int32_t *>(ws + cv.pipe_counts), cfg->timer, stream, B.min_reads <= 64);
       case SAMPLER_SPEC: return launch_spec(T, pl.K, pl.G, SP, n_units, cfg->chains, cfg->n_temps, cfg->timer, stream);
-      default: return launch_simt(pl.K, SP, n_units, cfg->chains, lds_simt, cfg->timer, stream);  // lanes over chains
+      default: return launch_simt(pl.K, SP, n_units, cfg->chains, lds_simt, cfg->timer, stream, pl.wide);  // lanes over chains
     }
   }
 

@@ -150,6 +150,9 @@ class DenovoDeviceBatch(_OwnBuffers):
         self.ws_bytes = int(L.mchap_denovo_workspace_bytes(C.byref(self.cfg), U, _lib.ptr(units)))
         if self.ws_bytes < 0:
             raise NotImplementedError("mchap_hip: unsupported unit shape")
+        if int(L.mchap_denovo_trace_words_per_haplotype(C.byref(self.cfg), U, _lib.ptr(units))) != 1:
+            raise NotImplementedError("DenovoDeviceBatch holds one trace word per haplotype: units wider than 62 SNVs / 64 bits go "
+                                      "through DenovoMCMC.fit_batch or DenovoRaggedBatch")
         self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
         self.post = None
         self.sampler_name = _lib.sampler_name(self.cfg, units)
@@ -424,6 +427,13 @@ class DenovoRaggedBatch(_OwnBuffers):
             D["stream_id"] = int(u.get("stream_id", 0))
         self.units_host = desc
         self.n_units = U
+        self.cfg = model._cfg(self.max_pos)
+        # uint64 words per haplotype of the traces: 2 when the batch holds a unit of more than 62 SNVs / 64 bits per haplotype
+        self.wph = int(_lib.lib().mchap_denovo_trace_words_per_haplotype(C.byref(self.cfg), U, _lib.ptr(desc)))
+        if self.wph < 1:
+            raise NotImplementedError("mchap_hip: unsupported unit shape (" + _lib.last_error() + ")")
+        desc["trace_off"] *= self.wph
+        t_off *= self.wph
         self.d_units = torch.from_numpy(desc.view(np.uint8).reshape(-1)).to(dev)
         self.d_reads = torch.from_numpy(np.concatenate(r_parts)).to(dev)
         self.d_counts = torch.from_numpy(np.concatenate(c_parts)).to(dev) if c_parts else None
@@ -441,8 +451,57 @@ class DenovoRaggedBatch(_OwnBuffers):
     def _p(self, t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
+    def _run_wide(self, burn, incongruence_threshold):
+        """A batch with a unit wider than 64 bits per haplotype (two words per haplotype in the traces): the sampler only; the
+        posterior summaries of such batches are formed by the host classes in results()."""
+        stream = self._begin().cuda_stream
+        type(self).n_runs += 1
+        _lib.check(_lib.lib().mchap_denovo_fit_batch_device(
+            C.byref(self.cfg), self.n_units, self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_reads), self._p(self.d_counts),
+            self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks), self._p(self.d_fixed),
+            self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream)))
+        self.burn = int(burn)
+        self.incongruence_threshold = float(incongruence_threshold)
+        self._end()
+
+    def _results_wide(self, raise_on_limit):
+        from .classes import GenotypeMultiTrace
+
+        self._begin()
+        status = self.d_status.cpu().numpy()
+        fixed = self.d_fixed.cpu().numpy()
+        trace = self.d_trace.cpu().numpy().view(np.uint64)
+        llks = self.d_llks.cpu().numpy()
+        out = []
+        for u in range(self.n_units):
+            D = self.units_host[u]
+            Ku, M, A = int(D["ploidy"]), int(D["n_pos"]), int(D["max_allele"])
+            st = int(status[u])
+            if st == _lib.UNIT_NAN_LLK:
+                raise ValueError("Encountered log likelihood of nan")
+            if st == _lib.UNIT_BREAKS:
+                raise ValueError("breaks must be smaller then n")
+            if st < 0:
+                if raise_on_limit:
+                    raise NotImplementedError("mchap_hip: unit %d exceeds the packed haplotype width" % u)
+                out.append(dict(status=st, limit="more than 128 bits of sampled alleles per haplotype"))
+                continue
+            fx = fixed[int(D["fixed_off"]): int(D["fixed_off"]) + M]
+            w = trace[int(D["trace_off"]): int(D["trace_off"]) + self.Cn * self.S * Ku * 2].reshape(self.Cn, self.S, Ku, 2)
+            g = unpack_trace(w, fx, A, 2)
+            lk = llks[int(D["llk_off"]): int(D["llk_off"]) + self.Cn * self.S].reshape(self.Cn, self.S)
+            tr = GenotypeMultiTrace._from_sorted(g, lk).burn(self.burn)
+            post = tr.posterior()
+            sup = post.mode_genotype_support()
+            mg, gp = sup.mode_genotype()
+            out.append(dict(genotypes=post.genotypes, probabilities=post.probabilities, spm=float(sup.probabilities.sum()),
+                            gpm=float(gp), mode_genotype=mg, mci=int(tr.replicate_incongruence(self.incongruence_threshold)), status=st))
+        return out
+
     def run(self, burn, max_states=512, incongruence_threshold=0.6):
         """Sampler, posterior summary and incongruence code, all enqueued on torch's current stream."""
+        if self.wph > 1:
+            return self._run_wide(burn, incongruence_threshold)
         torch = self.torch
         dev = self.device
         U, K = self.n_units, self.Kmax
@@ -481,6 +540,8 @@ class DenovoRaggedBatch(_OwnBuffers):
         back as dict(status, limit=reason)."""
         from .classes import GenotypeMultiTrace
 
+        if self.wph > 1:
+            return self._results_wide(raise_on_limit)
         U, K, ms = self.n_units, self.Kmax, self.max_states
         self._begin()  # (the pass may have been issued on another stream)
         words = self.p_words.cpu().numpy().view(np.uint64).reshape(U, ms, K)

@@ -25,7 +25,7 @@ extern "C" {
 
 #define ORC_MAX_TEMPS 16
 #define ORC_MAX_PLOIDY 16
-#define ORC_MAX_POS 64
+#define ORC_MAX_POS 128  /* (64 until round 4: the wide sampler is checked at 80 / 120 SNVs) */
 #define ORC_MAX_ALLELE 8
 
 enum { ORC_RNG_PHILOX = 0, ORC_RNG_NUMPY_MT19937 = 1 };

@@ -1,7 +1,8 @@
-"""GPU: targets beyond the library's limits neither end a run nor vanish from its output.  The reference has no limit on the SNVs
-of a target; this build takes 62 SNVs per target and 64 bits of sampled alleles per haplotype (one bit per biallelic SNV, two per
-tri- / tetra-allelic one).  `application.assemble` writes such a target's record with null genotypes and FILTER=LIMIT (declared
-in the header), warns on stderr, and the command line exits with status 3; the other targets are not affected."""
+"""GPU: wide targets in the program, and targets beyond the library's limits.  The reference has no limit on the SNVs of a target.
+This build runs up to 62 SNVs / 64 bits of sampled alleles per haplotype (one bit per biallelic SNV, two per tri- / tetra-allelic
+one) on its fast samplers, up to 126 SNVs / 128 bits on the general sampler with 128-bit haplotype words (round 4: such targets used
+to be refused) -- and beyond that `application.assemble` writes the target's record with null genotypes and FILTER=LIMIT (declared in
+the header), warns on stderr, and the command line exits with status 3; the other targets are not affected."""
 import numpy as np
 import pytest
 
@@ -31,7 +32,8 @@ def test_targets_beyond_the_limits_are_written_with_a_filter(capsys):
     from mchap_amd import application
 
     rng = np.random.default_rng(5)
-    specs = [("ok1", 100, 6, "AC"), ("toomany", 1000, 70, "AC"), ("toowide", 2000, 40, "ACG"), ("ok2", 3000, 9, "AG"), ("wide_ok", 4000, 44, "AC")]
+    specs = [("ok1", 100, 6, "AC"), ("toomany", 1000, 130, "AC"), ("toowide", 2000, 70, "ACG"), ("ok2", 3000, 9, "AG"), ("wide_ok", 4000, 44, "AC"),
+             ("wide70", 5000, 70, "AC"), ("wide40x2", 6000, 40, "ACG")]   # (70 biallelic / 40 tri-allelic SNVs: refused until round 4)
     targets, variants, matrices = [], [], {}
     for name, start, n, al in specs:
         t, v, m = _target(name, start, n, al, rng)
@@ -41,22 +43,22 @@ def test_targets_beyond_the_limits_are_written_with_a_filter(capsys):
     source = application.MatrixSource(["S1"], matrices)
     lines = list(application.assemble(None, variants, {"c1": _NSeq()}, source, ploidy=4, steps=120, burn=60, chains=2, seed=3, targets=targets))
     names = [ln.split("\t")[2] for ln in lines]
-    assert names == ["ok1", "toomany", "toowide", "ok2", "wide_ok"]   # every target has its record, in target order
+    assert names == ["ok1", "toomany", "toowide", "ok2", "wide_ok", "wide70", "wide40x2"]   # every target has its record, in target order
     by = {ln.split("\t")[2]: ln.split("\t") for ln in lines}
-    for nm in ("ok1", "ok2", "wide_ok"):  # (44 biallelic SNVs: 176 sub-steps per step, the phased sampler's widest shape)
+    for nm in ("ok1", "ok2", "wide_ok", "wide70", "wide40x2"):  # (44 biallelic SNVs: the phased sampler's widest shape)
         assert by[nm][6] in ("PASS", "NOA") and "." not in by[nm][9].split(":")[0]
-    for nm, n_snv in (("toomany", 70), ("toowide", 40)):
+    for nm, n_snv in (("toomany", 130), ("toowide", 70)):
         f = by[nm]
         assert f[4] == "." and f[6] == "LIMIT" and "NVAR=%d;" % n_snv in f[7] and f[7].startswith("AN=0;UAN=0;AC=.;NS=0")
         assert f[8].split(":")[0] == "GT" and f[9].split(":")[0] == "./././." and len(f[9].split(":")) == len(f[8].split(":"))
         assert len(f[3]) == 3 * n_snv  # the reference sequence of the target
     err = capsys.readouterr().err
-    assert "target toomany" in err and "70 SNVs" in err
-    assert "target toowide" in err and "64 bits" in err
+    assert "target toomany" in err and "130 SNVs" in err
+    assert "target toowide" in err and "128 bits" in err
     # the records of the targets that ran do not depend on their neighbours
     alone = list(application.assemble(None, variants, {"c1": _NSeq()}, source, ploidy=4, steps=120, burn=60, chains=2, seed=3,
-                                      targets=[targets[0], targets[3], targets[4]]))
-    assert alone == [lines[0], lines[3], lines[4]]
+                                      targets=[targets[0], targets[3], targets[4], targets[5]]))
+    assert alone == [lines[0], lines[3], lines[4], lines[5]]
     from mchap_amd import vcfheader
 
     assert any(ln.startswith("##FILTER=<ID=LIMIT,") for ln in vcfheader.header_lines("assemble", "x", ["S1"], [("c1", 9000)]))
