@@ -153,6 +153,11 @@ __device__ __forceinline__ uint32_t nib(uint32_t p, int h) { return (p >> (4 * h
 __device__ __forceinline__ uint32_t nib_set(uint32_t p, int h, uint32_t v) {
   return (p & ~(15u << (4 * h))) | (v << (4 * h));
 }
+// ... and packs of sixteen nibbles (ploidies 9 to 15: the general lanes-over-chains sampler, denovo_simt_kernel<0, u128>)
+__device__ __forceinline__ uint32_t nib(uint64_t p, int h) { return (uint32_t)(p >> (4 * h)) & 15u; }
+__device__ __forceinline__ uint64_t nib_set(uint64_t p, int h, uint32_t v) {
+  return (p & ~(15ull << (4 * h))) | ((uint64_t)v << (4 * h));
+}
 
 // jitutils.py:7-26
 __device__ __forceinline__ double add_log_prob(double x, double y) {
@@ -173,16 +178,17 @@ __device__ __forceinline__ int choose_from(const double *p, int n, double u) {
 
 // first-occurrence dosage of the rows (in[h], out[h]) (jitutils.py:378-422 on label rows);
 // a zero nibble marks a duplicate.
-__device__ __forceinline__ uint32_t dosage_of_labels(uint32_t in, uint32_t out, int K, bool use_out) {
-  uint32_t d = 0;
-  for (int h = 0; h < K; h++) d |= 1u << (4 * h);
+template <class P>
+__device__ __forceinline__ P dosage_of_labels(P in, P out, int K, bool use_out) {
+  P d = 0;
+  for (int h = 0; h < K; h++) d |= (P)1 << (4 * h);
   for (int h = 0; h < K; h++) {
     if (nib(d, h) == 0) continue;
     for (int p = h + 1; p < K; p++) {
       if (nib(d, p) == 0) continue;
       if (nib(in, h) == nib(in, p) && (!use_out || nib(out, h) == nib(out, p))) {
-        d += 1u << (4 * h);
-        d &= ~(15u << (4 * p));
+        d += (P)1 << (4 * h);
+        d &= ~((P)15 << (4 * p));
       }
     }
   }
@@ -190,8 +196,9 @@ __device__ __forceinline__ uint32_t dosage_of_labels(uint32_t in, uint32_t out, 
 }
 
 // structural.py:74-118
-__device__ __forceinline__ int recombination_n_options(uint32_t in, uint32_t out, int K) {
-  const uint32_t d = dosage_of_labels(in, out, K, true);
+template <class P>
+__device__ __forceinline__ int recombination_n_options(P in, P out, int K) {
+  const P d = dosage_of_labels(in, out, K, true);
   int n = 0;
   for (int h0 = 0; h0 < K; h0++) {
     if (nib(d, h0) == 0) continue;
@@ -205,9 +212,10 @@ __device__ __forceinline__ int recombination_n_options(uint32_t in, uint32_t out
 }
 
 // structural.py:181-237
-__device__ __forceinline__ int dosage_n_options(uint32_t in, uint32_t out, int K) {
-  const uint32_t hd = dosage_of_labels(in, out, K, true);
-  const uint32_t sd = dosage_of_labels(in, out, K, false);
+template <class P>
+__device__ __forceinline__ int dosage_n_options(P in, P out, int K) {
+  const P hd = dosage_of_labels(in, out, K, true);
+  const P sd = dosage_of_labels(in, out, K, false);
   int n = 0;
   for (int h0 = 0; h0 < K; h0++) {
     if (nib(hd, h0) == 0) continue;
@@ -617,7 +625,8 @@ __device__ inline double snv_log_prior(uint32_t g, int K, int n_alleles, double 
 }
 
 // jitutils.py:114-146 on a nibble pack
-__device__ inline uint32_t increment_snv_genotype(uint32_t g, int K) {
+template <class P>
+__device__ inline P increment_snv_genotype(P g, int K) {
   if (K == 1) return g + 1;
   const uint32_t previous = nib(g, 0);
   for (int i = 1; i < K; i++) {

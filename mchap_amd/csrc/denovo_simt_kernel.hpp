@@ -263,8 +263,9 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
   // inbreeding, lgamma(dose + alpha_n), lgamma(alpha_n) and the normaliser for every allele count n: a few dozen
   // distinct values per unit.  Every lane used to recompute K + 1 of them per genotype (200 calls of ~400
   // instructions per unit: 60 % of this pass); now each value is formed once, one per lane.
-  __shared__ double s_lg1[MCHAP_MAX_PLOIDY + 1];                              // lgamma(d + 1)
-  __shared__ double s_lga[(MCHAP_MAX_ALLELE + 1) * (MCHAP_MAX_PLOIDY + 1)];   // lgamma(d + alpha_n), d >= 1
+  constexpr int KP = MCHAP_MAX_PLOIDY_DENOVO;  // (the prepare pass serves every sampler: ploidies up to 15, packs of sixteen nibbles)
+  __shared__ double s_lg1[KP + 1];                              // lgamma(d + 1)
+  __shared__ double s_lga[(MCHAP_MAX_ALLELE + 1) * (KP + 1)];   // lgamma(d + alpha_n), d >= 1
   __shared__ double s_lgb[MCHAP_MAX_ALLELE + 1], s_left[MCHAP_MAX_ALLELE + 1];  // lgamma(alpha_n); normaliser
   const double Fp = U.inbreeding;
   const bool with_prior = !isnan(Fp);
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
     if (Fp != 0.0) {
       for (int e = lane; e < (A + 1) * (K + 1); e += WAVE) {
         const int n = e / (K + 1), d = e % (K + 1);
-        if (n >= 1 && d >= 1) s_lga[n * (MCHAP_MAX_PLOIDY + 1) + d] = lgamma((double)d + (1.0 / (double)n) * ((1.0 - Fp) / Fp));
+        if (n >= 1 && d >= 1) s_lga[n * (KP + 1) + d] = lgamma((double)d + (1.0 / (double)n) * ((1.0 - Fp) / Fp));
       }
       for (int n = 1 + lane; n <= A; n += WAVE) {
         const double alpha = (1.0 / (double)n) * ((1.0 - Fp) / Fp);
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
     __syncthreads();
   }
   // snv_log_prior(g, K, n, F) from the tables: same arguments to the same lgamma, same order of the sums
-  auto snv_prior = [&](uint32_t g, int n) -> double {
-    int dose[MCHAP_MAX_PLOIDY];
+  auto snv_prior = [&](uint64_t g, int n) -> double {
+    int dose[KP];
     for (int i = 0; i < K; i++) dose[i] = 0;
     for (int i = 0; i < K; i++) {
       int j = 0;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
     }
     double prod = 0.0;
     for (int i = 0; i < K; i++)
-      if (dose[i] > 0) prod += s_lga[n * (MCHAP_MAX_PLOIDY + 1) + dose[i]] - (s_lg1[dose[i]] + s_lgb[n]);
+      if (dose[i] > 0) prod += s_lga[n * (KP + 1) + dose[i]] - (s_lg1[dose[i]] + s_lgb[n]);
     return s_left[n] + prod;
   };
   // without the LDS copy of the whole table, the A rows of the current position are staged in LDS (each lane its own
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
         for (int i = 0; i < RPL; i++) pl[(size_t)a * rpad + lane + WAVE * i] = rt[(size_t)(j * A + a) * rpad + lane + WAVE * i];
       rowp = pl;
     }
-    uint32_t g = 0;
+    uint64_t g = 0;  // the SNV genotype's alleles, one nibble each
     for (int q = 0; q < u_gens; q++) {
       double lprior = 0.0;
       if (with_prior) lprior = snv_prior(g, n);
@@ -468,6 +469,11 @@ __device__ __forceinline__ uint64_t word_mix(uint64_t t, u128 x) {
   return mix64(t ^ (uint64_t)x) + 0x9E3779B97F4A7C15ull;
 }
 
+// nibble packs of per-haplotype labels / doses: eight nibbles (ploidy <= 8) beside 64-bit words, sixteen (ploidy <= 15: a dose of
+// 16 would not fit a nibble) beside 128-bit words -- the general instantiation takes both the wide and the high-ploidy units
+template <class W> struct PackOf { typedef uint32_t type; static constexpr int KMAX = MCHAP_MAX_PLOIDY; };
+template <> struct PackOf<u128> { typedef uint64_t type; static constexpr int KMAX = MCHAP_MAX_PLOIDY_DENOVO; };
+
 template <class W>
 struct SimtLdsT {
   W *w;             // [T*Kmax][64]
@@ -475,7 +481,7 @@ struct SimtLdsT {
   double *llk_t;    // [T][64]
   uint64_t *rngn;   // [T][64]
   double *prior;    // [2Kmax+5][64]
-  uint32_t *optin;  // [Kmax*Kmax][64]
+  uint8_t *optin;   // [Kmax*Kmax][64] option i of the lane's interval step as (h0 << 4) | h1: the move, not the label pack it yields
   uint16_t *sub;    // [Kmax*Mmax][64]
   uint16_t *cols;   // [Mmax][64]
   uint8_t *shift;   // [Mmax][64]
@@ -489,7 +495,7 @@ __host__ __device__ inline size_t simt_lds_bytes(int Kmax, int Mmax, int T, int 
   b += (size_t)word_bytes * Kmax * 64;
   b += (size_t)8 * T * 64 * 2;
   b += (size_t)8 * (2 * Kmax + 5) * 64;
-  b += (size_t)4 * Kmax * Kmax * 64;
+  b += (size_t)Kmax * Kmax * 64;
   b += (size_t)2 * Kmax * Mmax * 64;
   b += (size_t)2 * Mmax * 64;
   b += (size_t)1 * Mmax * 64 * 2;
@@ -521,15 +527,16 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // per-lane helpers on the lane's haplotype words (row `base` .. base+K-1 of an LDS [..][64] array)
 // KT > 0: compile-time ploidy shared by every chain of the launch (loops unroll to exactly K); KT == 0: per-lane K
 template <int KT, class W>
-__device__ __forceinline__ uint32_t lane_dosage_of_words(const W *arr, int base, int K, int lane) {
-  constexpr int KM = KT ? KT : MCHAP_MAX_PLOIDY;
+__device__ __forceinline__ typename PackOf<W>::type lane_dosage_of_words(const W *arr, int base, int K, int lane) {
+  typedef typename PackOf<W>::type P;
+  constexpr int KM = KT ? KT : PackOf<W>::KMAX;
   W x[KM];
 #pragma unroll
   for (int h = 0; h < KM; h++) x[h] = h < K ? L_(arr, base + h) : (W)0;
-  uint32_t d = 0;
+  P d = 0;
 #pragma unroll
   for (int h = 0; h < KM; h++)
-    if (h < K) d |= 1u << (4 * h);
+    if (h < K) d |= (P)1 << (4 * h);
 #pragma unroll
   for (int h = 0; h < KM; h++) {
     if (h >= K || nib(d, h) == 0) continue;
@@ -537,8 +544,8 @@ __device__ __forceinline__ uint32_t lane_dosage_of_words(const W *arr, int base,
     for (int p = 0; p < KM; p++) {
       if (p <= h || p >= K || nib(d, p) == 0) continue;
       if (x[h] == x[p]) {
-        d += 1u << (4 * h);
-        d &= ~(15u << (4 * p));
+        d += (P)1 << (4 * h);
+        d &= ~((P)15 << (4 * p));
       }
     }
   }
@@ -547,7 +554,7 @@ __device__ __forceinline__ uint32_t lane_dosage_of_words(const W *arr, int base,
 
 template <int KT, class W>
 __device__ __forceinline__ int lane_count_copies(const W *arr, int base, int K, int h, int lane) {
-  constexpr int KM = KT ? KT : MCHAP_MAX_PLOIDY;
+  constexpr int KM = KT ? KT : PackOf<W>::KMAX;
   const W x = L_(arr, base + h);
   int n = 0;
 #pragma unroll
@@ -557,7 +564,7 @@ __device__ __forceinline__ int lane_count_copies(const W *arr, int base, int K, 
 }
 
 template <class W>
-__device__ inline double lane_prior_of_dosage(const SimtLdsT<W> &S, const Lane &c, uint32_t d, int lane) {
+__device__ inline double lane_prior_of_dosage(const SimtLdsT<W> &S, const Lane &c, typename PackOf<W>::type d, int lane) {
   const int K = c.K;
   if (c.inbreeding == 0.0) {
     double den = 0.0;
@@ -579,12 +586,13 @@ __device__ __forceinline__ double lane_words_prior(const SimtLdsT<W> &S, const L
 }
 
 template <int KT, class W>
-__device__ __forceinline__ uint32_t lane_segment_labels(const W *arr, int base, int K, W mask, int lane) {
-  constexpr int KM = KT ? KT : MCHAP_MAX_PLOIDY;
+__device__ __forceinline__ typename PackOf<W>::type lane_segment_labels(const W *arr, int base, int K, W mask, int lane) {
+  typedef typename PackOf<W>::type P;
+  constexpr int KM = KT ? KT : PackOf<W>::KMAX;
   W x[KM];
 #pragma unroll
   for (int h = 0; h < KM; h++) x[h] = h < K ? (L_(arr, base + h) & mask) : (W)0;
-  uint32_t lab = 0;
+  P lab = 0;
 #pragma unroll
   for (int h = 1; h < KM; h++) {
     if (h >= K) continue;
@@ -592,7 +600,7 @@ __device__ __forceinline__ uint32_t lane_segment_labels(const W *arr, int base, 
 #pragma unroll
     for (int g = KM - 1; g >= 0; g--)
       if (g < h && x[g] == x[h]) l = g;  // smallest matching index wins
-    lab |= (uint32_t)l << (4 * h);
+    lab |= (P)l << (4 * h);
   }
   return lab;
 }
@@ -893,39 +901,44 @@ template <int KT, class W>
 __device__ inline double simt_interval_step(bool act, const SimtLdsT<W> &S, Lane &c, int wb, double llk, int start, int stop,
                                             int step_type, double temp, int rpad, int lane) {
   const int K = KT ? KT : c.K;
+  typedef typename PackOf<W>::type P;
   W min_ = 0;
-  uint32_t lout = 0;
+  P lin = 0, lout = 0;
+  // option (h0, h1) of the enumeration -> the `in` label pack after the move (structural.py:121-178 / 240-307)
+  auto option_labels = [&](uint8_t hh) -> P {
+    const int h0 = hh >> 4, h1 = hh & 15;
+    if (step_type == 0) return nib_set(nib_set(lin, h0, nib(lin, h1)), h1, nib(lin, h0));
+    return nib_set(lin, h0, nib(lin, h1));
+  };
   int n_options = 0;
   double lprior = 0.0, log_proposal_prob = 0.0, ln_opt = 0.0, u = 2.0;
   if (act) {
     const W full = lane_interval_mask<W>(c, 0, c.Mh);
     min_ = lane_interval_mask<W>(c, start, stop);
-    const uint32_t lin = lane_segment_labels<KT, W>(S.w, wb, K, min_, lane);
+    lin = lane_segment_labels<KT, W>(S.w, wb, K, min_, lane);
     lout = lane_segment_labels<KT, W>(S.w, wb, K, full & ~min_, lane);
     // enumerate straight into the lane's LDS column
     {
-      const uint32_t hd = dosage_of_labels(lin, lout, K, true);
+      const P hd = dosage_of_labels(lin, lout, K, true);
       if (step_type == 0) {
         for (int h0 = 0; h0 < K; h0++) {
           if (nib(hd, h0) == 0) continue;
           for (int h1 = h0 + 1; h1 < K; h1++) {
             if (nib(hd, h1) == 0) continue;
             if (nib(lin, h0) == nib(lin, h1) || nib(lout, h0) == nib(lout, h1)) continue;
-            uint32_t o = nib_set(lin, h0, nib(lin, h1));
-            o = nib_set(o, h1, nib(lin, h0));
-            L_(S.optin, n_options) = o;
+            L_(S.optin, n_options) = (uint8_t)((h0 << 4) | h1);
             n_options++;
           }
         }
       } else {
-        const uint32_t sd = dosage_of_labels(lin, lout, K, false);
+        const P sd = dosage_of_labels(lin, lout, K, false);
         for (int h0 = 0; h0 < K; h0++) {
           if (nib(hd, h0) == 0) continue;
           if (nib(sd, h0) == 1) continue;
           for (int h1 = 0; h1 < K; h1++) {
             if (nib(sd, h1) == 0) continue;
             if (nib(lin, h0) == nib(lin, h1)) continue;
-            L_(S.optin, n_options) = nib_set(lin, h0, nib(lin, h1));
+            L_(S.optin, n_options) = (uint8_t)((h0 << 4) | h1);
             n_options++;
           }
         }
@@ -944,9 +957,9 @@ __device__ inline double simt_interval_step(bool act, const SimtLdsT<W> &S, Lane
   double llk_choice = llk;
   for (int i = 0; i < nmax; i++) {
     const bool prop = act && i < n_options && choice < 0;  // options after the chosen one cannot matter
-    uint32_t oin = 0;
+    P oin = 0;
     if (prop) {
-      oin = L_(S.optin, i);
+      oin = option_labels(L_(S.optin, i));
       for (int h = 0; h < K; h++) L_(S.pw, h) = (L_(S.w, wb + h) & ~min_) | (L_(S.w, wb + nib(oin, h)) & min_);
     }
     const double llk_i = lane_eval_cached<KT, W>(prop, S, c, rpad, lane);
@@ -965,7 +978,7 @@ __device__ inline double simt_interval_step(bool act, const SimtLdsT<W> &S, Lane
     }
   }
   if (act && choice >= 0) {
-    const uint32_t oin = L_(S.optin, choice);
+    const P oin = option_labels(L_(S.optin, choice));
     for (int h = 0; h < K; h++) L_(S.pw, h) = (L_(S.w, wb + h) & ~min_) | (L_(S.w, wb + nib(oin, h)) & min_);
     for (int h = 0; h < K; h++) L_(S.w, wb + h) = L_(S.pw, h);
     llk = llk_choice;
@@ -1048,7 +1061,7 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
     S.llk_t = reinterpret_cast<double *>(p); p += (size_t)8 * T * 64;
     S.rngn = reinterpret_cast<uint64_t *>(p); p += (size_t)8 * T * 64;
     S.prior = reinterpret_cast<double *>(p); p += (size_t)8 * (2 * Kmax + 5) * 64;
-    S.optin = reinterpret_cast<uint32_t *>(p); p += (size_t)4 * Kmax * Kmax * 64;
+    S.optin = p; p += (size_t)Kmax * Kmax * 64;
     S.sub = reinterpret_cast<uint16_t *>(p); p += (size_t)2 * Kmax * Mmax * 64;
     S.cols = reinterpret_cast<uint16_t *>(p); p += (size_t)2 * Mmax * 64;
     S.shift = p; p += (size_t)Mmax * 64;

@@ -326,10 +326,12 @@ struct BatchDims {
   int uniform_ploidy = -1;  // the ploidy shared by all units, 0 if mixed
 };
 
+bool use_simt(const mchap_denovo_cfg *cfg);
 int batch_dims(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host, BatchDims &B) {
   for (int u = 0; u < n_units; u++) {
     const mchap_unit &U = units_host[u];
-    if (U.ploidy < 1 || U.ploidy > MCHAP_MAX_PLOIDY) return fail(MCHAP_ERR_LIMIT, "unit %d: ploidy %d not in 1..%d", u, U.ploidy, MCHAP_MAX_PLOIDY);
+    const int kmax = use_simt(cfg) ? MCHAP_MAX_PLOIDY_DENOVO : MCHAP_MAX_PLOIDY;
+    if (U.ploidy < 1 || U.ploidy > kmax) return fail(MCHAP_ERR_LIMIT, "unit %d: ploidy %d not in 1..%d", u, U.ploidy, kmax);
     if (U.max_allele < 1 || U.max_allele > MCHAP_MAX_ALLELE) return fail(MCHAP_ERR_LIMIT, "unit %d: max_allele %d not in 1..%d", u, U.max_allele, MCHAP_MAX_ALLELE);
     if (U.n_reads < 1 || U.n_reads > MCHAP_MAX_READS) return fail(MCHAP_ERR_LIMIT, "unit %d: n_reads %d not in 1..%d (zero reads are mocked by the caller as one NaN read)", u, U.n_reads, MCHAP_MAX_READS);
     if (U.n_pos < 1 || U.n_pos > MCHAP_MAX_POS) return fail(MCHAP_ERR_LIMIT, "unit %d: n_pos %d not in 1..%d", u, U.n_pos, MCHAP_MAX_POS);
@@ -415,7 +417,10 @@ struct Plan {
 };
 // A batch whose units may need more than 64 bits of sampled alleles per haplotype, or hold more than 62 SNVs (the 64-bit
 // samplers keep a unit's interval end points in one word): the lanes-over-chains sampler with 128-bit words takes it.
-bool wide_batch(const BatchDims &B) { return mchap::allele_bits(B.max_allele) * B.max_pos > 64 || B.max_pos > 62; }
+// The same kernel takes ploidies 9 to 15 (packs of sixteen nibbles).
+bool wide_batch(const BatchDims &B) {
+  return mchap::allele_bits(B.max_allele) * B.max_pos > 64 || B.max_pos > 62 || B.max_ploidy > MCHAP_MAX_PLOIDY;
+}
 int plan_sampler(const mchap_denovo_cfg *cfg, const Tune &T, const BatchDims &B, Plan &pl) {
   pl.K = B.uniform_ploidy;
   if (use_simt(cfg) && wide_batch(B)) {

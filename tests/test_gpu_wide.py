@@ -1,7 +1,7 @@
-"""GPU: targets wider than the fast samplers take -- more than 62 SNVs, or more than 64 bits of sampled alleles per haplotype.
-The reference has no such limits (assemble/mcmc.py:24-40); until round 4 this build refused these shapes.  They now run on the
-lanes-over-chains sampler instantiated with 128-bit haplotype words (denovo_simt_kernel<0, u128>: up to 126 SNVs / 128 bits), and
-their traces hold two uint64 words per haplotype.  Parity as everywhere: the oracle on the same Philox streams, step for step --
+"""GPU: units beyond what the fast samplers take -- more than 62 SNVs, more than 64 bits of sampled alleles per haplotype, or a
+ploidy above 8.  The reference has no such limits (assemble/mcmc.py:24-40); until round 4 this build refused these shapes.  They now
+run on the lanes-over-chains sampler instantiated with 128-bit haplotype words and sixteen-nibble label packs
+(denovo_simt_kernel<0, u128>: up to 126 SNVs / 128 bits / ploidy 15), and their traces hold two uint64 words per haplotype.  Parity as everywhere: the oracle on the same Philox streams, step for step --
 int8 genotypes bit-exact, llks to 1e-10."""
 import numpy as np
 import pytest
@@ -16,6 +16,10 @@ CASES = {
     "tetraploid-70-snvs-ladder": (2, 4, 70, 40, 2, None, (0.1, 1.0), dict(window=(20, 70))),
     "octoploid-16-tetraallelic": (2, 8, 16, 40, 4, 0.0, (1.0,), dict(window=(6, 16))),      # 32 bits per haplotype: a 64-bit sampler, wide cache keys
     "tetraploid-63-snvs": (2, 4, 63, 40, 2, None, (1.0,), dict(window=(20, 63))),           # 63 bits, but more than 62 positions
+    # ploidies above 8 (packs of sixteen nibbles for labels and doses): the same general kernel
+    "decaploid-6-snvs": (3, 10, 6, 60, 2, None, (1.0,), dict(window=(3, 6))),
+    "dodecaploid-5-triallelic-inbred": (2, 12, 5, 50, 3, 0.2, (1.0,), dict(window=(2, 5))),
+    "ploidy-15-null-prior-ladder": (2, 15, 4, 40, 2, 0.0, (0.2, 1.0), dict(window=(2, 4))),
 }
 
 
@@ -33,7 +37,7 @@ def test_wide_units_against_the_oracle(case):
     steps = 25
     model = DenovoMCMC(ploidy=K, n_alleles=[A] * M, steps=steps, chains=2, inbreeding=F, temperatures=temps, random_seed=5)
     traces = model.fit_batch(list(reads))
-    wide = M > 62 or (1 if A <= 2 else 2 if A <= 4 else 3) * M > 64
+    wide = M > 62 or (1 if A <= 2 else 2 if A <= 4 else 3) * M > 64 or K > 8
     assert ("u128" in model.last_sampler) == wide, model.last_sampler
     for u in range(U):
         cfg = orc.make_cfg(K, steps, 2, F, temps, llk_cache_threshold=-1, rng_kind=orc.RNG_PHILOX, seed=5, stream_id=u,
@@ -84,3 +88,6 @@ def test_beyond_the_widest_sampler_is_still_refused_by_name():
     reads, _, _ = synth_units(1, ploidy=2, n_pos=127, n_reads=20, window=(30, 127))
     with pytest.raises(NotImplementedError):
         DenovoMCMC(ploidy=2, n_alleles=[2] * 127, steps=5, chains=1, random_seed=1).fit_batch(list(reads))
+    reads, _, _ = synth_units(1, ploidy=16, n_pos=4, n_reads=20, window=(2, 4))
+    with pytest.raises(NotImplementedError):
+        DenovoMCMC(ploidy=16, n_alleles=[2] * 4, steps=5, chains=1, random_seed=1).fit_batch(list(reads))
