@@ -47,7 +47,8 @@ namespace mchap {
 constexpr int FILLW_NW = MCHAP_FILLW_NW;
 constexpr int FILLW_NT = 64 * FILLW_NW;
 constexpr int FILLW_ENT = 256;     // entries listed per pass (one thread each: an entry of a chunk is named by one byte)
-constexpr int FILLW_SLOTS = 768;   // option slots of one chunk of intervals
+constexpr int FILLW_SLOTS = 768;   // option slots of one chunk of intervals (packed keys: configs[1]'s 648 slots are one chunk)
+constexpr int FILLW_SLOTS_WIDE = 512;  // ... for genotypes wider than 64 bits: a slot's key is its one or two changed words
 constexpr int FILLW_HASH = 2048;   // open-addressing slots of a chunk's request table (uint32: slot + 1 of the representative)
 constexpr int FILLW_TAB_BYTES = 32 * 1024;  // the unit's float64 table in LDS, when it fits
 static_assert(FILLW_NT >= FILLW_ENT, "one thread per listed entry");
@@ -59,12 +60,15 @@ __host__ __device__ inline int fillw_tab_rows(int max_pos, int max_allele, int r
   return (size_t)rows * nb * 64 * 8 <= (size_t)FILLW_TAB_BYTES ? rows : 0;
 }
 
+__host__ __device__ inline int fillw_slots(bool wide) { return wide ? FILLW_SLOTS_WIDE : FILLW_SLOTS; }
 struct FillwLds {
+  size_t skey2, shh;  // (wide keys only)
   size_t tab, bp, cw, dict, pt, ln, lninv, skey, sllk, htab, urep, umiss, elin, elout, ese, eoff, eno, slrep, slent, slopt, cols, shift, scal, total;
 };
-__host__ __device__ inline FillwLds fillw_lds(int K, int max_pos, int tab_rows, int rpad) {
+__host__ __device__ inline FillwLds fillw_lds(int K, int max_pos, int tab_rows, int rpad, bool wide = false) {
   FillwLds L;
   const int nb = rpad / 64 < 4 ? rpad / 64 : 4;
+  const size_t NS = (size_t)fillw_slots(wide);
   size_t o = 0;
   L.tab = o; o += (size_t)8 * tab_rows * nb * 64;  // [position x allele][chunk][lane] float64 factors, or nothing
   L.bp = o; o += (size_t)8 * K * 4 * 64;          // haplotype products / K of the current genotype, first four read chunks
@@ -73,30 +77,37 @@ __host__ __device__ inline FillwLds fillw_lds(int K, int max_pos, int tab_rows, 
   L.pt = o; o += (size_t)8 * (2 * K + 5);
   L.ln = o; o += (size_t)8 * SPEC_LN;
   L.lninv = o; o += (size_t)8 * SPEC_LN;
-  L.skey = o; o += (size_t)8 * FILLW_SLOTS;       // packed proposal genotype of a slot; later the slot's probability
-  L.sllk = o; o += (size_t)8 * FILLW_SLOTS;       // log likelihood, at the representative's slot
+  L.skey = o; o += (size_t)8 * NS;       // packed proposal genotype of a slot; later the slot's probability
+  L.skey2 = o; o += wide ? (size_t)8 * NS : 0;  // second changed word of a wide slot
+  L.sllk = o; o += (size_t)8 * NS;       // log likelihood, at the representative's slot
   L.htab = o; o += (size_t)4 * FILLW_HASH;
   L.elin = o; o += (size_t)4 * FILLW_ENT;         // per entry of the chunk (= per listing thread): labels, interval, offset, options
   L.elout = o; o += (size_t)4 * FILLW_ENT;
   L.ese = o; o += (size_t)4 * FILLW_ENT;
   L.scal = o; o += (size_t)4 * 16;                // block scalars: wave totals of the scan, cut, slots, distinct requests, misses
-  L.urep = o; o += (size_t)2 * FILLW_SLOTS;       // distinct request -> its representative slot
-  L.umiss = o; o += (size_t)2 * FILLW_SLOTS;      // ... those the chain's cache does not hold
-  L.slrep = o; o += (size_t)2 * FILLW_SLOTS;      // slot -> representative slot
+  L.urep = o; o += (size_t)2 * NS;       // distinct request -> its representative slot
+  L.umiss = o; o += (size_t)2 * NS;      // ... those the chain's cache does not hold
+  L.slrep = o; o += (size_t)2 * NS;      // slot -> representative slot
   L.eoff = o; o += (size_t)2 * FILLW_ENT;
   L.eno = o; o += (size_t)2 * FILLW_ENT;
   L.cols = o; o += (size_t)2 * max_pos;
-  L.slent = o; o += (size_t)FILLW_SLOTS;
-  L.slopt = o; o += (size_t)FILLW_SLOTS;
+  L.slent = o; o += NS;
+  L.slopt = o; o += NS;
+  L.shh = o; o += wide ? NS : 0;  // (h1 << 4) | h2 of a wide slot's changed haplotypes (h2 = 15: one only)
   L.shift = o; o += (size_t)max_pos;
   L.total = (o + 63) & ~(size_t)63;
   return L;
 }
-__host__ __device__ inline size_t fillw_lds_bytes(int K, int max_pos, int tab_rows, int rpad) { return fillw_lds(K, max_pos, tab_rows, rpad).total; }
-// Shapes the kernel takes: the packed genotype is the request's key
-__host__ __device__ inline bool fillw_takes(int K, int max_pos, int max_allele) {
-  return K >= 2 && K <= 8 && K * allele_bits(max_allele) * max_pos <= 64 && max_pos <= 64;
+__host__ __device__ inline size_t fillw_lds_bytes(int K, int max_pos, int tab_rows, int rpad, bool wide = false) {
+  return fillw_lds(K, max_pos, tab_rows, rpad, wide).total;
 }
+// Shapes the kernel takes: ploidy 2..8, a haplotype word of at most 64 bits (every shape the phased sampler runs).  The packed
+// genotype is a request's key while it fits 64 bits; beyond that (fillw_wide) a request is keyed by the one or two haplotype words
+// it changes (the genotype it proposes differs from the chain's in those only).
+__host__ __device__ inline bool fillw_takes(int K, int max_pos, int max_allele) {
+  return K >= 2 && K <= 8 && allele_bits(max_allele) * max_pos <= 64 && max_pos <= 64;
+}
+__host__ __device__ inline bool fillw_wide(int K, int max_pos, int max_allele) { return K * allele_bits(max_allele) * max_pos > 64; }
 
 // (start, stop) of entry e of an interval table: e = stop (stop - 1) / 2 + start, 0 <= start < stop
 __device__ __forceinline__ void fillw_entry_interval(int e, int &start, int &stop) {
@@ -192,9 +203,11 @@ struct FillwUnit {
   LDSP(const double) tab;   // the table of the first block in LDS ([sampled position x allele][chunk][lane]) + lane, or null
   LDSP(const double) bpk;   // haplotype products / K of the current genotype, first block ([h][4][64]) + lane, or null
   LDSP(const double) cwl;   // read weights of the first block + lane
+  GLBP(double) gbp;         // deep units: the chain's [K][rpad] rows of haplotype products for the chunks beyond the fourth + lane, or null
   int Mh, A, bits, crow, rpad, nch, tab_rs;
   uint32_t amask;
   bool coded;
+  bool has_gbp;
   bool has_tab, has_bpk;  // (explicit flags: an LDS pointer at offset 0 -- lane 0's `tab + lane` -- must not read as "no table")
 };
 
@@ -227,7 +240,7 @@ __device__ __forceinline__ void fillw_hap_tab(const FillwUnit &U, uint64_t w, do
 // h2 >= 0, h2 (word w2): the lane's partial sum  sum_i read_log(sum_h prod_h / K) * weight  -- haplotype terms added in haplotype
 // order, chunks in chunk order, as spec_coop_reuse / spec_coop_coded / spec_coop_body do.  FIRST: the block of chunks 0..RPL-1,
 // whose base terms (and, when it fits, table) live in LDS; else every haplotype's product is formed from the coded table.
-template <int KT, int RPL, class CT, bool FIRST>
+template <int KT, int RPL, class CT, bool FIRST, bool DEEP>
 __device__ __forceinline__ double fillw_block(const FillwUnit &U, const GWords<KT> g, int h1, uint64_t w1, int h2, uint64_t w2, int cb,
                                               int lane) {
   const double invK = 1.0 / (double)KT;
@@ -263,6 +276,28 @@ __device__ __forceinline__ double fillw_block(const FillwUnit &U, const GWords<K
     for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * U.cwl[i * WAVE];
     return s;
   }
+  if (DEEP && !FIRST && U.has_gbp) {
+    // deep units: the products of the haplotypes the request did not change come from the chain's rows in the workspace (formed
+    // once per chain in the set-up: spec_coop_reuse_g's arithmetic) -- all K x RPL loads go out together, ahead of the products
+    double bpv[KT][RPL];
+#pragma unroll
+    for (int h = 0; h < KT; h++)
+#pragma unroll
+      for (int i = 0; i < RPL; i++) bpv[h][i] = U.gbp[(size_t)h * U.rpad + (size_t)(cb + i) * WAVE];
+    double p1[RPL], p2[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; i++) p2[i] = 1.0;
+    fillw_hap<RPL, CT>(U, w1, cb, lane, p1);
+    if (h2 >= 0) fillw_hap<RPL, CT>(U, w2, cb, lane, p2);
+#pragma unroll
+    for (int h = 0; h < KT; h++)
+#pragma unroll
+      for (int i = 0; i < RPL; i++) acc[i] += ((h == h1) ? p1[i] : ((h == h2) ? p2[i] : bpv[h][i])) * invK;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * U.cw[(size_t)(cb + i) * WAVE];
+    return s;
+  }
 #pragma unroll 1
   for (int h = 0; h < KT; h++) {
     const uint64_t w = (h == h1) ? w1 : ((h == h2) ? w2 : sel_word<KT>(g, h));
@@ -277,17 +312,21 @@ __device__ __forceinline__ double fillw_block(const FillwUnit &U, const GWords<K
   return s;
 }
 
-template <int KT, bool FIRST>
+template <int KT, bool FIRST, bool DEEP>
 __device__ __forceinline__ double fillw_blocks(const FillwUnit &U, const GWords<KT> g, int h1, uint64_t w1, int h2, uint64_t w2, int cb,
                                                int nb, int lane) {
-  if (nb >= 4) return fillw_block<KT, 4, uint32_t, FIRST>(U, g, h1, w1, h2, w2, cb, lane);
-  if (nb == 3) return fillw_block<KT, 3, uint32_t, FIRST>(U, g, h1, w1, h2, w2, cb, lane);
-  if (nb == 2) return fillw_block<KT, 2, uint16_t, FIRST>(U, g, h1, w1, h2, w2, cb, lane);
-  return fillw_block<KT, 1, uint8_t, FIRST>(U, g, h1, w1, h2, w2, cb, lane);
+  if (nb >= 4) return fillw_block<KT, 4, uint32_t, FIRST, DEEP>(U, g, h1, w1, h2, w2, cb, lane);
+  if (nb == 3) return fillw_block<KT, 3, uint32_t, FIRST, DEEP>(U, g, h1, w1, h2, w2, cb, lane);
+  if (nb == 2) return fillw_block<KT, 2, uint16_t, FIRST, DEEP>(U, g, h1, w1, h2, w2, cb, lane);
+  return fillw_block<KT, 1, uint8_t, FIRST, DEEP>(U, g, h1, w1, h2, w2, cb, lane);
 }
 
-template <int KT>
+// WIDE: genotypes of more than 64 bits (requests keyed by their changed words); DEEP: units of more than four read chunks keep
+// the current genotype's products of the later chunks in the chain's workspace rows.  Separate instantiations: the paths of one
+// must not cost the other its registers (BASELINE configs[1] runs <K, false, false>).
+template <int KT, bool WIDE = false, bool DEEP = false>
 __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel(const SimtParams P) {
+  constexpr int NSLOTS = WIDE ? FILLW_SLOTS_WIDE : FILLW_SLOTS;
   extern __shared__ __align__(16) unsigned char smem[];
   const DenovoParams &D = P.d;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -319,7 +358,7 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
   const bool flat = mi[META_I_FLAT] != 0 && !(P.flags & 128);
   const int tab_rows = (P.flags & 4096) ? 0 : P.fill_lt;  // rows the LDS table was sized for (0: none)
   const int nbmax = rpad / WAVE < 4 ? rpad / WAVE : 4;
-  const FillwLds L = fillw_lds(KT, P.max_pos, P.fill_lt, rpad);
+  const FillwLds L = fillw_lds(KT, P.max_pos, P.fill_lt, rpad, WIDE);
   LDSP(double) tab = lds_cast<double>(smem + L.tab);
   LDSP(double) bp = lds_cast<double>(smem + L.bp);
   LDSP(double) cwl = lds_cast<double>(smem + L.cw);
@@ -327,7 +366,9 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
   LDSP(double) pt = lds_cast<double>(smem + L.pt);
   LDSP(double) ln = lds_cast<double>(smem + L.ln);
   LDSP(double) lninv = lds_cast<double>(smem + L.lninv);
-  LDSP(uint64_t) skey = lds_cast<uint64_t>(smem + L.skey);
+  LDSP(uint64_t) skey = lds_cast<uint64_t>(smem + L.skey);     // packed genotype, or (WIDE) the first changed word
+  LDSP(uint64_t) skey2 = lds_cast<uint64_t>(smem + L.skey2);   // (WIDE) the second changed word
+  LDSP(uint8_t) shh = lds_cast<uint8_t>(smem + L.shh);         // (WIDE) which haplotypes: (h1 << 4) | h2, h2 = 15 when one only
   LDSP(double) ptab = lds_cast<double>(smem + L.skey);  // (after the evaluation: the keys are no longer needed)
   LDSP(double) sllk = lds_cast<double>(smem + L.sllk);
   unsigned int *htab = reinterpret_cast<unsigned int *>(smem + L.htab);
@@ -456,8 +497,44 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
       for (int i = 0; i < 4; i++) bp[(h * 4 + i) * WAVE + lane] = ph[i] * invK;
     }
   }
+  // deep units (more than four read chunks): the current genotype's haplotype products of the chunks beyond the fourth go to the
+  // chain's rows in the workspace (SimtParams::gbp, as the deep instantiation of denovo_spec_kernel keeps them) -- formed once
+  // here, so that a request forms only the products of the words it changed in every block of chunks
+  FU.gbp = nullptr;
+  FU.has_gbp = false;
+  if (DEEP && !flat && FU.nch > 4 && P.gbp != nullptr && !(P.flags & 4096)) {
+    GLBP(double) rows = (GLBP(double))(P.gbp + (size_t)q * P.max_ploidy * rpad) + lane;
+    for (int h = wv; h < KT; h += FILLW_NW) {
+      const uint64_t w = sel_word<KT>(g, h);
+      for (int cb = 4; cb < FU.nch; cb += 4) {
+        const int rem = FU.nch - cb;
+        double ph[4] = {1.0, 1.0, 1.0, 1.0};
+        if (rem >= 4) {
+          fillw_hap<4, uint32_t>(FU, w, cb, lane, ph);
+        } else if (rem == 3) {
+          double p3[3];
+          fillw_hap<3, uint32_t>(FU, w, cb, lane, p3);
+          ph[0] = p3[0]; ph[1] = p3[1]; ph[2] = p3[2];
+        } else if (rem == 2) {
+          double p2[2];
+          fillw_hap<2, uint16_t>(FU, w, cb, lane, p2);
+          ph[0] = p2[0]; ph[1] = p2[1];
+        } else {
+          double p1[1];
+          fillw_hap<1, uint8_t>(FU, w, cb, lane, p1);
+          ph[0] = p1[0];
+        }
+        for (int i = 0; i < (rem < 4 ? rem : 4); i++) rows[(size_t)h * rpad + (size_t)(cb + i) * WAVE] = ph[i];
+      }
+    }
+    FU.gbp = rows;
+    FU.has_gbp = true;
+    __syncthreads();  // (workgroup-scope release / acquire: the rows are read by every wavefront of the chain)
+  }
   // the chain's likelihood cache (what its own steps evaluated), probed when the packed genotype is its tag (tag_of)
-  const bool probe = D.cache_slots > 0 && KT * key_bits <= 63 && !(P.flags & 2048) && !flat;
+  // ... exact tags (the packed genotype) up to 63 bits; wider genotypes are tagged by a hash and verified against their words
+  const uint64_t *ckeys = D.cache_keys ? D.cache_keys + (size_t)q * (size_t)D.cache_slots * D.cache_key_words : nullptr;
+  const bool probe = D.cache_slots > 0 && !(P.flags & 2048) && !flat && (WIDE ? (ckeys != nullptr && KT * key_bits > 63) : KT * key_bits <= 63);
   const ulonglong2 *cache = reinterpret_cast<const ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots;
   const uint32_t cache_mask = probe ? (uint32_t)(D.cache_slots / 8) - 1u : 0u;
 
@@ -495,7 +572,7 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
     __syncthreads();
     int excl = incl - no;
     for (int w = 0; w < wv && w < FILLW_ENT / WAVE; w++) excl += scal[w];
-    if (unk && no > 0 && excl + no > FILLW_SLOTS) atomicMin(&scal[8], tid);
+    if (unk && no > 0 && excl + no > NSLOTS) atomicMin(&scal[8], tid);
     __syncthreads();
     const int cut = scal[8];
     const bool mine = unk && tid < cut;
@@ -533,18 +610,52 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
       int my_no, ty_s;
       uint64_t min_;
       slot_option(s, oin, lo, my_no, ty_s, min_);
-      uint64_t key = 0;
+      if constexpr (!WIDE) {
+        uint64_t key = 0;
 #pragma unroll
-      for (int h = 0; h < KT; h++) {
-        const uint64_t wh = (g.w[h] & ~min_) | (sel_word<KT>(g, (int)nib(oin, h)) & min_);
-        key = (key << key_bits) | wh;  // (K words of key_bits <= 32 bits: fillw_takes)
+        for (int h = 0; h < KT; h++) {
+          const uint64_t wh = (g.w[h] & ~min_) | (sel_word<KT>(g, (int)nib(oin, h)) & min_);
+          key = (key << key_bits) | wh;  // (K words of key_bits bits, together at most 64)
+        }
+        skey[s] = key;
+      } else {
+        // the one or two words the option changes, in haplotype order: the proposal is the chain's genotype but for them
+        int h1 = 15, h2 = 15;
+        uint64_t w1 = 0, w2 = 0;
+#pragma unroll
+        for (int h = 0; h < KT; h++) {
+          const uint64_t wh = (g.w[h] & ~min_) | (sel_word<KT>(g, (int)nib(oin, h)) & min_);
+          if (wh != g.w[h]) {
+            if (h1 == 15) {
+              h1 = h;
+              w1 = wh;
+            } else {
+              h2 = h;
+              w2 = wh;
+            }
+          }
+        }
+        if (h1 == 15) {  // (an option that changes nothing cannot occur; keyed as haplotype 0 unchanged)
+          h1 = 0;
+          w1 = g.w[0];
+        }
+        skey[s] = w1;
+        skey2[s] = w2;
+        shh[s] = (uint8_t)((h1 << 4) | h2);
       }
-      skey[s] = key;
     }
     __syncthreads();
     for (int s = tid; s < n_slots; s += FILLW_NT) {
       const uint64_t key = skey[s];
-      uint32_t hsh = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u);
+      uint64_t key2 = 0;
+      uint8_t hh = 0;
+      uint64_t hk = key;
+      if constexpr (WIDE) {
+        key2 = skey2[s];
+        hh = shh[s];
+        hk = mix64(key ^ mix64(key2 + hh));
+      }
+      uint32_t hsh = (uint32_t)hk ^ ((uint32_t)(hk >> 32) * 0x9E3779B1u);
       hsh ^= hsh >> 16;
       hsh *= 0x7FEB352Du;
       hsh ^= hsh >> 15;
@@ -556,7 +667,7 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
         if (v == 0u) {
           rep = s;  // this slot represents its genotype
           urep[atomicAdd(&scal[10], 1)] = (uint16_t)s;
-        } else if (skey[v - 1] == key) {
+        } else if (skey[v - 1] == key && (!WIDE || (skey2[v - 1] == key2 && shh[v - 1] == hh))) {
           rep = (int)v - 1;
         }
       }
@@ -572,21 +683,39 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
         sllk[rep] = cur_llk;  // a unit without information: every genotype has the chain's likelihood (spec_eval)
         hit = true;
       } else if (probe) {
-        const uint64_t key = skey[rep];
-        const uint64_t tag = (key << 1) | 1ull;
+        uint64_t key = skey[rep];
+        uint64_t tag = (key << 1) | 1ull;
+        GWords<KT> pwv = g;
+        if constexpr (WIDE) {
+          // the proposal's words; its tag is a hash (tag_of), a tag match is verified against the words kept beside the entry
+          const int hh_ = (int)shh[rep];
+          set_word<KT>(pwv, hh_ >> 4, key);
+          if ((hh_ & 15) != 15) set_word<KT>(pwv, hh_ & 15, skey2[rep]);
+          tag = tag_of<KT>(pwv, key_bits);
+          key = tag >> 1;
+        }
         uint32_t hsh = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u);
         hsh ^= hsh >> 16;
         hsh *= 0x7FEB352Du;
         hsh ^= hsh >> 15;
         hsh *= 0x846CA68Bu;
         hsh ^= hsh >> 16;
-        const ulonglong2 *set = cache + 8 * (size_t)((hsh >> 12) & cache_mask);
+        const size_t set_i = (size_t)((hsh >> 12) & cache_mask);
+        const ulonglong2 *set = cache + 8 * set_i;
 #pragma unroll
         for (int w = 0; w < 8; w++) {
           const ulonglong2 en = set[w];
           if (en.x == tag) {
-            sllk[rep] = __longlong_as_double((long long)en.y);
-            hit = true;
+            bool same = true;
+            if constexpr (WIDE) {
+              const uint64_t *kw = ckeys + (8 * set_i + w) * (size_t)D.cache_key_words;
+#pragma unroll
+              for (int h = 0; h < KT; h++) same = same && kw[h] == pwv.w[h];
+            }
+            if (same) {
+              sllk[rep] = __longlong_as_double((long long)en.y);
+              hit = true;
+            }
           }
         }
       }
@@ -603,25 +732,35 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
       // recombination swaps segments of two), and their words
       int h1 = 0, h2 = -1, ndiff = 0;
       uint64_t w1 = g.w[0], w2 = 0;
+      if constexpr (WIDE) {
+        const int hh_ = (int)shh[rep];
+        h1 = hh_ >> 4;
+        w1 = key;
+        if ((hh_ & 15) != 15) {
+          h2 = hh_ & 15;
+          w2 = skey2[rep];
+        }
+      } else {
 #pragma unroll
-      for (int h = 0; h < KT; h++) {
-        const uint64_t wh = (key >> (key_bits * (KT - 1 - h))) & key_mask;
-        if (wh != g.w[h]) {
-          if (ndiff == 0) {
-            h1 = h;
-            w1 = wh;
-          } else {
-            h2 = h;
-            w2 = wh;
+        for (int h = 0; h < KT; h++) {
+          const uint64_t wh = (key >> (key_bits * (KT - 1 - h))) & key_mask;
+          if (wh != g.w[h]) {
+            if (ndiff == 0) {
+              h1 = h;
+              w1 = wh;
+            } else {
+              h2 = h;
+              w2 = wh;
+            }
+            ndiff++;
           }
-          ndiff++;
         }
       }
       h1 = __builtin_amdgcn_readfirstlane(h1);
       h2 = __builtin_amdgcn_readfirstlane(h2);
       double s = 0.0;
-      s += fillw_blocks<KT, true>(FU, g, h1, w1, h2, w2, 0, nb0, lane);
-      for (int cb = 4; cb < FU.nch; cb += 4) s += fillw_blocks<KT, false>(FU, g, h1, w1, h2, w2, cb, FU.nch - cb, lane);
+      s += fillw_blocks<KT, true, DEEP>(FU, g, h1, w1, h2, w2, 0, nb0, lane);
+      for (int cb = 4; cb < FU.nch; cb += 4) s += fillw_blocks<KT, false, DEEP>(FU, g, h1, w1, h2, w2, cb, FU.nch - cb, lane);
       const double val = wave_sum(s);
       if (lane == 0) sllk[rep] = val;
     }

@@ -15,9 +15,12 @@ extern "C" __attribute__((visibility("hidden"))) int FILLW_CAT(mchap_fillw_init_
   return 0;
 }
 
+// (lds: fillw_lds_bytes; wide != 0: genotypes of more than 64 bits, keyed by their changed words)
 extern "C" __attribute__((visibility("hidden"))) int FILLW_CAT(mchap_fillw_launch_, FILLW_K)(const mchap::SimtParams *P, unsigned grid,
                                                                                             size_t lds, hipStream_t stream) {
-  auto ks = mchap::denovo_fillw_kernel<FILLW_K>;
+  const bool wide = (P->fill_kw & 1) != 0, deep = (P->fill_kw & 2) != 0;
+  auto ks = wide ? (deep ? mchap::denovo_fillw_kernel<FILLW_K, true, true> : mchap::denovo_fillw_kernel<FILLW_K, true, false>)
+                 : (deep ? mchap::denovo_fillw_kernel<FILLW_K, false, true> : mchap::denovo_fillw_kernel<FILLW_K, false, false>);
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

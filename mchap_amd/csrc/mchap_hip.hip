@@ -658,8 +658,12 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   // the in-kernel completion instead; the tables are the same bit for bit: tests/test_gpu_fillw.py)
   const bool fillw = G == 64 && !(T.flags & (64 | 1024 | 32)) && mchap::fillw_takes(K, P.max_pos, P.max_allele);
   const int fillw_rows = mchap::fillw_tab_rows(P.max_pos, P.max_allele, P.d.rpad);
-  const size_t lds_fillw = mchap::fillw_lds_bytes(K, P.max_pos, fillw_rows, P.d.rpad);
-  if (fillw) P.fill_lt = fillw_rows;
+  const bool fillw_wide = mchap::fillw_wide(K, P.max_pos, P.max_allele);
+  const size_t lds_fillw = mchap::fillw_lds_bytes(K, P.max_pos, fillw_rows, P.d.rpad, fillw_wide);
+  if (fillw) {
+    P.fill_lt = fillw_rows;
+    P.fill_kw = (fillw_wide ? 1 : 0) | (P.gbp != nullptr ? 2 : 0);  // (the instantiation: keyed by changed words / deep units: fillw_inst.hip)
+  }
 #define ROW_FILLW_LAUNCH(k) mchap_fillw_launch_##k,
   const simt_launch_fn fillw_launches[] = {FILLW_LIST(ROW_FILLW_LAUNCH)};
 #ifdef MCHAP_TEST_KERNELS

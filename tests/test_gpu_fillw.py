@@ -55,6 +55,12 @@ CASES = {
     "triallelic": (12, 4, 7, 150, 3, None, dict(window=(4, 7))),             # two bits per allele: 56-bit genotypes
     "tetraploid-16-snvs": (8, 4, 16, 200, 2, None, dict(window=(6, 16))),    # the widest packed key: 64 bits
     "shallow": (24, 4, 8, 20, 2, None, dict(qual=(25, 40))),
+    # genotypes of more than 64 bits: requests keyed by their changed words, the cache probe verified against the stored words
+    "tetraploid-20-snvs-wide": (12, 4, 20, 150, 2, None, dict(window=(6, 20))),
+    "triallelic-wide-keys": (12, 4, 12, 150, 3, 0.1, dict(window=(4, 12))),
+    "hexaploid-14-snvs-wide": (8, 6, 14, 120, 2, None, dict(window=(5, 14))),
+    # ... and deep units on top (more than four read chunks: product rows in the workspace)
+    "octoploid-deep-wide": (4, 8, 20, 1000, 2, None, dict(window=(8, 20))),
     "deep-2600-reads": (3, 4, 6, 2600, 2, None, dict(window=(2, 6), qual=(10, 40))),
 }
 
