@@ -72,6 +72,7 @@ struct SimtParams {
   int pipe_parts;             // wavefronts a short list of chains may spread the completion of one chain's tables over
   int bp_cache;               // speculative sampler with one chain per wave: base-product cache carved after its LDS
   int fill_lt, fill_kw;       // denovo_fill_kernel: lanes per tile of the read table, words kept per distinct request
+  int tw_lds;                 // denovo_spec_kernel<.., TW>: bytes of one wavefront's LDS layout behind the workgroup's exchange area
   int word_bits;              // bits of a packed haplotype word of this launch's sampler: 0 / 64, or 128 (denovo_simt_kernel<0, u128>)
 };
 constexpr int PIPE_RESUME = 1;  // start from the chains' PipeState records

@@ -2056,12 +2056,29 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
 // PIPE: the phased form (kernel 5).  A launch runs the chains of P.pipe_list for P.pipe_iters compound steps each,
 // starting from scratch or (PIPE_RESUME) from their PipeState records, and (PIPE_EXPORT) leaves records + complete
 // interval memos behind for denovo_coast_kernel.  Single temperature only.
-template <int KT, int G, bool PIPE = false, int VAR = MCHAP_SPEC_VAR>  // (VAR only names the object: the code is selected by the macro)
-__global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const SimtParams P) {
-  extern __shared__ __align__(16) unsigned char smem[];
+// TW (round 4, temperature ladders: G = 64, not PIPE): ONE WAVEFRONT PER REPLICA.  The T replicas of a chain are independent within
+// an MCMC step (assemble/mcmc.py:323-395: every replica's moves start from its own state of the previous step); only the swap
+// attempts couple neighbours, in the order t = 1 .. T-1, each with the state its lower neighbour holds THEN (tempering.py:61-151).
+// A workgroup of T wavefronts therefore runs the replicas' moves side by side -- every wavefront with the sampler's LDS layout of its
+// own behind a small exchange area --, publishes (genotype, llk), and the swap chain runs through that area behind workgroup
+// barriers: wavefront t attempts its swap with t-1 in turn.  Same draws, same arithmetic, same order of the swaps: same traces as
+// the one-wavefront form, which walks the replicas one after the other (tests/test_gpu_denovo.py::test_priors_and_tempering).
+constexpr int SPEC_TW_MAX = 8;  // replicas a workgroup takes (longer ladders run on one wavefront)
+__host__ __device__ inline size_t spec_tw_exchange_bytes(int K, int T) { return (((size_t)8 * T * (K + 1) + 16) + 63) & ~(size_t)63; }
+
+template <int KT, int G, bool PIPE = false, int VAR = MCHAP_SPEC_VAR, bool TW = false>  // (VAR only names the object: the code is selected by the macro)
+__global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE) void denovo_spec_kernel(const SimtParams P) {
+  extern __shared__ __align__(16) unsigned char smem_all[];
   constexpr int NG = 64 / G;
   const DenovoParams &D = P.d;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int tw = TW ? (int)(threadIdx.x / WAVE) : 0;  // TW: the replica (temperature) this wavefront runs
+  // TW: [exchange area][wavefront 0's layout][wavefront 1's] ..; else the workgroup is one wavefront and smem its layout
+  unsigned char *smem = smem_all + (TW ? spec_tw_exchange_bytes(KT, D.n_temps) + (size_t)tw * (size_t)P.tw_lds : 0);
+  LDSP(uint64_t) xw = lds_cast<uint64_t>(smem_all);                                  // TW: [T][K] the replicas' genotypes
+  LDSP(double) xllk = lds_cast<double>(smem_all + (size_t)8 * D.n_temps * KT);       //     [T] their log likelihoods
+  LDSP(int) xdead = lds_cast<int>(smem_all + (size_t)8 * D.n_temps * (KT + 1));      //     a replica stopped on an error
+  if (TW && threadIdx.x == 0) *xdead = 0;
   const int gi = lane / G, gl = lane % G;
   int n_list = 0;
   long long my_slot = (long long)blockIdx.x * NG + gi;  // the group's position in the launch's list of chains
@@ -2203,11 +2220,16 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     gp[GP_RT] = (uint64_t)(uintptr_t)(P.rt + (size_t)u * P.max_ma * rpad);
     gp[GP_CW] = (uint64_t)(uintptr_t)(P.cntw + (size_t)u * rpad);
     gp[GP_CT] = (uint64_t)(uintptr_t)(P.codes + (size_t)u * P.max_ma * WAVE * P.cstride);
-    gp[GP_CACHE] = S.cache_on ? (uint64_t)(uintptr_t)(reinterpret_cast<ulonglong2 *>(D.cache) + (size_t)q * (size_t)D.cache_slots) : 0ull;
-    gp[GP_CKEYS] = (S.cache_on && D.cache_keys) ? (uint64_t)(uintptr_t)(D.cache_keys + (size_t)q * (size_t)D.cache_slots * D.cache_key_words) : 0ull;
+    // (TW: the replicas of a chain run on different wavefronts AT THE SAME TIME, and an entry is two 8-byte accesses -- a reader
+    // could pair one wavefront's tag with another's value; every replica therefore has a table of its own: the workspace holds
+    // n_temps tables per chain for a ladder on this kernel.  One wavefront walking the replicas shares the first, as before.)
+    const size_t qc = (size_t)q * (size_t)(PIPE ? 1 : D.n_temps) + (size_t)tw;
+    gp[GP_CACHE] = S.cache_on ? (uint64_t)(uintptr_t)(reinterpret_cast<ulonglong2 *>(D.cache) + qc * (size_t)D.cache_slots) : 0ull;
+    gp[GP_CKEYS] = (S.cache_on && D.cache_keys) ? (uint64_t)(uintptr_t)(D.cache_keys + qc * (size_t)D.cache_slots * D.cache_key_words) : 0ull;
     gp[GP_TRACE] = (uint64_t)(uintptr_t)(D.trace + U.trace_off + (size_t)chain * D.steps * KT);
     gp[GP_LLK] = (uint64_t)(uintptr_t)(D.llks + U.llk_off + (size_t)chain * D.steps);
-    gp[GP_GBP] = P.gbp ? (uint64_t)(uintptr_t)(P.gbp + (size_t)q * P.max_ploidy * rpad) : 0ull;
+    // (a ladder's replicas run side by side, TW: each its own rows -- the workspace holds n_temps sets per chain then)
+    gp[GP_GBP] = P.gbp ? (uint64_t)(uintptr_t)(P.gbp + ((size_t)q * (PIPE ? 1 : D.n_temps) + tw) * P.max_ploidy * rpad) : 0ull;
   }
   c.ctr = 0;
   c.doff = 0;
@@ -2393,7 +2415,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
     if constexpr (PIPE) {
       if (step >= Sn) c.alive = false;  // this chain is complete; others of the wave go on
     }
-    for (int t = 0; t < T; t++) {
+    for (int t = TW ? tw : 0; t < (TW ? tw + 1 : T); t++) {
       GPHASE(c, 8);
       if (T > 1) {
         GWords<KT> gt;
@@ -2422,6 +2444,66 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
           c.alive = false;
         }
       }
+      if constexpr (TW) {
+        // publish this replica's state, then the swap chain: wavefront tt attempts its swap with tt - 1 (tempering.py:61-151)
+        // against what tt - 1 holds then; a replica's own state is only touched again by its upper neighbour's later attempt
+        {
+          const GWords<KT> gp_ = c.g;
+          if (lane == 0) {
+#pragma unroll
+            for (int h = 0; h < KT; h++) xw[(size_t)tw * KT + h] = gp_.w[h];
+            xllk[tw] = c.llk;
+            if (status != MCHAP_UNIT_OK) *xdead = 1;
+          }
+        }
+        __syncthreads();
+        if (*xdead) c.alive = false;  // (the reference raises: every replica of the chain stops; the barriers go on)
+        for (int tt = 1; tt < T; tt++) {
+          if (tw == tt && c.alive) {
+            LDSP(double) pt = S.prior + gi * (2 * KT + 5);
+            GWords<KT> gj;
+#pragma unroll
+            for (int h = 0; h < KT; h++) gj.w[h] = xw[(size_t)(tt - 1) * KT + h];
+            const double llk_j = xllk[tt - 1];
+            double prior_i = 0.0, prior_j = 0.0;
+            if (!isnan(C_INB(S, gi))) {
+              prior_i = prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(c.g));
+              prior_j = prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(gj));
+            }
+            const double ui = c.llk + prior_i, uj = llk_j + prior_j;
+            double acc = exp((uj - ui) * temp + (ui - uj) * D.temps[tt - 1]);
+            if (acc > 1.0) acc = 1.0;
+            const double val = stream_double(ld_stream(S, gi), c.ctr++);
+            if (acc >= val) {
+              const GWords<KT> gi_ = c.g;
+              if (lane == 0) {
+#pragma unroll
+                for (int h = 0; h < KT; h++) {
+                  xw[(size_t)(tt - 1) * KT + h] = gi_.w[h];
+                  xw[(size_t)tt * KT + h] = gj.w[h];
+                }
+                xllk[tt - 1] = c.llk;
+                xllk[tt] = llk_j;
+              }
+            }
+          }
+          __syncthreads();
+        }
+        if (c.alive) {  // this replica's state after every attempt that involved it
+          GWords<KT> gn;
+#pragma unroll
+          for (int h = 0; h < KT; h++) gn.w[h] = xw[(size_t)tw * KT + h];
+          c.g = gn;
+          c.llk = xllk[tw];
+          if (gl == 0) {
+#pragma unroll
+            for (int h = 0; h < KT; h++) S.wst[((size_t)gi * T + t) * KT + h] = gn.w[h];
+            S.llk_t[(size_t)gi * T + t] = c.llk;
+          }
+        }
+        __syncthreads();  // (the exchange area is rewritten in the next step)
+        lds_sync();
+      } else
       if (T > 1) {
         if (c.alive && t > 0) {
           // tempering.py:61-151 with the previous (warmer) temperature
@@ -2468,7 +2550,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       LDSP(uint64_t) tb = S.tbuf + (size_t)gi * SPEC_TB * (KT + 1);
       const int slot = it % SPEC_TB;
       if (c.alive) n_done = it + 1;
-      if (c.alive) {
+      if (c.alive && (!TW || tw == T - 1)) {  // (TW: the cold replica's wavefront records)
         if (gl < KT) {
           const GWords<KT> gr = c.g;
           const uint64_t x = sel_word<KT>(gr, gl);
@@ -2490,7 +2572,7 @@ __global__ __launch_bounds__(64, MCHAP_SPEC_WPE) void denovo_spec_kernel(const S
       const bool flush = slot == SPEC_TB - 1 || last || step == Sn - 1;
       if (PIPE ? wave_any(flush && c.alive) : flush) {
         lds_sync();
-        if (c.alive && flush) {
+        if (c.alive && flush && (!TW || tw == T - 1)) {
           const int first = step - slot;  // first step of the block
           const int nw = (slot + 1) * KT;
           uint64_t *tp = reinterpret_cast<uint64_t *>((uintptr_t)S.gptr[gi * GP_N + GP_TRACE]) + (size_t)first * KT;

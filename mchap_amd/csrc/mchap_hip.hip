@@ -445,6 +445,8 @@ int plan_sampler(const mchap_denovo_cfg *cfg, const Tune &T, const BatchDims &B,
   } else if (cfg->kernel != 2 && B.uniform_ploidy > 0 && spec_group(T, B.uniform_ploidy, B.max_pos)) {
     pl.kind = SAMPLER_SPEC;
     pl.G = spec_group(T, B.uniform_ploidy, B.max_pos);
+    // a temperature ladder runs its replicas side by side, one wavefront each: that form is one chain per wavefront
+    if (cfg->n_temps > 1 && cfg->n_temps <= mchap::SPEC_TW_MAX && !T.spec_group && !(T.flags & 16384)) pl.G = 64;
   } else {
     pl.kind = SAMPLER_SIMT;
     pl.K = (pl.K == 2 || pl.K == 4 || pl.K == 6 || pl.K == 8) ? pl.K : 0;  // (specialised for even ploidies, else generic)
@@ -477,11 +479,13 @@ SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, c
   SimtCarve c;
   size_t o = 0;
   const size_t nc = (size_t)n_units * cfg->chains;
-  c.cache = o; o += up256(nc * cache_slots * 16);
+  // (a temperature ladder on the speculative sampler: a likelihood cache per REPLICA -- they run side by side, one wavefront each)
+  const size_t ncc = nc * (size_t)(pl.kind == SAMPLER_SPEC ? cfg->n_temps : 1);
+  c.cache = o; o += up256(ncc * cache_slots * 16);
   // genotypes of more than 63 bits: their words beside the (hashed) tags, so that a cache hit is always exact
   if (cache_slots > 0 && B.max_ploidy * mchap::allele_bits(B.max_allele) * B.max_pos > 63) {
     c.key_words = B.max_ploidy * (pl.wide ? 2 : 1);  // (uint64 words per entry: K haplotype words of 64 or 128 bits)
-    c.ckeys = o; o += up256(nc * cache_slots * c.key_words * 8);
+    c.ckeys = o; o += up256(ncc * cache_slots * c.key_words * 8);
   }
   c.rt = o; o += up256((size_t)n_units * B.max_ma * rpad * 8);
   c.cntw = o; o += up256((size_t)n_units * rpad * 8);
@@ -498,7 +502,7 @@ SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, c
   // deep units (more than four chunks of 64 reads): the haplotype products of every chain's current genotype for the
   // chunks beyond the fourth (denovo_spec_kernel.hpp BaseProductsG), [chain][ploidy][rpad] doubles
   if ((pl.kind == SAMPLER_PIPE || pl.kind == SAMPLER_SPEC) && rpad > 4 * 64) {
-    c.gbp = o; o += up256(nc * (size_t)B.max_ploidy * rpad * 8);
+    c.gbp = o; o += up256(nc * (size_t)(pl.kind == SAMPLER_SPEC ? cfg->n_temps : 1) * B.max_ploidy * rpad * 8);  // (a set per replica)
     c.has_gbp = true;
   }
   if (pl.kind == SAMPLER_PIPE) {  // hand-over records of the phased sampler
@@ -539,6 +543,9 @@ int bp_cache_fits(const Tune &T, int G, size_t lds, int K) {
   return ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K) <= 160 * 1024 ? 1 : 0;
 }
 
+#define DECL_SPEC_TW(k) extern "C" int mchap_spec_launchtw_##k##_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+DECL_SPEC_TW(2) DECL_SPEC_TW(3) DECL_SPEC_TW(4) DECL_SPEC_TW(5) DECL_SPEC_TW(6) DECL_SPEC_TW(7) DECL_SPEC_TW(8)
+
 int launch_spec(const Tune &T, int K, int G, const mchap::SimtParams &P, int n_units, int chains, int n_temps, void *timer, hipStream_t stream) {
   const SpecInst *inst = FIND_SPEC(K, G);
   if (!inst) return fail(MCHAP_ERR_LIMIT, "speculative sampler: no instantiation for ploidy %d with %d lanes per chain", K, G);
@@ -548,6 +555,21 @@ int launch_spec(const Tune &T, int K, int G, const mchap::SimtParams &P, int n_u
   Q.bp_cache = bp_cache_fits(T, G, lds, K);
   if (Q.bp_cache) lds = ((lds + 15) & ~(size_t)15) + mchap::spec_bp_cache_bytes(K);
   const long long n_chains = (long long)n_units * chains;
+  // A temperature ladder with one chain per wavefront: a workgroup of n_temps wavefronts per chain, one replica each
+  // (denovo_spec_kernel<.., TW>; tuning flag 16384: the replicas one after the other on one wavefront, as before round 4)
+  if (G == 64 && n_temps > 1 && n_temps <= mchap::SPEC_TW_MAX && !(T.flags & 16384) && K >= 2 && K <= 8) {
+    const size_t per_wave = (lds + 63) & ~(size_t)63;
+    const size_t lds_tw = mchap::spec_tw_exchange_bytes(K, n_temps) + per_wave * n_temps;
+    if (lds_tw <= 160 * 1024) {
+      const simt_launch_fn tw[] = {mchap_spec_launchtw_2_64, mchap_spec_launchtw_3_64, mchap_spec_launchtw_4_64, mchap_spec_launchtw_5_64,
+                                   mchap_spec_launchtw_6_64, mchap_spec_launchtw_7_64, mchap_spec_launchtw_8_64};
+      Q.tw_lds = (int)per_wave;
+      SamplerTimer tm(timer, stream);
+      const int e = tw[K - 2](&Q, (unsigned)n_chains, lds_tw, stream);
+      if (e != 0) return fail(MCHAP_ERR_HIP, "launch of denovo_spec_kernel<%d, 64, replicas side by side>: %s", K, hipGetErrorString((hipError_t)e));
+      return MCHAP_OK;
+    }
+  }
   const int per_wave = 64 / G;
   SamplerTimer tm(timer, stream);
   const int e = inst->launch(&Q, (unsigned)((n_chains + per_wave - 1) / per_wave), lds, stream);
@@ -1005,7 +1027,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
       P.cache = reinterpret_cast<uint64_t *>(ws + cv.cache);
       P.cache_slots = slots;
       // (the words of wide genotypes need no clearing: they are only read behind a matching tag)
-      HIP_TRY(hipMemsetAsync(ws + cv.cache, 0, (size_t)n_units * cfg->chains * slots * 16, stream));
+      HIP_TRY(hipMemsetAsync(ws + cv.cache, 0, (size_t)n_units * cfg->chains * (pl.kind == SAMPLER_SPEC ? cfg->n_temps : 1) * slots * 16, stream));
       if (cv.key_words) {
         P.cache_keys = reinterpret_cast<uint64_t *>(ws + cv.ckeys);
         P.cache_key_words = cv.key_words;

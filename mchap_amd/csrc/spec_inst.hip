@@ -57,6 +57,20 @@ extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_launch_
   return (int)hipGetLastError();
 }
 
+#if SPEC_G == 64
+// one wavefront per replica of a temperature ladder (denovo_spec_kernel<.., TW = true>): a workgroup of n_temps wavefronts per chain
+extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_launchtw_, SPEC_K, SPEC_G)(
+    const mchap::SimtParams *P, unsigned grid, size_t lds, hipStream_t stream) {
+  auto ks = mchap::denovo_spec_kernel<SPEC_K, SPEC_G, false, MCHAP_SPEC_VAR, true>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(ks, dim3(grid), dim3(64 * P->d.n_temps), lds, stream, *P);
+  return (int)hipGetLastError();
+}
+#endif
+
 #endif  // SPEC_PIPE
 
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
