@@ -147,23 +147,26 @@ def test_config5_full_shape_four_chains_300_steps(monkeypatch):
 
 
 def test_config5_full_shape_tempered(monkeypatch):
-    """configs[4]'s secondary variant: one chain under the temperature ladder (0.001, 0.01, 0.1, 1.0), 25 steps
-    step for step against the oracle: the speculative kernel with three sub-steps per lane (which is also what the default
-    dispatch selects for a ladder) and the lanes-over-chains kernel."""
+    """configs[4]'s secondary variant: one chain under the temperature ladder (0.001, 0.01, 0.1, 1.0), step for
+    step against the oracle: 200 steps through the default dispatch (round 4: the replicas side by side, one wavefront each) --
+    the hot replicas move at every other sub-step, so this is some 60 000 accepted moves and 800 swap attempts per unit --, and
+    the first 25 of them on the one-wavefront form of the speculative kernel and on the lanes-over-chains kernel (draws are
+    numbered per step: a shorter run is a prefix of a longer one)."""
     from mchap_amd import DenovoMCMC
     from mchap_amd.synth import synth_units
 
     reads, _, _ = synth_units(2, ploidy=8, n_pos=20, n_reads=1000, window=(8, 20), first_unit=77)
     temps = (0.001, 0.01, 0.1, 1.0)
-    ref = _config5_oracle(list(reads), 25, 1, temps, 11)
-    for kernel in (3, 2, 0):
+    ref = _config5_oracle(list(reads), 200, 1, temps, 11)
+    for kernel, flags, steps in ((0, "0", 200), (3, "16384", 25), (2, "0", 25)):
         monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
-        model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=25, random_seed=11, chains=1, temperatures=temps)
+        monkeypatch.setenv("MCHAP_HIP_FLAGS", flags)
+        model = DenovoMCMC(ploidy=8, n_alleles=[2] * 20, steps=steps, random_seed=11, chains=1, temperatures=temps)
         traces = model.fit_batch(list(reads))
         for u, tr in enumerate(traces):
-            assert tr.genotypes.shape == (1, 25, 8, 20)
-            assert np.array_equal(tr.genotypes, ref[u][0]), "kernel %d unit %d" % (kernel, u)
-            np.testing.assert_allclose(tr.llks, ref[u][1], rtol=1e-10)
+            assert tr.genotypes.shape == (1, steps, 8, 20)
+            assert np.array_equal(tr.genotypes, ref[u][0][:, :steps]), "kernel %d unit %d" % (kernel, u)
+            np.testing.assert_allclose(tr.llks, ref[u][1][:, :steps], rtol=1e-10)
 
 
 def test_config2_default_dispatch_1000_steps_against_the_oracle(monkeypatch):
