@@ -674,13 +674,14 @@ def bench_config1(args):
             for s_ in samples:
                 sr = source.reads(locus, s_)
                 if M and len(sr["dists"]):
-                    todo.append((M, sr))
+                    todo.append((M, sr, list(locus.n_alleles)))
 
         def one(i):
-            M, sr = todo[i % len(todo)]
+            M, sr, n_alleles = todo[i % len(todo)]
             cfg = orc.make_cfg(4, 2000, 2, None, (1.0,), llk_cache_threshold=100, seed=42, rng_kind=orc.RNG_PHILOX, stream_id=0,
                                break_table=break_table(M, 1.0, 3.0))
-            assert orc.denovo_fit(cfg, sr["dists"], [2] * M, sr["counts"])[2] == 0
+            # (the locus's own allele counts: the oracle's trie cache has n_alleles branches per position)
+            assert orc.denovo_fit(cfg, sr["dists"], n_alleles, sr["counts"])[2] == 0
 
         n4 = sum(1 for _ in range(4 * len(samples)))
         # one thread: the units of the first 4 targets; all threads: EVERY unit of the example (the same job the GPU ran)
