@@ -176,6 +176,7 @@ __host__ __device__ inline size_t spec_memo_bytes(int Mmax, int T, int G) {
 }
 
 constexpr int SPEC_LC_ENTRIES = 256;  // entries of the LDS front cache of a chain's likelihoods (16 bytes each)
+constexpr uint32_t SPEC_LC_SECOND_LEVEL_GEN = 48;  // genotype changes after which a front-cache miss also probes the workspace table
 __host__ __device__ inline size_t spec_lc_bytes() { return (size_t)16 * SPEC_LC_ENTRIES + 16; }
 // LDS of the base-product cache (SpecLds::bpc / bpt) of a one-chain-per-wave launch
 __host__ __device__ inline size_t spec_bp_cache_bytes(int K) { return (size_t)8 * K * 4 * 64 + (size_t)8 * (K + 1); }
@@ -1280,6 +1281,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
   const bool wide = C_KEYBITS(c) * KT > 63;
   uint64_t *kslot = nullptr;
   LDSP(uint64_t) lslot = S.lc;  // (only used where lc_mask != 0)
+  bool promote = false;
   if (need && S.cache_on) {
     // 8-way sets (one 128-byte line).  The lanes of a group probe and fill the chain's table concurrently, so the
     // policy must not depend on read-modify-write sequences: hits never move entries, a miss goes to the first
@@ -1310,6 +1312,20 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
         miss = false;
       }
       lslot = le;
+      // A chain that keeps moving (dozens of genotypes behind it: samples with few reads) revisits more genotypes than 256
+      // entries hold; its front-cache misses go on to the 1024-entry table in the workspace (whose latency such a chain pays
+      // anyway: a round of it is mostly evaluations).  A settling chain -- BASELINE configs[1]: ~15 moves -- never gets here.
+      if (miss && c.gen > SPEC_LC_SECOND_LEVEL_GEN) {
+#pragma unroll
+        for (int w = 7; w >= 0; w--) {
+          const ulonglong2 e = set[w];
+          if (e.x == tag) {
+            val = __longlong_as_double((long long)e.y);
+            miss = false;
+          }
+        }
+        promote = !miss;  // (the next visit hits in LDS: written below, tag first, as after an evaluation)
+      }
     } else {
     int hit_way = -1;
 #pragma unroll
@@ -1338,6 +1354,12 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
     }
     }
     slot = set + way;
+  }
+  if (wave_any(promote)) {
+    if (promote) lslot[0] = tag;
+    lds_sync();
+    if (promote && lslot[0] == tag) lslot[1] = (uint64_t)__double_as_longlong(val);
+    lds_sync();
   }
   STAT_ADD(0, need);
   STAT_ADD(1, miss);
