@@ -409,16 +409,24 @@ def bench_config4(args):
 
 
 def sq_counters_of(pattern, kernel_prefix):
-    """Per-kernel SQ counter sums of the newest profiles/<pattern> summary (tools/pmc_sq.py output: {kernel: {counter: sum}})."""
+    """SQ counter sums of the newest profiles/<pattern> summary (tools/pmc_sq.py output: {kernel: {counter: sum}}) over the kernels
+    whose name starts with kernel_prefix (a string or a tuple of strings: a sampler call is several kernels)."""
     import glob
 
+    prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=_profile_order, reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
+            tot, names = {}, []
             for name, c in t.items():
-                if name.startswith(kernel_prefix) and "SQ_INSTS_VALU" in c:
-                    return c, "profiles/" + os.path.basename(path), name
+                if name.startswith(prefixes) and "SQ_INSTS_VALU" in c:
+                    names.append(name)
+                    for k, v in c.items():
+                        if k != "launches_seen":
+                            tot[k] = tot.get(k, 0.0) + float(v)
+            if names:
+                return tot, "profiles/" + os.path.basename(path), " + ".join(sorted(names))
         except Exception:
             pass
     return None, None, None
@@ -427,7 +435,8 @@ def sq_counters_of(pattern, kernel_prefix):
 def config5_roofline(U, substeps, kms):
     """VALU issue at configs[4]: wavefront VALU instructions of the sampler's launches from the committed SQ counter passes of this
     workload at 256 loci (static figures of an earlier profiling run, scaled per sub-step), priced per class in issue cycles."""
-    c, src, kname = sq_counters_of("*_config5_sq_counters.json", "denovo_spec_kernel<8")
+    c, src, kname = sq_counters_of("*_config5_sq_counters.json", ("denovo_spec_kernel<8", "denovo_fillw_kernel<8", "mchap::denovo_coast_kernel",
+                                                                   "denovo_coast_kernel"))
     if c is None:
         return None
     ref_substeps = 256.0 * 4 * 2000 * (8 * 20 + 3)
@@ -555,7 +564,7 @@ def call_mcmc_workload(U):
 def call_mcmc_roofline(U, S, Cn, K, ms):
     """VALU issue of call_mcmc_kernel from the committed SQ counter passes of this workload at 4096 units (static figures of an
     earlier rocprofv3 --pmc run, scaled per allele sub-step), priced per instruction class; None while no such profile exists."""
-    c, src, kname = sq_counters_of("*_call_sq_counters.json", "call_mcmc_kernel")
+    c, src, kname = sq_counters_of("*_call_sq_counters.json", ("call_mcmc_kernel", "mchap::call_mcmc_kernel"))
     if c is None:
         return None
     ref = 4096.0 * 2 * 2000 * 4
