@@ -62,10 +62,19 @@ __host__ __device__ inline int fillw_tab_rows(int max_pos, int max_allele, int r
 
 __host__ __device__ inline int fillw_slots(bool wide) { return wide ? FILLW_SLOTS_WIDE : FILLW_SLOTS; }
 struct FillwLds {
+  size_t mk1, mk2, mllk, mhh, mtab;  // (memo of evaluated requests across a chain's chunks: memo_cap > 0 only)
   size_t skey2, shh;  // (wide keys only)
   size_t tab, bp, cw, dict, pt, ln, lninv, skey, sllk, htab, urep, umiss, elin, elout, ese, eoff, eno, slrep, slent, slopt, cols, shift, scal, total;
 };
-__host__ __device__ inline FillwLds fillw_lds(int K, int max_pos, int tab_rows, int rpad, bool wide = false) {
+// memo_cap: entries of the memo of evaluated requests kept ACROSS a chain's chunks (0: none): the in-kernel completion found a
+// genotype that recurs in a later round in the chain's likelihood cache; this kernel's chunks are de-duplicated one by one, so at
+// big shapes (configs[4]: 17 000 slots in 34 chunks, 3 200 distinct genotypes) the same request used to be evaluated in several
+// chunks (its first evaluation may not even stay in the cache: the blind way a store picks).  The memo is exact (full keys).
+__host__ __device__ inline int fillw_memo_cap(int K, int max_pos, int tab_rows, bool wide) {
+  if (K >= 5) return 2048;                      // (one workgroup per CU at these ploidies anyway: the LDS is there)
+  return (wide && tab_rows == 0) ? 1024 : 0;    // two workgroups per CU: only beside a layout without the float64 table
+}
+__host__ __device__ inline FillwLds fillw_lds(int K, int max_pos, int tab_rows, int rpad, bool wide = false, int memo_cap = 0) {
   FillwLds L;
   const int nb = rpad / 64 < 4 ? rpad / 64 : 4;
   const size_t NS = (size_t)fillw_slots(wide);
@@ -95,11 +104,17 @@ __host__ __device__ inline FillwLds fillw_lds(int K, int max_pos, int tab_rows, 
   L.slopt = o; o += NS;
   L.shh = o; o += wide ? NS : 0;  // (h1 << 4) | h2 of a wide slot's changed haplotypes (h2 = 15: one only)
   L.shift = o; o += (size_t)max_pos;
+  o = (o + 7) & ~(size_t)7;
+  L.mk1 = o; o += (size_t)8 * memo_cap;
+  L.mk2 = o; o += (size_t)8 * memo_cap;
+  L.mllk = o; o += (size_t)8 * memo_cap;
+  L.mtab = o; o += (size_t)4 * 2 * memo_cap;
+  L.mhh = o; o += (size_t)memo_cap;
   L.total = (o + 63) & ~(size_t)63;
   return L;
 }
-__host__ __device__ inline size_t fillw_lds_bytes(int K, int max_pos, int tab_rows, int rpad, bool wide = false) {
-  return fillw_lds(K, max_pos, tab_rows, rpad, wide).total;
+__host__ __device__ inline size_t fillw_lds_bytes(int K, int max_pos, int tab_rows, int rpad, bool wide = false, int memo_cap = 0) {
+  return fillw_lds(K, max_pos, tab_rows, rpad, wide, memo_cap).total;
 }
 // Shapes the kernel takes: ploidy 2..8, a haplotype word of at most 64 bits (every shape the phased sampler runs).  The packed
 // genotype is a request's key while it fits 64 bits; beyond that (fillw_wide) a request is keyed by the one or two haplotype words
@@ -358,7 +373,8 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
   const bool flat = mi[META_I_FLAT] != 0 && !(P.flags & 128);
   const int tab_rows = (P.flags & 4096) ? 0 : P.fill_lt;  // rows the LDS table was sized for (0: none)
   const int nbmax = rpad / WAVE < 4 ? rpad / WAVE : 4;
-  const FillwLds L = fillw_lds(KT, P.max_pos, P.fill_lt, rpad, WIDE);
+  const int memo_cap = (P.fill_kw >> 8) * 256;  // entries of the cross-chunk memo (host: fillw_memo_cap)
+  const FillwLds L = fillw_lds(KT, P.max_pos, P.fill_lt, rpad, WIDE, memo_cap);
   LDSP(double) tab = lds_cast<double>(smem + L.tab);
   LDSP(double) bp = lds_cast<double>(smem + L.bp);
   LDSP(double) cwl = lds_cast<double>(smem + L.cw);
@@ -369,6 +385,13 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
   LDSP(uint64_t) skey = lds_cast<uint64_t>(smem + L.skey);     // packed genotype, or (WIDE) the first changed word
   LDSP(uint64_t) skey2 = lds_cast<uint64_t>(smem + L.skey2);   // (WIDE) the second changed word
   LDSP(uint8_t) shh = lds_cast<uint8_t>(smem + L.shh);         // (WIDE) which haplotypes: (h1 << 4) | h2, h2 = 15 when one only
+  LDSP(uint64_t) mk1 = lds_cast<uint64_t>(smem + L.mk1);       // memo across chunks: key, second word, haplotypes, llk
+  LDSP(uint64_t) mk2 = lds_cast<uint64_t>(smem + L.mk2);
+  LDSP(double) mllk = lds_cast<double>(smem + L.mllk);
+  LDSP(uint8_t) mhh = lds_cast<uint8_t>(smem + L.mhh);
+  unsigned int *mtab = reinterpret_cast<unsigned int *>(smem + L.mtab);  // [2 memo_cap] open addressing: entry + 1
+  for (int i = tid; i < 2 * memo_cap; i += FILLW_NT) mtab[i] = 0u;
+  if (tid == 0) reinterpret_cast<int *>(smem + L.scal)[12] = 0;
   LDSP(double) ptab = lds_cast<double>(smem + L.skey);  // (after the evaluation: the keys are no longer needed)
   LDSP(double) sllk = lds_cast<double>(smem + L.sllk);
   unsigned int *htab = reinterpret_cast<unsigned int *>(smem + L.htab);
@@ -682,7 +705,23 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
       if (flat) {
         sllk[rep] = cur_llk;  // a unit without information: every genotype has the chain's likelihood (spec_eval)
         hit = true;
-      } else if (probe) {
+      }
+      if (!hit && memo_cap > 0) {  // evaluated for an earlier chunk of this chain
+        const uint64_t k1 = skey[rep], k2 = WIDE ? skey2[rep] : 0ull;
+        const uint8_t hh = WIDE ? shh[rep] : (uint8_t)0;
+        const uint64_t hk = mix64(k1 ^ mix64(k2 + hh));
+        const uint32_t m2 = (uint32_t)(2 * memo_cap - 1);
+        for (uint32_t pr = 0, hi = (uint32_t)hk & m2; pr < 2u * (uint32_t)memo_cap; pr++, hi = (hi + 1u) & m2) {
+          const unsigned int v = mtab[hi];
+          if (v == 0u) break;
+          if (mk1[v - 1] == k1 && mk2[v - 1] == k2 && mhh[v - 1] == hh) {
+            sllk[rep] = mllk[v - 1];
+            hit = true;
+            break;
+          }
+        }
+      }
+      if (!hit && probe) {
         uint64_t key = skey[rep];
         uint64_t tag = (key << 1) | 1ull;
         GWords<KT> pwv = g;
@@ -765,6 +804,25 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
       if (lane == 0) sllk[rep] = val;
     }
     __syncthreads();
+    if (memo_cap > 0) {  // what this chunk evaluated, for the chain's later chunks (while the memo has room)
+      for (int m = tid; m < n_miss; m += FILLW_NT) {
+        const int rep = (int)umiss[m];
+        const int idx = atomicAdd(&scal[12], 1);
+        if (idx < memo_cap) {
+          const uint64_t k1 = skey[rep], k2 = WIDE ? skey2[rep] : 0ull;
+          const uint8_t hh = WIDE ? shh[rep] : (uint8_t)0;
+          mk1[idx] = k1;
+          mk2[idx] = k2;
+          mhh[idx] = hh;
+          mllk[idx] = sllk[rep];
+          const uint64_t hk = mix64(k1 ^ mix64(k2 + hh));
+          const uint32_t m2 = (uint32_t)(2 * memo_cap - 1);
+          for (uint32_t pr = 0, hi = (uint32_t)hk & m2; pr < 2u * (uint32_t)memo_cap; pr++, hi = (hi + 1u) & m2)
+            if (mtab[hi] == 0u && atomicCAS(&mtab[hi], 0u, (unsigned int)(idx + 1)) == 0u) break;
+        }
+      }
+      __syncthreads();
+    }
 
     // ---- (4) option probabilities, then the totals a visit without a move would have formed ----
     // (ptab shares the keys' array: every request has been evaluated, nothing reads a key any more)

@@ -681,10 +681,12 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   const bool fillw = G == 64 && !(T.flags & (64 | 1024 | 32)) && mchap::fillw_takes(K, P.max_pos, P.max_allele);
   const int fillw_rows = mchap::fillw_tab_rows(P.max_pos, P.max_allele, P.d.rpad);
   const bool fillw_wide = mchap::fillw_wide(K, P.max_pos, P.max_allele);
-  const size_t lds_fillw = mchap::fillw_lds_bytes(K, P.max_pos, fillw_rows, P.d.rpad, fillw_wide);
+  const int fillw_memo = (T.flags & 32768) ? 0 : mchap::fillw_memo_cap(K, P.max_pos, fillw_rows, fillw_wide);  // (flag 32768: no memo across chunks)
+  const size_t lds_fillw = mchap::fillw_lds_bytes(K, P.max_pos, fillw_rows, P.d.rpad, fillw_wide, fillw_memo);
   if (fillw) {
     P.fill_lt = fillw_rows;
-    P.fill_kw = (fillw_wide ? 1 : 0) | (P.gbp != nullptr ? 2 : 0);  // (the instantiation: keyed by changed words / deep units: fillw_inst.hip)
+    // (the instantiation: keyed by changed words / deep units: fillw_inst.hip; bits 8..: entries / 256 of the memo across chunks)
+    P.fill_kw = (fillw_wide ? 1 : 0) | (P.gbp != nullptr ? 2 : 0) | ((fillw_memo / 256) << 8);
   }
 #define ROW_FILLW_LAUNCH(k) mchap_fillw_launch_##k,
   const simt_launch_fn fillw_launches[] = {FILLW_LIST(ROW_FILLW_LAUNCH)};

@@ -82,8 +82,9 @@ def test_tables_equal_the_in_kernel_completion(case):
     assert np.array_equal(new[done].view(np.uint64), old[done].view(np.uint64)), \
         "max |diff| %.3e" % np.nanmax(np.abs(new - old))
     assert (old[done] >= 0).any() and (old[done] == -1.0).any()  # both kinds of entries occur
-    # ... and without the probe of the chain's likelihood cache (2048) / without the unit's table in LDS (4096): the same tables
-    for flags in (2048, 4096, 2048 | 4096):
+    # ... and without the probe of the chain's likelihood cache (2048) / without the unit's table in LDS (4096) / without the memo of
+    # evaluated requests across a chain's chunks (32768): the same tables
+    for flags in (2048, 4096, 2048 | 4096, 32768, 32768 | 2048):
         alt = _tables(reads, flags, **kw)
         assert np.array_equal(np.isnan(alt), np.isnan(old)) and np.array_equal(alt[done].view(np.uint64), old[done].view(np.uint64)), flags
 
