@@ -711,7 +711,7 @@ def assemble_targets(bed_path=None, region=None, region_id=None):
 def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploidy=4, inbreeding=None, steps=1000, burn=500,
              chains=2, seed=42, error_rate=0.0024, use_phred=False, haplotype_posterior_threshold=0.20,
              incongruence_threshold=0.60, report=(), temperatures=(1.0,), read_kw=None, targets=None, units_per_block=None,
-             shard=None, sampler=None, timings=None, **mcmc_kw):
+             shard=None, sampler=None, timings=None, block_path=None, _batch_factory=None, **mcmc_kw):
     """`mchap assemble` over the targets of a BED4 file (or `targets`: a list of (contig, start, stop, name)): yields one
     VCF record line per target (no header).  reference_sequences: {contig: sequence string} or an io.Reference;
     sample_bams: ordered mapping sample name -> BAM path (or pool -> [(sample, path)], or a ReadSource); ploidy /
@@ -727,7 +727,13 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
 
     variants_vcf_path may be the list of variant records itself.  sampler: None = the device batch; or a callable
     (units, settings dict) -> per-unit summaries (the oracle-backed replay of the tests).  timings: a dict that receives
-    the seconds spent encoding reads, in the sampler (launch to results on the host) and formatting records."""
+    the seconds spent encoding reads, in the sampler (launch to results on the host) and formatting records.
+
+    block_path: None = the host work of a block (read extraction, allele calls, de-duplication, the sampler's descriptors, the
+    posterior haplotypes and the record fields) as array operations over the whole block (mchap_amd/blockpath.py, _BlockState
+    below) whenever the inputs allow -- alignment files read whole, one file per sample, base qualities ignored --, else locus
+    by locus; False = always locus by locus (the definition: tests hold the two against each other line for line); True =
+    fail if the block path cannot take the inputs."""
     from .assemble import DenovoMCMC
     from .classes import PosteriorGenotypeDistribution
     from .device import DenovoRaggedBatch, PassesInFlight
@@ -884,18 +890,428 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
     # stream, so fetching them does not wait for the next block's launches); a job of one block runs on the current stream.
     blocks = list(_blocks(targets, loci_per_block))
     streams = [None, None]
-    if len(blocks) > 1 and sampler is None:
+    if len(blocks) > 1 and sampler is None and _batch_factory is None:
         import torch
 
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    fast = block_path is not False and sampler is None and _block_path_takes(source)
+    if block_path is True and not fast:
+        raise ValueError("block_path=True: the inputs need the per-locus path")
+
+    def start(block, stream):
+        if fast:
+            from .blockpath import BlockPathUnavailable
+
+            try:
+                return _BlockState(block, stream, locals_of_run)
+            except BlockPathUnavailable:
+                if block_path is True:
+                    raise
+        return start_block(block, stream)
+
+    def finish(state):
+        if isinstance(state, _BlockState):
+            return state.finish()
+        return finish_block(state)
+
+    locals_of_run = dict(source=source, samples=samples, ploidy_of=ploidy_of, inbreeding_of=inbreeding_of, temps_of=temps_of,
+                         by_contig=by_contig, fetch=fetch, seq_known=seq_known, timings=timings, steps=steps, chains=chains, seed=seed,
+                         burn=burn, incongruence_threshold=incongruence_threshold, mcmc_kw=mcmc_kw, report=report,
+                         threshold=haplotype_posterior_threshold, batch_factory=_batch_factory)
     prev = None
     for bi, block in enumerate(blocks):
-        cur = start_block(block, streams[bi % 2])
+        cur = start(block, streams[bi % 2])
         if prev is not None:
-            yield from finish_block(prev)
+            yield from finish(prev)
         prev = cur
     if prev is not None:
-        yield from finish_block(prev)
+        yield from finish(prev)
+
+
+def _block_path_takes(source):
+    """The array path of a block reads every sample from one alignment file held whole in memory (or from pileup matrices the
+    caller has already), base qualities ignored."""
+    from .io import BamFile
+
+    if isinstance(source, MatrixSource):
+        return not source.use_phred
+    if not isinstance(source, ReadSource) or source.use_phred:
+        return False
+    for pairs in source.pools.values():
+        if len(pairs) != 1:
+            return False
+        bam = source.bams[pairs[0][1]]
+        if not isinstance(bam, BamFile) or (bam.index is not None and len(bam.data) > source.WHOLE_FILE_BYTES):
+            return False
+    return True
+
+
+def _rounded_text(r):
+    """io._number_text of a value already rounded by np.round (an array's worth at a time)."""
+    if r != r:
+        return "."
+    if abs(r) != float("inf") and r == int(r):
+        return str(int(r))
+    return repr(r)[:16]
+
+
+class _BlockState:
+    """One block of targets of `assemble` on the array path: __init__ is stage 1 (loci, extraction and encoding of every
+    sample over all loci at once, the sampler launches enqueued), finish() stage 2 (summaries as arrays, records)."""
+
+    def __init__(self, block, stream, run):
+        import time as _time
+
+        from . import blockpath as bp
+        from .assemble import DenovoMCMC
+        from .device import DenovoRaggedBatch, PassesInFlight
+
+        self.run, self.stream = run, stream
+        source, samples, timings = run["source"], run["samples"], run["timings"]
+        self.loci = loci = [DenovoLocus(c, a, b, nm, _variants_within(run["by_contig"], c, a, b), run["fetch"](c, a, b),
+                                        sequence_known=run["seq_known"](c)) for c, a, b, nm in block]
+        t0 = _time.perf_counter()
+        self.skipped = {li: "%d SNVs (at most %d per target)" % (len(l.positions), MAX_SNVS_PER_LOCUS)
+                        for li, l in enumerate(loci) if len(l.positions) > MAX_SNVS_PER_LOCUS}
+        self.xi_of = {}
+        self.lx = lx = [l for li, l in enumerate(loci) if li not in self.skipped]
+        for li in range(len(loci)):
+            if li not in self.skipped:
+                self.xi_of[li] = len(self.xi_of)
+        tables = bp.locus_tables(lx)
+        M, snv_start, _ = tables
+        self.M = M
+        self.enc = []
+        for sample in samples:
+            if isinstance(source, MatrixSource):
+                self.enc.append(bp.encode_block(lx, bp.pile_from_matrices(lx, [source.matrices[(l.name, sample)] for l in lx], tables=tables)))
+                continue
+            name, path = source.pools[sample][0]
+            tp = _time.perf_counter()
+            cols = source.bams[path].columns()   # (the first use of a file inflates and parses it)
+            timings["bam_parse_s"] = timings.get("bam_parse_s", 0.0) + _time.perf_counter() - tp
+            self.enc.append(bp.encode_block(lx, bp.extract_block(lx, cols, name, tables=tables, **source.filter)))
+        # the sampler's units: every (sample, locus with SNVs), one launch per (ploidy, temperature ladder, wide) present
+        nal = np.fromiter((a for l in lx for a in l.n_alleles), dtype=np.int8, count=int(snv_start[-1]))
+        amax = np.array([max(l.n_alleles) if l.n_alleles else 0 for l in lx], dtype=np.int64)
+        bits = np.where(amax <= 2, 1, np.where(amax <= 4, 2, 3))
+        wide = (M > 62) | (M * bits > 64)
+        sampled = M > 0
+        self.batches = []   # (batch, samples [n], loci [m], unit arrays): unit = position of the sample * m + position of the locus
+        self.unit_at = np.full((len(samples), len(lx), 2), -1, dtype=np.int64)  # (batch, unit) of every (sample, locus)
+        groups = {}
+        for si, sample in enumerate(samples):
+            groups.setdefault((int(run["ploidy_of"](sample)), tuple(run["temps_of"](sample))), []).append(si)
+        plans = []
+        for (K, temps), sis in groups.items():
+            for w in (False, True):
+                use = np.flatnonzero(sampled & (wide == w))
+                if len(use):
+                    plans.append((K, temps, sis, use))
+        t1 = _time.perf_counter()
+        timings["encode_s"] += t1 - t0
+        factory = run["batch_factory"] or DenovoRaggedBatch.from_calls
+        if run["batch_factory"] is None:
+            import torch
+
+            ctx = torch.cuda.stream(stream) if stream is not None else _nullcontext()
+        else:
+            ctx = _nullcontext()
+        with ctx:
+            flight = PassesInFlight(min(4, len(plans))) if (len(plans) > 1 and run["batch_factory"] is None) else None
+            for bi, (K, temps, sis, use) in enumerate(plans):
+                parts = [bp.unit_inputs(self.enc[si], use) for si in sis]
+                m = len(use)
+                c_base = np.cumsum([0] + [len(p[0]) for p in parts])
+                n_base = np.cumsum([0] + [len(p[1]) for p in parts])
+                u = dict(calls=np.concatenate([p[0] for p in parts]), counts=np.concatenate([p[1] for p in parts]),
+                         n_reads=np.concatenate([p[2] for p in parts]),
+                         reads_off=np.concatenate([p[3] + c_base[i] for i, p in enumerate(parts)]),
+                         counts_off=np.concatenate([np.where(p[4] >= 0, p[4] + n_base[i], -1) for i, p in enumerate(parts)]),
+                         n_pos=np.tile(M[use], len(sis)), max_allele=np.tile(amax[use], len(sis)), nalleles_off=np.tile(snv_start[use], len(sis)),
+                         ploidy=np.full(m * len(sis), K, dtype=np.int64))
+                F = np.array([np.nan if run["inbreeding_of"](samples[si]) is None else float(run["inbreeding_of"](samples[si])) for si in sis])
+                model = DenovoMCMC(ploidy=K, n_alleles=[2], inbreeding=None, steps=run["steps"], chains=run["chains"], random_seed=run["seed"],
+                                   temperatures=temps, **run["mcmc_kw"])
+                batch = factory(model, u["calls"], u["reads_off"], u["n_reads"], u["n_pos"], u["max_allele"], u["ploidy"], u["counts"],
+                                u["counts_off"], nal, u["nalleles_off"], inbreeding=np.repeat(F, m), error_rate=source.error_rate)
+                go = (lambda b=batch: b.run(run["burn"], incongruence_threshold=run["incongruence_threshold"]))
+                if flight is not None:
+                    flight.submit(go)
+                else:
+                    go()
+                for k, si in enumerate(sis):
+                    self.unit_at[si, use, 0] = bi
+                    self.unit_at[si, use, 1] = k * m + np.arange(m)
+                u["bits"] = np.tile(bits[use], len(sis))
+                self.batches.append((batch, u, K))
+            if flight is not None:
+                flight.join()
+        timings["units"] += int(sum(len(b[1]["n_reads"]) for b in self.batches))
+        timings["sampler_s"] += _time.perf_counter() - t1
+
+    # ---- stage 2 ----
+    def _summaries(self, batch, u, K):
+        """Per unit of a batch, from the device's summary arrays: GQ / SQ / GPM / SPM / MCI / MEC values, the listed haplotypes
+        (allele rows as bytes) with their expected dosages, the mode genotype's haplotypes; None for the units whose summary
+        is not complete in the arrays (their loci go through the per-locus formatter)."""
+        from . import blockpath as bp
+
+        run = self.run
+        if getattr(batch, "wph", 1) != 1:
+            return None
+        arr = batch.summary_arrays()
+        plain = arr["plain"]
+        if not plain.any():
+            return None
+        U = len(plain)
+        M, total = u["n_pos"], arr["total"]
+        n = np.where(plain, arr["n"], 0).astype(np.int64)
+        gu, gi = bp._ragged_arange(n)
+        W = arr["words"][gu, gi, :K]
+        p = arr["counts"][gu, gi] / total
+        # allele_frequencies(dosage=True) of every unit (classes.py): one term per (genotype, distinct haplotype), summed in
+        # genotype order; haplotypes in order of first appearance
+        same = W[:, :, None] == W[:, None, :]
+        dose = same.sum(axis=2)
+        first = ~(same & np.tril(np.ones((K, K), dtype=bool), -1)[None]).any(axis=2)
+        ent_u = np.broadcast_to(gu[:, None], W.shape)[first]
+        ent_w, ent_p, ent_d = W[first], np.broadcast_to(p[:, None], W.shape)[first], dose[first]
+        o = np.lexsort((ent_w, ent_u))
+        su, sw = ent_u[o], ent_w[o]
+        new = np.r_[True, (su[1:] != su[:-1]) | (sw[1:] != sw[:-1])] if len(o) else np.zeros(0, dtype=bool)
+        first_idx = o[np.flatnonzero(new)]
+        order = np.argsort(first_idx, kind="stable")
+        rank = np.empty(len(order), dtype=np.int64)
+        rank[order] = np.arange(len(order))
+        gid = np.empty(len(o), dtype=np.int64)
+        gid[o] = rank[np.cumsum(new) - 1]
+        H = len(first_idx)
+        weight = np.bincount(gid, weights=ent_p * ent_d, minlength=H)
+        occur = np.bincount(gid, weights=ent_p, minlength=H)
+        hap_u, hap_w = ent_u[first_idx[order]], ent_w[first_idx[order]]
+        listed = occur >= run["threshold"]
+        lu, lw, lwt = hap_u[listed], hap_w[listed], weight[listed]
+        pu = np.flatnonzero(plain)
+        words = np.concatenate([lw, arr["mode_words"][pu, :K].reshape(-1)])
+        unit = np.concatenate([lu, np.repeat(pu, K)])
+        fixed_off = batch.units_host["fixed_off"].astype(np.int64)
+        flat, cell_of = bp.unpack_words(words, unit, arr["fixed"], fixed_off, M, u["bits"])
+        B = flat.tobytes()
+        lstart = np.zeros(U + 1, dtype=np.int64)
+        np.cumsum(np.bincount(lu, minlength=U), out=lstart[1:])
+        mode_slot = np.full(U, -1, dtype=np.int64)
+        mode_slot[pu] = len(lw) + np.arange(len(pu)) * K      # index of the unit's first mode haplotype among `words`
+        # MEC of the mode genotype over the unit's reads: distinct rows x their counts (encoding/integer/stats.py:18-39)
+        R = u["n_reads"]
+        ru, rk = bp._ragged_arange(R)
+        cr, cj = bp._ragged_arange(M[ru])
+        cu = ru[cr]
+        c = u["calls"][u["reads_off"][cu] + rk[cr] * M[cu] + cj]
+        row_first = np.cumsum(M[ru]) - M[ru]
+        best = None
+        ms_ = np.where(mode_slot >= 0, mode_slot, 0)
+        for h in range(K):
+            g = flat[cell_of[ms_[cu] + h] + cj]
+            per_row = np.add.reduceat(((c != g) & (c >= 0)).astype(np.int64), row_first)
+            best = per_row if best is None else np.minimum(best, per_row)
+        cnt = np.where(u["counts_off"][ru] >= 0, u["counts"][np.maximum(u["counts_off"][ru], 0) + rk] if len(u["counts"]) else 1, 1)
+        mec = np.bincount(ru, weights=best * cnt, minlength=U).astype(np.int64)
+        gpm, spm = arr["stats"][:, 1], arr["stats"][:, 0]
+        unit6 = 10 ** 6
+
+        def qual(prob):  # io.qual_of_prob over an array
+            kept = np.floor(np.minimum(prob, 1 - 0.1 ** 6) * unit6) / unit6
+            with np.errstate(invalid="ignore"):
+                return np.round(-10 * np.log10(1 - kept))
+        return dict(plain=plain, B=B, cell_of=cell_of, lstart=lstart, lweight=lwt.tolist(), mode_slot=mode_slot, mec=mec,
+                    gq=qual(gpm), sq=qual(spm), gpm=np.round(gpm, 3).tolist(), spm=np.round(spm, 3).tolist(), mci=arr["mci"], M=M)
+
+    def finish(self):
+        import sys
+        import time as _time
+
+        run = self.run
+        samples, timings, report = run["samples"], run["timings"], run["report"]
+        t1 = _time.perf_counter()
+        if run["batch_factory"] is None:
+            import torch
+
+            ctx = torch.cuda.stream(self.stream) if self.stream is not None else _nullcontext()
+        else:
+            ctx = _nullcontext()
+        with ctx:
+            sums = [self._summaries(*b) for b in self.batches]
+            # the loci that go through the per-locus formatter (no SNVs, --report fields, a unit whose summary is not in the arrays)
+            # and the units it will ask for
+            slow_x = (self.M == 0) | bool(report)
+            for si in range(len(samples)):
+                bi_, uu = self.unit_at[si, :, 0], self.unit_at[si, :, 1]
+                for b, sm in enumerate(sums):
+                    m = bi_ == b
+                    slow_x[m] |= True if sm is None else ~sm["plain"][uu[m]]
+            self.slow_res = []
+            for b, (batch, u, K) in enumerate(self.batches):
+                need = sorted(int(x) for si in range(len(samples)) for x in self.unit_at[si, (self.unit_at[si, :, 0] == b) & slow_x, 1])
+                self.slow_res.append(dict(zip(need, batch.results(raise_on_limit=False, only=need))) if need else {})
+            self.slow_x = slow_x
+            # MEC / MECP of every (sample, locus) whose unit is in the arrays
+            self.mec = np.zeros((len(samples), len(self.lx)), dtype=np.int64)
+            for si in range(len(samples)):
+                bi_, uu = self.unit_at[si, :, 0], self.unit_at[si, :, 1]
+                for b, sm in enumerate(sums):
+                    m = (bi_ == b) & ~slow_x
+                    if sm is not None and m.any():
+                        self.mec[si, m] = sm["mec"][uu[m]]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                self.mecp = [np.round(self.mec[si] / self.enc[si].rcalls, 3).tolist() for si in range(len(samples))]
+        t2 = _time.perf_counter()
+        timings["sampler_s"] += t2 - t1
+        S = len(samples)
+        K_of = [int(run["ploidy_of"](s_)) for s_ in samples]
+        fmt_head = ":".join(SAMPLE_FIELDS)
+        for li, locus in enumerate(self.loci):
+            if li in self.skipped:
+                sys.stderr.write("mchap_amd assemble: target %s (%s:%d-%d) not assembled (record written with FILTER=LIMIT): %s\n" % (
+                    locus.name, locus.contig, locus.start + 1, locus.stop, self.skipped[li]))
+                timings["limit_records"] = timings.get("limit_records", 0) + 1
+                yield _limit_record_line(locus, samples, report, run["ploidy_of"])
+                continue
+            xi = self.xi_of[li]
+            M = int(self.M[xi])
+            at = self.unit_at[:, xi]
+            ok = not self.slow_x[xi]
+            if not ok:
+                line = self._slow_record(li, xi, sums)
+                if line is None:   # (a unit beyond a limit)
+                    yield _limit_record_line(locus, samples, report, run["ploidy_of"])
+                else:
+                    yield line
+                continue
+            # call_posterior_haplotypes: the haplotypes any sample lists, ranked by expected dosage summed over the samples
+            index, score = {}, []
+            for si in range(S):
+                sm = sums[at[si, 0]]
+                u = int(at[si, 1])
+                B, cell_of, lw = sm["B"], sm["cell_of"], sm["lweight"]
+                for k in range(int(sm["lstart"][u]), int(sm["lstart"][u + 1])):
+                    c0 = int(cell_of[k])
+                    key = B[c0:c0 + M]
+                    i = index.get(key)
+                    if i is None:
+                        index[key] = len(score)
+                        score.append(0.0 + lw[k])
+                    else:
+                        score[i] += lw[k]
+            ref = bytes(M)
+            ref_called = ref in index
+            keys = [k_ for k_ in index if k_ != ref]
+            vals = [score[index[k_]] for k_ in keys]
+            keys.append(ref)
+            vals.append((max(vals) if vals else -1.0) + 1.0)
+            if len(keys) > 2:
+                if len(set(vals)) == len(vals):   # (no ties: the descending order is unique)
+                    keys = [keys[i] for i in sorted(range(len(vals)), key=vals.__getitem__, reverse=True)]
+                else:
+                    keys = [keys[i] for i in np.flip(np.argsort(np.array(vals))).tolist()]
+            elif len(keys) == 2:
+                keys = [keys[1], keys[0]]
+            labels = {k_: i for i, k_ in enumerate(keys)}
+            flt = "PASS"
+            if not ref_called:
+                labels.pop(ref)
+                if len(keys) == 1:
+                    flt = "NOA"
+            H = len(keys)
+            seq0 = list(locus.sequence)
+            alts = []
+            rel = [p_ - locus.start for p_ in locus.positions]
+            for key in keys[1:]:
+                chars = seq0[:]
+                for r_, tup, a in zip(rel, locus.alleles, key):
+                    chars[r_] = tup[a]
+                alts.append("".join(chars))
+            counts = [0] * H
+            cols, ns, n_mci, dp_sum, rc_sum = [], 0, 0, 0.0, 0
+            any_dp = False
+            for si in range(S):
+                sm = sums[at[si, 0]]
+                u = int(at[si, 1])
+                K = K_of[si]
+                enc = self.enc[si]
+                m0 = int(sm["mode_slot"][u])
+                cell_of, B = sm["cell_of"], sm["B"]
+                a = []
+                for h in range(K):
+                    c0 = int(cell_of[m0 + h])
+                    a.append(labels.get(B[c0:c0 + M], -1))
+                a.sort()
+                neg = [x for x in a if x < 0]
+                a = [x for x in a if x >= 0]
+                for x in a:
+                    counts[x] += 1
+                if a:
+                    ns += 1
+                mci = int(sm["mci"][u])
+                n_mci += mci > 0
+                mec = int(self.mec[si, xi])
+                rcalls, rcount, dp = int(enc.rcalls[xi]), int(enc.rcount[xi]), float(enc.dp[xi])
+                if dp == dp:
+                    dp_sum += dp
+                rc_sum += rcount
+                mecp = _rounded_text(self.mecp[si][xi]) if rcalls > 0 else "."
+                cols.append(":".join(["/".join([str(x) for x in a] + ["."] * len(neg)), str(int(sm["gq"][u])), str(int(sm["sq"][u])),
+                                      _rounded_text(dp), str(rcount), str(rcalls), str(mec), mecp,
+                                      _rounded_text(sm["gpm"][u]), _rounded_text(sm["spm"][u]), str(mci)]))
+            info = ["AN=%d" % sum(counts), "UAN=%d" % sum(1 for x in counts if x > 0), "AC=" + (",".join(str(x) for x in counts[1:]) if H > 1 else ".")]
+            if not ref_called:
+                info.append("REFMASKED")
+            info += ["NS=%d" % ns, "MCI=%d" % n_mci, "DP=" + _rounded_text(dp_sum), "RCOUNT=%d" % rc_sum, "END=%d" % locus.stop,
+                     "NVAR=%d" % M, "SNVPOS=" + ",".join(str(r_ + 1) for r_ in rel)]
+            line = "\t".join([locus.contig, str(locus.start + 1), locus.name, locus.sequence, ",".join(alts) if alts else ".", ".", flt,
+                              ";".join(info), fmt_head] + cols)
+            timings["format_s"] += _time.perf_counter() - t2
+            yield line
+            t2 = _time.perf_counter()
+
+    def _slow_record(self, li, xi, sums):
+        """A locus the array formatter does not take (no SNVs, --report fields, a unit whose summary is not in the arrays): the
+        per-locus formatter on the same data.  None: a unit of the locus is beyond a limit of the library."""
+        import sys
+
+        from .classes import PosteriorGenotypeDistribution
+
+        run = self.run
+        samples, report = run["samples"], run["report"]
+        locus = self.loci[li]
+        M = int(self.M[xi])
+        per, posteriors, encoded = {}, [], {}
+        for si, sample in enumerate(samples):
+            K = int(run["ploidy_of"](sample))
+            d = self.enc[si].per_locus(xi)
+            calls, depth = d["calls"], d["depth"]
+            sr = dict(calls=calls, depth=depth, counts=d["counts"])
+            if "GL" in report and M:
+                sr["dists"] = encoding.encode_read_distributions(locus.n_alleles, d["ucalls"], None, error_rate=run["source"].error_rate)
+            encoded[sample] = sr
+            if M == 0:
+                res = dict(genotypes=np.zeros((1, K, 0), np.int8), probabilities=np.ones(1), spm=1.0, gpm=1.0,
+                           mode_genotype=np.zeros((K, 0), np.int8), mci=0)
+            else:
+                bi, u = (int(x) for x in self.unit_at[si, xi])
+                res = self.slow_res[bi][u]
+                if res.get("limit"):
+                    sys.stderr.write("mchap_amd assemble: target %s (%s:%d-%d) not assembled (record written with FILTER=LIMIT): sample %s: %s\n" % (
+                        locus.name, locus.contig, locus.start + 1, locus.stop, sample, res["limit"]))
+                    run["timings"]["limit_records"] = run["timings"].get("limit_records", 0) + 1
+                    return None
+            posteriors.append(PosteriorGenotypeDistribution(res["genotypes"], res["probabilities"]))
+            mec = _mec(calls, res["mode_genotype"])
+            denom = int((calls >= 0).sum())
+            per[sample] = dict(genotype=res["mode_genotype"], gprob=float(res["gpm"]), sprob=float(res["spm"]), mec=mec,
+                               mecp=mec / denom if denom > 0 else np.nan, mci=int(res["mci"]), rcount=len(calls), rcalls=denom,
+                               dp=np.round(np.mean(depth)) if len(depth) else np.nan, depth=depth)
+        return _assemble_record_line(locus, samples, per, posteriors, run["threshold"], report, run["ploidy_of"], encoded)
 
 
 # ---------------------------------------------------------------------------------------------------------

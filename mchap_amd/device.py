@@ -451,20 +451,85 @@ class DenovoRaggedBatch(_OwnBuffers):
     def _p(self, t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
+    def _fit(self, stream):
+        """The sampler launch on `stream` (a raw hipStream_t): from the float64 read tensors, or -- a batch built by from_calls --
+        from int8 calls, the tensors formed on the device by the prepare pass (mchap_denovo_fit_batch_calls_device)."""
+        L = _lib.lib()
+        if self.d_reads is None:
+            _lib.check(L.mchap_denovo_fit_batch_calls_device(
+                C.byref(self.cfg), self.n_units, self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_calls), None,
+                self._p(self.d_qual_prob), 1, self._p(self.d_counts), self._p(self.d_nalleles), None, self._p(self.d_trace),
+                self._p(self.d_llks), self._p(self.d_fixed), self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes),
+                C.c_void_p(stream)))
+            return
+        _lib.check(L.mchap_denovo_fit_batch_device(
+            C.byref(self.cfg), self.n_units, self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_reads), self._p(self.d_counts),
+            self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks), self._p(self.d_fixed),
+            self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream)))
+
+    @classmethod
+    def from_calls(cls, model, calls, reads_off, n_reads, n_pos, max_allele, ploidy, counts, counts_off, n_alleles, nalleles_off,
+                   inbreeding=None, error_rate=0.0024, device=None):
+        """The same batch from the compact input (reference encoders: encoding/integer/transcode.py:16-77 with base qualities
+        ignored, as the programs do by default), built with array operations only -- one row of every array per unit:
+        calls int8 (all units' [n_reads, n_pos] matrices of allele calls, < 0 = gap, unit u at reads_off[u]), counts int64 (unit u's
+        n_reads[u] counts at counts_off[u]; -1 = none), n_alleles int8 (unit u's n_pos[u] values at nalleles_off[u]; units may
+        share them), inbreeding float [U] (NaN = none) or None."""
+        self = cls.__new__(cls)
+        torch = _torch()
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        dev = self.device
+        self.model = model
+        n_reads, n_pos, ploidy = (np.asarray(x, dtype=np.int64) for x in (n_reads, n_pos, ploidy))
+        U = len(n_reads)
+        Cn, S = int(model.chains), int(model.steps)
+        self.Cn, self.S = Cn, S
+        assert U and (n_reads >= 1).all() and (n_pos >= 1).all()
+        desc = np.zeros(U, dtype=_lib.UNIT_DTYPE)
+        desc["reads_off"], desc["counts_off"], desc["nalleles_off"] = reads_off, counts_off, nalleles_off
+        desc["initial_off"] = -1
+        t = Cn * S * ploidy
+        desc["trace_off"] = np.cumsum(t) - t
+        desc["llk_off"] = np.arange(U, dtype=np.int64) * (Cn * S)
+        desc["fixed_off"] = np.cumsum(n_pos) - n_pos
+        desc["n_reads"], desc["n_pos"], desc["max_allele"], desc["ploidy"] = n_reads, n_pos, max_allele, ploidy
+        desc["inbreeding"] = np.nan if inbreeding is None else inbreeding
+        desc["stream_id"] = 0
+        self.Kmax, self.max_pos = int(ploidy.max()), int(n_pos.max())
+        self.units_host, self.n_units = desc, U
+        self.cfg = model._cfg(self.max_pos)
+        self.wph = int(_lib.lib().mchap_denovo_trace_words_per_haplotype(C.byref(self.cfg), U, _lib.ptr(desc)))
+        if self.wph < 1:
+            raise NotImplementedError("mchap_hip: unsupported unit shape (" + _lib.last_error() + ")")
+        desc["trace_off"] *= self.wph
+        self.d_units = torch.from_numpy(desc.view(np.uint8).reshape(-1)).to(dev)
+        self.d_reads = None
+        self.d_calls = torch.from_numpy(np.ascontiguousarray(calls, dtype=np.int8)).to(dev)
+        self.d_qual_prob = torch.from_numpy(np.array([1.0 - error_rate], dtype=np.float64)).to(dev)
+        self.d_counts = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64)).to(dev) if len(counts) else None
+        self.d_nalleles = torch.from_numpy(np.ascontiguousarray(n_alleles, dtype=np.int8)).to(dev)
+        self.d_trace = torch.empty(int(t.sum()) * self.wph, dtype=torch.int64, device=dev)
+        self.d_llks = torch.empty(U * Cn * S, dtype=torch.float64, device=dev)
+        self.d_fixed = torch.empty(int(n_pos.sum()), dtype=torch.int8, device=dev)
+        self.d_status = torch.empty(U, dtype=torch.int32, device=dev)
+        self.ws_bytes = int(_lib.lib().mchap_denovo_workspace_bytes(C.byref(self.cfg), U, _lib.ptr(desc)))
+        if self.ws_bytes < 0:
+            raise NotImplementedError("mchap_hip: unsupported unit shape")
+        self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
+        return self
+
     def _run_wide(self, burn, incongruence_threshold):
         """A batch with a unit wider than 64 bits per haplotype (two words per haplotype in the traces): the sampler only; the
         posterior summaries of such batches are formed by the host classes in results()."""
         stream = self._begin().cuda_stream
         type(self).n_runs += 1
-        _lib.check(_lib.lib().mchap_denovo_fit_batch_device(
-            C.byref(self.cfg), self.n_units, self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_reads), self._p(self.d_counts),
-            self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks), self._p(self.d_fixed),
-            self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream)))
+        self._fit(stream)
         self.burn = int(burn)
         self.incongruence_threshold = float(incongruence_threshold)
         self._end()
 
-    def _results_wide(self, raise_on_limit):
+    def _results_wide(self, raise_on_limit, only=None):
         from .classes import GenotypeMultiTrace
 
         self._begin()
@@ -473,7 +538,7 @@ class DenovoRaggedBatch(_OwnBuffers):
         trace = self.d_trace.cpu().numpy().view(np.uint64)
         llks = self.d_llks.cpu().numpy()
         out = []
-        for u in range(self.n_units):
+        for u in (range(self.n_units) if only is None else only):
             D = self.units_host[u]
             Ku, M, A = int(D["ploidy"]), int(D["n_pos"]), int(D["max_allele"])
             st = int(status[u])
@@ -508,10 +573,7 @@ class DenovoRaggedBatch(_OwnBuffers):
         stream = self._begin().cuda_stream
         L = _lib.lib()
         type(self).n_runs += 1
-        _lib.check(L.mchap_denovo_fit_batch_device(
-            C.byref(self.cfg), U, self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_reads), self._p(self.d_counts),
-            self._p(self.d_nalleles), None, self._p(self.d_trace), self._p(self.d_llks), self._p(self.d_fixed),
-            self._p(self.d_status), self._p(self.d_ws), C.c_int64(self.ws_bytes), C.c_void_p(stream)))
+        self._fit(stream)
         self.max_states = max_states
         self.p_words = torch.empty(U * max_states * K, dtype=torch.int64, device=dev)
         self.p_counts = torch.empty(U * max_states, dtype=torch.int32, device=dev)
@@ -532,8 +594,25 @@ class DenovoRaggedBatch(_OwnBuffers):
         self.incongruence_threshold = float(incongruence_threshold)
         self._end()
 
-    def results(self, raise_on_limit=True):
-        """Per unit: dict(genotypes int8 [n, K, M] distinct states (probability descending), probabilities [n], spm, gpm,
+    def summary_arrays(self):
+        """The posterior summaries of all units as arrays (what results() turns into one dict per unit): dict(words uint64
+        [U, max_states, K] packed distinct genotypes most probable first, counts int32 [U, max_states], n [U] how many,
+        stats float64 [U, 2] (SPM, GPM), mode_words uint64 [U, K], mci [U], status [U], fixed int8 flat (unit u at
+        units_host['fixed_off'][u]), total = the steps a probability is a count of; plain [U] bool: the unit's summary is
+        complete in these arrays -- the others (more distinct states than max_states, beyond a limit) go through
+        results(only=...))."""
+        assert self.wph == 1
+        U, K, ms = self.n_units, self.Kmax, self.max_states
+        self._begin()
+        out = dict(words=self.p_words.cpu().numpy().view(np.uint64).reshape(U, ms, K), counts=self.p_counts.cpu().numpy().reshape(U, ms),
+                   n=self.p_n.cpu().numpy(), stats=self.p_stats.cpu().numpy().reshape(U, 2),
+                   mode_words=self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K), mci=self.p_mci.cpu().numpy(),
+                   status=self.d_status.cpu().numpy(), fixed=self.d_fixed.cpu().numpy(), total=self.Cn * (self.S - self.burn))
+        out["plain"] = (out["status"] >= 0) & (out["n"] >= 0) & (out["n"] <= ms) & (out["mci"] >= 0)
+        return out
+
+    def results(self, raise_on_limit=True, only=None):
+        """(only: the units to report, default all.)  Per unit: dict(genotypes int8 [n, K, M] distinct states (probability descending), probabilities [n], spm, gpm,
         mode_genotype int8 [K, M], mci, status).  Units with more distinct states than the batch kernels keep (512) are
         summarised by a second, listed launch with a table of chains x (steps - burn) states (as many as the LDS holds).
         A unit beyond the library's packed haplotype width raises NotImplementedError, or with raise_on_limit=False comes
@@ -541,7 +620,7 @@ class DenovoRaggedBatch(_OwnBuffers):
         from .classes import GenotypeMultiTrace
 
         if self.wph > 1:
-            return self._results_wide(raise_on_limit)
+            return self._results_wide(raise_on_limit, only)
         U, K, ms = self.n_units, self.Kmax, self.max_states
         self._begin()  # (the pass may have been issued on another stream)
         words = self.p_words.cpu().numpy().view(np.uint64).reshape(U, ms, K)
@@ -557,6 +636,8 @@ class DenovoRaggedBatch(_OwnBuffers):
         # their chains wander): summarised again on the device with a table that cannot overflow, a list launch over
         # those units only -- no trace is downloaded, no posterior formed on the host
         over = np.flatnonzero((status >= 0) & ((n < 0) | (n > ms) | (mci < 0))).astype(np.int32)
+        if only is not None:
+            over = np.intersect1d(over, np.asarray(only, dtype=np.int32)).astype(np.int32)
         over_row = {}
         if len(over):
             torch = self.torch
@@ -582,7 +663,7 @@ class DenovoRaggedBatch(_OwnBuffers):
             over_row = {int(u): (ow[i], oc[i], cap) for i, u in enumerate(over)}
         out = []
         trace = llks = None
-        for u in range(U):
+        for u in (range(U) if only is None else only):
             D = self.units_host[u]
             Ku, M, A = int(D["ploidy"]), int(D["n_pos"]), int(D["max_allele"])
             fx = fixed[int(D["fixed_off"]): int(D["fixed_off"]) + M]
