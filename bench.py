@@ -864,8 +864,11 @@ def bench_program_e2e(args):
                         "chains, burn 1000: files -> VCF records through application.assemble" % (args.e2e_loci, nbytes / 1e6),
             "value": len(lines) / dt, "unit": "loci/s", "wall_ms": dt * 1e3, "bam_read_ms": tm["read_s"] * 1e3, "encode_ms": tm["encode_s"] * 1e3,
             "sampler_ms": tm["sampler_s"] * 1e3, "format_ms": tm["format_s"] * 1e3, "records": len(lines),
-            "note": "host side is numpy: BGZF blocks inflated by 4 threads, records as columns, extract_read_variants vectorised per locus; "
-                    "synthetic inputs written in %.1f s (not timed)" % t_make,
+            "bam_parse_ms": tm.get("bam_parse_s", 0.0) * 1e3, "device_wait_ms": tm.get("device_wait_s", 0.0) * 1e3,
+            "note": "host work of the block as array operations (mchap_amd/blockpath.py): BGZF blocks inflated by 4 threads, records walked once by "
+                    "the library (mchap_bam_columns), extraction / calls / de-duplication / descriptors / posterior haplotypes over all loci at once; "
+                    "encode_ms includes bam_parse_ms, sampler_ms = launch + device_wait_ms (the launch lasts as long as its slowest chain) + "
+                    "summaries; synthetic inputs written in %.1f s (not timed)" % t_make,
         }
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -340,6 +340,21 @@ int mchap_denovo_trace_words_per_haplotype(const mchap_denovo_cfg *cfg, int n_un
 /* name of the sampler kernel(s) a fit of this batch dispatches to (a pure function of cfg and the units' shapes) */
 int mchap_denovo_sampler_name(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host, char *out, int out_len);
 
+/* Host-side helpers of the programs' alignment reader (no GPU involved; the counterpart of the htslib records the reference's
+ * io/bam.py:54-229 walks): the records of an INFLATED BAM payload `buf[0 .. n)` from byte `start` (just past the header, or a
+ * region's first record) as columns.  mchap_bam_count: the complete records from `start` and the sum of their CIGAR operations.
+ * mchap_bam_columns fills, per record: its byte offset, ref_id, pos, end (pos + reference bases its CIGAR consumes), mapq, flag,
+ * byte offsets of its packed sequence and of its base qualities, the index of its RG:Z value among the `n_rg` NUL-separated
+ * read-group ids `rg_ids` (-1: no such field / unknown id; the fields are walked in order as pysam's get_tag does), qname_id
+ * = the index of the first record with the same query name; seg_first [n_records + 1] = first CIGAR operation of each
+ * record among the flattened c_* arrays: record, operation code, length, reference / read coordinate at which it starts.
+ * Returns MCHAP_OK, or MCHAP_ERR_BAD_ARG for a truncated / malformed record. */
+int64_t mchap_bam_count(const uint8_t *buf, int64_t n, int64_t start, int64_t *n_cigar_ops);
+int mchap_bam_columns(const uint8_t *buf, int64_t n, int64_t start, int64_t n_records, const char *rg_ids, int n_rg,
+                      int64_t *offset, int32_t *ref_id, int32_t *pos, int64_t *end, int32_t *mapq, int32_t *flag,
+                      int64_t *seq_off, int64_t *qual_off, int64_t *rg, int64_t *qname_id, int64_t *seg_first,
+                      int64_t *c_rec, int64_t *c_op, int64_t *c_len, int64_t *c_ref0, int64_t *c_read0);
+
 /* Introspection */
 const char *mchap_version(void);
 const char *mchap_last_error(void);

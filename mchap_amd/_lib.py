@@ -183,6 +183,9 @@ def lib():
         L.mchap_call_mcmc_workspace_bytes.restype = C.c_int64
         L.mchap_call_mcmc_workspace_bytes_for.restype = C.c_int64
         L.mchap_timer_ms.restype = C.c_double
+        L.mchap_bam_count.restype = C.c_int64
+        L.mchap_bam_count.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.mchap_bam_columns.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int] + [C.c_void_p] * 16
         L.mchap_timer_ms.argtypes = [C.c_void_p]
         L.mchap_timer_destroy.argtypes = [C.c_void_p]
         _libs[path] = L
@@ -222,6 +225,8 @@ def sampler_name(cfg, units_host):
 
 
 EXPORTS = [
+    "mchap_bam_count",
+    "mchap_bam_columns",
     "mchap_denovo_fit_batch_device",
     "mchap_denovo_fit_batch_calls_device",
     "mchap_denovo_fit_batch",

@@ -1049,6 +1049,7 @@ class _BlockState:
                 flight.join()
         timings["units"] += int(sum(len(b[1]["n_reads"]) for b in self.batches))
         timings["sampler_s"] += _time.perf_counter() - t1
+        timings["launch_s"] = timings.get("launch_s", 0.0) + _time.perf_counter() - t1   # (part of sampler_s: descriptors, H2D, enqueue)
 
     # ---- stage 2 ----
     def _summaries(self, batch, u, K):
@@ -1068,8 +1069,8 @@ class _BlockState:
         M, total = u["n_pos"], arr["total"]
         n = np.where(plain, arr["n"], 0).astype(np.int64)
         gu, gi = bp._ragged_arange(n)
-        W = arr["words"][gu, gi, :K]
-        p = arr["counts"][gu, gi] / total
+        W = arr["words"][:, :K]
+        p = arr["counts"] / total
         # allele_frequencies(dosage=True) of every unit (classes.py): one term per (genotype, distinct haplotype), summed in
         # genotype order; haplotypes in order of first appearance
         same = W[:, :, None] == W[:, None, :]
@@ -1141,6 +1142,9 @@ class _BlockState:
         else:
             ctx = _nullcontext()
         with ctx:
+            if run["batch_factory"] is None:
+                torch.cuda.current_stream().synchronize()
+                timings["device_wait_s"] = timings.get("device_wait_s", 0.0) + _time.perf_counter() - t1   # (part of sampler_s)
             sums = [self._summaries(*b) for b in self.batches]
             # the loci that go through the per-locus formatter (no SNVs, --report fields, a unit whose summary is not in the arrays)
             # and the units it will ask for

@@ -595,20 +595,25 @@ class DenovoRaggedBatch(_OwnBuffers):
         self._end()
 
     def summary_arrays(self):
-        """The posterior summaries of all units as arrays (what results() turns into one dict per unit): dict(words uint64
-        [U, max_states, K] packed distinct genotypes most probable first, counts int32 [U, max_states], n [U] how many,
-        stats float64 [U, 2] (SPM, GPM), mode_words uint64 [U, K], mci [U], status [U], fixed int8 flat (unit u at
-        units_host['fixed_off'][u]), total = the steps a probability is a count of; plain [U] bool: the unit's summary is
-        complete in these arrays -- the others (more distinct states than max_states, beyond a limit) go through
-        results(only=...))."""
+        """The posterior summaries of all units as arrays (what results() turns into one dict per unit): dict(n [U] distinct
+        genotypes of each unit, plain [U] bool: the unit's summary is complete in these arrays -- the others (more distinct
+        states than max_states, beyond a limit) go through results(only=...); words uint64 [N, K] / counts int32 [N]: the
+        packed distinct genotypes of the plain units, unit after unit, most probable first (N = n[plain].sum(): only these
+        rows leave the device); stats float64 [U, 2] (SPM, GPM), mode_words uint64 [U, K], mci [U], status [U], fixed int8
+        flat (unit u at units_host['fixed_off'][u]), total = the steps a probability is a count of)."""
         assert self.wph == 1
+        torch = self.torch
         U, K, ms = self.n_units, self.Kmax, self.max_states
         self._begin()
-        out = dict(words=self.p_words.cpu().numpy().view(np.uint64).reshape(U, ms, K), counts=self.p_counts.cpu().numpy().reshape(U, ms),
-                   n=self.p_n.cpu().numpy(), stats=self.p_stats.cpu().numpy().reshape(U, 2),
+        out = dict(n=self.p_n.cpu().numpy(), stats=self.p_stats.cpu().numpy().reshape(U, 2),
                    mode_words=self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K), mci=self.p_mci.cpu().numpy(),
                    status=self.d_status.cpu().numpy(), fixed=self.d_fixed.cpu().numpy(), total=self.Cn * (self.S - self.burn))
         out["plain"] = (out["status"] >= 0) & (out["n"] >= 0) & (out["n"] <= ms) & (out["mci"] >= 0)
+        n = np.where(out["plain"], out["n"], 0).astype(np.int64)
+        rows = np.repeat(np.arange(U, dtype=np.int64) * ms - (np.cumsum(n) - n), n) + np.arange(int(n.sum()), dtype=np.int64)
+        d_rows = torch.from_numpy(rows).to(self.device)
+        out["words"] = self.p_words.view(U * ms, K)[d_rows].cpu().numpy().view(np.uint64)
+        out["counts"] = self.p_counts[d_rows].cpu().numpy()
         return out
 
     def results(self, raise_on_limit=True, only=None):

@@ -784,6 +784,45 @@ class AlignmentColumns:
         self.sorted = bool(n < 2 or (self.sort_key[1:] >= self.sort_key[:-1]).all())
         self.max_span = int((self.end - self.pos).max()) if n else 0
 
+    @classmethod
+    def native(cls, refs, rg_table, buf, start, id_field="SM"):
+        """The same table from the library's record walk (mchap_bam_columns, include/mchap_hip.h: one pass over the bytes in
+        C++) for the records of `buf` from byte `start`; None when the library cannot be loaded (the constructor's array
+        operations are the definition: tests/test_io_bam_matrices.py holds the two against each other)."""
+        try:
+            from . import _lib
+
+            L = _lib.lib()
+        except Exception:  # noqa: BLE001 -- no library: the numpy construction
+            return None
+        import ctypes as C
+
+        b = np.frombuffer(buf, dtype=np.uint8)
+        base = b.ctypes.data if len(b) else 0
+        ops = C.c_int64(0)
+        n = int(L.mchap_bam_count(C.c_void_p(base), len(b), int(start), C.byref(ops)))
+        total = int(ops.value)
+        self = cls.__new__(cls)
+        self.refs, self.n, self.buf = refs, n, b
+        i8 = lambda k: np.empty(k, dtype=np.int64)  # noqa: E731
+        i4 = lambda k: np.empty(k, dtype=np.int32)  # noqa: E731
+        offs, self.ref_id, self.pos, self.end, self.mapq, self.flag = i8(n), i4(n), i4(n), i8(n), i4(n), i4(n)
+        self.seq_off, self.qual_off, self.rg, self.qname, self.seg_first = i8(n), i8(n), i8(n), i8(n), i8(n + 1)
+        self.c_rec, self.c_op, self.c_len, self.c_ref0, self.c_read0 = i8(total), i8(total), i8(total), i8(total), i8(total)
+        rg_names = list(rg_table)
+        self.rg_samples = [rg_table[k] if id_field == "SM" else k for k in rg_names]
+        ids = b"".join(k.encode() + b"\0" for k in rg_names) + b"\0"
+        rc = L.mchap_bam_columns(C.c_void_p(base), len(b), int(start), n, ids, len(rg_names), *(C.c_void_p(a.ctypes.data) for a in (
+            offs, self.ref_id, self.pos, self.end, self.mapq, self.flag, self.seq_off, self.qual_off, self.rg, self.qname, self.seg_first,
+            self.c_rec, self.c_op, self.c_len, self.c_ref0, self.c_read0)))
+        if rc != 0:
+            raise ValueError("malformed BAM record")
+        rid = np.where(self.ref_id < 0, np.int64(1) << 30, self.ref_id.astype(np.int64))  # unplaced reads sort last
+        self.sort_key = (rid << 32) | self.pos.astype(np.int64).clip(0)
+        self.sorted = bool(n < 2 or (self.sort_key[1:] >= self.sort_key[:-1]).all())
+        self.max_span = int((self.end - self.pos).max()) if n else 0
+        return self
+
     def window(self, tid, start, stop):
         """[lo, hi): the run of records that can overlap [start, stop) of reference `tid` (all records of an unsorted file)."""
         if not self.sorted or tid < 0:
@@ -853,6 +892,9 @@ class BamFile:
                 self.rg[f["ID"]] = f.get("SM", f["ID"])
 
     def _columns_of(self, payload, start):
+        cols = AlignmentColumns.native(self.refs, self.rg, payload, start, self.id_field)
+        if cols is not None:
+            return cols
         offsets, o, n = [], start, len(payload)
         while o + 4 <= n:
             (block,) = struct.unpack_from("<i", payload, o)

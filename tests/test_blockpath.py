@@ -174,14 +174,15 @@ class _FakeBatch:
     def summary_arrays(self):
         res = self._all()
         U, K, ms = len(res), self.K, self.MS
-        a = dict(words=np.zeros((U, ms, K), dtype=np.uint64), counts=np.zeros((U, ms), dtype=np.int32), n=np.zeros(U, dtype=np.int32),
-                 stats=np.zeros((U, 2)), mode_words=np.zeros((U, K), dtype=np.uint64), mci=np.zeros(U, dtype=np.int32),
+        a = dict(n=np.zeros(U, dtype=np.int32), stats=np.zeros((U, 2)), mode_words=np.zeros((U, K), dtype=np.uint64), mci=np.zeros(U, dtype=np.int32),
                  status=np.zeros(U, dtype=np.int32), total=self.total)
         for u, (w, c, fx, spm, gpm, mw, mci, plain, A) in enumerate(res):
-            a["words"][u, :len(w)], a["counts"][u, :len(w)], a["n"][u] = w, c, (len(w) if plain else -1)
+            a["n"][u] = len(w) if plain else -1
             a["stats"][u], a["mode_words"][u], a["mci"][u] = (spm, gpm), mw, mci
         a["fixed"] = np.concatenate([r[2] for r in res])
         a["plain"] = a["n"] >= 0
+        a["words"] = np.concatenate([r[0] for r in res if r[7]] + [np.zeros((0, K), dtype=np.uint64)])   # (the plain units' rows only)
+        a["counts"] = np.concatenate([r[1] for r in res if r[7]] + [np.zeros(0, dtype=np.int32)])
         return a
 
     def results(self, raise_on_limit=True, only=None):

@@ -56,8 +56,11 @@ def test_from_calls_equals_the_tensor_batch():
         assert np.array_equal(x["genotypes"], y["genotypes"]) and np.array_equal(x["probabilities"], y["probabilities"]) and x["mci"] == y["mci"]
     arr = b.summary_arrays()
     assert arr["plain"].all() and arr["total"] == 2 * 200
+    assert len(arr["words"]) == len(arr["counts"]) == int(arr["n"].sum())
+    first = np.cumsum(arr["n"]) - arr["n"]
     for u, x in enumerate(ra):
         assert arr["n"][u] == len(x["genotypes"]) and arr["stats"][u, 1] == x["gpm"] and arr["stats"][u, 0] == x["spm"]
+        assert np.array_equal(arr["counts"][first[u]: first[u] + arr["n"][u]] / arr["total"], x["probabilities"])
 
 
 def _both(tmp_path=None, **kw):

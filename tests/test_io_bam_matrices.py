@@ -140,3 +140,43 @@ def test_read_group_behind_a_decoy_tag(tmp_path):
     # region fetches of one file share the last region's columns (one inflate + parse per locus, not per sample)
     bf = io.BamFile(path)
     assert bf.columns("chrD", 100, 130) is bf.columns("chrD", 100, 130)
+
+
+def test_native_record_walk_equals_the_array_construction(tmp_path):
+    """mchap_bam_columns (the library's one-pass walk of the inflated records) against AlignmentColumns.__init__ (array operations,
+    itself pinned to the record reader above): every column, the CIGAR table, the read groups (decoy 'RGZ' bytes inside other
+    fields included) and the same partition of the records by query name."""
+    import glob
+    import struct
+
+    from mchap_amd import synth
+
+    job = synth.synth_assembly_inputs(str(tmp_path), n_loci=30, n_samples=1, reads_per_locus=20, gap=50)
+    recs = [dict(qname="p", flag=0, ref=0, pos=105, mapq=60, cigar=[(30, "M")], seq="A" * 30, qual=[30] * 30, rg="g"),
+            dict(qname="q", flag=1024, ref=0, pos=106, mapq=3, cigar=[(10, "M"), (3, "D"), (5, "I"), (15, "M")], seq="A" * 30, qual=[25] * 30, rg="h"),
+            dict(qname="p", flag=16, ref=0, pos=108, mapq=60, cigar=[(2, "S"), (28, "M")], seq="T" * 30, qual=[20] * 30, rg="g",
+                 tags_before=b"XAZRGZg\0" + b"XBBc" + struct.pack("<i", 4) + bytes([82, 71, 90, 104]) + b"XCi" + struct.pack("<i", 0x5A4752)),
+            dict(qname="r", flag=4, ref=-1, pos=-1, mapq=0, cigar=[], seq="ACGT", qual=[9] * 4, rg="nobody")]
+    odd = str(tmp_path / "odd.bam")
+    synth.write_bam(odd, [("chrS", 1000)], {"g": "X", "h": "Y"}, recs)
+    n_files = 0
+    for path in sorted(glob.glob(os.path.join(HERE, "*.bam"))) + job["bams"] + [odd]:
+        bf = io.BamFile(path)
+        payload = b"".join(io.bgzf_inflate(bf.data, bf.blocks))
+        offsets, o = [], bf.header_end
+        while o + 4 <= len(payload):
+            (block,) = struct.unpack_from("<i", payload, o)
+            offsets.append(o)
+            o += 4 + block
+        for id_field in ("SM", "ID"):
+            a = io.AlignmentColumns(bf.refs, bf.rg, payload, offsets, id_field)
+            b = io.AlignmentColumns.native(bf.refs, bf.rg, payload, bf.header_end, id_field)
+            assert b is not None and a.n == b.n == len(offsets) and a.rg_samples == b.rg_samples
+            for name in ("ref_id", "pos", "end", "mapq", "flag", "seq_off", "qual_off", "rg", "seg_first", "c_rec", "c_op", "c_len", "c_ref0",
+                         "c_read0", "sort_key"):
+                np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
+            assert a.sorted == b.sorted and a.max_span == b.max_span
+            # query-name ids: any labels, the same classes
+            assert len(np.unique(a.qname)) == len(np.unique(b.qname)) == len(np.unique(np.stack([a.qname, b.qname]), axis=1).T)
+        n_files += 1
+    assert n_files >= 8
