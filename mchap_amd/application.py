@@ -88,6 +88,16 @@ class MatrixSource:
         self.matrices = matrices
         self.error_rate, self.use_phred = error_rate, use_phred
         self.bams = {}
+        self._codes = {}
+
+    def codes(self, name, sample):
+        """(characters as uint8 ASCII codes, qualities as int16) of a (target, sample): converted once."""
+        key = (name, sample)
+        got = self._codes.get(key)
+        if got is None:
+            chars, quals = self.matrices[key]
+            got = self._codes[key] = (_codes(chars), np.asarray(quals, dtype=np.int16))
+        return got
 
     def reads(self, locus, sample):
         chars, quals = self.matrices[(locus.name, sample)]
@@ -982,15 +992,16 @@ class _BlockState:
         M, snv_start, _ = tables
         self.M = M
         self.enc = []
+        lut = bp.allele_lut(lx, int(snv_start[-1]))
         for sample in samples:
             if isinstance(source, MatrixSource):
-                self.enc.append(bp.encode_block(lx, bp.pile_from_matrices(lx, [source.matrices[(l.name, sample)] for l in lx], tables=tables)))
+                self.enc.append(bp.encode_block(lx, bp.pile_from_matrices(lx, [source.codes(l.name, sample) for l in lx], tables=tables), lut))
                 continue
             name, path = source.pools[sample][0]
             tp = _time.perf_counter()
             cols = source.bams[path].columns()   # (the first use of a file inflates and parses it)
             timings["bam_parse_s"] = timings.get("bam_parse_s", 0.0) + _time.perf_counter() - tp
-            self.enc.append(bp.encode_block(lx, bp.extract_block(lx, cols, name, tables=tables, **source.filter)))
+            self.enc.append(bp.encode_block(lx, bp.extract_block(lx, cols, name, tables=tables, **source.filter), lut))
         # the sampler's units: every (sample, locus with SNVs), one launch per (ploidy, temperature ladder, wide) present
         nal = np.fromiter((a for l in lx for a in l.n_alleles), dtype=np.int8, count=int(snv_start[-1]))
         amax = np.array([max(l.n_alleles) if l.n_alleles else 0 for l in lx], dtype=np.int64)

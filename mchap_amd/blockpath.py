@@ -191,13 +191,8 @@ class BlockEncoding:
                     ucalls=self.ucalls[ua:ub].reshape(nu, m), counts=self.ucounts[int(self.urow_start[l]):int(self.urow_start[l + 1])])
 
 
-def encode_block(loci, pile):
-    """Allele index of every character (the first allele of the SNV that has it, else -1), depth per SNV (characters that are
-    not '-'), reads and called cells per locus, DP (the rounded mean depth), distinct call rows with counts."""
-    L, M = pile.L, pile.M
-    n_snv = int(pile.snv_start[-1])
-    enc = BlockEncoding()
-    enc.pile = pile
+def allele_lut(loci, n_snv):
+    """int8 [SNVs of all loci, 256]: allele index of every character at every SNV (the first allele that has it; -1: none)."""
     lut = np.full((max(n_snv, 1), 256), -1, dtype=np.int8)
     si, ai, ci = [], [], []
     j = 0
@@ -212,6 +207,19 @@ def encode_block(loci, pile):
         si, ai, ci = np.array(si, dtype=np.int64), np.array(ai, dtype=np.int8), np.array(ci, dtype=np.int64)
         _, first = np.unique(si * 256 + ci, return_index=True)  # (an allele character listed twice: its first index)
         lut[si[first], ci[first]] = ai[first]
+    return lut
+
+
+def encode_block(loci, pile, lut=None):
+    """Allele index of every character (the first allele of the SNV that has it, else -1), depth per SNV (characters that are
+    not '-'), reads and called cells per locus, DP (the rounded mean depth), distinct call rows with counts.  lut: allele_lut of
+    the loci (shared by the samples of a block)."""
+    L, M = pile.L, pile.M
+    n_snv = int(pile.snv_start[-1])
+    enc = BlockEncoding()
+    enc.pile = pile
+    if lut is None:
+        lut = allele_lut(loci, n_snv)
     n_rows = len(pile.row_locus)
     row_M = M[pile.row_locus]
     row_of_cell, jj = _ragged_arange(row_M)

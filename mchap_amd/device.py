@@ -594,6 +594,28 @@ class DenovoRaggedBatch(_OwnBuffers):
         self.incongruence_threshold = float(incongruence_threshold)
         self._end()
 
+    def _summarise_listed(self, over):
+        """The units `over` (int32 indices) summarised again with a table of chains x (steps - burn) states (as many as the LDS
+        holds): their entries of p_n / p_stats / p_mode_words / p_mci are rewritten; returns (words int64 [len(over) * cap * K],
+        counts int32 [len(over) * cap] on the device, cap)."""
+        torch = self.torch
+        L = _lib.lib()
+        K = self.Kmax
+        total = self.Cn * (self.S - self.burn)
+        cap = min(total, int(L.mchap_trace_posterior_max_states(K)))
+        stream = torch.cuda.current_stream().cuda_stream
+        d_list = torch.from_numpy(np.ascontiguousarray(over, dtype=np.int32)).to(self.device)
+        o_words = torch.empty(len(over) * cap * K, dtype=torch.int64, device=self.device)
+        o_counts = torch.empty(len(over) * cap, dtype=torch.int32, device=self.device)
+        _lib.check(L.mchap_trace_posterior_listed_device(
+            len(over), self._p(d_list), self._p(self.d_units), self.S, self.Cn, self.burn, self._p(self.d_trace), cap, K,
+            self._p(o_words), self._p(o_counts), self._p(self.p_n), self._p(self.p_stats), self._p(self.p_mode),
+            self._p(self.p_mode_words), self._p(self.p_mode_count), C.c_void_p(stream)))
+        _lib.check(L.mchap_trace_incongruence_listed_device(
+            len(over), self._p(d_list), self._p(self.d_units), self.S, self.Cn, self.burn, self._p(self.d_trace),
+            min(self.S - self.burn, cap), K, C.c_double(self.incongruence_threshold), self._p(self.p_mci), C.c_void_p(stream)))
+        return o_words, o_counts, cap
+
     def summary_arrays(self):
         """The posterior summaries of all units as arrays (what results() turns into one dict per unit): dict(n [U] distinct
         genotypes of each unit, plain [U] bool: the unit's summary is complete in these arrays -- the others (more distinct
@@ -605,15 +627,38 @@ class DenovoRaggedBatch(_OwnBuffers):
         torch = self.torch
         U, K, ms = self.n_units, self.Kmax, self.max_states
         self._begin()
-        out = dict(n=self.p_n.cpu().numpy(), stats=self.p_stats.cpu().numpy().reshape(U, 2),
-                   mode_words=self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K), mci=self.p_mci.cpu().numpy(),
-                   status=self.d_status.cpu().numpy(), fixed=self.d_fixed.cpu().numpy(), total=self.Cn * (self.S - self.burn))
-        out["plain"] = (out["status"] >= 0) & (out["n"] >= 0) & (out["n"] <= ms) & (out["mci"] >= 0)
-        n = np.where(out["plain"], out["n"], 0).astype(np.int64)
-        rows = np.repeat(np.arange(U, dtype=np.int64) * ms - (np.cumsum(n) - n), n) + np.arange(int(n.sum()), dtype=np.int64)
-        d_rows = torch.from_numpy(rows).to(self.device)
-        out["words"] = self.p_words.view(U * ms, K)[d_rows].cpu().numpy().view(np.uint64)
-        out["counts"] = self.p_counts[d_rows].cpu().numpy()
+        status, n, mci = self.d_status.cpu().numpy(), self.p_n.cpu().numpy(), self.p_mci.cpu().numpy()
+        # units with more distinct genotypes than the batch kernels keep (samples with few or no reads: their chains wander):
+        # summarised again by the listed launch, their rows taken from its table
+        over = np.flatnonzero((status >= 0) & ((n < 0) | (n > ms) | (mci < 0))).astype(np.int32)
+        cap = ms
+        if len(over):
+            o_words, o_counts, cap = self._summarise_listed(over)
+            n, mci = self.p_n.cpu().numpy(), self.p_mci.cpu().numpy()
+        out = dict(n=n, stats=self.p_stats.cpu().numpy().reshape(U, 2), mode_words=self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K),
+                   mci=mci, status=status, fixed=self.d_fixed.cpu().numpy(), total=self.Cn * (self.S - self.burn))
+        is_over = np.zeros(U, dtype=bool)
+        is_over[over] = True
+        out["plain"] = (status >= 0) & (n >= 0) & (n <= np.where(is_over, cap, ms)) & (mci >= 0)
+        nn = np.where(out["plain"], n, 0).astype(np.int64)
+        first = np.cumsum(nn) - nn                         # where each unit's rows start in the ragged result
+
+        def gather(sel, table_row, words, counts):
+            """rows of the units `sel` (indices): unit k's rows start at table_row[k] of the device table"""
+            k_ = nn[sel]
+            rows = np.repeat(table_row - (np.cumsum(k_) - k_), k_) + np.arange(int(k_.sum()), dtype=np.int64)
+            d_rows = torch.from_numpy(rows).to(self.device)
+            return words.view(-1, K)[d_rows].cpu().numpy().view(np.uint64), counts[d_rows].cpu().numpy(), np.repeat(first[sel] - (np.cumsum(k_) - k_), k_) + np.arange(int(k_.sum()), dtype=np.int64)
+
+        N = int(nn.sum())
+        W, Cc = np.empty((N, K), dtype=np.uint64), np.empty(N, dtype=np.int32)
+        reg = np.flatnonzero(~is_over)
+        w_, c_, dst = gather(reg, reg.astype(np.int64) * ms, self.p_words, self.p_counts)
+        W[dst], Cc[dst] = w_, c_
+        if len(over):
+            w_, c_, dst = gather(over.astype(np.int64), np.arange(len(over), dtype=np.int64) * cap, o_words, o_counts)
+            W[dst], Cc[dst] = w_, c_
+        out["words"], out["counts"] = W, Cc
         return out
 
     def results(self, raise_on_limit=True, only=None):
@@ -645,20 +690,7 @@ class DenovoRaggedBatch(_OwnBuffers):
             over = np.intersect1d(over, np.asarray(only, dtype=np.int32)).astype(np.int32)
         over_row = {}
         if len(over):
-            torch = self.torch
-            L = _lib.lib()
-            cap = min(total, int(L.mchap_trace_posterior_max_states(K)))
-            stream = torch.cuda.current_stream().cuda_stream
-            d_list = torch.from_numpy(over).to(self.device)
-            o_words = torch.empty(len(over) * cap * K, dtype=torch.int64, device=self.device)
-            o_counts = torch.empty(len(over) * cap, dtype=torch.int32, device=self.device)
-            _lib.check(L.mchap_trace_posterior_listed_device(
-                len(over), self._p(d_list), self._p(self.d_units), self.S, self.Cn, self.burn, self._p(self.d_trace), cap, K,
-                self._p(o_words), self._p(o_counts), self._p(self.p_n), self._p(self.p_stats), self._p(self.p_mode),
-                self._p(self.p_mode_words), self._p(self.p_mode_count), C.c_void_p(stream)))
-            _lib.check(L.mchap_trace_incongruence_listed_device(
-                len(over), self._p(d_list), self._p(self.d_units), self.S, self.Cn, self.burn, self._p(self.d_trace),
-                min(self.S - self.burn, cap), K, C.c_double(self.incongruence_threshold), self._p(self.p_mci), C.c_void_p(stream)))
+            o_words, o_counts, cap = self._summarise_listed(over)
             n = self.p_n.cpu().numpy()
             stats = self.p_stats.cpu().numpy().reshape(U, 2)
             mode_words = self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K)
