@@ -1199,9 +1199,10 @@ class _BlockState:
             if not ok:
                 line = self._slow_record(li, xi, sums)
                 if line is None:   # (a unit beyond a limit)
-                    yield _limit_record_line(locus, samples, report, run["ploidy_of"])
-                else:
-                    yield line
+                    line = _limit_record_line(locus, samples, report, run["ploidy_of"])
+                timings["format_s"] += _time.perf_counter() - t2
+                yield line
+                t2 = _time.perf_counter()
                 continue
             # call_posterior_haplotypes: the haplotypes any sample lists, ranked by expected dosage summed over the samples
             index, score = {}, []
