@@ -993,6 +993,16 @@ class _BlockState:
         self.M = M
         self.enc = []
         lut = bp.allele_lut(lx, int(snv_start[-1]))
+        if isinstance(source, ReadSource) and source.workers > 1:
+            # files not parsed yet: inflated and walked side by side (zlib and the library's record walk release the interpreter lock)
+            todo = [b for b in dict.fromkeys(source.bams[source.pools[s_][0][1]] for s_ in samples) if getattr(b, "_all", 0) is None]
+            if len(todo) > 1:
+                from concurrent.futures import ThreadPoolExecutor
+
+                tp = _time.perf_counter()
+                with ThreadPoolExecutor(max_workers=min(source.workers, len(todo))) as ex:
+                    list(ex.map(lambda b: b.columns(), todo))
+                timings["bam_parse_s"] = timings.get("bam_parse_s", 0.0) + _time.perf_counter() - tp
         for sample in samples:
             if isinstance(source, MatrixSource):
                 self.enc.append(bp.encode_block(lx, bp.pile_from_matrices(lx, [source.codes(l.name, sample) for l in lx], tables=tables), lut))

@@ -235,8 +235,8 @@ def test_assemble_lines_equal_the_per_locus_path(tmp_path, report, monkeypatch, 
     assert err_slow == err_fast and "two_windows" in err_fast and tm["limit_records"] == 1
     assert sum("LIMIT" in x for x in fast) == 1 and any("\tNOA\t" in x or "REFMASKED" in x for x in fast)
     # several blocks: the same lines
-    again = list(application.assemble(None, variants, ref, application.ReadSource(bams), block_path=True, _batch_factory=_FakeBatch,
-                                      units_per_block=3 * 7, **kw))
+    again = list(application.assemble(None, variants, ref, application.ReadSource(bams, workers=3), block_path=True, _batch_factory=_FakeBatch,
+                                      units_per_block=3 * 7, **kw))   # (workers: the files are inflated and walked side by side)
     assert again == fast
 
 
