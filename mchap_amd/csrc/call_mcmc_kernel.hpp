@@ -72,10 +72,38 @@ __host__ __device__ inline int call_memo_entries(int H) {
   const int n = 16384 / per;
   return n > CALL_MEMO ? CALL_MEMO : n;
 }
-inline size_t call_lds_bytes(int R, int H, int K) {
-  // ptab, cnt, lgd, lgf, lfreq (exact_setup) + rtab [H][K] + 3 arrays [H] + request words + the Gibbs memo
-  return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)H * K + 4 * (size_t)CALL_MAX_HAPS + 64 +
-          (size_t)CALL_MEMO + (size_t)call_memo_entries(H) * 2 * H) * 8;
+// A workgroup is up to CALL_WG_CHAINS wavefronts: the chains of ONE unit, which share the unit's tables (product table, read
+// weights, prior tables: 28 of the 32 KB a chain needed at the `mchap call` bench shape -- the LDS, not the registers, set the
+// occupancy: 4 wavefronts per CU with a table per chain, 8 with two chains per table).  Each chain keeps its own option arrays,
+// request words and Gibbs memo behind the shared part.
+#ifndef MCHAP_CALL_WG_CHAINS
+#define MCHAP_CALL_WG_CHAINS 4
+#endif
+constexpr int CALL_WG_CHAINS = MCHAP_CALL_WG_CHAINS;
+// doubles of a chain's private part: 4 arrays [H] + request words + the Gibbs memo
+__host__ __device__ inline size_t call_lds_private(int H) { return 4 * (size_t)H + 64 + (size_t)CALL_MEMO + (size_t)call_memo_entries(H) * 2 * H; }
+inline size_t call_lds_bytes(int R, int H, int K, int wg_chains = 1) {
+  // shared: ptab, cnt, lgd, lgf, lfreq (exact_setup) + rtab [H][K]
+  return ((size_t)R * H + R + (size_t)H * (K + 1) + (K + 1) + H + (size_t)H * K + (size_t)wg_chains * call_lds_private(H)) * 8;
+}
+// LDS hand-over between the lanes of ONE wavefront (the chains of a workgroup run apart).  The fence names the LDS only: a
+// fence over all address spaces also waits for the step's trace stores to HBM (measured: 150 -> 194 ms per call).
+__device__ __forceinline__ void call_sync() {
+#ifdef MCHAP_CALL_SYNC_BARRIER
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+// ... and of the chain's table of remembered likelihoods in HBM (written by one lane, probed by all)
+__device__ __forceinline__ void call_sync_global() {
+#ifdef MCHAP_CALL_SYNC_BARRIER
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+#endif
 }
 
 // calling/prior.py:116-179 on the alleles in ARRAY order (allelic dosage at first occurrence, calling/utils.py:7-35)
@@ -129,10 +157,11 @@ __device__ __forceinline__ long long call_key(const int *g, int K) {
   return rank_genotype(s, K);
 }
 
-__global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
+__global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const CallParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int unit = blockIdx.y, chain = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int wv = (int)(threadIdx.x >> 6), nwv = (int)(blockDim.x >> 6);
+  const int unit = blockIdx.y, chain = (int)blockIdx.x * nwv + wv;
+  const int lane = (int)(threadIdx.x & 63);
   const int R = P.R, H = P.H, K = P.K;
   ExactParams EP;
   EP.reads = P.reads;
@@ -143,40 +172,47 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
   EP.R = R; EP.M = P.M; EP.A = P.A; EP.H = H; EP.K = K;
   EP.has_prior = P.has_prior;
   EP.Rcap = 0;  // the whole product table (the sampler does not tile the reads)
+  // (a table in the workspace is a table per chain: the host then launches one chain per workgroup)
   EP.ptab_ext = P.ptab_ext ? P.ptab_ext + ((size_t)unit * P.chains + chain) * ((size_t)R * H + R) : nullptr;
   ExactLds E;
   PriorTab pt;
-  exact_setup(EP, unit, smem, E, pt);
-  double *rtab = E.red;                     // [H][K]: lgamma(1 + alpha_a + ibs) - lgamma(alpha_a + ibs)
-  double *o_llk = rtab + (size_t)H * K;     // [CALL_MAX_HAPS]
-  double *o_lpr = o_llk + CALL_MAX_HAPS;
-  double *o_prob = o_lpr + CALL_MAX_HAPS;
-  double *o_aux = o_prob + CALL_MAX_HAPS;   // proposal ratios (Metropolis-Hastings)
+  exact_setup(EP, unit, smem, E, pt);       // (all wavefronts of the workgroup together)
+  double *rtab = E.red;                     // [H][K]: lgamma(1 + alpha_a + ibs) - lgamma(alpha_a + ibs)   (shared)
+  double *o_llk = rtab + (size_t)H * K + (size_t)wv * call_lds_private(H);   // [H] each: this chain's
+  double *o_lpr = o_llk + H;
+  double *o_prob = o_lpr + H;
+  double *o_aux = o_prob + H;               // proposal ratios (Metropolis-Hastings)
   // Gibbs memo (call_memo_entries): keys (context rank + 1, 0 = empty), then per entry H probabilities and H likelihoods
   const int n_memo = (P.step_type == 0) ? call_memo_entries(H) : 0;
-  long long *memo_key = reinterpret_cast<long long *>(o_aux + CALL_MAX_HAPS + 64);
+  long long *memo_key = reinterpret_cast<long long *>(o_aux + H + 64);
   double *memo_val = reinterpret_cast<double *>(memo_key + CALL_MEMO);
   for (int i = lane; i < CALL_MEMO; i += WAVE) memo_key[i] = 0;
   int memo_next = 0;                        // (wave-uniform) the entry the next miss replaces
-  __shared__ double s_acc, s_choice_llk;
-  __shared__ int s_g[MCHAP_MAX_PLOIDY];     // the chain's genotype (array order)
-  __shared__ int s_req[MCHAP_MAX_PLOIDY];   // alleles of the request being evaluated
-  __shared__ double s_left;                 // Gibbs prior: lgamma(sum_alpha) - lgamma(1 + sum_alpha)
-  __shared__ int s_choice;
-  __shared__ int s_full;
+  __shared__ double s_acc_[CALL_WG_CHAINS], s_choice_llk_[CALL_WG_CHAINS];
+  __shared__ int s_g_[CALL_WG_CHAINS][MCHAP_MAX_PLOIDY];     // the chain's genotype (array order)
+  __shared__ int s_req_[CALL_WG_CHAINS][MCHAP_MAX_PLOIDY];   // alleles of the request being evaluated
+  __shared__ double s_left;                 // Gibbs prior: lgamma(sum_alpha) - lgamma(1 + sum_alpha)   (shared)
+  __shared__ int s_choice_[CALL_WG_CHAINS];
+  __shared__ int s_full_[CALL_WG_CHAINS];
+  // (LDS-qualified: through a generic pointer picked by the wavefront's index these become flat loads -- measured 150 -> 194 ms)
+  typedef __attribute__((address_space(3))) double lds_f64;
+  typedef __attribute__((address_space(3))) int lds_i32;
+  lds_f64 &s_acc = *(lds_f64 *)&s_acc_[wv], &s_choice_llk = *(lds_f64 *)&s_choice_llk_[wv];
+  lds_i32 *s_g = (lds_i32 *)s_g_[wv], *s_req = (lds_i32 *)s_req_[wv];
+  lds_i32 &s_choice = *(lds_i32 *)&s_choice_[wv], &s_full = *(lds_i32 *)&s_full_[wv];
   const bool has_prior = P.has_prior != 0;
   const bool has_freqs = has_prior && P.freqs != nullptr;
   const double F = pt.F;
   if (lane == 0) s_full = 0;
   if (has_prior && F != 0.0) {
     const double scale = (1.0 - F) / F;
-    for (int q = lane; q < H * K; q += WAVE) {
+    for (int q = (int)threadIdx.x; q < H * K; q += (int)blockDim.x) {
       const int a = q / K, ibs = q % K;
       const double alpha = has_freqs ? P.freqs[(size_t)unit * H + a] * scale : (1.0 / (double)H) * scale;
       const double va = alpha + (double)ibs;
       rtab[q] = lgamma(1.0 + va) - lgamma(va);
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       double sum_alpha;
       if (has_freqs) {
         double s = 0.0;
@@ -188,7 +224,8 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
       s_left = lgamma(sum_alpha) - lgamma(1.0 + sum_alpha);
     }
   }
-  __syncthreads();
+  __syncthreads();  // (the last workgroup-wide barrier: from here on every wavefront runs its chain alone)
+  if (chain >= P.chains) return;
   const double invK_full = 1.0 / (double)K;
   ulonglong2 *cache = P.cache + ((size_t)unit * P.chains + chain) * (size_t)P.cache_slots;
   const unsigned long long cmask = (unsigned long long)P.cache_slots - 1ull;
@@ -221,7 +258,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
   // ---- initial genotype: the caller's, or greedy_caller (calling/mcmc.py:393-453) ----
   if (P.initial) {
     if (lane < K) s_g[lane] = (int)P.initial[(size_t)unit * K + lane];
-    __syncthreads();
+    call_sync();
   } else {
     for (int i = 0; i < K; i++) {
       double best = -INFINITY;
@@ -231,7 +268,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
           for (int q = 0; q < i; q++) s_req[q] = s_g[q];
           s_req[i] = a;
         }
-        __syncthreads();
+        call_sync();
         const double llk = coop_llk(i + 1);
         double lprior = 0.0;
         if (has_prior) {
@@ -291,10 +328,10 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
           best = lprob;
           best_a = a;
         }
-        __syncthreads();
+        call_sync();
       }
       if (lane == 0) s_g[i] = best_a;
-      __syncthreads();
+      call_sync();
     }
     // genotype.sort()
     if (lane == 0) {
@@ -308,7 +345,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
         s_g[b + 1] = v;
       }
     }
-    __syncthreads();
+    call_sync();
   }
 
   CallStream st;
@@ -362,7 +399,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
       todo &= todo - 1;
       if (lane == src)
         for (int i = 0; i < K; i++) s_req[i] = g[i];
-      __syncthreads();
+      call_sync();
       const double v = coop_llk(K);
       if (lane == src) {
         val = v;
@@ -377,7 +414,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
           else s_full = 1;
         }
       }
-      __syncthreads();
+      call_sync_global();  // (the next lane of this loop probes behind this entry)
     }
     if (act) o_llk[a] = val;
   };
@@ -417,10 +454,10 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
         if (!hit) {
           if (lane == 0)
             for (int i = 0; i < K; i++) s_req[i] = g[i];
-          __syncthreads();
+          call_sync();
           val = coop_llk(K);
           if (lane == 0 && slot) *slot = make_ulonglong2((unsigned long long)key + 1ull, (unsigned long long)__double_as_longlong(val));
-          __syncthreads();
+          call_sync_global();
         }
         cur_llk = __shfl(val, 0, WAVE);
       }
@@ -478,7 +515,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
           }
         }
       }
-      __syncthreads();
+      call_sync();
       if (P.step_type == 0) {
         // normalise_log_probs(llks + lpriors): sequential add_log_prob in allele order (jitutils.py:30-74) -- one lane --,
         // then the H exponentials, one lane each (the same function of the same arguments as the sequential loop)
@@ -487,10 +524,10 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
           for (int a = 1; a < H; a++) acc = add_log_prob(acc, o_llk[a] + o_lpr[a]);
           s_acc = acc;
         }
-        __syncthreads();
+        call_sync();
         const double acc = s_acc;
         for (int a = lane; a < H; a += WAVE) o_prob[a] = exp((o_llk[a] + o_lpr[a]) - acc);
-        __syncthreads();
+        call_sync();
         if (n_memo > 0) {  // remember the context
           double *mv = memo_val + (size_t)memo_next * 2 * H;
           for (int a = lane; a < H; a += WAVE) {
@@ -499,7 +536,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
           }
           if (lane == 0) memo_key[memo_next] = ctx;
           memo_next = memo_next + 1 == n_memo ? 0 : memo_next + 1;
-          __syncthreads();
+          call_sync();
         }
       }
       }  // (memo miss)
@@ -533,7 +570,7 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
         s_g[k] = ch;
       }
       ctr++;
-      __syncthreads();
+      call_sync();
       choice = s_choice;
     }
     // genotype_alleles.sort(); the step's llk is that of the last choice
@@ -549,9 +586,9 @@ __global__ __launch_bounds__(64) void call_mcmc_kernel(const CallParams P) {
       }
       lout[step] = s_choice_llk;
     }
-    __syncthreads();
+    call_sync();
     if (lane < K) gout[(size_t)step * K + lane] = s_g[lane];
-    __syncthreads();
+    call_sync();
   }
   if (lane == 0 && s_full) atomicMin(&P.status[unit], MCHAP_ERR_LIMIT);
 }

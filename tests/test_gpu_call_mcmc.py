@@ -70,6 +70,22 @@ def test_initial_genotype_zero_reads_and_errors():
     assert none.genotypes.shape == (2, 10, 4) and np.isnan(none.llks).all()
 
 
+@pytest.mark.parametrize("chains", [1, 4, 5, 9])
+def test_chains_of_a_unit_share_its_tables(chains):
+    """The chains of a unit run as the wavefronts of one workgroup over shared LDS tables (up to four per workgroup: five chains are
+    a full workgroup and one of a single chain whose other wavefronts leave at once): every chain's trace equals the oracle's."""
+    from mchap_amd.calling_mcmc import CallingMCMC
+
+    reads, haps, counts, rng = _inputs(3, 4, 7, 6, 90, seed=40 + chains)
+    for step_type, st in (("Gibbs", 0), ("Metropolis-Hastings", 1)):
+        traces = CallingMCMC(ploidy=4, haplotypes=haps[0], prior=None, steps=60, chains=chains, random_seed=9, step_type=step_type).fit_batch(
+            reads, None, haplotypes=haps, prior=(np.full(3, 0.1), None))
+        for u in range(3):
+            g, l = orc.call_mcmc(reads[u], haps[u], 4, steps=60, chains=chains, step_type=st, prior=(0.1, None), rng_kind=orc.RNG_PHILOX, seed=9, stream_id=u)
+            assert np.array_equal(traces[u].genotypes, g)
+            np.testing.assert_allclose(traces[u].llks, l, rtol=1e-10, atol=1e-9)
+
+
 @pytest.mark.parametrize("prior", [None, (0.2, None)])
 def test_gibbs_and_mh_agree_with_the_exact_posterior(prior):
     """25 000 steps x 2 chains of either step type against genotype_posteriors over all genotypes (2 decimals)."""

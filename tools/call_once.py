@@ -8,7 +8,12 @@ import bench
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 once, shapes, arrays = bench.call_mcmc_workload(U)
+import time
 for _ in range(reps):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
     once()
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    print("call sampler: %.1f ms -> %.0f units/s" % (dt * 1e3, U / dt), flush=True)
 print("done", U, shapes)
