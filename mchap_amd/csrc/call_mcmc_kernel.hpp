@@ -159,7 +159,8 @@ __device__ __forceinline__ long long call_key(const int *g, int K) {
 
 __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const CallParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int wv = (int)(threadIdx.x >> 6), nwv = (int)(blockDim.x >> 6);
+  // (wave-uniform by construction; said so, or everything derived from it -- the chain, its pointers -- lives in vector registers)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwv = (int)(blockDim.x >> 6);
   const int unit = blockIdx.y, chain = (int)blockIdx.x * nwv + wv;
   const int lane = (int)(threadIdx.x & 63);
   const int R = P.R, H = P.H, K = P.K;

@@ -17,4 +17,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_c5_trace -- 
 python3 /root/repo/tools/pmc_sq.py $OUT/${TAG}_c5_sq1 $OUT/${TAG}_c5_sq2 $OUT/${TAG}_c5_sq3 > $OUT/${TAG}_c5_sq.json 2>> $OUT/${TAG}_c5_sq1.log
 find $OUT/${TAG}_c5_trace -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_c5_kernel_stats.csv \;
 rm -rf $OUT/${TAG}_c5_sq1 $OUT/${TAG}_c5_sq2 $OUT/${TAG}_c5_sq3 $OUT/${TAG}_c5_trace
-ls $OUT | grep ${TAG}_c5
+ls $OUT | grep ${TAG}_c5 || true
