@@ -575,9 +575,10 @@ def call_mcmc_roofline(U, S, Cn, K, ms):
            "frac": cyc * sub / (ms * 1e-3) / SIMD_CYCLES_PER_S, "valu_insts_per_allele_sub_step": float(c["SQ_INSTS_VALU"]) / ref,
            "issue_cycles_per_allele_sub_step": cyc, "per_class_complete": w["per_class_complete"],
            "counters": "%s (%s; static: an earlier rocprofv3 --pmc run)" % (src, kname),
-           "note": "one wavefront per (unit, chain): a sub-step is bookkeeping on a handful of lanes (a categorical draw over 16 options from "
-                   "remembered likelihoods), so the issue slots it uses are a small fraction of the chip's; what bounds it is the dependent "
-                   "latency of that bookkeeping at the occupancy 8 192 wavefronts give"}
+           "note": "one wavefront per (unit, chain), the chains of a unit in one workgroup over shared LDS tables (two wavefronts per SIMD; a table "
+                   "per chain left one): a sub-step is bookkeeping on a handful of lanes (a categorical draw over 16 options from remembered "
+                   "likelihoods), so the issue slots it uses are a small fraction of the chip's; what bounds it is the dependent latency of "
+                   "that bookkeeping at the occupancy the LDS tables allow"}
     if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
         out["wait_any_frac_of_wave_cycles"] = float(c["SQ_WAIT_ANY"]) / float(c["SQ_WAVE_CYCLES"])
     return out
