@@ -260,3 +260,63 @@ def test_matrix_source_goes_the_block_path_too(tmp_path):
     from_bam = list(application.assemble(None, variants, ref, application.ReadSource(dict(zip(("S000", "S001"), job["bams"]))), block_path=True,
                                          _batch_factory=_FakeBatch, **kw))
     assert slow == fast == from_bam and len(fast) == 12
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_alignments(tmp_path, seed):
+    """Random coordinate-sorted files -- two contigs, three read groups of two samples, CIGARs with soft clips, insertions, deletions,
+    skips and = / X runs, mates that overlap, duplicates / QC failures / supplementary records, low mapping qualities, reads
+    without a read group, unplaced reads -- and random targets (overlapping each other, tri-allelic SNVs, some without SNVs):
+    the block extraction and encoding against the per-locus functions."""
+    rng = np.random.default_rng(seed)
+    contigs = [("c1", 3000), ("c2", 1500)]
+    groups = {"g1": "A", "g2": "B", "g3": "A"}
+    recs = []
+    for ci, (cn, ln) in enumerate(contigs):
+        for q in range(220):
+            name = "q%d_%d" % (ci, rng.integers(0, 150))     # names repeat: mates
+            pos = int(rng.integers(0, ln - 150))
+            ops, rl = [], 0
+            if rng.random() < 0.2:
+                ops.append((int(rng.integers(1, 6)), "S"))
+            for _ in range(int(rng.integers(1, 5))):
+                ops.append((int(rng.integers(5, 40)), str(rng.choice(["M", "M", "M", "=", "X"]))))
+                k = rng.random()
+                if k < 0.2:
+                    ops.append((int(rng.integers(1, 5)), "I"))
+                elif k < 0.4:
+                    ops.append((int(rng.integers(1, 8)), "D"))
+                elif k < 0.45:
+                    ops.append((int(rng.integers(5, 30)), "N"))
+            while ops and ops[-1][1] in "IDN":
+                ops.pop()
+            if rng.random() < 0.2:
+                ops.append((int(rng.integers(1, 6)), "S"))
+            rl = sum(l for l, o in ops if o in "MIS=X")
+            flag = int(rng.choice([0, 0, 0, 16, 1024, 512, 2048, 4]))
+            recs.append(dict(qname=name, flag=flag, ref=(-1 if flag == 4 else ci), pos=(-1 if flag == 4 else pos), mapq=int(rng.choice([60, 60, 30, 5])),
+                             cigar=([] if flag == 4 else ops), seq="".join(rng.choice(list("ACGT"), size=rl)), qual=rng.integers(2, 41, size=rl).tolist(),
+                             rg=str(rng.choice(["g1", "g2", "g3", "unknown"]))))
+    recs.sort(key=lambda r: (r["ref"] if r["ref"] >= 0 else 99, r["pos"]))
+    path = str(tmp_path / "r.bam")
+    synth.write_bam(path, contigs, groups, recs)
+    cols = io.BamFile(path).columns()
+    assert cols.sorted and cols.n == len(recs)
+    variants = []
+    for cn, ln in contigs:
+        for p in np.sort(rng.choice(np.arange(10, ln - 10), size=ln // 25, replace=False)):
+            ref = str(rng.choice(list("ACGT")))
+            alts = tuple(str(x) for x in rng.permutation([b for b in "ACGT" if b != ref])[: int(rng.integers(1, 4))])
+            variants.append(dict(chrom=cn, pos=int(p) + 1, id=".", ref=ref, alts=alts, info={}))
+    by = application._variants_by_contig(variants)
+    loci = []
+    for t in range(60):
+        cn, ln = contigs[int(rng.integers(0, 2))]
+        a = int(rng.integers(0, ln - 200))
+        b = a + int(rng.integers(5, 200))
+        loci.append(io.DenovoLocus(cn, a, b, "t%d" % t, application._variants_within(by, cn, a, b), "N" * (b - a)))
+    total = 0
+    for sample in ("A", "B", "nobody"):
+        for kw in ({}, dict(min_quality=0, skip_duplicates=False, skip_qcfail=False, skip_supplementary=False)):
+            total += _compare(loci, cols, sample, **kw)
+    assert total > 500
