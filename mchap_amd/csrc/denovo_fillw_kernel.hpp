@@ -722,8 +722,8 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
         }
       }
       if (!hit && probe) {
-        uint64_t key = skey[rep];
-        uint64_t tag = (key << 1) | 1ull;
+        uint64_t tag = (skey[rep] << 1) | 1ull | P.cache_epoch;  // (the call's epoch in the upper bits of a packed genotype's tag: tag_of)
+        uint64_t key = tag >> 1;
         GWords<KT> pwv = g;
         if constexpr (WIDE) {
           // the proposal's words; its tag is a hash (tag_of), a tag match is verified against the words kept beside the entry

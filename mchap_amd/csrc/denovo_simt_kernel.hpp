@@ -74,6 +74,8 @@ struct SimtParams {
   int fill_lt, fill_kw;       // denovo_fill_kernel: lanes per tile of the read table, words kept per distinct request
   int tw_lds;                 // denovo_spec_kernel<.., TW>: bytes of one wavefront's LDS layout behind the workgroup's exchange area
   int word_bits;              // bits of a packed haplotype word of this launch's sampler: 0 / 64, or 128 (denovo_simt_kernel<0, u128>)
+  uint64_t cache_epoch;       // speculative / phased sampler: this call's epoch << 33, OR-ed into every likelihood-cache tag (0: the
+                              // caches were cleared for this call instead): entries of earlier calls never match, nothing is cleared
 };
 constexpr int PIPE_RESUME = 1;  // start from the chains' PipeState records
 constexpr int PIPE_EXPORT = 2;  // at the end: complete the interval memo of the current genotype, write the records

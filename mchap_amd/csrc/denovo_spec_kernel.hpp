@@ -153,6 +153,7 @@ struct SpecLds {
   uint32_t cache_mask;    // sets of the likelihood cache - 1; cache off: cache_on == false
   int key_words;          // words per entry of the wide-genotype key table (DenovoParams::cache_key_words)
   bool cache_on;
+  uint64_t epoch = 0ull;  // SimtParams::cache_epoch (this call's epoch << 33, part of every tag of packed genotypes; 0: none)
   bool reuse_on;          // haplotype products of the chain's current genotype are reused by its proposals
   LDSP(const uint8_t) lds_ct;  // the unit's coded table / read weights copied into LDS (settling kernel), else null
   LDSP(const double) lds_cw;
@@ -383,12 +384,15 @@ __device__ __forceinline__ double prior_of(LDSP(double) pt, double inbreeding, u
   }
   return pt[2 * KT + 2] + prod;
 }
+// epoch: SimtParams::cache_epoch -- with it the packed genotype is at most 32 bits (the host's condition) and the call's epoch sits
+// in the tag's upper 31 bits: what an earlier call left in the table never matches, so the table is not cleared between calls
 template <int KT>
-__device__ __forceinline__ uint64_t tag_of(const GWords<KT> g, int key_bits) {
+__device__ __forceinline__ uint64_t tag_of(const GWords<KT> g, int key_bits, uint64_t epoch = 0ull) {
   uint64_t t = 0;
   if (key_bits * KT <= 63) {
 #pragma unroll
     for (int h = 0; h < KT; h++) t = (t << key_bits) | g.w[h];
+    return (t << 1) | 1ull | epoch;
   } else {
 #pragma unroll
     for (int h = 0; h < KT; h++) t = mix64(t ^ g.w[h]) + 0x9E3779B97F4A7C15ull;
@@ -1286,7 +1290,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
     // 8-way sets (one 128-byte line).  The lanes of a group probe and fill the chain's table concurrently, so the
     // policy must not depend on read-modify-write sequences: hits never move entries, a miss goes to the first
     // empty way it saw (else to a way picked by the key); a lost race only costs one more evaluation later.
-    tag = tag_of<KT>(pw, C_KEYBITS(c));
+    tag = tag_of<KT>(pw, C_KEYBITS(c), S.epoch);
     const uint64_t key = tag >> 1;
     // full-avalanche 32-bit mix: the keys probed together are single-field neighbours of one genotype, so a
     // plain multiplicative hash would send all neighbours that differ in a high field to the same set
@@ -1336,7 +1340,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
         miss = false;
         hit_way = w;
       }
-      if (e.x == 0ull) way = w;  // lowest empty way wins
+      if (e.x == 0ull || (S.epoch != 0ull && (e.x ^ S.epoch) >> 33 != 0ull)) way = w;  // lowest empty way wins (an earlier call's entry is empty too)
     }
     if (wide) {
       uint64_t *kset = reinterpret_cast<uint64_t *>((uintptr_t)S.gptr[(lane / G) * GP_N + GP_CKEYS]) + 8 * set_i * S.key_words;
@@ -2236,6 +2240,7 @@ __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE
   S.crow = WAVE * P.cstride;
   S.cache_on = D.cache_slots > 0 && !fillonly;
   S.cache_mask = S.cache_on ? (uint32_t)(D.cache_slots / 8) - 1u : 0u;  // sets of 8 ways
+  S.epoch = P.cache_epoch;
   S.key_words = D.cache_key_words;
   if (gl == 0) {
     LDSP(uint64_t) gp = S.gptr + gi * GP_N;

@@ -143,3 +143,41 @@ def test_against_the_oracle_step_for_step():
         assert code == 0
         assert np.array_equal(b.genotypes(u, words, fixed), sort_haplotypes(g))
         np.testing.assert_allclose(llks[u], l, rtol=1e-10)
+
+
+def test_a_workspace_reused_for_other_data_needs_no_clearing():
+    """Packed genotypes of at most 32 bits: the likelihood caches are not cleared between fits, their entries carry the fit's epoch
+    (mchap_hip.hip g_cache_epoch).  A batch run on one data set, its input then overwritten IN PLACE with another data set of the
+    same shape (same workspace, same cache tables, full of the first run's entries under the same keys) and run again: the traces of
+    the second data set exactly, as from a fresh batch and as with the caches cleared per call (tuning flag 65536)."""
+    import torch
+
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.device import DenovoDeviceBatch
+    from mchap_amd.synth import synth_units
+
+    kw = dict(ploidy=4, n_pos=8, n_reads=40, qual=(3, 20))        # chains that keep moving: thousands of cache entries each
+    a, _, _ = synth_units(64, first_unit=0, **kw)
+    b, _, _ = synth_units(64, first_unit=500, **kw)
+    model = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=300, chains=2, random_seed=11)
+    for kernel in (5, 3):
+        m = DenovoMCMC(ploidy=4, n_alleles=[2] * 8, steps=300, chains=2, random_seed=11, kernel=kernel)
+        fresh = DenovoDeviceBatch(m, b)
+        fresh.run()
+        reused = DenovoDeviceBatch(m, a)
+        reused.run()
+        torch.cuda.synchronize()
+        first = reused.d_trace.clone()
+        reused.d_reads.copy_(torch.from_numpy(np.ascontiguousarray(b).reshape(-1)).to(reused.d_reads.device))
+        reused.run()
+        torch.cuda.synchronize()
+        assert not torch.equal(first, reused.d_trace)
+        assert torch.equal(fresh.d_trace, reused.d_trace) and torch.equal(fresh.d_llks.view(torch.int64), reused.d_llks.view(torch.int64))
+        os.environ["MCHAP_HIP_FLAGS"] = "65536"
+        try:
+            cleared = DenovoDeviceBatch(m, b)
+            cleared.run()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MCHAP_HIP_FLAGS", None)
+        assert torch.equal(cleared.d_trace, reused.d_trace)
