@@ -177,7 +177,10 @@ __host__ __device__ inline size_t spec_memo_bytes(int Mmax, int T, int G) {
 }
 
 constexpr int SPEC_LC_ENTRIES = 256;  // entries of the LDS front cache of a chain's likelihoods (16 bytes each)
-constexpr uint32_t SPEC_LC_SECOND_LEVEL_GEN = 48;  // genotype changes after which a front-cache miss also probes the workspace table
+#ifndef MCHAP_LC_GEN
+#define MCHAP_LC_GEN 48
+#endif
+constexpr uint32_t SPEC_LC_SECOND_LEVEL_GEN = MCHAP_LC_GEN;  // genotype changes after which a front-cache miss also probes the workspace table
 __host__ __device__ inline size_t spec_lc_bytes() { return (size_t)16 * SPEC_LC_ENTRIES + 16; }
 // LDS of the base-product cache (SpecLds::bpc / bpt) of a one-chain-per-wave launch
 __host__ __device__ inline size_t spec_bp_cache_bytes(int K) { return (size_t)8 * K * 4 * 64 + (size_t)8 * (K + 1); }
