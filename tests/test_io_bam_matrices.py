@@ -180,3 +180,26 @@ def test_native_record_walk_equals_the_array_construction(tmp_path):
             assert len(np.unique(a.qname)) == len(np.unique(b.qname)) == len(np.unique(np.stack([a.qname, b.qname]), axis=1).T)
         n_files += 1
     assert n_files >= 8
+
+
+def test_native_record_walk_on_truncated_and_empty_payloads(tmp_path):
+    """A payload cut in the middle of a record (a region's last block) yields the complete records before it; one without any
+    record yields empty columns; a record whose own fields overrun its length is refused."""
+    import struct
+
+    from mchap_amd import synth
+
+    job = synth.synth_assembly_inputs(str(tmp_path), n_loci=3, n_samples=1, reads_per_locus=10, gap=50)
+    bf = io.BamFile(job["bams"][0])
+    payload = b"".join(io.bgzf_inflate(bf.data, bf.blocks))
+    whole = io.AlignmentColumns.native(bf.refs, bf.rg, payload, bf.header_end)
+    assert whole.n == 30
+    cut = io.AlignmentColumns.native(bf.refs, bf.rg, payload[:-7], bf.header_end)
+    assert cut.n == 29 and np.array_equal(cut.pos, whole.pos[:29]) and np.array_equal(cut.c_len, whole.c_len[: cut.seg_first[-1]])
+    none = io.AlignmentColumns.native(bf.refs, bf.rg, payload[: bf.header_end], bf.header_end)
+    assert none.n == 0 and none.sorted and len(none.c_rec) == 0 and none.seg_first.tolist() == [0]
+    bad = bytearray(payload)
+    (first_len,) = struct.unpack_from("<i", payload, bf.header_end)
+    struct.pack_into("<i", bad, bf.header_end + 4 + 16, 1 << 20)      # l_seq far beyond the record
+    with pytest.raises(ValueError):
+        io.AlignmentColumns.native(bf.refs, bf.rg, bytes(bad), bf.header_end)
