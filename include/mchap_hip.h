@@ -60,13 +60,18 @@ enum {
  * depend on them -- every setting produces the same traces (tests/test_gpu_denovo.py runs the extremes) -- only the time does.
  * A zero field means "default". */
 typedef struct mchap_denovo_tuning {
-  int32_t cache_slots;   /* {tag, llk} entries per chain of the likelihood cache: a power of two in 64..65536 (default 1024) */
+  int32_t cache_slots;   /* {tag, llk} entries per chain of the likelihood cache: a power of two in 64..65536 (default: what 4 GiB
+                            over the batch's chains allow, 1024..65536) */
   int32_t flags;         /* 1: no mutation memo, 2: no interval memo, 4: no coded read table, 8: no product reuse,
                             16: no LDS base-product cache, 32: skip the phased sampler's table completion (timing only: with
                             pipe_stop), 64 (libmchap_hip_test.so only): the tables completed by denovo_fill_kernel, one lane per request,
                             128: units without information (all gaps) are evaluated like any other,
                             256: never the instantiation that evaluates the requests of shallow units (<= 64 reads) side by side,
-                            512: no haplotype-product rows in the workspace for deep units (> 256 reads) */
+                            512: no haplotype-product rows in the workspace for deep units (> 256 reads),
+                            1024: table completion inside the exporting launch, 8192: no LDS front cache of a chain's likelihoods,
+                            16384: a ladder's replicas on one wavefront, 32768: no completion memo across chunks, 65536: caches
+                            cleared per call instead of epoch tags, 131072: one wavefront per chain in every coasting launch
+                            (DESIGN.md section 4 names each) */
   int32_t spec_group;    /* kernel 3: lanes per chain, 16 / 32 / 64 (default: the smallest the shape allows) */
   int32_t pipe_first;    /* kernel 5: MCMC steps before the first hand-over (default ploidy * n_pos / 10, clamped to 4..32) */
   int32_t pipe_resume;   /*           steps a handed-back chain runs before it is handed over again (default 8) */

@@ -145,8 +145,8 @@ struct SpecLds {
   LDSP(double) bpc;       // [K][4][64] one chain per wave only (G = 64), else null: the haplotype products of ...
   LDSP(uint64_t) bpt;     // [K + 1] ... these base words (bpt[K] != 0: valid), kept from one evaluation call to the next
   LDSP(uint64_t) gbt;     // [NG][K + 1] the words whose products the chain's rows of SimtParams::gbp hold (deep units), [K] != 0: valid
-  LDSP(const uint8_t) sct;  // [rows][64] code of read `lane` in every row of the table, for a shallow unit (<= 32 reads, <= 24
-                            // rows) of a one-chain-per-wave launch: kept in the product cache's unused chunk slots; else null
+  LDSP(const uint8_t) sct;  // code of read `lane` in every row of the table (row r at sct_off(r)), for a unit of at most 64 reads
+                            // and 24 K rows in a one-chain-per-wave launch: kept in the product cache's unused chunk slots; else null
   LDSP(uint64_t) tbuf;    // [NG][SPEC_TB][K + 1] trace records (K sorted words + llk) waiting to be written as a line
   LDSP(uint64_t) lc;      // [lc_mask + 1][2] {tag, value bits}: the chain's likelihood cache IN LDS (one chain per wave), or lc_mask == 0
   uint32_t lc_mask;       // entries - 1 of that front cache (0: none -- the cache in the workspace is probed instead)
@@ -182,11 +182,17 @@ constexpr int SPEC_LC_ENTRIES = 256;  // entries of the LDS front cache of a cha
 #endif
 constexpr uint32_t SPEC_LC_SECOND_LEVEL_GEN = MCHAP_LC_GEN;  // genotype changes after which a front-cache miss also probes the workspace table
 __host__ __device__ inline size_t spec_lc_bytes() { return (size_t)16 * SPEC_LC_ENTRIES + 16; }
+// Where row `row` of a one-chunk unit's code table sits behind SpecLds::sct: the product cache is [K][4 chunks][64] float64 and a
+// one-chunk unit only uses chunk 0 of every haplotype, so the chunks 1..3 of haplotype h hold the rows 24 h .. 24 h + 23 (64
+// codes each) -- 24 K rows in all (round 4, late: haplotype 0's slots alone held 24 rows, i.e. 12 biallelic SNVs; docs/example's
+// units that keep moving have 13 to 23)
+__device__ __forceinline__ uint32_t sct_off(uint32_t row) { return (row / 24u) * (uint32_t)(4 * WAVE * 8) + (row % 24u) * (uint32_t)WAVE; }
 // LDS of the base-product cache (SpecLds::bpc / bpt) of a one-chain-per-wave launch
 __host__ __device__ inline size_t spec_bp_cache_bytes(int K) { return (size_t)8 * K * 4 * 64 + (size_t)8 * (K + 1); }
 
-// dynamic LDS of denovo_coast_kernel (denovo_coast_kernel.hpp): a chain's two memo tables, its break distribution,
-// its sorted words
+// dynamic LDS of denovo_coast_kernel<NW> (denovo_coast_kernel.hpp): a chain's two memo tables, its break distribution,
+// its sorted words, the wavefronts' first undecided steps
+constexpr int COAST_NW_LIST = 4;  // wavefronts per chain of a coasting launch over a list of handed-back chains
 __host__ __device__ inline size_t coast_lds_bytes(int Mmax) {
   return (size_t)8 * (2 * spec_memo_entries(Mmax) + Mmax) + (size_t)8 * 12;
 }
@@ -988,7 +994,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
                 }
                 if (sct != nullptr) {  // (wave-uniform) the unit's codes are in LDS: no memory round trip at all
 #pragma unroll
-                  for (int t = 0; t < 8; t++) cd[t] = sct[row[t] * WAVE + r];
+                  for (int t = 0; t < 8; t++) cd[t] = sct[sct_off(row[t]) + r];
                 } else {
 #pragma unroll
                   for (int t = 0; t < 8; t++) cd[t] = ctb[(size_t)(row[t] * WAVE + r) * cstride];
@@ -1090,7 +1096,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
                 if (k < RK) {  // (wave-uniform)
                   if (sct != nullptr) {  // the unit's codes are in LDS: no memory round trip at all
 #pragma unroll
-                    for (int t = 0; t < 4; t++) cd[k][t] = sct[row[t] * WAVE + r + 16 * k];
+                    for (int t = 0; t < 4; t++) cd[k][t] = sct[sct_off(row[t]) + r + 16 * k];
                   } else {
 #pragma unroll
                     for (int t = 0; t < 4; t++) cd[k][t] = ctb[(size_t)(row[t] * WAVE + r + 16 * k) * cstride];
@@ -2283,13 +2289,13 @@ __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE
   S.sct = nullptr;
   if constexpr (G == 64 && MCHAP_SPEC_SBS != 0) {
     // A unit of one chunk (at most 64 reads: spec_coop_all evaluates its requests side by side) with a small table:
-    // every lane's code of every row goes into LDS once per launch -- into the chunk slots 1..3 of haplotype 0 of the
-    // product cache, which a one-chunk unit never uses -- and its evaluations then make no memory round trip.
+    // every lane's code of every row goes into LDS once per launch -- into the chunk slots 1..3 of every haplotype of the
+    // product cache (sct_off), which a one-chunk unit never uses -- and its evaluations then make no memory round trip.
     const int rows = U.n_pos * A;
-    if (S.bpc != nullptr && c.alive && U.n_reads <= 64 && rows <= 24 && mi[META_I_NDICT] != 0 && !(P.flags & 4)) {
+    if (S.bpc != nullptr && c.alive && U.n_reads <= 64 && rows <= 24 * KT && mi[META_I_NDICT] != 0 && !(P.flags & 4)) {
       LDSP(uint8_t) t = (LDSP(uint8_t))(S.bpc + WAVE);
       GLBP(const uint8_t) ct = (GLBP(const uint8_t))(P.codes + (size_t)u * P.max_ma * WAVE * P.cstride);
-      for (int r_ = 0; r_ < rows; r_++) t[r_ * WAVE + lane] = ct[(size_t)(r_ * WAVE + lane) * P.cstride];
+      for (int r_ = 0; r_ < rows; r_++) t[sct_off((uint32_t)r_) + lane] = ct[(size_t)(r_ * WAVE + lane) * P.cstride];
       S.sct = t;
     }
   }

@@ -64,7 +64,7 @@ SIMT_LIST(DECL_SIMT)
 // ... and its instantiation with 128-bit haplotype words (simt_inst.hip -DSIMT_WIDE): the general fallback for wide targets
 extern "C" int mchap_simt_init_w(const double *, const double *);
 extern "C" int mchap_simt_launch_w(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
-extern "C" int mchap_coast_launch(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+extern "C" int mchap_coast_launch(const mchap::SimtParams *, unsigned, int, hipStream_t);
 // table completion of the phased sampler, one workgroup per chain and one wavefront per request (denovo_fillw_kernel.hpp): shipped
 #define FILLW_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #define DECL_FILLW(k)                                                    \
@@ -299,12 +299,16 @@ struct Tune {
   int pipe_group = 64;
   size_t prep_lds_limit = 8 * 1024;
   int pipe_stop = 0;
+  bool cache_auto = true;  // cache_slots not named by the caller: cache_slots_of() sizes the tables by the batch
 };
 Tune tune_of(const mchap_denovo_cfg *cfg) {
   Tune t;
   const mchap_denovo_tuning *u = cfg->tuning;
   if (!u) return t;
-  if (u->cache_slots >= 64 && u->cache_slots <= 65536 && (u->cache_slots & (u->cache_slots - 1)) == 0) t.cache_slots = u->cache_slots;
+  if (u->cache_slots >= 64 && u->cache_slots <= 65536 && (u->cache_slots & (u->cache_slots - 1)) == 0) {
+    t.cache_slots = u->cache_slots;
+    t.cache_auto = false;
+  }
   t.flags = u->flags;
   if (u->spec_group == 16 || u->spec_group == 32 || u->spec_group == 64) t.spec_group = u->spec_group;
   if (u->pipe_first > 0) t.pipe_first = u->pipe_first;
@@ -481,6 +485,24 @@ struct SimtCarve {
   bool has_gbp = false;
 };
 constexpr int PIPE_MAX_ROUNDS = 6;  // resume rounds of the phased sampler (counters in the workspace)
+
+// Entries per chain of the likelihood cache.  The reference's cache is unbounded (assemble/mcmc.py: a dictionary per chain); a
+// chain that never settles -- phase-ambiguous samples of real pileups: docs/example locus015 requests ~100 likelihoods per step
+// and 95 % of them are genotypes it has seen -- re-evaluates what a small table has dropped: at 1024 entries three quarters of
+// such a chain's time were evaluations (24 per step against the 5 an unbounded table leaves; profiles/r04d_stats_example.txt).
+// Unless the caller names a size, the tables therefore take what CACHE_BUDGET bytes over the batch's chains allow, between 1024
+// and 65536 entries: 880 chains of wide genotypes get 65536 each, 20 000 chains of configs[1] 8192.
+constexpr size_t CACHE_BUDGET = (size_t)4 << 30;
+int cache_slots_of(const mchap_denovo_cfg *cfg, const Tune &T, const Plan &pl, int n_units, const BatchDims &B) {
+  if (!cfg->llk_cache) return 0;
+  if (!T.cache_auto) return T.cache_slots;
+  const size_t ncc = (size_t)n_units * cfg->chains * (size_t)(pl.kind == SAMPLER_SPEC ? cfg->n_temps : 1);
+  const bool keyed = B.max_ploidy * mchap::allele_bits(B.max_allele) * B.max_pos > 63;
+  const size_t entry = 16 + (keyed ? (size_t)B.max_ploidy * (pl.wide ? 2 : 1) * 8 : 0);
+  int slots = 1024;
+  while (slots < 65536 && ncc * (size_t)(2 * slots) * entry <= CACHE_BUDGET) slots *= 2;
+  return slots;
+}
 
 SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, const BatchDims &B, int rpad, int cache_slots) {
   SimtCarve c;
@@ -671,7 +693,6 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   P.pipe_iters_max = T.pipe_max;  // ... extended to while a chain of the wave is unsettled
   P.pipe_parts = T.pipe_parts;    // wavefronts per chain completing tables when chains are few
   const unsigned grid_f = (unsigned)((mchap::PIPE_FILL_SLOTS + 64 / G - 1) / (64 / G));
-  const size_t lds_c = mchap::coast_lds_bytes(P.max_pos);
   const unsigned grid_s = (unsigned)((n_chains + 64 / G - 1) / (64 / G)), grid_c = (unsigned)n_chains;
   const size_t list_stride = up256((size_t)n_chains * 4) / 4;
   HIP_TRY(hipMemsetAsync(counts, 0, (PIPE_MAX_ROUNDS + 2) * 4, stream));
@@ -726,7 +747,7 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   // coast; then rounds of (resume the chains handed back for a few steps, coast again); the rest runs to the end
   P.pipe_out = lists;
   P.pipe_out_count = counts;
-  if (e == 0) e = mchap_coast_launch(&P, grid_c, lds_c, stream);
+  if (e == 0) e = mchap_coast_launch(&P, grid_c, 0, stream);
   for (int r = 0; r <= rounds && e == 0 && T.pipe_stop != 1; r++) {
     P.pipe_list = lists + (size_t)(r & 1) * list_stride;
     P.pipe_count = counts + r;
@@ -740,7 +761,9 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
     P.pipe_out = lists + (size_t)((r + 1) & 1) * list_stride;
     P.pipe_out_count = counts + r + 1;
     if (T.pipe_stop == -(r + 2)) break;  // (debugging: stop before this round's coasting launch)
-    e = mchap_coast_launch(&P, grid_c, lds_c, stream);
+    // (the chains handed back are few -- 23 of 20 000 at configs[1] --: four wavefronts per chain, 256 steps per sweep; tuning
+    // flag 131072: one, as the launch over every chain)
+    e = mchap_coast_launch(&P, grid_c, (T.flags & 131072) ? 0 : 1, stream);
     if (T.pipe_stop == r + 2) break;  // (measurement / debugging: stop after this round's coasting launch)
   }
   if (e != 0) return fail(MCHAP_ERR_HIP, "launch of the phased sampler <%d, %d>: %s", K, G, hipGetErrorString((hipError_t)e));
@@ -864,7 +887,7 @@ int mchap_debug_pipe_records(const mchap_denovo_cfg *cfg, int n_units, const mch
   const Tune T = tune_of(cfg);
   Plan pl;
   if (plan_sampler(cfg, T, B, pl) || pl.kind != SAMPLER_PIPE) return fail(MCHAP_ERR_BAD_ARG, "not a phased-sampler batch");
-  const SimtCarve cv = simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, cfg->llk_cache ? T.cache_slots : 0);
+  const SimtCarve cv = simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, cache_slots_of(cfg, T, pl, n_units, B));
   const unsigned char *ws = reinterpret_cast<const unsigned char *>(workspace) + break_table_bytes(cfg);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(records, ws + cv.pipe_state, (size_t)n_units * cfg->chains * sizeof(mchap::PipeState), hipMemcpyDeviceToHost));
@@ -879,7 +902,7 @@ int mchap_debug_pipe_memo(const mchap_denovo_cfg *cfg, int n_units, const mchap_
   const Tune T = tune_of(cfg);
   Plan pl;
   if (plan_sampler(cfg, T, B, pl) || pl.kind != SAMPLER_PIPE) return fail(MCHAP_ERR_BAD_ARG, "not a phased-sampler batch");
-  const SimtCarve cv = simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, cfg->llk_cache ? T.cache_slots : 0);
+  const SimtCarve cv = simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, cache_slots_of(cfg, T, pl, n_units, B));
   const unsigned char *ws = reinterpret_cast<const unsigned char *>(workspace) + break_table_bytes(cfg);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(memo, ws + cv.pipe_memo, (size_t)n_units * cfg->chains * 2 * mchap::spec_memo_entries(B.max_pos) * 8, hipMemcpyDeviceToHost));
@@ -904,15 +927,14 @@ int64_t mchap_denovo_lds_bytes(int n_reads, int n_pos, int max_allele, int ploid
 int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_host) {
   if (!cfg || n_units <= 0) return 0;
   const Tune T = tune_of(cfg);
-  const int slots = cfg->llk_cache ? T.cache_slots : 0;
   const int64_t bt = (int64_t)break_table_bytes(cfg);
-  if (!use_simt(cfg)) return bt + (int64_t)n_units * cfg->chains * slots * 16;
+  if (!use_simt(cfg)) return bt + (int64_t)n_units * cfg->chains * (cfg->llk_cache ? T.cache_slots : 0) * 16;
   if (!units_host) return -1;
   BatchDims B;
   if (batch_dims(cfg, n_units, units_host, B)) return -1;
   Plan pl;
   if (plan_sampler(cfg, T, B, pl)) return -1;
-  return bt + (int64_t)simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, slots).total;
+  return bt + (int64_t)simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, cache_slots_of(cfg, T, pl, n_units, B)).total;
 }
 
 static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
@@ -1017,7 +1039,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
   P.cache_slots = 0;
 
   if (use_simt(cfg)) {
-    const int want_slots = cfg->llk_cache ? T.cache_slots : 0;
+    const int want_slots = cache_slots_of(cfg, T, pl, n_units, B);
     int slots = want_slots;
     SimtCarve cv = simt_carve(cfg, pl, n_units, B, rpad, slots);
     while (slots >= 32 && (int64_t)cv.total > workspace_bytes) {

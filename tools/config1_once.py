@@ -16,11 +16,12 @@ class NSeq:
 
 src = application.MatrixSource(samples, matrices)
 reps = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1, 1, 16, 16)
+upb = int(sys.argv[3]) if len(sys.argv) > 3 else None  # units per block (default: by free memory; several blocks overlap host and device work)
 for rep in reps:
     for bp in ((None, False) if len(sys.argv) < 3 else (None,)):
         tm = {}
         t = time.perf_counter()
         lines = list(application.assemble(None, variants, {c: NSeq() for c, _ in contigs}, src, ploidy=4, steps=2000, burn=1000, chains=2, seed=42,
-                                          targets=list(targets) * rep, timings=tm, block_path=bp))
+                                          targets=list(targets) * rep, timings=tm, block_path=bp, units_per_block=upb))
         dt = time.perf_counter() - t
-        print("x%d block_path=%s %.1f ms  %.0f units/s  %s" % (rep, bp, dt * 1e3, tm["units"] / dt, {k: round(v * 1e3, 1) for k, v in tm.items() if k.endswith("_s")}), flush=True)
+        print("x%d block_path=%s upb=%s %.1f ms  %.0f units/s  %s" % (rep, bp, upb, dt * 1e3, tm["units"] / dt, {k: round(v * 1e3, 1) for k, v in tm.items() if k.endswith("_s")}), flush=True)
