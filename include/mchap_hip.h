@@ -73,7 +73,7 @@ typedef struct mchap_denovo_tuning {
                             cleared per call instead of epoch tags, 131072: one wavefront per chain in every coasting launch
                             (DESIGN.md section 4 names each) */
   int32_t spec_group;    /* kernel 3: lanes per chain, 16 / 32 / 64 (default: the smallest the shape allows) */
-  int32_t pipe_first;    /* kernel 5: MCMC steps before the first hand-over (default ploidy * n_pos / 10, clamped to 4..32) */
+  int32_t pipe_first;    /* kernel 5: MCMC steps before the first hand-over (default ploidy * n_pos / 10, clamped to 3..32) */
   int32_t pipe_resume;   /*           steps a handed-back chain runs before it is handed over again (default 8) */
   int32_t pipe_rounds;   /*           resume rounds + 1 before the rest runs to the end in kernel 3 (default 2 + 1; 1 = none) */
   int32_t pipe_max;      /*           cap of a launch's extension while a chain of the wave is unsettled (default 64) */

@@ -685,9 +685,10 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   const long long n_chains = (long long)n_units * chains;
   // steps before the first hand-over: a chain handed over before it has settled comes back and has its tables
   // completed a second time, which costs more the more sub-steps and intervals a step has (config #2: 32 sub-steps,
-  // best at 4; config #5: 160 sub-steps, 1251 / 912 / 570 / 632 ms at 4 / 8 / 16 / 32)
+  // best at 3 since the listed coasting launches run four wavefronts per chain -- 1.060 / 1.080 / 1.081 M loci/s at 4 / 3 / 2,
+  // one pass at a time 860 / 870 / 854 k --, at 4 before; config #5: 160 sub-steps, 1251 / 912 / 570 / 632 ms at 4 / 8 / 16 / 32)
   const int n_sub = K * P.max_pos;
-  const int s0 = T.pipe_first > 0 ? T.pipe_first : (n_sub / 10 < 4 ? 4 : (n_sub / 10 > 32 ? 32 : n_sub / 10));
+  const int s0 = T.pipe_first > 0 ? T.pipe_first : (n_sub / 10 < 3 ? 3 : (n_sub / 10 > 32 ? 32 : n_sub / 10));
   const int nr = T.pipe_resume;   // steps a handed-back chain runs before the next hand-over
   const int rounds = T.pipe_rounds < PIPE_MAX_ROUNDS ? T.pipe_rounds : PIPE_MAX_ROUNDS;
   P.pipe_iters_max = T.pipe_max;  // ... extended to while a chain of the wave is unsettled
