@@ -1102,7 +1102,7 @@ def main():
                 "valu_counters": None if not w else "%s (static, as traffic); issue cycles = float64 x 4 + 64-bit integer x 4 + "
                                                     "transcendental x 8 + other x 2 over 1024 SIMDs x 2.4 GHz" % prof_src,
                 "note": "a sampler call is several launches (phased sampler: speculative kernel phases + coasting kernel, "
-                        "DESIGN.md 4.1c); kernel_ms is the span of HIP events around all of them, measured with ONE pass in "
+                        "DESIGN.md 4.2.2); kernel_ms is the span of HIP events around all of them, measured with ONE pass in "
                         "flight in %d passes right after the timed region (in the timed region passes overlap on separate "
                         "streams and a launch's span is not its cost).  It is bound by wave-wide " % n_iso +
                         "likelihood evaluations at two waves per SIMD (first phase) and Philox throughput (coasting), not by "

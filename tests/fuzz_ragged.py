@@ -95,8 +95,9 @@ def run(n_cases, seed, max_units=300, max_pos=24, verbose=True):
             D = b.units_host[i]
             M, A = int(D["n_pos"]), int(D["max_allele"])
             g, l, summary = oracle_unit(u, steps, chains, sd, burn, 0.6)
-            w = trace[int(D["trace_off"]): int(D["trace_off"]) + chains * steps * K].reshape(chains, steps, K)
-            got = unpack_trace(w, fixed[int(D["fixed_off"]): int(D["fixed_off"]) + M], A)
+            wph = b.wph  # (2: the general sampler's 128-bit haplotype words -- a batch whose widest unit x most alleles exceed 64 bits)
+            w = trace[int(D["trace_off"]): int(D["trace_off"]) + chains * steps * K * wph].reshape((chains, steps, K) + ((wph,) if wph > 1 else ()))
+            got = unpack_trace(w, fixed[int(D["fixed_off"]): int(D["fixed_off"]) + M], A, wph)
             lk = llks[int(D["llk_off"]): int(D["llk_off"]) + chains * steps].reshape(chains, steps)
             ok = np.array_equal(got, g) and np.allclose(lk, l, rtol=1e-10, atol=1e-9, equal_nan=True)
             r = res[i]
