@@ -49,5 +49,13 @@ for i, nm in enumerate(pnames):
 print("total ticks per chain-step %.0f (s_memtime: 100 MHz)" % (tot / ws))
 print("nested: cache probe %.0f ticks per chain-step; probe + evaluation %.0f; request-lanes evaluated %.2f per chain-step -> %.0f ticks each" % (
     out[33] / ws, out[34] / ws, out[35] / ws, (out[34] - out[33]) / max(out[35], 1)))
-if out[8]:
-    print("mutation: wave-calls %d  slow-path %.3f  rounds per wave-call %.3f; requests %d misses %d" % (out[8], out[9] / out[8], out[11] / out[8], out[0], out[1]))
+if out[8]:  # (event counters: the `stats` build)
+    print("mutation: wave-calls %d  on the slow path %.3f  rounds per slow-path call %.2f; requests %d misses %d (%.1f %%)" % (
+        out[8], out[9] / out[8], out[11] / max(out[9], 1), out[0], out[1], 100.0 * out[1] / max(out[0], 1)))
+    for nm, b, w in (("recombination", 12, 20), ("dosage (both kinds)", 16, 21)):
+        n = max(out[b], 1)
+        print("%s: wave-calls %d  executing %.3f  needing rounds %.3f  rounds per call with rounds %.2f" % (
+            nm, out[b], out[b + 1] / n, out[b + 2] / n, out[b + 3] / max(out[w], 1)))
+    slow = max(out[9], 1)
+    print("per slow-path mutation call: %.0f ticks; cache probe %.0f + evaluations %.0f of them (mutation + structural together), %.2f request-lanes evaluated" % (
+        out[25] / slow, out[33] / slow, (out[34] - out[33]) / slow, out[35] / slow))
