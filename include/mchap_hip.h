@@ -70,7 +70,8 @@ typedef struct mchap_denovo_tuning {
                             512: no haplotype-product rows in the workspace for deep units (> 256 reads),
                             1024: table completion inside the exporting launch, 8192: no LDS front cache of a chain's likelihoods,
                             16384: a ladder's replicas on one wavefront, 32768: no completion memo across chunks, 65536: caches
-                            cleared per call instead of epoch tags, 131072: one wavefront per chain in every coasting launch
+                            cleared per call instead of epoch tags, 131072: one wavefront per chain in every coasting launch,
+                            262144: a round's misses behind a sub-step known to move are evaluated as well
                             (DESIGN.md section 4 names each) */
   int32_t spec_group;    /* kernel 3: lanes per chain, 16 / 32 / 64 (default: the smallest the shape allows) */
   int32_t pipe_first;    /* kernel 5: MCMC steps before the first hand-over (default ploidy * n_pos / 10, clamped to 3..32) */

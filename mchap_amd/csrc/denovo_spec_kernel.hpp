@@ -155,6 +155,7 @@ struct SpecLds {
   bool cache_on;
   uint64_t epoch = 0ull;  // SimtParams::cache_epoch (this call's epoch << 33, part of every tag of packed genotypes; 0: none)
   bool reuse_on;          // haplotype products of the chain's current genotype are reused by its proposals
+  bool cut_off = false;   // tuning flag 262144: spec_mutation evaluates the misses behind a sub-step known to move as well
   LDSP(const uint8_t) lds_ct;  // the unit's coded table / read weights copied into LDS (settling kernel), else null
   LDSP(const double) lds_cw;
   int crow;               // bytes per row of the coded table (64 lanes x SimtParams::cstride)
@@ -1274,9 +1275,15 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
 
 // Likelihood of the lane's proposal `pw` (where need): 4-way cache probe, then co-operative evaluation of the
 // misses by the whole wavefront (request words staged through LDS).  Every lane of the wave must call.
-template <int KT, int G, bool LT = false>
+// `filt(miss, val)` is asked once, by every lane, between the look-up and the evaluations: it may withdraw a lane's miss (the
+// caller then gets no value for that lane and must not use one) -- spec_mutation drops the proposals behind a sub-step that is
+// already known to move.
+struct SpecKeepAll {
+  __device__ __forceinline__ bool operator()(bool miss, double) const { return miss; }
+};
+template <int KT, int G, bool LT = false, class Filter = SpecKeepAll>
 __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, const Grp<KT> &c, const SpecLds &S, int mmax,
-                                            int rpad, int lane) {
+                                            int rpad, int lane, Filter filt = Filter()) {
   double val = 0.0;
   // A unit without information (a sample with no reads at the locus: one all-gap row, every factor 1.0) gives every
   // genotype the same likelihood -- the same arithmetic on the same values --, which the chain already holds: no
@@ -1374,6 +1381,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
     if (promote && lslot[0] == tag) lslot[1] = (uint64_t)__double_as_longlong(val);
     lds_sync();
   }
+  miss = filt(miss, val);
   STAT_ADD(0, need);
   STAT_ADD(1, miss);
   STAT_ADD(2, true);
@@ -1545,6 +1553,8 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
   // window of fewer than four sub-steps would leave that pass partly empty; 17-32 reads: two)
   const int nrd_ = (int)S.nreads[gi];
   const int wmin = (MCHAP_SPEC_SBS != 0 && G == 64 && S.bpc != nullptr && (nrd_ <= 16 || (nrd_ > 32 && nrd_ <= 64))) ? 4 : MCHAP_SPEC_WIN_MIN;
+  // (wave-uniform where it matters: one chain per wave; groups of a shared wave all take the branch their wave takes)
+  const bool cut_on = amax == 2 && S.cache_on && !S.cut_off && wave_any(c.alive && c.gen > SPEC_LC_SECOND_LEVEL_GEN);
   int start = 0;
   int win = max(c.mwin, wmin);
   bool done = !run;
@@ -1576,6 +1586,7 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
       // are parked in the lane's LDS column so that the loop needs no unrolling
       const double ln_opt = S.ln[n_alleles - 1];
       double sum = 0.0;
+      bool dropped = false;  // this lane's proposal was neither found nor evaluated: it lies behind a sub-step known to move
 #pragma unroll 1
       for (int o = 0; o < amax - 1; o++) {  // wave-uniform trip count
         const bool prop = act && o < n_alleles - 1;
@@ -1583,7 +1594,30 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
         GWords<KT> pw = c.g;
         const uint64_t nw = (wh & ~((uint64_t)C_AMASK(c) << sh)) | ((uint64_t)i << sh);
         set_word<KT>(pw, h, nw);
-        const double llk_i = spec_eval<KT, G, LT>(prop, pw, c, S, mmax, rpad, lane);
+        // A chain with a history finds most of its proposals in its cache; the sub-steps whose proposal was found decide
+        // themselves at once, and a miss BEHIND the first of them that moves cannot matter to this round -- it is not
+        // evaluated (a chain that never settles evaluated four times what the sequential algorithm asks for: 18 per step at
+        // docs/example's locus015 against the oracle's 4.4, profiles/r04m_*).  Biallelic sub-steps only (one proposal decides);
+        // the look-ahead repeats the decision below operation for operation: stay = 1 - (0 + pr), the first cumulative value
+        // above u chooses, beyond the last the reference clamps to the last allele.
+        auto known_mover_cuts = [&](bool miss, double v) -> bool {
+          if (!cut_on) return miss;  // (wave-uniform)
+          bool mv = false;
+          if (prop && !miss) {
+            double lprior_ratio = 0.0;
+            if (!isnan(C_INB(S, gi))) lprior_ratio = prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(pw)) - lprior;
+            const double lproposal_ratio = S.ln[copies_of<KT>(pw, nw)] - lhapcount;
+            const double mh = ((v - c.llk) + lprior_ratio) * temp + lproposal_ratio;
+            const double pr = exp(fmin(0.0, mh) - ln_opt);
+            const double stay = 1.0 - (0.0 + pr);
+            mv = current == 0 ? !(0.0 + stay > u) : (0.0 + pr > u);
+          }
+          const uint64_t mm = grp_ballot<G>(mv, gi);
+          const bool keep = miss && (mm == 0ull || gl < __ffsll((long long)mm) - 1);
+          dropped = dropped || (miss && !keep);
+          return keep;
+        };
+        const double llk_i = spec_eval<KT, G, LT>(prop, pw, c, S, mmax, rpad, lane, known_mover_cuts);
         if (prop) {
           double lprior_ratio = 0.0;
           if (!isnan(C_INB(S, gi))) lprior_ratio = prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(pw)) - lprior;
@@ -1598,7 +1632,7 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
       bool changed = false;
       uint64_t neww = 0;
       double newllk = 0.0;
-      if (act) {
+      if (act && !dropped) {
         const double stay = 1.0 - sum;
         double cacc = 0.0;
         int choice = -1;
@@ -2244,6 +2278,7 @@ __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE
     S.gstream[gi * 4 + 3] = (uint32_t)U.stream_id;
   }
   S.reuse_on = !(P.flags & 8);
+  S.cut_off = (P.flags & 262144) != 0;
   S.lds_ct = nullptr;
   S.lds_cw = nullptr;
   S.crow = WAVE * P.cstride;

@@ -1092,7 +1092,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.max_ploidy = B.max_ploidy;
     SP.max_ma = B.max_ma;
     SP.cstride = code_stride(rpl);
-    SP.flags = T.flags & (63 | 128 | 2048 | 4096);  // (2048 / 4096: denovo_fillw_kernel without the cache probe / the LDS table)  // (256, 512: host only -- never the side-by-side instantiation / no deep-chunk product rows)
+    SP.flags = T.flags & (63 | 128 | 2048 | 4096 | 262144);  // (2048 / 4096: denovo_fillw_kernel without the cache probe / the LDS table)  // (256, 512: host only -- never the side-by-side instantiation / no deep-chunk product rows)
     // the prepare pass keeps the transposed table in LDS when it fits, else it re-reads its own global copy
     SP.max_ugens_pad = (B.max_ugens + 8) & ~7;
     const size_t lds_dict = (size_t)mchap::DICT_HASH * (8 + 2) + 64;  // hash set of the dictionary pass

@@ -10,6 +10,7 @@ from tests.helpers import beta_break_table
 
 pytestmark = pytest.mark.gpu
 
+EVALUATE_BEHIND_KNOWN_MOVERS = 262144  # (flag 262144: spec_mutation evaluates every miss of a round's window, as before)
 NO_CODED_TABLE = 4  # (flag 4: float64 rows from memory instead of the coded table -- and so no code table in LDS either)
 ONE_WAVE_COASTING = 131072
 
@@ -58,6 +59,29 @@ def test_moving_chains_of_shallow_units(monkeypatch, kernel, shape):
         g, l = _oracle(model, reads[u], None, u)
         assert np.array_equal(x.genotypes, sort_haplotypes(g)), "unit %d" % u
         np.testing.assert_allclose(x.llks, l, rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("kernel", [5, 3, 2])
+@pytest.mark.parametrize("shape", [(4, 8, 16, None), (4, 13, 24, 0.2), (4, 21, 45, None), (2, 10, 12, 0.0), (6, 7, 20, None)])
+def test_cutting_the_evaluations_behind_a_known_mover_is_results_neutral(monkeypatch, kernel, shape):
+    """A chain with a history (more than 48 genotype changes) does not evaluate the proposals of a round that lie behind a
+    sub-step whose cached proposal already says it moves (denovo_spec_kernel.hpp spec_mutation).  With the cut, without it
+    (flag 262144) and on the lanes-over-chains kernel, which has no such thing: identical traces and log likelihoods."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    K, M, R, F = shape
+    reads, _, _ = synth_units(6, ploidy=K, n_pos=M, n_reads=R, qual=(3, 20), window=(4, M) if M > 8 else (4, 8), first_unit=700)
+    kw = dict(ploidy=K, n_alleles=[2] * M, inbreeding=F, steps=500, chains=2, random_seed=11)
+    monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
+    monkeypatch.delenv("MCHAP_HIP_FLAGS", raising=False)
+    a = DenovoMCMC(**kw).fit_batch(list(reads))
+    monkeypatch.setenv("MCHAP_HIP_FLAGS", str(EVALUATE_BEHIND_KNOWN_MOVERS))
+    b = DenovoMCMC(**kw).fit_batch(list(reads))
+    assert sum(_moves(t) for t in a) > 6 * 2 * 100
+    for u, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x.genotypes, y.genotypes), "unit %d" % u
+        assert np.array_equal(x.llks, y.llks)
 
 
 def test_moving_chains_under_a_temperature_ladder_and_inbreeding(monkeypatch):
