@@ -1,5 +1,5 @@
 """GPU parity of denovo_fill_kernel (the phased sampler's table completion with ONE LANE PER REQUEST: an alternative engine
-kept in the parity suite's library) against the shipped completion inside the exporting launch (the code of a visit: structural.py:433-673 through
+kept in the parity suite's library, DESIGN.md Appendix A.1, former 4.1d) against the shipped completion inside the exporting launch (the code of a visit: structural.py:433-673 through
 denovo_spec_kernel's spec_structural, wave-wide likelihood evaluations).
 
 The tables hold the total move probability of every interval step of a settled chain's genotype; the coasting kernel
