@@ -679,6 +679,22 @@ def _assemble_record_line(locus, samples, per, posteriors, haplotype_posterior_t
 
 
 MAX_SNVS_PER_LOCUS = 126  # what mchap_denovo_fit_batch takes per unit (include/mchap_hip.h MCHAP_MAX_POS)
+MAX_ROWS_WIDE = 1024      # distinct read rows of a unit on the general sampler (128-bit haplotype words, ploidy above 8)
+
+
+def _lib_max_reads():
+    from ._lib import MAX_READS
+
+    return MAX_READS
+
+
+def _row_limit(n_snvs, max_allele, ploidy):
+    """Distinct read rows the library takes for a unit of this shape (include/mchap_hip.h): MCHAP_MAX_READS on the fast samplers,
+    1024 on the general one (more than 62 SNVs, more than 64 bits of sampled alleles per haplotype, or ploidy above 8)."""
+    from ._lib import MAX_READS
+
+    bits = 1 if max_allele <= 2 else (2 if max_allele <= 4 else 3)
+    return MAX_ROWS_WIDE if (n_snvs > 62 or n_snvs * bits > 64 or ploidy > 8) else MAX_READS
 
 
 def _variants_by_contig(variants):
@@ -799,6 +815,7 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
                 # warning instead of ending a run of many targets
                 skipped[li] = "%d SNVs (at most %d per target)" % (M, MAX_SNVS_PER_LOCUS)
                 continue
+            mine = []
             for sample in samples:
                 sr = source.reads(locus, sample)
                 encoded[(li, sample)] = sr
@@ -807,9 +824,16 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
                 dists, counts = sr["dists"], sr["counts"]
                 if len(dists) == 0:  # no reads: one all-gap read (assemble/mcmc.py:132-137)
                     dists, counts = np.full((1, M, int(max(locus.n_alleles))), np.nan), None
-                units.append(dict(reads=dists, counts=counts, n_alleles=locus.n_alleles, ploidy=int(ploidy_of(sample)),
-                                  inbreeding=inbreeding_of(sample), stream_id=0, temps=tuple(temps_of(sample))))
-                where.append((li, sample))
+                lim = _row_limit(M, int(max(locus.n_alleles)), int(ploidy_of(sample)))
+                if len(dists) > lim:  # (a deep target of a wide shape: its record says LIMIT, the other targets go on)
+                    skipped[li] = "sample %s: %d distinct read rows (at most %d for a target of this shape)" % (sample, len(dists), lim)
+                    break
+                mine.append((dict(reads=dists, counts=counts, n_alleles=locus.n_alleles, ploidy=int(ploidy_of(sample)),
+                                  inbreeding=inbreeding_of(sample), stream_id=0, temps=tuple(temps_of(sample))), (li, sample)))
+            if li not in skipped:
+                for u_, w_ in mine:
+                    units.append(u_)
+                    where.append(w_)
         t1_ = _time.perf_counter()
         timings["encode_s"] += t1_ - t0_
         timings["units"] += len(units)
@@ -1018,6 +1042,17 @@ class _BlockState:
         bits = np.where(amax <= 2, 1, np.where(amax <= 4, 2, 3))
         wide = (M > 62) | (M * bits > 64)
         sampled = M > 0
+        # a unit with more distinct read rows than the library takes for its shape: the target's record says LIMIT (the batch
+        # constructor would refuse the whole launch -- and with it every other target of the block)
+        li_of = {xi: li for li, xi in self.xi_of.items()}
+        for si, sample in enumerate(samples):
+            nu = self.enc[si].urow_start[1:] - self.enc[si].urow_start[:-1]
+            K_ = int(run["ploidy_of"](sample))
+            lim = np.where(wide | (K_ > 8), MAX_ROWS_WIDE, _lib_max_reads())
+            for xi in np.flatnonzero(sampled & (nu > lim)):
+                self.skipped.setdefault(li_of[int(xi)], "sample %s: %d distinct read rows (at most %d for a target of this shape)" % (
+                    sample, int(nu[xi]), int(lim[xi])))
+                sampled[xi] = False
         self.batches = []   # (batch, samples [n], loci [m], unit arrays): unit = position of the sample * m + position of the locus
         self.unit_at = np.full((len(samples), len(lx), 2), -1, dtype=np.int64)  # (batch, unit) of every (sample, locus)
         groups = {}

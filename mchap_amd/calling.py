@@ -130,23 +130,21 @@ def genotypes_in_vcf_order(n, ploidy):
 
 
 def alternate_dosage_posteriors(genotype_alleles, probabilities):
-    """Posterior of every dosage variant of the genotype's support, in VCF order."""
-    genotype_alleles = np.asarray(genotype_alleles)
-    ploidy = len(genotype_alleles)
-    support = np.unique(genotype_alleles)
-    n_alleles = len(support)
-    remainder = ploidy - n_alleles
-    options = list(combinations_with_replacement(support, remainder))
-    genotypes = np.zeros((len(options), ploidy), int)
-    indices = np.zeros(len(options), int)
-    probs = np.zeros(len(options), float)
-    for i, opt in enumerate(options):
-        array = np.sort(np.concatenate([support, np.array(opt, dtype=support.dtype)]))
-        genotypes[i] = array
-        indices[i] = genotype_alleles_as_index(array)
-        probs[i] = probabilities[indices[i]]
-    idx = np.argsort(indices)
-    return genotypes[idx], probs[idx]
+    """Posterior of every dosage variant of the genotype's support (calling/exact.py:363-407): the genotypes that hold each allele
+    of the support at least once, in VCF order, with their entries of `probabilities`.  A variant is the support plus a multiset of
+    `ploidy - len(support)` extra copies; all of them are formed as one array (multisets as rows of indices into the support), their
+    VCF indices by the combinatorial number system over the sorted rows, and the rows ordered by index."""
+    support = np.unique(np.asarray(genotype_alleles))
+    ploidy, extra = len(genotype_alleles), len(genotype_alleles) - len(support)
+    combos = list(combinations_with_replacement(range(len(support)), extra))  # (extra == 0: the one empty multiset)
+    picks = np.array(combos, dtype=np.int64).reshape(len(combos), extra)
+    rows = np.sort(np.concatenate([np.broadcast_to(support, (len(picks), len(support))), support[picks]], axis=1), axis=1).astype(np.int64)
+    # index of a sorted row a_1 <= ... <= a_K in VCF order: sum_k C(a_k + k - 1, k)
+    index = np.zeros(len(rows), dtype=np.int64)
+    for k in range(1, ploidy + 1):
+        index += np.array([comb(int(a) + k - 1, k) for a in rows[:, k - 1]], dtype=np.int64)
+    order = np.argsort(index, kind="stable")
+    return rows[order], np.asarray(probabilities, dtype=float)[index[order]]
 
 
 def posterior_mode_batch(reads, ploidy, haplotypes, read_counts=None, prior=None, return_support_prob=False,

@@ -76,6 +76,8 @@ struct SimtParams {
   int word_bits;              // bits of a packed haplotype word of this launch's sampler: 0 / 64, or 128 (denovo_simt_kernel<0, u128>)
   uint64_t cache_epoch;       // speculative / phased sampler: this call's epoch << 33, OR-ed into every likelihood-cache tag (0: the
                               // caches were cleared for this call instead): entries of earlier calls never match, nothing is cleared
+  uint64_t *ctx;              // phased sampler, resumed chains: [U * chains][ctx_n][spec_ctx_words] decision contexts per genotype
+  int ctx_n;                  // (denovo_spec_kernel.hpp "decision contexts"), or null / 0
 };
 constexpr int PIPE_RESUME = 1;  // start from the chains' PipeState records
 constexpr int PIPE_EXPORT = 2;  // at the end: complete the interval memo of the current genotype, write the records
@@ -724,7 +726,7 @@ __device__ __forceinline__ uint64_t lane_genotype_tag(const SimtLdsT<W> &S, cons
 }
 
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
-constexpr int N_STATS = 48;  // [0..23] event counters, [24..35] phase timers of the steps, [36..47] ... of the table completion
+constexpr int N_STATS = 64;  // [0..23] event counters, [24..35] phase timers of the steps, [36..47] ... of the table completion, [48..55] sub-timers of the steps
 static __device__ unsigned long long g_stats[N_STATS];
 #endif
 #ifdef MCHAP_STATS

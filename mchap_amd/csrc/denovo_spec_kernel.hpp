@@ -165,6 +165,16 @@ struct SpecLds {
   LDSP(double) bdist;        // [NG][Mmax] the chain's cumulative break-count distribution
   int memo_stride;           // 2 * spec_memo_entries(Mmax), or 0 when the tables do not fit
   int ndraws;                // staged draws per group
+  // Decision contexts per genotype (CTX instantiations, one chain per wave; see "decision contexts" below): ONE pointer to their
+  // LDS area -- [SPEC_CTX_MAX] uint64 directory (tag of the genotype whose context sits in slot i of the chain's region; 0: empty),
+  // [SPEC_CTX_MAX] uint32 last use of slot i (the least recently used slot is replaced), [CX_N] uint32 the chain's context state
+  // (below), [K Mmax] float64 the CURRENT genotype's move probabilities by sub-step e = h Mh + j (-1: not known yet), [K Mmax]
+  // float64 the likelihoods of the genotypes those moves lead to -- read through the CXP_* accessors (more pointers here would
+  // be more registers held through the whole kernel)
+  LDSP(unsigned char) cx_lds;   // directory, last uses, state
+  LDSP(double) cx_val;          // move probabilities, then likelihoods
+  uint64_t *cx_base = nullptr;  // the chain's region of the workspace (SimtParams::ctx), or null: no contexts in this launch
+  int cx_n = 0;                 // slots in use
 };
 
 // interval-step memo (see spec_structural): only for a single temperature and while it stays small
@@ -182,7 +192,16 @@ constexpr int SPEC_LC_ENTRIES = 256;  // entries of the LDS front cache of a cha
 #define MCHAP_LC_GEN 48
 #endif
 constexpr uint32_t SPEC_LC_SECOND_LEVEL_GEN = MCHAP_LC_GEN;  // genotype changes after which a front-cache miss also probes the workspace table
-__host__ __device__ inline size_t spec_lc_bytes() { return (size_t)16 * SPEC_LC_ENTRIES + 16; }
+__host__ __device__ inline size_t spec_lc_bytes(int entries = SPEC_LC_ENTRIES) { return (size_t)16 * entries + 16; }
+// SimtParams::bp_cache: bit 0 the base-product cache, bit 1 the front cache, bit 2 ... with half the entries (the launches with
+// decision contexts where the full table would cost a resident wavefront per CU)
+// ... bit 3: every unit of the batch has at most 64 reads and a small table, so the product cache's chunk slots 1..3 of its last two
+// haplotypes are free (sct_off: a one-chunk unit's code table starts at haplotype 0's) -- the decision contexts' LDS goes there
+// instead of behind the front cache: their directory into haplotype K - 1's slots, their values into haplotype K - 2's
+__host__ __device__ inline bool spec_ctx_in_bpc(int K, int Mmax, int Amax, int max_reads) {
+  return K >= 3 && max_reads <= 64 && Mmax * Amax <= 24 * (K - 2) && 16 * K * Mmax <= 3 * 64 * 8 && 12 * 64 + 4 * 8 <= 3 * 64 * 8;
+}
+__host__ __device__ inline int spec_lc_entries(int bp_cache) { return (bp_cache & 2) ? ((bp_cache & 4) ? SPEC_LC_ENTRIES / 2 : SPEC_LC_ENTRIES) : 0; }
 // Where row `row` of a one-chunk unit's code table sits behind SpecLds::sct: the product cache is [K][4 chunks][64] float64 and a
 // one-chunk unit only uses chunk 0 of every haplotype, so the chunks 1..3 of haplotype h hold the rows 24 h .. 24 h + 23 (64
 // codes each) -- 24 K rows in all (round 4, late: haplotype 0's slots alone held 24 rows, i.e. 12 biallelic SNVs; docs/example's
@@ -433,7 +452,7 @@ struct Grp {
   int fill_part, fill_parts;  // PIPE_FILLONLY: this group completes the unknown entries e with e % fill_parts == fill_part
   uint32_t gen, memo_gen;  // memo_gen: the generation the interval memo table currently describes
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
-  unsigned long long ph[12], pt0;
+  unsigned long long ph[20], pt0;
 #endif
 };
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
@@ -446,7 +465,11 @@ struct Grp {
 #define GSUB_T0() const unsigned long long gsub_t0_ = __builtin_amdgcn_s_memtime()
 #define GSUB(c, i) const_cast<unsigned long long &>((c).ph[i]) += __builtin_amdgcn_s_memtime() - gsub_t0_
 #define GCOUNT(c, i, n) const_cast<unsigned long long &>((c).ph[i]) += (n)
+#define GT0(name) const unsigned long long name = __builtin_amdgcn_s_memtime()
+#define GT1(c, i, name) const_cast<unsigned long long &>((c).ph[i]) += __builtin_amdgcn_s_memtime() - (name)
 #else
+#define GT0(name)
+#define GT1(c, i, name)
 #define GPHASE(c, i)
 #define GSUB_T0()
 #define GSUB(c, i)
@@ -471,6 +494,141 @@ template <int KT>
 __device__ __forceinline__ void genotype_changed(Grp<KT> &c) {
   c.mvalid = false;
   c.gen += 1;  // the interval memo of the group is wiped by memo_wipe() before it is read again
+}
+
+// ---- decision contexts per genotype (round 5) ----
+// A chain that never settles (phase-ambiguous samples, shallow pileups) keeps coming back to genotypes it has held before: at
+// docs/example's slowest units 98 % of the accepted moves lead to one of the last 64 ORDERED genotypes, at the shallow synthetic
+// units (40 reads of quality 3-20) 95 % to one of the last 32 (tests/analyze_moves.py: the oracle's sub-step log).  Everything a
+// sub-step decides with is a pure function of the ordered genotype g it starts from (mutation.py:60-161): for sub-step e = (h, j)
+// the move probability pr(g, e) and the likelihood of the genotype the move leads to; for an interval step (structural.py:490-587)
+// the total move probability tot(g, type, start, stop).  Without contexts every accepted move starts a new speculation round --
+// proposals, cache probes, the evaluations of the misses -- only to re-derive these numbers, and wipes the interval memo.
+// With them (CTX instantiations: the resumed chains of the phased sampler, one chain per wavefront, biallelic units) the chain
+// keeps up to SPEC_CTX_MAX contexts in its region of the workspace -- slot = {K words, pr[K M], llk[K M], tot[2][M (M + 1) / 2]} --
+// and the current genotype's in LDS (CXP_PR / CXP_LLK, memo_tot).  A move into a genotype with a context is a context switch: one
+// directory look-up (the tags of the slots, one per lane, a ballot) and one round trip that loads pr / llk; the round after it is
+// a ballot over stored numbers.  What is not known yet (-1 / NaN) is evaluated as before and written through.  Results-neutral
+// by the argument of the likelihood cache: a stored value is what this arithmetic computed for that ordered genotype (tuning
+// flag 524288 switches the contexts off: same traces -- tests/test_gpu_moving_chains.py).
+constexpr int SPEC_CTX_MAX = 64;   // contexts per chain (one directory entry per lane)
+constexpr int SPEC_CTX_HDR = 8;    // 8-byte words at the head of a slot: the genotype's haplotype words (K <= 8)
+#ifndef MCHAP_CTX_GEN
+#define MCHAP_CTX_GEN 24           // genotype changes (in this launch) after which a chain keeps contexts
+#endif
+// the chain's context state (cold, kept out of the registers): [CX_CUR] the slot whose context the LDS holds (+ 1; 0: none),
+// [CX_GEN] the generation it was looked up for, [CX_CLOCK] the LRU clock, and the chain's trial -- [CX_HITS] contexts found among
+// the [CX_LOOKS] look-ups of the current window, [CX_PAUSE] the generation until which the chain does without contexts (a chain
+// that wanders -- shallow units visit thousands of genotypes once -- pays for look-ups that miss)
+enum { CX_CUR = 0, CX_GEN, CX_CLOCK, CX_HITS, CX_LOOKS, CX_PAUSE, CX_FAILS, CX_N = 8 };
+#define CXP_TAG(S) ((LDSP(uint64_t))(S).cx_lds)
+#define CXP_STAMP(S) ((LDSP(uint32_t))((S).cx_lds + 8 * SPEC_CTX_MAX))
+#define CXP_ST(S) ((LDSP(uint32_t))((S).cx_lds + 12 * SPEC_CTX_MAX))
+#define CXP_PR(S) ((S).cx_val)
+#define CXP_LLK(S, nmax) (CXP_PR(S) + (nmax))
+constexpr uint32_t SPEC_CTX_TRIAL = 64;     // look-ups per trial window
+constexpr uint32_t SPEC_CTX_MIN_HITS = 24;  // ... of which at least this many must find their context, or the chain pauses
+constexpr uint32_t SPEC_CTX_PAUSE = 2048;   // ... for this many genotype changes
+__host__ __device__ inline int spec_ctx_words(int K, int Mmax) { return SPEC_CTX_HDR + 2 * K * Mmax + 2 * spec_memo_entries(Mmax); }
+__host__ __device__ inline size_t spec_ctx_lds_bytes(int K, int Mmax) { return (size_t)SPEC_CTX_MAX * 12 + (size_t)16 * K * Mmax + 4 * CX_N + 16; }
+// The contexts are written and read by different lanes of the same wavefront at different times: both sides go to the L2
+// (agent scope), and an lds_sync() -- which waits for the wave's outstanding stores -- separates a context's writes from its loads.
+__device__ __forceinline__ uint64_t ctx_ld(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ctx_st(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ctx_st(uint64_t *p, double v) { ctx_st(p, (uint64_t)__double_as_longlong(v)); }
+
+// Make the context in LDS (CXP_PR / CXP_LLK) describe the chain's current genotype (every lane of the wave calls; one chain per wave).
+// Returns true if the context is new (nothing known: the caller's interval memo starts empty as well).
+template <int KT>
+__device__ __forceinline__ bool ctx_acquire(Grp<KT> &c, const SpecLds &S, int n, int mmax, int lane) {
+  const int cx_nmax = KT * mmax, cx_words = spec_ctx_words(KT, mmax);
+  if (CXP_ST(S)[CX_GEN] == c.gen && CXP_ST(S)[CX_CUR] != 0u) return false;
+  STAT_WAVE(3, 1);
+  GT0(t_acq);
+  lds_sync();  // (the wave's write-through stores have reached the L2; nobody reads the context in LDS any more)
+  const GWords<KT> g = c.g;
+  const bool wide = C_KEYBITS(c) * KT > 63;
+  const uint64_t tag = tag_of<KT>(g, C_KEYBITS(c));
+  const uint64_t mine = lane < S.cx_n ? CXP_TAG(S)[lane] : 0ull;
+  const uint32_t stamp = lane < S.cx_n ? CXP_STAMP(S)[lane] : 0xFFFFFFFFu;
+  unsigned long long hit = __ballot(mine == tag);
+  int slot = hit ? __ffsll((long long)hit) - 1 : -1;
+  bool fresh = false;
+  uint64_t *sp = nullptr;
+  if (slot >= 0) {
+    sp = S.cx_base + (size_t)slot * cx_words;
+    uint64_t vp[3], vl[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {  // (n <= 192)
+      const int e = lane + WAVE * t;
+      vp[t] = e < n ? ctx_ld(sp + SPEC_CTX_HDR + e) : 0ull;
+      vl[t] = e < n ? ctx_ld(sp + SPEC_CTX_HDR + cx_nmax + e) : 0ull;
+    }
+    bool same = true;
+    if (wide) {  // the tag is a hash: the slot's words decide
+      const uint64_t w = lane < KT ? ctx_ld(sp + lane) : 0ull;
+      same = __ballot(lane < KT && w != sel_word<KT>(g, lane)) == 0ull;
+    }
+    if (same) {
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int e = lane + WAVE * t;
+        if (e < n) {
+          CXP_PR(S)[e] = __longlong_as_double((long long)vp[t]);
+          CXP_LLK(S, cx_nmax)[e] = __longlong_as_double((long long)vl[t]);
+        }
+      }
+    } else {
+      fresh = true;  // another genotype with this tag: its slot is taken over
+    }
+  } else {
+    // least recently used slot (an empty one first: stamp 0); ties go to the lowest lane
+    uint32_t key = stamp, best = stamp;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, WAVE));
+    const unsigned long long who = __ballot(key == best && lane < S.cx_n);
+    slot = __ffsll((long long)who) - 1;
+    sp = S.cx_base + (size_t)slot * cx_words;
+    fresh = true;
+  }
+  const uint32_t clock = CXP_ST(S)[CX_CLOCK] + 1u;
+  uint32_t looks = CXP_ST(S)[CX_LOOKS] + 1u, hits = CXP_ST(S)[CX_HITS] + (fresh ? 0u : 1u), pause = CXP_ST(S)[CX_PAUSE];
+  uint32_t fails = CXP_ST(S)[CX_FAILS];
+  if (looks >= SPEC_CTX_TRIAL) {  // (the slots stay as they are: a context never goes stale)
+    if (hits < SPEC_CTX_MIN_HITS) {  // each failed trial doubles the pause
+      pause = c.gen + (SPEC_CTX_PAUSE << (fails < 12u ? fails : 12u));
+      fails += 1u;
+    }
+    looks = 0;
+    hits = 0;
+  }
+  if (lane == slot) {
+    CXP_TAG(S)[lane] = tag;
+    CXP_STAMP(S)[lane] = clock;
+  }
+  if (fresh) {
+    if (lane < KT) ctx_st(sp + lane, sel_word<KT>(g, lane));
+    for (int e = lane; e < n; e += WAVE) {
+      ctx_st(sp + SPEC_CTX_HDR + e, -1.0);
+      CXP_PR(S)[e] = -1.0;
+    }
+    const int ms = cx_words - SPEC_CTX_HDR - 2 * cx_nmax;
+    for (int i = lane; i < ms; i += WAVE) ctx_st(sp + SPEC_CTX_HDR + 2 * cx_nmax + i, (double)NAN);
+  }
+  lds_sync();  // (every lane has read the state)
+  if (lane == 0) {
+    CXP_ST(S)[CX_CUR] = (uint32_t)slot + 1u;
+    CXP_ST(S)[CX_GEN] = c.gen;
+    CXP_ST(S)[CX_CLOCK] = clock;
+    CXP_ST(S)[CX_LOOKS] = looks;
+    CXP_ST(S)[CX_HITS] = hits;
+    CXP_ST(S)[CX_PAUSE] = pause;
+    CXP_ST(S)[CX_FAILS] = fails;
+  }
+  lds_sync();
+  STAT_WAVE(4, fresh ? 1 : 0);
+  GT1(c, 13, t_acq);
+  return fresh;
 }
 
 template <int KT, int RPL>
@@ -1441,7 +1599,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
 #define MCHAP_SPEC_WPE 2
 #endif
 
-template <int KT, int G, bool LT = false>
+template <int KT, int G, bool LT = false, bool CTX = false>
 __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, double temp, int amax, int mmax, int nmax, int rpad,
                                               int lane, int gi, int gl) {
   const int Mh = c.Mh;
@@ -1483,6 +1641,7 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
   if (!wave_any(run)) return;
   STAT_WAVE(9, 1);
   STAT_ADD(10, run && gl == 0);
+  GT0(t_mut0);
   LDSP(uint8_t) ktab = S.ktab + gi * nmax;
   LDSP(uint16_t) permtab = S.permtab + gi * nmax;
   LDSP(uint8_t) shift = S.shift + gi * mmax;
@@ -1498,21 +1657,40 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
   const bool staged = 2 * n - 1 <= S.ndraws;
   stage_draws<G>(ld_stream(S, gi), ctr0, 2 * n - 1, dtab, gl, run && staged);
   lds_sync();
+  int kv[NS];  // k_p of the lane's positions p = gl + s G
+#pragma unroll
+  for (int s = 0; s < NS; s++) kv[s] = 0;
   if (run) {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       const int p = gl + s * G;
-      if (p >= 1 && p < n)
-        ktab[p] = (uint8_t)(staged ? draw_interval(dtab[n - 1 - p], (uint32_t)p)
-                                   : stream_interval(ld_stream(S, gi), ctr0 + (uint64_t)(n - 1 - p), (uint32_t)p));
+      if (p >= 1 && p < n) {
+        kv[s] = (int)(staged ? draw_interval(dtab[n - 1 - p], (uint32_t)p)
+                             : stream_interval(ld_stream(S, gi), ctr0 + (uint64_t)(n - 1 - p), (uint32_t)p));
+        if constexpr (G != 64) ktab[p] = (uint8_t)kv[s];
+      }
     }
   }
-  lds_sync();
+  if constexpr (G != 64) lds_sync();
   // (2) every lane traces the element that starts at its position through the transpositions
   int xs[NS];
 #pragma unroll
   for (int s = 0; s < NS; s++) xs[s] = gl + s * G;
-  {
+  if constexpr (G == 64) {
+    // one chain per wave: k_i sits in lane i % 64 of kv[i / 64] and i is wave-uniform -- a v_readlane per transposition
+    // instead of a dependent LDS read (the loop was 9 000 of the 11 000 cycles a slow-path step spends before its first
+    // round at 32 sub-steps: profiles/r05d_phases_moving.txt)
+    const int nl = __builtin_amdgcn_readfirstlane(run ? n : 0);
+#pragma unroll
+    for (int s2 = NS - 1; s2 >= 0; s2--) {
+      const int hi = min(nl - 1, s2 * 64 + 63), lo = max(1, s2 * 64);
+      for (int i = hi; i >= lo; i--) {
+        const int ki = __builtin_amdgcn_readlane(kv[s2], i & 63);
+#pragma unroll
+        for (int s = 0; s < NS; s++) xs[s] = (xs[s] == i) ? ki : ((xs[s] == ki) ? i : xs[s]);
+      }
+    }
+  } else {
     const int nloop = run ? n : 0;
     int nl = nloop;
 #pragma unroll
@@ -1554,27 +1732,107 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
   const int nrd_ = (int)S.nreads[gi];
   const int wmin = (MCHAP_SPEC_SBS != 0 && G == 64 && S.bpc != nullptr && (nrd_ <= 16 || (nrd_ > 32 && nrd_ <= 64))) ? 4 : MCHAP_SPEC_WIN_MIN;
   // (wave-uniform where it matters: one chain per wave; groups of a shared wave all take the branch their wave takes)
-  const bool cut_on = amax == 2 && S.cache_on && !S.cut_off && wave_any(c.alive && c.gen > SPEC_LC_SECOND_LEVEL_GEN);
+  // decision contexts (CTX: one chain per wave, so everything here is wave-uniform): the sub-steps whose move probability the
+  // current genotype's context holds decide themselves from it -- no proposal, no probe, no evaluation
+  bool cx = false;
+  if constexpr (CTX && G == 64) cx = S.cx_base != nullptr && amax == 2 && run && c.gen > (uint32_t)MCHAP_CTX_GEN && c.gen >= CXP_ST(S)[CX_PAUSE];
+  const bool cut_on = amax == 2 && !S.cut_off && ((S.cache_on && wave_any(c.alive && c.gen > SPEC_LC_SECOND_LEVEL_GEN)) || cx);
   int start = 0;
   int win = max(c.mwin, wmin);
   bool done = !run;
   bool any_move = false;
   double my_lo = 0.0, my_hi = 2.0;  // this lane's sub-steps: max lo_e, min hi_e
+  GT1(c, 12, t_mut0);
   while (wave_any(!done)) {
     STAT_WAVE(11, 1);
-    const double lprior = (!done && !isnan(C_INB(S, gi))) ? prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(c.g)) : 0.0;
+    if constexpr (CTX) STAT_WAVE(7, cx ? 1 : 0);
     bool found = false;
-    const int wstop = min(n, start + win);
+    int wstop = min(n, start + win);
+    if constexpr (CTX && G == 64) {
+      if (cx && !done) {
+        // Known pass.  The sub-steps whose move probability the current genotype's context holds decide themselves: no proposal,
+        // no option table, no exp().  The decisions are those of the general pass below for two alleles: with stay =
+        // 1 - (0 + pr), a sub-step at allele 0 moves iff !(0 + stay > u), one at allele 1 iff 0 + pr > u.  fk: the first of
+        // them that moves; fu: the first sub-step that is not in the context.
+        ctx_acquire<KT>(c, S, n, mmax, lane);
+        int fk = n, fu = n, m_h = 0;
+        uint32_t m_w0 = 0, m_w1 = 0, m_l0 = 0, m_l1 = 0;
+#pragma unroll 1
+        for (int s = 0; s < nslots; s++) {
+          const int p = gl + s * G;
+          const bool in = p >= start && p < n;
+          bool known = false, mv = false;
+          int h = 0, sh = 0, current = 0;
+          uint64_t wh = 0;
+          double kllk = 0.0;
+          if (in) {
+            const int e = permtab[p];
+            h = e >> 8;
+            const int j = e & 255;
+            const int ei = h * Mh + j;
+            const double kpr = CXP_PR(S)[ei];
+            known = kpr >= 0.0;
+            if (known) {
+              kllk = CXP_LLK(S, nmax)[ei];
+              sh = shift[j];
+              const double u = staged ? draw_double(dtab[n - 1 + p]) : stream_double(ld_stream(S, gi), ctr0 + (uint64_t)(n - 1) + (uint64_t)p);
+              wh = sel_word<KT>(c.g, h);
+              current = (int)((wh >> sh) & C_AMASK(c));
+              const double stay = 1.0 - (0.0 + kpr);
+              const double below = current == 0 ? 0.0 : 0.0 + kpr;  // cumulative probability below the current allele
+              my_lo = fmax(my_lo, below);
+              my_hi = fmin(my_hi, below + stay);
+              mv = current == 0 ? !(0.0 + stay > u) : (0.0 + kpr > u);
+            }
+          }
+          const unsigned long long km = __ballot(known), mm = __ballot(mv), um = __ballot(in && !known);
+          STAT_WAVE(5, __popcll(km));
+          STAT_WAVE(6, __popcll(um));
+          if (mm && fk == n) {
+            const int fl = __ffsll((long long)mm) - 1;
+            fk = fl + s * G;
+            const uint64_t nw_ = (wh & ~((uint64_t)C_AMASK(c) << sh)) | ((uint64_t)(1 - current) << sh);
+            const long long lb = __double_as_longlong(kllk);
+            m_h = __builtin_amdgcn_readlane(h, fl);
+            m_w0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nw_, fl);
+            m_w1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(nw_ >> 32), fl);
+            m_l0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lb, fl);
+            m_l1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)lb >> 32), fl);
+          }
+          if (um && fu == n) fu = __ffsll((long long)um) - 1 + s * G;
+        }
+        if (fk < fu || fu >= n) {  // nothing unknown stands before the first known mover (or before the end of the step)
+          if (fk < n) {
+            set_word<KT>(c.g, m_h, (uint64_t)m_w0 | ((uint64_t)m_w1 << 32));
+            c.llk = __longlong_as_double((long long)((uint64_t)m_l0 | ((uint64_t)m_l1 << 32)));
+            genotype_changed<KT>(c);
+            any_move = true;
+            start = fk + 1;
+          } else {
+            start = n;
+          }
+          if (start >= n) done = true;
+          continue;
+        }
+        // the general pass takes the unknown sub-steps of a window that counts from the first of them and ends at the first
+        // known mover (the next round's known pass applies that one if nothing before it moves)
+        wstop = min(fk, fu + win);
+      }
+    }
+    const double lprior = (!done && !isnan(C_INB(S, gi))) ? prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(c.g)) : 0.0;
 #pragma unroll 1
     for (int s = 0; s < nslots; s++) {
       const int p = gl + s * G;
-      const bool act = !done && !found && p >= start && p < wstop;
+      bool act = !done && !found && p >= start && p < wstop;
       int h = 0, sh = 0, n_alleles = 2;
       double u = 2.0;
       if (act) {
         const int e = permtab[p];
         h = e >> 8;
         const int j = e & 255;
+        if constexpr (CTX && G == 64) {
+          if (cx && CXP_PR(S)[h * Mh + j] >= 0.0) act = false;  // (the known pass took it)
+        }
         sh = shift[j];
         n_alleles = nal[j];
         u = staged ? draw_double(dtab[n - 1 + p]) : stream_double(ld_stream(S, gi), ctr0 + (uint64_t)(n - 1) + (uint64_t)p);
@@ -1617,13 +1875,26 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
           dropped = dropped || (miss && !keep);
           return keep;
         };
+        GT0(t_ev);
         const double llk_i = spec_eval<KT, G, LT>(prop, pw, c, S, mmax, rpad, lane, known_mover_cuts);
+        GT1(c, 16, t_ev);
         if (prop) {
           double lprior_ratio = 0.0;
           if (!isnan(C_INB(S, gi))) lprior_ratio = prior_of<KT>(pt, C_INB(S, gi), dosage_words<KT>(pw)) - lprior;
           const double lproposal_ratio = S.ln[copies_of<KT>(pw, nw)] - lhapcount;
           const double mh = ((llk_i - c.llk) + lprior_ratio) * temp + lproposal_ratio;
           const double pr = exp(fmin(0.0, mh) - ln_opt);
+          if constexpr (CTX && G == 64) {
+            if (cx && !dropped) {  // into the current genotype's context: LDS, and written through to its slot
+              const int e_ = permtab[p];
+              const int ei = (e_ >> 8) * Mh + (e_ & 255);
+              CXP_PR(S)[ei] = pr;
+              CXP_LLK(S, nmax)[ei] = llk_i;
+              uint64_t *sp = S.cx_base + (size_t)(CXP_ST(S)[CX_CUR] - 1u) * spec_ctx_words(KT, mmax) + SPEC_CTX_HDR;
+              ctx_st(sp + ei, pr);
+              ctx_st(sp + nmax + ei, llk_i);
+            }
+          }
           S.optp[o * WAVE + lane] = pr;
           S.optl[o * WAVE + lane] = llk_i;
           sum += pr;
@@ -1713,10 +1984,10 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
 // With PIPE, kind 3 / 4 is not a step: it completes the interval memo of step type 0 / 1 for the current genotype --
 // every (start, stop) still unknown is evaluated by the same code (and so to the same totals) as a visit would, but
 // without draws or decisions (phased sampler: the coasting kernel then decides every interval step from the table).
-template <int KT, int G, bool PIPE = false>
+template <int KT, int G, bool PIPE = false, bool CTX = false>
 __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, const DenovoParams &D, int kind, double temp,
                                                 const double *break_dist, int n_break_dist, int mmax, int rpad, int lane,
-                                                int gi, int gl) {
+                                                int gi, int gl, int amax = 0) {
   const int Mh = c.Mh;
   const bool fill = PIPE && kind >= 3;  // wave-uniform
   const int step_type = (kind == 0 || kind == 3) ? 0 : 1;
@@ -1803,14 +2074,41 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
   // total.  The table describes genotype generation memo_gen and is wiped when the genotype has changed.
   LDSP(double) mtot = S.memo_tot + gi * S.memo_stride + step_type * spec_memo_entries(mmax);
   const bool memo = PIPE || S.memo_stride != 0;  // (the phased form is only launched with the tables in place)
+  // (CTX: one chain per wave) a chain with contexts takes the table of a genotype it has held before from that genotype's slot
+  bool cx = false;
+  if constexpr (CTX && G == 64) cx = S.cx_base != nullptr && amax == 2 && c.alive && c.gen > (uint32_t)MCHAP_CTX_GEN && c.gen >= CXP_ST(S)[CX_PAUSE];
   if (memo && wave_any(c.alive && c.gen != c.memo_gen)) {
-    if (c.alive && c.gen != c.memo_gen) {
+    bool loaded = false;
+    if constexpr (CTX && G == 64) {
+      if (cx && !ctx_acquire<KT>(c, S, KT * Mh, mmax, lane)) {
+        const uint64_t *tp = S.cx_base + (size_t)(CXP_ST(S)[CX_CUR] - 1u) * spec_ctx_words(KT, mmax) + SPEC_CTX_HDR + 2 * KT * mmax;
+        LDSP(double) all = S.memo_tot + gi * S.memo_stride;
+        for (int i0 = 0; i0 < S.memo_stride; i0 += 4 * WAVE) {
+          uint64_t v[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) v[t] = i0 + t * WAVE + lane < S.memo_stride ? ctx_ld(tp + i0 + t * WAVE + lane) : 0ull;
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            if (i0 + t * WAVE + lane < S.memo_stride) all[i0 + t * WAVE + lane] = __longlong_as_double((long long)v[t]);
+        }
+        c.memo_gen = c.gen;
+        loaded = true;
+      }
+    }
+    if (!loaded && c.alive && c.gen != c.memo_gen) {
       LDSP(double) all = S.memo_tot + gi * S.memo_stride;
       for (int i = gl; i < S.memo_stride; i += G) all[i] = NAN;
       c.memo_gen = c.gen;
     }
     lds_sync();
   }
+  // (CTX) where a total of the current genotype goes besides the table in LDS
+  auto ctx_tot = [&](int idx, double v) {
+    if constexpr (CTX && G == 64) {
+      if (cx && CXP_ST(S)[CX_GEN] == c.gen && CXP_ST(S)[CX_CUR] != 0u)
+        ctx_st(S.cx_base + (size_t)(CXP_ST(S)[CX_CUR] - 1u) * spec_ctx_words(KT, mmax) + SPEC_CTX_HDR + 2 * KT * mmax + step_type * spec_memo_entries(mmax) + idx, v);
+    }
+  };
   GPHASE(c, 4);
   bool done = !doit;
   // Single-interval steps (the whole-haplotype dosage step, or no break drawn): one memo entry and at most one
@@ -2040,7 +2338,9 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
 #pragma unroll
       for (int h = 0; h < KT; h++) pw.w[h] = (cg.w[h] & ~min_) | (sel_word<KT>(cg, (int)nib(oin, h)) & min_);
     }
+    GT0(t_ev);
     const double llk_i = spec_eval<KT, G>(prop, pw, c, S, mmax, rpad, lane);
+    GT1(c, 17, t_ev);
     if (prop) {
       double lprior_ratio = 0.0;
       if (!isnan(C_INB(S, gi)))
@@ -2064,6 +2364,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
         if (gl == 0) {
           const uint32_t se = ivse[ii];
           mtot[spec_memo_index((int)(se & 255u), (int)(se >> 8))] = no > 0 ? cacc : -1.0;
+          ctx_tot(spec_memo_index((int)(se & 255u), (int)(se >> 8)), no > 0 ? cacc : -1.0);
         }
         off += no;
       }
@@ -2094,6 +2395,7 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
           const uint32_t se = ivse[ii];
           const int idx = spec_memo_index((int)(se & 255u), (int)(se >> 8));
           mtot[idx] = no > 0 ? cacc : -1.0;
+          ctx_tot(idx, no > 0 ? cacc : -1.0);
         }
         off += no;
       }
@@ -2135,7 +2437,9 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
 constexpr int SPEC_TW_MAX = 8;  // replicas a workgroup takes (longer ladders run on one wavefront)
 __host__ __device__ inline size_t spec_tw_exchange_bytes(int K, int T) { return (((size_t)8 * T * (K + 1) + 16) + 63) & ~(size_t)63; }
 
-template <int KT, int G, bool PIPE = false, int VAR = MCHAP_SPEC_VAR, bool TW = false>  // (VAR only names the object: the code is selected by the macro)
+// CTX (round 5, PIPE with G = 64): the chain keeps decision contexts per genotype in SimtParams::ctx (see "decision contexts" above);
+// its own instantiation, so that the launches without contexts -- the first phase of every chain -- keep their code and registers.
+template <int KT, int G, bool PIPE = false, int VAR = MCHAP_SPEC_VAR, bool TW = false, bool CTX = false>  // (VAR only names the object: the code is selected by the macro)
 __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE) void denovo_spec_kernel(const SimtParams P) {
   extern __shared__ __align__(16) unsigned char smem_all[];
   constexpr int NG = 64 / G;
@@ -2236,8 +2540,30 @@ __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE
       if (P.bp_cache & 2) {  // the chain's likelihood cache in LDS (spec_eval), carved behind the product cache
         p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
         S.lc = lds_cast<uint64_t>(p);
-        S.lc_mask = (uint32_t)SPEC_LC_ENTRIES - 1u;
-        for (int i = lane; i < 2 * SPEC_LC_ENTRIES; i += WAVE) S.lc[i] = 0ull;  // (a tag is never 0: tag_of)
+        const int lce = spec_lc_entries(P.bp_cache);
+        S.lc_mask = (uint32_t)lce - 1u;
+        for (int i = lane; i < 2 * lce; i += WAVE) S.lc[i] = 0ull;  // (a tag is never 0: tag_of)
+        p += spec_lc_bytes(lce);
+      }
+    } else {
+      p += spec_memo_bytes(mmax, T, G);
+    }
+    if constexpr (CTX && G == 64 && PIPE) {
+      if (P.ctx != nullptr && P.ctx_n > 0) {  // directory and current context behind everything else (the host sized the LDS for it)
+        if (P.bp_cache & 8) {  // inside the product cache (spec_ctx_in_bpc)
+          S.cx_lds = (LDSP(unsigned char))(S.bpc + (size_t)((KT - 1) * 4 + 1) * WAVE);
+          S.cx_val = S.bpc + (size_t)((KT - 2) * 4 + 1) * WAVE;
+        } else {
+          p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
+          S.cx_lds = lds_cast<unsigned char>(p); p += (size_t)12 * SPEC_CTX_MAX + 4 * CX_N;
+          S.cx_val = lds_cast<double>(p); p += (size_t)16 * nmax;
+        }
+        S.cx_n = P.ctx_n < SPEC_CTX_MAX ? P.ctx_n : SPEC_CTX_MAX;
+        if (lane < CX_N) CXP_ST(S)[lane] = 0u;
+        if (lane < SPEC_CTX_MAX) {
+          CXP_TAG(S)[lane] = 0ull;
+          CXP_STAMP(S)[lane] = 0u;
+        }
       }
     }
   }
@@ -2313,6 +2639,9 @@ __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE
   c.fill_parts = fillonly ? parts_eff : 1;
   c.gen = 1;
   c.memo_gen = 1;
+  if constexpr (CTX && G == 64 && PIPE) {  // the chain's region: [chain][ctx_n slots][spec_ctx_words]
+    if (S.cx_n > 0 && c.alive) S.cx_base = P.ctx + (size_t)q * (size_t)P.ctx_n * (size_t)spec_ctx_words(KT, mmax);
+  }
   const int Mh = c.Mh;
   if (gl == 0) S.nreads[gi] = (uint16_t)(c.alive ? U.n_reads : 0);
   {
@@ -2456,7 +2785,7 @@ __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE
   int status = MCHAP_UNIT_OK;
 
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
-  for (int i_ = 0; i_ < 12; i_++) c.ph[i_] = 0;
+  for (int i_ = 0; i_ < 20; i_++) c.ph[i_] = 0;
   c.pt0 = __builtin_amdgcn_s_memtime();
 #endif
   int n_iter = Sn;
@@ -2507,10 +2836,10 @@ __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE
         status = MCHAP_UNIT_NAN_LLK;
         c.alive = false;
       }
-      spec_mutation<KT, G>(c, S, temp, amax, mmax, nmax, rpad, lane, gi, gl);
+      spec_mutation<KT, G, false, CTX>(c, S, temp, amax, mmax, nmax, rpad, lane, gi, gl);
 #pragma unroll 1
       for (int kind = 0; kind < 3; kind++) {
-        if (!spec_structural<KT, G, PIPE>(c, S, D, kind, temp, break_dist, n_break_dist, mmax, rpad, lane, gi, gl)) {
+        if (!spec_structural<KT, G, PIPE, CTX>(c, S, D, kind, temp, break_dist, n_break_dist, mmax, rpad, lane, gi, gl, amax)) {
           status = MCHAP_UNIT_BREAKS;
           c.alive = false;
         }
@@ -2657,8 +2986,8 @@ __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE
   }
 #if defined(MCHAP_STATS) || defined(MCHAP_PHASES)
   if (threadIdx.x == 0)
-    for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_stats[24 + i_], c.ph[i_]);
-  for (int i_ = 0; i_ < 12; i_++) c.ph[i_] = 0;
+    for (int i_ = 0; i_ < 20; i_++) atomicAdd(&g_stats[i_ < 12 ? 24 + i_ : 36 + i_], c.ph[i_]);
+  for (int i_ = 0; i_ < 20; i_++) c.ph[i_] = 0;
   c.pt0 = __builtin_amdgcn_s_memtime();
 #endif
   if constexpr (PIPE) {

@@ -61,6 +61,12 @@ SPEC_LIST(DECL_SPEC)
 SPECP_LIST(DECL_SPECP)
 SPECS_LIST(DECL_SPECS)
 SIMT_LIST(DECL_SIMT)
+// the phased form's instantiations with decision contexts per genotype (one chain per wavefront; plain / side by side / deep)
+#define DECL_SPECC(k)                                                                                        \
+  extern "C" int mchap_specp_launchc_##k##_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t); \
+  extern "C" int mchap_specs_launchc_##k##_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t); \
+  extern "C" int mchap_specd_launchc_##k##_64(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
+DECL_SPECC(2) DECL_SPECC(3) DECL_SPECC(4) DECL_SPECC(5) DECL_SPECC(6) DECL_SPECC(7) DECL_SPECC(8)
 // ... and its instantiation with 128-bit haplotype words (simt_inst.hip -DSIMT_WIDE): the general fallback for wide targets
 extern "C" int mchap_simt_init_w(const double *, const double *);
 extern "C" int mchap_simt_launch_w(const mchap::SimtParams *, unsigned, size_t, hipStream_t);
@@ -165,6 +171,9 @@ const SpecInst *find_inst(const SpecInst *tab, size_t n, int K, int G) {
 #define FIND_SPECP(K, G) find_inst(SPECP_INSTS, sizeof(SPECP_INSTS) / sizeof(SPECP_INSTS[0]), K, G)
 #define FIND_SPECS(K, G) find_inst(SPECS_INSTS, sizeof(SPECS_INSTS) / sizeof(SPECS_INSTS[0]), K, G)
 #define FIND_SPECD(K, G) find_inst(SPECD_INSTS, sizeof(SPECD_INSTS) / sizeof(SPECD_INSTS[0]), K, G)
+// ... and their launchers with decision contexts, by ploidy - 2: {plain, side by side, deep}
+#define ROW_SPECC(k) {mchap_specp_launchc_##k##_64, mchap_specs_launchc_##k##_64, mchap_specd_launchc_##k##_64},
+const simt_launch_fn SPECC_LAUNCH[7][3] = {ROW_SPECC(2) ROW_SPECC(3) ROW_SPECC(4) ROW_SPECC(5) ROW_SPECC(6) ROW_SPECC(7) ROW_SPECC(8)};
 
 int ensure_init() {
   int dev = 0;
@@ -483,6 +492,8 @@ struct SimtCarve {
   int key_words = 0;
   size_t gbp = 0;
   bool has_gbp = false;
+  size_t ctx = 0;  // decision contexts per genotype of the phased sampler's resumed chains: the LAST piece (ctx_n slots per chain)
+  int ctx_n = 0;
 };
 constexpr int PIPE_MAX_ROUNDS = 6;  // resume rounds of the phased sampler (counters in the workspace)
 
@@ -504,7 +515,26 @@ int cache_slots_of(const mchap_denovo_cfg *cfg, const Tune &T, const Plan &pl, i
   return slots;
 }
 
-SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, const BatchDims &B, int rpad, int cache_slots) {
+// Decision contexts per genotype (denovo_spec_kernel.hpp): slots per chain -- what CTX_BUDGET bytes (and an eighth of the
+// device's free memory) over the batch's chains allow, at most 64; fewer than 8 are not worth the look-ups.  The piece sits at the
+// end of the workspace and a fit takes as many slots as the workspace it was handed holds.
+constexpr size_t CTX_BUDGET = (size_t)6 << 30;
+bool ctx_shape(const Plan &pl, const BatchDims &B, const Tune &T) {
+  return pl.kind == SAMPLER_PIPE && pl.G == 64 && !(T.flags & 524288) && B.max_ploidy * B.max_pos <= 192;
+}
+size_t ctx_slot_bytes(const Plan &pl, const BatchDims &B) { return (size_t)mchap::spec_ctx_words(pl.K, B.max_pos) * 8; }
+int ctx_slots_for(size_t bytes, size_t n_chains, size_t slot_bytes) {
+  const size_t n = bytes / (n_chains * slot_bytes);
+  return n >= (size_t)mchap::SPEC_CTX_MAX ? mchap::SPEC_CTX_MAX : (n < 8 ? 0 : (int)n);
+}
+int ctx_slots_of(const mchap_denovo_cfg *cfg, const Tune &T, const Plan &pl, int n_units, const BatchDims &B) {
+  if (!ctx_shape(pl, B, T)) return 0;
+  size_t budget = CTX_BUDGET, free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 8 < budget) budget = free_b / 8;
+  return ctx_slots_for(budget, (size_t)n_units * cfg->chains, ctx_slot_bytes(pl, B));
+}
+
+SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, const BatchDims &B, int rpad, int cache_slots, int ctx_n = 0) {
   SimtCarve c;
   size_t o = 0;
   const size_t nc = (size_t)n_units * cfg->chains;
@@ -539,6 +569,9 @@ SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, c
     c.pipe_memo = o; o += up256(nc * 2 * mchap::spec_memo_entries(B.max_pos) * 8);
     c.pipe_lists = o; o += up256(nc * 4) * 2;
     c.pipe_counts = o; o += up256((PIPE_MAX_ROUNDS + 2) * 4);
+    c.ctx = o;
+    c.ctx_n = ctx_n;
+    o += up256(nc * (size_t)ctx_n * ctx_slot_bytes(pl, B));
   }
   c.total = o;
   return c;
@@ -658,13 +691,14 @@ int launch_lane(const Tune &T, int K, const mchap::SimtParams &P, int n_units, i
 // The phased sampler (kernel 5): denovo_spec_kernel<K, G, true> for the first steps, denovo_coast_kernel for the
 // chains' long no-move stretches, denovo_spec_kernel again for the chains handed back.
 int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, int chains, int32_t *lists, int32_t *counts, void *timer,
-                hipStream_t stream, bool shallow_units) {
+                hipStream_t stream, bool shallow_units, int max_reads) {
   // deep units (product rows in the workspace) or more than 128 (haplotype, position) pairs: the "deep" instantiation; else a
   // batch with a unit of at most 64 reads: the one that evaluates such a unit's requests side by side; else the plain one
   const SpecInst *inst = nullptr;
-  if (G == 64 && (P.gbp != nullptr || (K * P.max_pos > 128 && !(T.flags & 512)))) inst = FIND_SPECD(K, G);
-  else if (shallow_units && G == 64 && !(T.flags & 256)) inst = FIND_SPECS(K, G);
-  if (!inst) inst = FIND_SPECP(K, G);
+  int variant = 0;  // 0 plain, 1 side by side, 2 deep
+  if (G == 64 && (P.gbp != nullptr || (K * P.max_pos > 128 && !(T.flags & 512)))) inst = FIND_SPECD(K, G), variant = 2;
+  else if (shallow_units && G == 64 && !(T.flags & 256)) inst = FIND_SPECS(K, G), variant = 1;
+  if (!inst) inst = FIND_SPECP(K, G), variant = 0;
   if (!inst) return fail(MCHAP_ERR_LIMIT, "phased sampler: no instantiation for ploidy %d with %d lanes per chain", K, G);
   simt_launch_fn launch = inst->launch;
   size_t lds = mchap::spec_lds_bytes(K, P.max_pos, P.max_allele, 1, G);
@@ -674,14 +708,54 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
   // The chain's likelihood cache in LDS (denovo_spec_kernel.hpp spec_eval): exact tags only (packed genotype of at most 63
   // bits), and only where its 4 KB do not cost the launch a resident wavefront per CU (two per SIMD: eight per CU at most).
   // Tuning flag 8192: never (the table in the workspace is probed, as before round 4: same traces).
-  if (P.bp_cache && P.d.cache_slots > 0 && !(T.flags & 8192) && K * mchap::allele_bits(P.max_allele) * P.max_pos <= 63) {
+  auto per_cu = [](size_t b) { const size_t w = (160 * 1024) / b; return w > 8 ? (size_t)8 : w; };
+  const size_t lds_nolc = lds;
+  const bool lc_shape = P.bp_cache && P.d.cache_slots > 0 && !(T.flags & 8192) && K * mchap::allele_bits(P.max_allele) * P.max_pos <= 63;
+  if (lc_shape) {
     const size_t with = ((lds + 15) & ~(size_t)15) + mchap::spec_lc_bytes();
-    auto per_cu = [](size_t b) { const size_t w = (160 * 1024) / b; return w > 8 ? (size_t)8 : w; };
     if (with <= 160 * 1024 && per_cu(with) >= per_cu(lds)) {
       P.bp_cache |= 2;
       lds = with;
     }
   }
+  // The launches over handed-back chains keep decision contexts per genotype (denovo_spec_kernel<.., CTX>): its own instantiation
+  // and LDS size, so that the first launch -- every chain, three steps -- stays what it was.  The first launch gets no region.
+  // (a unit with more than two alleles at a position runs without them: the kernel's own check)
+  simt_launch_fn launch_c = launch;
+  size_t lds_c = lds;
+  int bp_cache_c = P.bp_cache;
+  uint64_t *ctx_region = nullptr;
+  int ctx_n = 0;
+  if (G == 64 && P.ctx != nullptr && P.ctx_n > 0 && K >= 2 && K <= 8) {
+    // the front cache beside the contexts: whole, halved or not at all -- the largest that keeps the launch's wavefronts per CU
+    // (the contexts answer most of what the front cache did); if nothing does, as in the other launches
+    const size_t cx = mchap::spec_ctx_lds_bytes(K, P.max_pos);
+    size_t with = ((lds + 15) & ~(size_t)15) + cx;
+    if ((P.bp_cache & 1) && mchap::spec_ctx_in_bpc(K, P.max_pos, P.max_allele, max_reads)) {
+      with = lds;  // (the product cache's free chunk slots hold them: nothing added, the front cache whole)
+      bp_cache_c = P.bp_cache | 8;
+    } else if (P.bp_cache & 2) {
+      for (int mode = 0; mode < 3; mode++) {  // 256 entries, 128, none
+        const size_t base = mode == 2 ? lds_nolc : ((lds_nolc + 15) & ~(size_t)15) + mchap::spec_lc_bytes(mode == 0 ? mchap::SPEC_LC_ENTRIES : mchap::SPEC_LC_ENTRIES / 2);
+        const size_t t = ((base + 15) & ~(size_t)15) + cx;
+        if (per_cu(t) >= per_cu(lds)) {
+          with = t;
+          bp_cache_c = mode == 0 ? P.bp_cache : (mode == 1 ? (P.bp_cache | 4) : (P.bp_cache & ~2));
+          break;
+        }
+      }
+    }
+    if (with <= 160 * 1024) {
+      launch_c = SPECC_LAUNCH[K - 2][variant];
+      lds_c = with;
+      ctx_region = P.ctx;
+      ctx_n = P.ctx_n;
+    } else {
+      bp_cache_c = P.bp_cache;
+    }
+  }
+  P.ctx = nullptr;
+  P.ctx_n = 0;
   const long long n_chains = (long long)n_units * chains;
   // steps before the first hand-over: a chain handed over before it has settled comes back and has its tables
   // completed a second time, which costs more the more sub-steps and intervals a step has (config #2: 32 sub-steps,
@@ -755,7 +829,13 @@ int launch_pipe(const Tune &T, int K, int G, mchap::SimtParams P, int n_units, i
     const bool last = r == rounds;
     P.pipe_iters = last ? 0 : nr;
     P.pipe_mode = mchap::PIPE_RESUME | (last ? 0 : export_mode);
-    e = launch(&P, grid_s, lds, stream);
+    {
+      mchap::SimtParams R = P;  // (this launch's list, counters and mode; the contexts' region)
+      R.ctx = ctx_region;
+      R.ctx_n = ctx_n;
+      R.bp_cache = bp_cache_c;
+      e = launch_c(&R, grid_s, lds_c, stream);
+    }
     if (last || e != 0) break;
     e = fill_launch();
     if (e != 0) break;
@@ -935,7 +1015,7 @@ int64_t mchap_denovo_workspace_bytes(const mchap_denovo_cfg *cfg, int n_units, c
   if (batch_dims(cfg, n_units, units_host, B)) return -1;
   Plan pl;
   if (plan_sampler(cfg, T, B, pl)) return -1;
-  return bt + (int64_t)simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, cache_slots_of(cfg, T, pl, n_units, B)).total;
+  return bt + (int64_t)simt_carve(cfg, pl, n_units, B, 64 * pl.rpl, cache_slots_of(cfg, T, pl, n_units, B), ctx_slots_of(cfg, T, pl, n_units, B)).total;
 }
 
 static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const mchap_unit *units_dev,
@@ -1055,6 +1135,14 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
       return fail(MCHAP_ERR_BAD_ARG, "workspace of %lld bytes is too small: kernel %d needs at least %zu (mchap_denovo_workspace_bytes)",
                   (long long)workspace_bytes, cfg->kernel, cv.total);
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    // decision contexts: as many slots per chain as the rest of the workspace holds (mchap_denovo_workspace_bytes sized it by its budget)
+    if (ctx_shape(pl, B, T) && workspace_bytes > (int64_t)cv.total) {
+      const int cn = ctx_slots_for((size_t)(workspace_bytes - (int64_t)cv.total), (size_t)n_units * cfg->chains, ctx_slot_bytes(pl, B));
+      if (cn > 0) {
+        SP.ctx = reinterpret_cast<uint64_t *>(ws + cv.ctx);
+        SP.ctx_n = cn;
+      }
+    }
     if (slots > 0) {
       P.cache = reinterpret_cast<uint64_t *>(ws + cv.cache);
       P.cache_slots = slots;
@@ -1136,7 +1224,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
 #endif
       case SAMPLER_PIPE:
         return launch_pipe(T, pl.K, pl.G, SP, n_units, cfg->chains, reinterpret_cast<int32_t *>(ws + cv.pipe_lists),
-                           reinterpret_cast<int32_t *>(ws + cv.pipe_counts), cfg->timer, stream, B.min_reads <= 64);
+                           reinterpret_cast<int32_t *>(ws + cv.pipe_counts), cfg->timer, stream, B.min_reads <= 64, B.max_reads);
       case SAMPLER_SPEC: return launch_spec(T, pl.K, pl.G, SP, n_units, cfg->chains, cfg->n_temps, cfg->timer, stream);
       default: return launch_simt(pl.K, SP, n_units, cfg->chains, lds_simt, cfg->timer, stream, pl.wide);  // lanes over chains
     }

@@ -15,10 +15,12 @@
 #if MCHAP_SPEC_VAR == 1
 #define mchap_specp_init_ mchap_specs_init_
 #define mchap_specp_launch_ mchap_specs_launch_
+#define mchap_specp_launchc_ mchap_specs_launchc_
 #define mchap_specp_stats_ mchap_specs_stats_
 #elif MCHAP_SPEC_VAR == 2
 #define mchap_specp_init_ mchap_specd_init_
 #define mchap_specp_launch_ mchap_specd_launch_
+#define mchap_specp_launchc_ mchap_specd_launchc_
 #define mchap_specp_stats_ mchap_specd_stats_
 #endif
 extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_specp_init_, SPEC_K, SPEC_G)(const double *ln,
@@ -38,6 +40,20 @@ extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_specp_launch
   hipLaunchKernelGGL(ks, dim3(grid), dim3(64), lds, stream, *P);
   return (int)hipGetLastError();
 }
+
+#if SPEC_G == 64
+// ... with decision contexts per genotype (denovo_spec_kernel<.., CTX = true>): the launches over handed-back chains
+extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_specp_launchc_, SPEC_K, SPEC_G)(
+    const mchap::SimtParams *P, unsigned grid, size_t lds, hipStream_t stream) {
+  auto ks = mchap::denovo_spec_kernel<SPEC_K, SPEC_G, true, MCHAP_SPEC_VAR, false, true>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(ks, dim3(grid), dim3(64), lds, stream, *P);
+  return (int)hipGetLastError();
+}
+#endif
 #else
 extern "C" __attribute__((visibility("hidden"))) int SPEC_CAT(mchap_spec_init_, SPEC_K, SPEC_G)(const double *ln,
                                                                                                 const double *ln_inv) {

@@ -482,6 +482,28 @@ typedef struct {
   orc_stats *stats;
 } orc_ctx;
 
+/* Optional event log for tests/analyze_moves.py (only with -DORC_MOVE_LOG, a separate build: the shipped oracle has none of it).
+   Entry = (FNV-1a hash of the ordered genotype bytes [+ step type, start, stop for kind 3]) << 2 | kind:
+   0 step start, 1 accepted mutation, 2 accepted structural move, 3 interval step visited (with options). */
+#ifdef ORC_MOVE_LOG
+static __thread uint64_t *orc_mlog_buf = NULL;
+static __thread size_t orc_mlog_cap = 0, orc_mlog_n = 0;
+void orc_move_log_set(uint64_t *buf, size_t cap) { orc_mlog_buf = buf; orc_mlog_cap = cap; orc_mlog_n = 0; }
+size_t orc_move_log_count(void) { return orc_mlog_n; }
+static void orc_mlog(const orc_ctx *c, const int8_t *genotype, int kind, int a, int b, int t) {
+  if (!orc_mlog_buf) return;
+  uint64_t h = 1469598103934665603ull;
+  size_t n = (size_t)c->ploidy * c->n_pos;
+  for (size_t i = 0; i < n; i++) { h ^= (uint8_t)genotype[i]; h *= 1099511628211ull; }
+  if (kind == 3) { h ^= (uint64_t)(a * 65536 + b * 256 + t + 1); h *= 1099511628211ull; }
+  if (orc_mlog_n < orc_mlog_cap) orc_mlog_buf[orc_mlog_n] = (h << 2) | (uint64_t)kind;
+  orc_mlog_n++;
+}
+#define ORC_MLOG(c, g, k, a, b, t) orc_mlog(c, g, k, a, b, t)
+#else
+#define ORC_MLOG(c, g, k, a, b, t) ((void)0)
+#endif
+
 /* likelihood.py:194-235 */
 static double llk_cached(orc_ctx *c, const int8_t *genotype) {
   if (!c->cache) {
@@ -675,7 +697,10 @@ static double base_step(orc_ctx *c, int8_t *genotype, double llk, int h, int j, 
   base_step_probs(c, genotype, llk, h, j, temp, probs, llks);
   int choice = choose_from(probs, n_alleles, rng_double(c->rng, slot));
   if (choice >= n_alleles) choice = n_alleles - 1;
+  int8_t before = genotype[(size_t)h * c->n_pos + j];
   genotype[(size_t)h * c->n_pos + j] = (int8_t)choice;
+  if (before != (int8_t)choice) ORC_MLOG(c, genotype, 1, 0, 0, 0);
+  (void)before;
   return llks[choice];
 }
 
@@ -863,12 +888,14 @@ static double interval_step(orc_ctx *c, int8_t *genotype, double llk, int start,
   int8_t option_labels[ORC_MAX_OPTIONS * ORC_MAX_PLOIDY * 2];
   int n_options = interval_step_probs(c, genotype, llk, start, stop, step_type, temp, probs, llks, option_labels);
   if (n_options == 0) return llk; /* structural.py:504-506: no RNG consumed */
+  ORC_MLOG(c, genotype, 3, start, stop, step_type);
   int choice = choose_from(probs, n_options + 1, rng_double(c->rng, slot));
   if (choice < n_options) {
     int8_t hidx[ORC_MAX_PLOIDY];
     for (int h = 0; h < c->ploidy; h++) hidx[h] = option_labels[((size_t)choice * c->ploidy + h) * 2];
     orc_structural_change(genotype, c->ploidy, c->n_pos, hidx, start, stop);
     llk = llks[choice];
+    ORC_MLOG(c, genotype, 2, 0, 0, 0);
   }
   return llk;
 }
@@ -1094,6 +1121,7 @@ static int denovo_assembler(const orc_denovo_cfg *cfg, orc_ctx *c, const int8_t 
       /* Philox mode: the draws of MCMC step i are numbered from i * ORC_STEP_DRAWS in each temperature's stream,
          whatever earlier steps consumed (the HIP kernels evaluate the steps of a settled chain independently) */
       c->rng->n[t] = (uint64_t)i * ORC_STEP_DRAWS;
+      ORC_MLOG(c, g, 0, 0, 0, 0);
       llk = mutation_compound_step(c, g, llk, temp, t);
       if (rng_double(c->rng, t) <= cfg->p_recomb) {
         int nb = choose_from(break_dist, n_break_dist, rng_double(c->rng, t));

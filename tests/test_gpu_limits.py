@@ -63,3 +63,35 @@ def test_targets_beyond_the_limits_are_written_with_a_filter(capsys):
 
     assert any(ln.startswith("##FILTER=<ID=LIMIT,") for ln in vcfheader.header_lines("assemble", "x", ["S1"], [("c1", 9000)]))
     assert not any("LIMIT" in ln for ln in vcfheader.header_lines("call-exact", "x", ["S1"], [("c1", 9000)]))
+
+
+@pytest.mark.parametrize("block_path", [None, False])
+def test_a_deep_wide_target_is_a_limit_record_not_an_abort(capsys, block_path):
+    """A target of 70 SNVs runs on the general sampler, which takes 1024 distinct read rows per unit.  One such target with more
+    rows used to raise out of the batch constructor and take the whole block with it; now its record says LIMIT and
+    the block's other targets -- a wide one that fits among them -- are assembled as if it were not there.  Both host paths."""
+    from mchap_amd import application
+
+    rng = np.random.default_rng(11)
+    specs = [("ok1", 100, 6, "AC", 30), ("deepwide", 1000, 70, "AC", 1300), ("wide_ok", 5000, 70, "AC", 40), ("ok2", 8000, 8, "AG", 30)]
+    targets, variants, matrices = [], [], {}
+    for name, start, n, al, nr in specs:
+        t, v, m = _target(name, start, n, al, rng, n_reads=nr, ploidy=4)
+        if name == "deepwide":  # every read its own row: random characters, not copies of four haplotypes
+            chars = np.frombuffer(b"AC", dtype=np.uint8)[rng.integers(0, 2, size=m[0].shape)]
+            m = (chars, m[1])
+        targets.append(t)
+        variants += v
+        matrices[(name, "S1")] = m
+    source = application.MatrixSource(["S1"], matrices)
+    kw = dict(ploidy=4, steps=100, burn=50, chains=2, seed=3, block_path=block_path)
+    lines = list(application.assemble(None, variants, {"c1": _NSeq()}, source, targets=targets, **kw))
+    by = {ln.split("\t")[2]: ln.split("\t") for ln in lines}
+    assert [ln.split("\t")[2] for ln in lines] == ["ok1", "deepwide", "wide_ok", "ok2"]
+    assert by["deepwide"][6] == "LIMIT" and by["deepwide"][9].split(":")[0] == "./././."
+    for nm in ("ok1", "wide_ok", "ok2"):
+        assert by[nm][6] in ("PASS", "NOA") and "." not in by[nm][9].split(":")[0]
+    err = capsys.readouterr().err
+    assert "target deepwide" in err and "distinct read rows" in err and "1024" in err
+    alone = list(application.assemble(None, variants, {"c1": _NSeq()}, source, targets=[targets[0], targets[2], targets[3]], **kw))
+    assert alone == [lines[0], lines[2], lines[3]]

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 EVALUATE_BEHIND_KNOWN_MOVERS = 262144  # (flag 262144: spec_mutation evaluates every miss of a round's window, as before)
 NO_CODED_TABLE = 4  # (flag 4: float64 rows from memory instead of the coded table -- and so no code table in LDS either)
 ONE_WAVE_COASTING = 131072
+NO_DECISION_CONTEXTS = 524288  # (flag 524288: the resumed chains of the phased sampler keep no decision contexts per genotype)
 
 
 def _oracle(model, reads, counts, stream_id):
@@ -161,6 +162,39 @@ def test_coasting_forms_agree_and_long_lists_are_walked(monkeypatch):
         assert np.array_equal(x.llks, y.llks)
     model = DenovoMCMC(**kw)
     for u in list(range(0, 1500, 250)) + [1500, 1699]:
+        g, l = _oracle(model, reads[u], None, u)
+        assert np.array_equal(a[u].genotypes, sort_haplotypes(g)), "unit %d" % u
+        np.testing.assert_allclose(a[u].llks, l, rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 40, None, 2), (4, 8, 16, None, 2), (4, 13, 24, 0.2, 2), (4, 21, 45, None, 2), (6, 7, 20, None, 2),
+                                   (2, 10, 12, 0.0, 2), (4, 8, 100, None, 2), (8, 10, 24, None, 2), (3, 9, 33, None, 3)])
+def test_decision_contexts_are_results_neutral(monkeypatch, shape):
+    """Round 5: a chain with a history keeps a decision context per ordered genotype -- the move probability and successor
+    likelihood of every sub-step, the interval totals -- in its region of the workspace (denovo_spec_kernel.hpp "decision
+    contexts"): a move into a genotype it has held before is a context switch, not a round of proposals, probes and evaluations.
+    What a context holds is what this arithmetic computed for that genotype, so the traces and likelihoods are those of the same
+    run without contexts (flag 524288), bit for bit, and the oracle's.  (4, 8, 40): nearly every move finds its context; (4, 8,
+    16): chains that wander -- their trial fails and they pause; (4, 21, 45): hashed tags, the slot's words decide; (4, 8, 100): two
+    read chunks, no side-by-side evaluation; K = 8: the deep instantiation; (3, 9, 33, 3): tri-allelic -- no contexts at all.)"""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.classes import sort_haplotypes
+    from mchap_amd.synth import synth_units
+
+    K, M, R, F, A = shape
+    monkeypatch.setenv("MCHAP_HIP_KERNEL", "5")
+    reads, _, _ = synth_units(6, ploidy=K, n_pos=M, n_reads=R, n_alleles=A, qual=(3, 20), window=(4, M) if M > 8 else (4, 8), first_unit=300)
+    kw = dict(ploidy=K, n_alleles=[A] * M, inbreeding=F, steps=1500, chains=2, random_seed=23)
+    monkeypatch.delenv("MCHAP_HIP_FLAGS", raising=False)
+    a = DenovoMCMC(**kw).fit_batch(list(reads))
+    monkeypatch.setenv("MCHAP_HIP_FLAGS", str(NO_DECISION_CONTEXTS))
+    b = DenovoMCMC(**kw).fit_batch(list(reads))
+    assert sum(_moves(t) for t in a) > 6 * 2 * 30  # (every chain passes the threshold of MCHAP_CTX_GEN genotype changes)
+    model = DenovoMCMC(**kw)
+    for u, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x.genotypes, y.genotypes), "unit %d" % u
+        assert np.array_equal(x.llks, y.llks)
+    for u in (0, 3):
         g, l = _oracle(model, reads[u], None, u)
         assert np.array_equal(a[u].genotypes, sort_haplotypes(g)), "unit %d" % u
         np.testing.assert_allclose(a[u].llks, l, rtol=1e-10, atol=1e-9)

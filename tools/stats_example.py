@@ -26,7 +26,7 @@ class NSeq:
 src = application.MatrixSource(samples[:n_samples], {k: v for k, v in matrices.items()})
 tg = [t for t in targets if t[3] in names]
 L = _lib.lib()
-out = (C.c_ulonglong * 48)()
+out = (C.c_ulonglong * 64)()
 for rep in range(2):
     L.mchap_debug_stats(out, 1)
     tm = {}
@@ -49,6 +49,8 @@ for i, nm in enumerate(pnames):
 print("total ticks per chain-step %.0f (s_memtime: 100 MHz)" % (tot / ws))
 print("nested: cache probe %.0f ticks per chain-step; probe + evaluation %.0f; request-lanes evaluated %.2f per chain-step -> %.0f ticks each" % (
     out[33] / ws, out[34] / ws, out[35] / ws, (out[34] - out[33]) / max(out[35], 1)))
+print("sub-timers (ticks per chain-step): mutation staging + permutation %.0f; context acquire %.0f; spec_eval inside mutation rounds %.0f; inside structural rounds %.0f" % (
+    out[48] / ws, out[49] / ws, out[52] / ws, out[53] / ws))
 if out[8]:  # (event counters: the `stats` build)
     print("mutation: wave-calls %d  on the slow path %.3f  rounds per slow-path call %.2f; requests %d misses %d (%.1f %%)" % (
         out[8], out[9] / out[8], out[11] / max(out[9], 1), out[0], out[1], 100.0 * out[1] / max(out[0], 1)))
