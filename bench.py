@@ -105,25 +105,63 @@ def usable_cores():
     return n, quota
 
 
-def cpu_rates(unit_fn, n_one, n_all, unit="units/s", what="", cores=None):
+def baseline_row(value, unit, cores, value_1_thread, sample, **more):
+    """A cpu_baseline object: the rate on `cores` threads with the one-thread rate beside it, how the one scales to the other
+    (`scaling` = value / (cores x value_1_thread); `scales` false below 0.6: then it is not a `cores`-thread figure), and the
+    host's hardware threads beside the threads the box's cgroup grants."""
+    scaling = value / (cores * value_1_thread) if value_1_thread and cores else None
+    row = {"value": value, "unit": unit, "cores": cores, "host_threads": os.cpu_count(), "kind": "port", "value_1_thread": value_1_thread,
+           "scaling": None if scaling is None else round(scaling, 3), "scales": bool(scaling is None or scaling >= 0.6), "sample": sample}
+    row.update(more)
+    return row
+
+
+def cpu_rates(unit_fn, n_one, n_all, unit="units/s", what="", cores=None, cost=None):
     """The oracle (a C port of the reference's algorithm: kind "port") timed on ONE thread and on all usable threads, one unit per
     thread: unit_fn(i) runs unit i through oracle/mchap_oracle.c (ctypes releases the interpreter lock, so a thread pool of
-    plain calls is real parallelism).  Every `extra` reports both rates, so that speed-ups are quoted against the same thing."""
+    plain calls is real parallelism).  Every `extra` reports both rates, so that speed-ups are quoted against the same thing.
+    cost: estimated cost of every unit (any scale) -- the units are then handed out longest first, so that one expensive unit
+    started last does not set the multi-thread time (docs/example's units differ 100-fold).  `scaling` = the multi-thread rate
+    over cores x the one-thread rate; below 0.6 the line says so (`scales`: false) -- such a baseline is not a 16-thread figure."""
     from concurrent.futures import ThreadPoolExecutor
 
     if cores is None:
         cores, _ = usable_cores()
+    order1 = list(range(n_one))
     t = time.perf_counter()
-    for i in range(n_one):
+    for i in order1:
         unit_fn(i)
     d1 = time.perf_counter() - t
     n_all = max(n_all, cores)
+    order = list(range(n_all))
+    if isinstance(cost, str) and cost == "measure":  # an untimed pass in the threads tells what every unit costs
+        took = [0.0] * n_all
+
+        def timed(i):
+            t_ = time.perf_counter()
+            unit_fn(i)
+            took[i] = time.perf_counter() - t_
+
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            list(ex.map(timed, order))
+        cost = took
+    if cost is not None:
+        order.sort(key=lambda i: -float(cost[i]))
     t = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(unit_fn, range(n_all)))
+        list(ex.map(unit_fn, order))
     dn = time.perf_counter() - t
-    return {"value": n_all / dn, "unit": unit, "cores": cores, "kind": "port", "value_1_thread": n_one / d1,
-            "sample": "%s: %d units on one thread (%.1f s), %d units on %d threads, one unit per thread (%.1f s)" % (what, n_one, d1, n_all, cores, dn)}
+    row = baseline_row(n_all / dn, unit, cores, n_one / d1,
+                       "%s: %d units on one thread (%.1f s), %d units on %d threads, one unit per thread%s (%.1f s)" % (
+                           what, n_one, d1, n_all, cores, ", longest first" if cost is not None else "", dn))
+    if cost is not None:
+        # the two legs run different units: what the threads achieve is compared per unit of cost -- the time the units took
+        # (or are estimated to take) over threads x wall time
+        w1, wn = sum(float(cost[i]) for i in order1), sum(float(cost[i]) for i in order)
+        if w1 > 0 and d1 > 0:
+            sc = (wn / dn) / (cores * (w1 / d1))
+            row["scaling"], row["scales"] = round(sc, 3), bool(sc >= 0.6)
+    return row
 
 
 def reference_postprocessing(args, batch, n=16):
@@ -208,13 +246,11 @@ def cpu_baseline(args, cores, quota=None):
     t = time.perf_counter()
     orc.denovo_fit_batch(cfg, reads[:n1], [2] * args.snvs, n_threads=1, keep_traces=False)
     dt1 = time.perf_counter() - t
-    return {
-        "value": n / dt, "unit": "loci/s", "cores": cores, "kind": "port", "value_1_thread": n1 / dt1,
-        "sample": "%d loci of the same workload, oracle/mchap_oracle.c with llk cache threshold 100, OpenMP over loci "
-                  "(%d threads = affinity capped by the cgroup CPU quota %s), %.2f s wall"
-                  % (n, cores, "none" if quota is None else "%.1f" % quota, dt),
-        "llk_evals_per_locus": st.llk_evals / n, "llk_cache_hits_per_locus": st.llk_cache_hits / n,
-    }
+    return baseline_row(n / dt, "loci/s", cores, n1 / dt1,
+                        "%d loci of the same workload, oracle/mchap_oracle.c with llk cache threshold 100, OpenMP over loci "
+                        "(%d threads = affinity capped by the cgroup CPU quota %s), %.2f s wall"
+                        % (n, cores, "none" if quota is None else "%.1f" % quota, dt),
+                        llk_evals_per_locus=st.llk_evals / n, llk_cache_hits_per_locus=st.llk_cache_hits / n)
 
 
 def _profile_order(path):
@@ -226,6 +262,21 @@ def _profile_order(path):
     return (int(m.group(1)), len(m.group(2)), m.group(2)) if m else (-1, 0, "")
 
 
+def kernel_sources_sha16():
+    """First 16 hex digits of the SHA-256 over the library's sources (mchap_amd/csrc/*.hpp, *.hip, *.inc, *.cpp, Makefile, in name
+    order): what a committed counter summary must carry to be quoted for the kernels this run executes."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(f for pat in ("*.hpp", "*.hip", "*.inc", "*.cpp", "Makefile") for f in glob.glob(os.path.join(ROOT, "mchap_amd", "csrc", pat)))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_profile(args):
     """The newest committed PMC summary that matches this workload (profiles/*_pmc_traffic.json, produced by
     tools/profile_round.sh + tools/pmc_traffic.py in separate rocprofv3 --pmc passes: FETCH_SIZE / WRITE_SIZE converted with
@@ -233,15 +284,20 @@ def pmc_profile(args):
     earlier profiling run of the same command, not measurements of this run: the line names the file they come from."""
     import glob
 
+    sha = kernel_sources_sha16()
+    stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=_profile_order, reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
             if t.get("loci") == args.loci and t.get("mcmc_steps") == args.mcmc_steps and t.get("chains") == args.chains:
-                return t, "profiles/" + os.path.basename(path)
+                # (round 5) only a summary taken from THESE kernel sources is quoted: counters of other kernels say nothing here
+                if t.get("kernel_sources_sha16") == sha:
+                    return t, "profiles/" + os.path.basename(path)
+                stale = stale or os.path.basename(path)
         except Exception:
             pass
-    return None, None
+    return None, (None if stale is None else "none of the current kernel sources (%s); newest of other sources: profiles/%s, not quoted" % (sha, stale))
 
 
 # Issue cycles of one wavefront instruction on a SIMD (MI355X_MICROARCH.md "Wave scheduling" / "Per-instruction cycle constants":
@@ -418,6 +474,8 @@ def sq_counters_of(pattern, kernel_prefix):
         try:
             with open(path) as f:
                 t = json.load(f)
+            if (t.get("_meta") or {}).get("kernel_sources_sha16") != kernel_sources_sha16():
+                continue  # (round 5) counters of other kernel sources are not quoted
             tot, names = {}, []
             for name, c in t.items():
                 if name.startswith(prefixes) and "SQ_INSTS_VALU" in c:
@@ -514,9 +572,9 @@ def bench_config5(args):
         t = time.perf_counter()
         orc.denovo_fit_batch(cfg, reads[:n_cpu], [2] * M, n_threads=cores, keep_traces=False)
         dc = time.perf_counter() - t
-        out["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": min(cores, n_cpu), "kind": "port", "value_1_thread": 1.0 / d1,
-                               "sample": "oracle with llk cache: 1 locus on one thread (%.1f s), %d loci of the same workload one locus per "
-                                         "thread (%.1f s wall)" % (d1, n_cpu, dc)}
+        out["cpu_baseline"] = baseline_row(n_cpu / dc, "loci/s", min(cores, n_cpu), 1.0 / d1,
+                                           "oracle with llk cache: 1 locus on one thread (%.1f s), %d loci of the same workload one locus per "
+                                           "thread (%.1f s wall)" % (d1, n_cpu, dc))
     return out
 
 
@@ -695,7 +753,7 @@ def bench_config1(args):
 
         n4 = sum(1 for _ in range(4 * len(samples)))
         # one thread: the units of the first 4 targets; all threads: EVERY unit of the example (the same job the GPU ran)
-        out["cpu_baseline"] = cpu_rates(one, min(n4, len(todo)), len(todo), "units/s", "oracle/mchap_oracle.c, sampler only")
+        out["cpu_baseline"] = cpu_rates(one, min(n4, len(todo)), len(todo), "units/s", "oracle/mchap_oracle.c, sampler only", cost="measure")
     return out
 
 
@@ -777,8 +835,8 @@ def bench_moving(args):
             t = time.perf_counter()
             orc.denovo_fit_batch(cfg, reads[:n1], [2] * args.snvs, n_threads=1, keep_traces=False)
             d1 = time.perf_counter() - t
-            row["cpu_baseline"] = {"value": n_cpu / dc, "unit": "loci/s", "cores": cores, "kind": "port", "value_1_thread": n1 / d1,
-                                   "sample": "oracle with llk cache: %d loci on %d threads, %d loci on one thread" % (n_cpu, cores, n1)}
+            row["cpu_baseline"] = baseline_row(n_cpu / dc, "loci/s", cores, n1 / d1,
+                                               "oracle with llk cache: %d loci on %d threads, %d loci on one thread" % (n_cpu, cores, n1))
         out["reads_%d" % R] = row
     return out
 
@@ -824,9 +882,9 @@ def bench_config5_tempered(args, steps=2000, loci=None):
         t = time.perf_counter()
         orc.denovo_fit_batch(cfg, reads[:n_cpu], [2] * M, n_threads=cores, keep_traces=False)
         dc = time.perf_counter() - t
-        out["cpu_baseline"] = {"value": n_cpu / dc, "unit": out["unit"], "cores": min(cores, n_cpu), "kind": "port", "value_1_thread": 1.0 / d1,
-                               "sample": "oracle with llk cache on the same reduced workload: 1 locus on one thread (%.1f s), %d loci one per "
-                                         "thread (%.1f s wall)" % (d1, n_cpu, dc)}
+        out["cpu_baseline"] = baseline_row(n_cpu / dc, out["unit"], min(cores, n_cpu), 1.0 / d1,
+                                           "oracle with llk cache on the same reduced workload: 1 locus on one thread (%.1f s), %d loci one per "
+                                           "thread (%.1f s wall)" % (d1, n_cpu, dc))
     return out
 
 
@@ -1094,8 +1152,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": kern_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": (prof or {}).get("hbm_bytes_per_launch"),
-                "traffic_source": None if prof is None else "%s: rocprofv3 --pmc passes of an EARLIER run of this command (static figure, "
-                                                             "not measured in this run)" % prof_src,
+                "traffic_source": prof_src if prof is None else "%s: rocprofv3 --pmc passes of an EARLIER run of this command on the same "
+                                                                "kernel sources (%s; static figure, not measured in this run)" % (prof_src, kernel_sources_sha16()),
                 "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": kern_ms, "sampler_span_ms": span_ms,
                 "valu_issue_frac": valu_frac, "valu_insts_per_launch": valu_insts, "valu_issue_cycles_per_launch": w["cycles"] if w else None,
                 "valu_classes": None if not w else {k: w[k] for k in ("f64", "int64", "trans", "other", "per_class_complete")},

@@ -969,7 +969,9 @@ __device__ __forceinline__ unsigned long long spec_same_request(LDSP(uint64_t) p
 
 // Serves every request of the wave (bit mask `todo`), chain by chain, with all 64 lanes.  Inlined on purpose: see the
 // note on device function calls in DESIGN.md section 4.1.
-template <int KT, int G, bool LT = false>
+// DEDUP = false: the caller's requests are distinct by construction (the proposals of a mutation round: different sub-steps of
+// one genotype) -- the comparisons that find equal requests are left out
+template <int KT, int G, bool LT = false, bool DEDUP = true>
 __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(uint64_t) pwbuf, LDSP(uint8_t) shift_tab,
                                                 LDSP(uint16_t) cols_tab, LDSP(uint16_t) nreads_tab, LDSP(uint16_t) ndict_tab,
                                                 LDSP(double) dict_tab, LDSP(uint64_t) gptr_tab, LDSP(uint64_t) bw_tab,
@@ -1041,6 +1043,37 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
           // and in a chain that keeps moving nearly every round follows a move -- re-forming all K products each time was
           // half of such a round (phase timers, 16-read units: 12 000 ticks per round, 6 000 of them here).
           const bool any_valid = bpt[KT] != 0ull;
+#if MCHAP_SPEC_SBS
+          if (sct != nullptr && nch == 1) {
+            // the unit's codes are in LDS (at most 64 reads, lane = read): the changed haplotypes' products without the memory
+            // round trip of the code loads -- after every accepted move of a chain that keeps moving.  The factors and their
+            // order are spec_hap_prod's (a position beyond Mh multiplies by 1.0: exact), hence the same products.
+            LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
+            LDSP(const uint8_t) shift = shift_tab + (size_t)sg * mmax;
+            LDSP(const uint16_t) cols = cols_tab + (size_t)sg * mmax;
+            for (int h = 0; h < KT; h++) {
+              const uint64_t wb = bw_tab[(size_t)sg * KT + h];
+              const bool ok = any_valid && bpt[h] == wb;
+              if (__builtin_amdgcn_readfirstlane((int)ok) != 0) continue;
+              double ph = 1.0;
+              for (int j0 = 0; j0 < Mh; j0 += 8) {
+                uint8_t cd[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                  const int j = min(j0 + t, Mh - 1);
+                  cd[t] = sct[sct_off((uint32_t)cols[j] + ((uint32_t)(wb >> shift[j]) & amask)) + lane];
+                }
+                double f[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) f[t] = dict[cd[t]];
+#pragma unroll
+                for (int t = 0; t < 8; t++) ph *= (j0 + t < Mh) ? f[t] : 1.0;
+              }
+              bp.set(h, 0, lane, ph);
+            }
+          } else
+#endif
+          {
           const PairRows rows = spec_pair_rows<KT>(bw_tab + (size_t)sg * KT, 1, 0, S, sg, mmax, Mh, amask, lane);
           for (int h = 0; h < KT; h++) {
             const bool ok = any_valid && bpt[h] == bw_tab[(size_t)sg * KT + h];
@@ -1049,6 +1082,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
             else if (nb0 == 2) spec_base_products_of<KT, 2, uint16_t, LT>(S, rows, sg, h, Mh, ct, crow, lane, bp);
             else if (nb0 == 3) spec_base_products_of<KT, 3, uint32_t, LT>(S, rows, sg, h, Mh, ct, crow, lane, bp);
             else spec_base_products_of<KT, 4, uint32_t, LT>(S, rows, sg, h, Mh, ct, crow, lane, bp);
+          }
           }
           lds_sync();
           if (lane == 0) {
@@ -1130,7 +1164,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
             for (int k = 0; k < 4; k++) {
               if (k < NQ && reqs) {
                 const int src = __ffsll((long long)reqs) - 1;
-                const unsigned long long dups = spec_same_request<KT>(pwbuf, reqs, src, lane);
+                const unsigned long long dups = (DEDUP ? spec_same_request<KT>(pwbuf, reqs, src, lane) : (1ull << src));
                 reqs &= ~dups;
                 srcs[k] = src;
                 dupm[k] = dups;
@@ -1282,7 +1316,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
             for (int k = 0; k < 4; k++) {
               if (reqs) {
                 const int src = __ffsll((long long)reqs) - 1;
-                const unsigned long long dups = spec_same_request<KT>(pwbuf, reqs, src, lane);
+                const unsigned long long dups = (DEDUP ? spec_same_request<KT>(pwbuf, reqs, src, lane) : (1ull << src));
                 reqs &= ~dups;
                 srcs[k] = src;
                 dupm[k] = dups;
@@ -1364,7 +1398,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
       while (reqs) {
         const int src = __ffsll((long long)reqs) - 1;
         // requests for the same genotype (options of different intervals often coincide) are evaluated once
-        const unsigned long long dups = spec_same_request<KT>(pwbuf, reqs, src, lane);
+        const unsigned long long dups = (DEDUP ? spec_same_request<KT>(pwbuf, reqs, src, lane) : (1ull << src));
         reqs &= ~dups;
         double s = 0.0;
         if (nb0 == 1) s += spec_coop_reuse<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
@@ -1396,7 +1430,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
     } else {
       while (reqs) {
         const int src = __ffsll((long long)reqs) - 1;
-        const unsigned long long dups = spec_same_request<KT>(pwbuf, reqs, src, lane);
+        const unsigned long long dups = (DEDUP ? spec_same_request<KT>(pwbuf, reqs, src, lane) : (1ull << src));
         reqs &= ~dups;
         // the lane's reads in blocks of at most 4 chunks of 64 (keeps the loads in flight, and the registers,
         // bounded whatever the read depth); the last block may hold 1-3 chunks
@@ -1439,7 +1473,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
 struct SpecKeepAll {
   __device__ __forceinline__ bool operator()(bool miss, double) const { return miss; }
 };
-template <int KT, int G, bool LT = false, class Filter = SpecKeepAll>
+template <int KT, int G, bool LT = false, class Filter = SpecKeepAll, bool DEDUP = true>
 __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, const Grp<KT> &c, const SpecLds &S, int mmax,
                                             int rpad, int lane, Filter filt = Filter()) {
   double val = 0.0;
@@ -1557,7 +1591,7 @@ __device__ __forceinline__ double spec_eval(bool need, const GWords<KT> pw, cons
       for (int h = 0; h < KT; h++) S.bw[(size_t)(lane / G) * KT + h] = cg.w[h];
     }
     lds_sync();
-    const double v = spec_coop_all<KT, G, LT>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw, S.bpc, S.bpt, S.sct, S.gbt);
+    const double v = spec_coop_all<KT, G, LT, DEDUP>(todo, S.pw, S.shift, S.cols, S.nreads, S.ndict, S.dict, S.gptr, S.bw, S.reuse_on, S.crow, mmax, c.Mh, C_AMASK(c), rpad, lane, S.lds_ct, S.lds_cw, S.bpc, S.bpt, S.sct, S.gbt);
     if (miss) val = v;
     bool writer = miss && slot != nullptr;
     if (wave_any(writer && wide)) {
@@ -1681,13 +1715,20 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
     // instead of a dependent LDS read (the loop was 9 000 of the 11 000 cycles a slow-path step spends before its first
     // round at 32 sub-steps: profiles/r05d_phases_moving.txt)
     const int nl = __builtin_amdgcn_readfirstlane(run ? n : 0);
+    if (nl <= 64) {  // one slot in use (configs[1]: 32 sub-steps): a third of the selects
+      for (int i = nl - 1; i >= 1; i--) {
+        const int ki = __builtin_amdgcn_readlane(kv[0], i);
+        xs[0] = (xs[0] == i) ? ki : ((xs[0] == ki) ? i : xs[0]);
+      }
+    } else {
 #pragma unroll
-    for (int s2 = NS - 1; s2 >= 0; s2--) {
-      const int hi = min(nl - 1, s2 * 64 + 63), lo = max(1, s2 * 64);
-      for (int i = hi; i >= lo; i--) {
-        const int ki = __builtin_amdgcn_readlane(kv[s2], i & 63);
+      for (int s2 = NS - 1; s2 >= 0; s2--) {
+        const int hi = min(nl - 1, s2 * 64 + 63), lo = max(1, s2 * 64);
+        for (int i = hi; i >= lo; i--) {
+          const int ki = __builtin_amdgcn_readlane(kv[s2], i & 63);
 #pragma unroll
-        for (int s = 0; s < NS; s++) xs[s] = (xs[s] == i) ? ki : ((xs[s] == ki) ? i : xs[s]);
+          for (int s = 0; s < NS; s++) xs[s] = (xs[s] == i) ? ki : ((xs[s] == ki) ? i : xs[s]);
+        }
       }
     }
   } else {
@@ -1876,7 +1917,7 @@ __device__ __forceinline__ void spec_mutation(Grp<KT> &c, const SpecLds &S, doub
           return keep;
         };
         GT0(t_ev);
-        const double llk_i = spec_eval<KT, G, LT>(prop, pw, c, S, mmax, rpad, lane, known_mover_cuts);
+        const double llk_i = spec_eval<KT, G, LT, decltype(known_mover_cuts), G != 64>(prop, pw, c, S, mmax, rpad, lane, known_mover_cuts);
         GT1(c, 16, t_ev);
         if (prop) {
           double lprior_ratio = 0.0;
@@ -2018,10 +2059,23 @@ __device__ __forceinline__ bool spec_structural(Grp<KT> &c, const SpecLds &S, co
     }
   }
   GPHASE(c, 2);
+  // One chain per wave: the step's next 64 staged draws in a register, one per lane -- a sequential draw is then two v_readlane
+  // instead of a dependent LDS read (a structural step makes 3 to 10 of them one after the other)
+  const int dbase = G == 64 ? __builtin_amdgcn_readfirstlane(c.doff) : 0;
+  uint64_t dreg = 0;
+  if constexpr (G == 64) dreg = (!fill && dbase + lane < c.dcount) ? dtab[dbase + lane] : 0ull;
   auto next_words = [&]() -> uint64_t {
     const int i = c.doff;
     c.doff++;
     c.ctr++;
+    if constexpr (G == 64) {
+      const int k = __builtin_amdgcn_readfirstlane(i) - dbase;
+      if (k >= 0 && k < WAVE && dbase + k < __builtin_amdgcn_readfirstlane(c.dcount)) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dreg, k);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dreg >> 32), k);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+      }
+    }
     if (i < c.dcount) return dtab[i];
     uint32_t a, b;
     stream_words(ld_stream(S, gi), c.ctr - 1, a, b);

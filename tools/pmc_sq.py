@@ -12,4 +12,7 @@ for d in sys.argv[1:]:
             ids.add((path, row.get("Dispatch_Id")))
 for k, e in out.items():
     e["launches_seen"] = len(e.pop("_ids"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_sources_sha16  # noqa: E402  (bench.py quotes a summary only for the sources it was taken from)
+out["_meta"] = {"kernel_sources_sha16": kernel_sources_sha16()}
 json.dump(out, sys.stdout, indent=1, sort_keys=True)

@@ -47,8 +47,12 @@ cw, _ = per_launch("cal_write", ("calib_write_f64",))
 f_factor = cal_bytes / (cf["FETCH_SIZE"] * 1024.0) if cf.get("FETCH_SIZE") else None
 w_factor = cal_bytes / (cw["WRITE_SIZE"] * 1024.0) if cw.get("WRITE_SIZE") else None
 fs, ws = fetch.get("FETCH_SIZE", 0.0), write.get("WRITE_SIZE", 0.0)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_sources_sha16  # noqa: E402  (the summary names the sources it was taken from: bench.py quotes no other)
+
 out = {
-    "loci": loci, "mcmc_steps": steps, "chains": chains,
+    "loci": loci, "mcmc_steps": steps, "chains": chains, "kernel_sources_sha16": kernel_sources_sha16(),
     "FETCH_SIZE_KiB_per_launch": fs, "WRITE_SIZE_KiB_per_launch": ws,
     "calibration": {
         "pattern": "8 bytes per lane, 512 contiguous bytes per wavefront, 1 GiB streamed (tools/pmc_calib.hip)",
