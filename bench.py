@@ -425,31 +425,40 @@ def bench_config4(args):
     # (mchap_exact_workspace_bytes_cached, ExactDeviceBatch's default), twice otherwise
     cached = batch.ws_bytes > int(_lib_exact_ws(U, H, K))
     terms = (1.0 if cached else 2.0) * U * G * R
-    # Measured, not assumed (profiles/r03h_config4_sq_counters.json, rocprofv3 --pmc on this workload, whole launch):
-    # SQ_INSTS_VALU 7.65e9 wavefront instructions for 1.085e8 wavefront-terms = 70.5 per term, of which float64
-    # FMA 11.2 + ADD 16.1 + MUL 17.1 (+ 1.0 reciprocal) = 55.6 flop per (genotype, read) term with an FMA as two;
+    # Instructions per (genotype, read) term from the SQ counter passes of THIS workload on the current kernel sources
+    # (profiles/*_config4_sq_counters.json, tools/profile_round.sh: exact_pass1_kernel of one pass over 256 units; a summary taken
+    # from other sources is not quoted -- sq_counters_of).  float64 flop per term = FMA x 2 + ADD + MUL + reciprocals;
     # -ffp-contract=off keeps the K multiply-adds of a read's mean apart, as the reference's compiled loop has them.
-    flop_per_term = 55.6
-    valu_per_wave_term = 70.5
-    # issue cycles per wavefront-term, weighted per class (r03h_config4_sq_counters.json): float64 FMA 11.2 + ADD 16.1 + MUL 17.1 at 4
-    # cycles, one float64 reciprocal at 8, 6.3 64-bit integer ops at 4, the other 18.8 (moves, compares, selects, 32-bit integer) at 2
-    cyc_per_wave_term = (11.2 + 16.1 + 17.1) * VALU_CYCLES["f64"] + 1.0 * VALU_CYCLES["trans"] + 6.3 * VALU_CYCLES["int64"] \
-        + (valu_per_wave_term - 11.2 - 16.1 - 17.1 - 1.0 - 6.3) * VALU_CYCLES["other"]
     ms = res["streaming"]
+    c4, c4_src, c4_names = sq_counters_of("*_config4_sq_counters.json", ("exact_pass1_kernel",))
+    roof = {"bound": "valu_fp64", "peak": 78.6, "unit": "TFLOP/s", "terms_per_s": terms / (ms * 1e-3),
+            "second_pass": "from the joint log-probabilities kept in the workspace" if cached else "recomputed",
+            "note": "log-throughput bound: one float64 log per group of four (genotype, read) terms where the reads carry no counts "
+                    "(round 5: read_log_product), else one per term; 80 KB in, < 1 KB out per unit"}
+    if c4 is not None and c4.get("SQ_INSTS_VALU"):
+        per_launch_terms = float(256) * G * R / 64.0  # wavefront-terms of one launch of the profiled workload (256 units)
+        launches = max(1.0, round(float(c4["SQ_WAVES"]) / max(1.0, 256.0 * ((G + 4095) // 4096) * 4)))  # (4 waves per workgroup of 256 threads)
+        wt = per_launch_terms * launches
+        vpt = float(c4["SQ_INSTS_VALU"]) / wt
+        fma, add, mul = (float(c4.get(k, 0.0)) / wt for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+        trans, i64 = float(c4.get("SQ_INSTS_VALU_TRANS_F64", 0.0)) / wt, float(c4.get("SQ_INSTS_VALU_INT64", 0.0)) / wt
+        flop_per_term = 2.0 * fma + add + mul + trans
+        cyc = (fma + add + mul) * VALU_CYCLES["f64"] + trans * VALU_CYCLES["trans"] + i64 * VALU_CYCLES["int64"] \
+            + max(0.0, vpt - fma - add - mul - trans - i64) * VALU_CYCLES["other"]
+        roof.update({"achieved": terms * flop_per_term / (ms * 1e-3) / 1e12, "frac": terms * flop_per_term / (ms * 1e-3) / 1e12 / 78.6,
+                     "flop_per_term": flop_per_term, "valu_insts_per_wave_term": vpt,
+                     "valu_issue_frac": terms / 64.0 * cyc / (ms * 1e-3) / SIMD_CYCLES_PER_S, "valu_issue_cycles_per_wave_term": cyc,
+                     "valu_issue_note": "issue cycles weighted per instruction class (float64 and 64-bit integer 4, transcendental 8, other 2 "
+                                        "cycles per wavefront instruction) over 1024 SIMDs x 2.4 GHz",
+                     "counters": "%s (%s; SQ_INSTS_VALU* over %d launch(es): static figures of an earlier run on these sources)" % (c4_src, c4_names, int(launches))})
+    else:
+        roof.update({"achieved": None, "frac": None, "counters": "no SQ counter summary of the current kernel sources under profiles/ "
+                                                                   "(tools/profile_round.sh writes one): instruction figures not quoted"})
     out = {
         "workload": "%d units: hexaploid, %d haplotypes x %d SNVs, %d reads, G = %d genotypes, prior (0.1, Dirichlet(1)); HBM resident" % (U, H, M, R, G),
         "value": U / (ms * 1e-3), "unit": "units/s", "kernel": "exact_pass1_kernel + exact_pass2_kernel", "kernel_ms": ms,
         "arrays_value": U / (res["arrays"] * 1e-3), "arrays_kernel_ms": res["arrays"],
-        "roofline": {"bound": "valu_fp64", "achieved": terms * flop_per_term / (ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                     "frac": terms * flop_per_term / (ms * 1e-3) / 1e12 / 78.6, "terms_per_s": terms / (ms * 1e-3),
-                     "flop_per_term": flop_per_term, "valu_insts_per_wave_term": valu_per_wave_term,
-                     "valu_issue_frac": terms / 64.0 * cyc_per_wave_term / (ms * 1e-3) / SIMD_CYCLES_PER_S,
-                     "valu_issue_cycles_per_wave_term": cyc_per_wave_term,
-                     "valu_issue_note": "issue cycles weighted per instruction class (float64 and 64-bit integer 4, transcendental 8, other 2 "
-                                        "cycles per wavefront instruction) over 1024 SIMDs x 2.4 GHz; round 3 priced every instruction at 4",
-                     "counters": "profiles/r03h_config4_sq_counters.json (SQ_INSTS_VALU* per launch)",
-                     "second_pass": "from the joint log-probabilities kept in the workspace" if cached else "recomputed",
-                     "note": "log-throughput bound: one float64 log per (genotype, read) term; 80 KB in, < 1 KB out per unit"},
+        "roofline": roof,
     }
     if not args.no_cpu_baseline:
         from oracle import binding as orc

@@ -71,7 +71,10 @@ typedef struct mchap_denovo_tuning {
                             1024: table completion inside the exporting launch, 8192: no LDS front cache of a chain's likelihoods,
                             16384: a ladder's replicas on one wavefront, 32768: no completion memo across chunks, 65536: caches
                             cleared per call instead of epoch tags, 131072: one wavefront per chain in every coasting launch,
-                            262144: a round's misses behind a sub-step known to move are evaluated as well
+                            262144: a round's misses behind a sub-step known to move are evaluated as well, 524288: no decision
+                            contexts per genotype for the phased sampler's resumed chains, 1048576: a logarithm per read even where
+                            the read weights are 0 / 1 (else one per group of four reads: the log likelihoods then differ in the last
+                            bits, the traces do not)
                             (DESIGN.md section 4 names each) */
   int32_t spec_group;    /* kernel 3: lanes per chain, 16 / 32 / 64 (default: the smallest the shape allows) */
   int32_t pipe_first;    /* kernel 5: MCMC steps before the first hand-over (default ploidy * n_pos / 10, clamped to 3..32) */
@@ -106,7 +109,12 @@ typedef struct mchap_denovo_cfg {
                                                MCMC step (single temperature, one ploidy per launch).  Identical results
                                                whichever runs.  (1 = wavefront per chain and 4 = settle/steady pipeline are
                                                earlier designs kept for the parity suite: libmchap_hip_test.so only.) */
-  int32_t reserved;
+  int32_t cache_epoch;                      /* 1 .. 2^31 - 2: a number no other fit on memory this fit's workspace may reuse has carried
+                                               (the likelihood caches of packed genotypes are tagged with it instead of being
+                                               cleared: what an earlier call left in the workspace never matches).  The Python
+                                               host hands out ONE process-wide sequence to every library copy it has loaded
+                                               (mchap_amd/_lib.py next_cache_epoch).  0: the library's own counter -- unique among
+                                               the fits of one loaded copy of the library, which is what a C caller has */
   const mchap_denovo_tuning *tuning;        /* HOST pointer or NULL */
   void *timer;                              /* mchap_timer_create() handle or NULL: the sampler launches of this call are
                                                bracketed by HIP events on the call's stream (not the prepare pass) */
@@ -191,6 +199,10 @@ int mchap_log_likelihood_batch(const double *reads, int n_reads, int n_pos, int 
 /* Test hook: the logarithm the likelihood kernels take of their per-read terms (csrc/read_log.hpp: < 1 ulp; 0 -> -inf,
  * negative or NaN -> NaN), for n arguments.  Host pointers. */
 int mchap_read_log_batch(const double *x, int64_t n, double *out);
+/* Test hook: the logarithm of the product of `group` (1..4) per-read terms as ONE logarithm -- mantissas multiplied, exponents
+ * summed (csrc/read_log.hpp read_log_product) -- which is what the likelihood kernels take of a lane's reads where the read weights
+ * are 0 / 1: out[i] for x[i * group .. i * group + group - 1].  Host pointers. */
+int mchap_read_log_product_batch(const double *x, int64_t n, int group, double *out);
 /* Test hook: the 64-lane sum every likelihood goes through (csrc/denovo_kernel.hpp wave_sum: the XOR butterfly's tree, its last
  * four steps through DPP row rotations): out[w] = sum of x[64 w .. 64 w + 63].  Host pointers. */
 int mchap_wave_sum_batch(const double *x, int64_t n_waves, double *out);

@@ -5,6 +5,7 @@ entry point is called, an exception is raised.
 """
 import ctypes as C
 import os
+import threading
 import subprocess
 
 import numpy as np
@@ -87,6 +88,19 @@ def tuning_from_env():
     return t if used else None
 
 
+_epoch_lock = threading.Lock()
+_epoch = [0]
+
+
+def next_cache_epoch():
+    """The number a fit tags its likelihood-cache entries with (mchap_denovo_cfg.cache_epoch): ONE sequence for the whole process,
+    whichever copy of the library runs the fit -- the parity suite loads libmchap_hip.so and libmchap_hip_test.so side by side, and
+    torch's allocator hands the same workspace block to both.  0 after 2^31 - 2 fits: the library then clears the tables."""
+    with _epoch_lock:
+        _epoch[0] += 1
+        return _epoch[0] if _epoch[0] < (1 << 31) - 1 else 0
+
+
 class DenovoCfg(C.Structure):
     _fields_ = [
         ("steps", C.c_int32),
@@ -103,7 +117,7 @@ class DenovoCfg(C.Structure):
         ("max_pos", C.c_int32),
         ("llk_cache", C.c_int32),
         ("kernel", C.c_int32),
-        ("reserved", C.c_int32),
+        ("cache_epoch", C.c_int32),
         ("tuning", C.POINTER(DenovoTuning)),
         ("timer", C.c_void_p),
     ]
@@ -258,6 +272,7 @@ EXPORTS = [
     "mchap_timer_destroy",
     "mchap_denovo_sampler_name",
     "mchap_read_log_batch",
+    "mchap_read_log_product_batch",
     "mchap_wave_sum_batch",
     "mchap_denovo_trace_words_per_haplotype",
 ]

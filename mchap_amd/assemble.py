@@ -231,6 +231,7 @@ class DenovoMCMC(Assembler):
         status = np.zeros(n_units, dtype=np.int32)
         L = _lib.lib()
         self.last_sampler = _lib.sampler_name(cfg, units)  # (not a reference field: which kernel(s) the batch ran on)
+        cfg.cache_epoch = _lib.next_cache_epoch()
         rc = L.mchap_denovo_fit_batch(
             C.byref(cfg), n_units, _lib.ptr(units), _lib.ptr(reads_flat), C.c_int64(reads_flat.size),
             _lib.ptr(counts_flat), C.c_int64(0 if counts_flat is None else counts_flat.size),

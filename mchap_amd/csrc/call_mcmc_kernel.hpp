@@ -245,11 +245,32 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
       }
     } else {  // table in the LDS: ds_read instead of flat_load (exact_kernel.hpp lds_table), same values
       lds_cdouble *ptab = lds_table(E.ptab), *cnt = lds_table(E.cnt);
-      for (int r = lane; r < R; r += WAVE) {
-        lds_cdouble *row = ptab + r * H;
-        double rp = 0.0;
-        for (int i = 0; i < kk; i++) rp += row[s_req[i]] * invk;
-        s += read_log(rp) * cnt[r];
+      int r = lane;
+      if (E.w01) {
+        // unweighted reads (round 5): the lane's reads four at a time, ONE logarithm for their product (read_log_product) --
+        // a lane without a fourth read takes the factor 1
+        for (; r < R; r += 4 * WAVE) {
+          double rp[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const int rr = r + t * WAVE;
+            rp[t] = 0.0;
+            if (rr < R) {
+              lds_cdouble *row = ptab + rr * H;
+              for (int i = 0; i < kk; i++) rp[t] += row[s_req[i]] * invk;
+            } else {
+              rp[t] = 1.0;
+            }
+          }
+          s += read_log_product<4>(rp);
+        }
+      } else {
+        for (; r < R; r += WAVE) {
+          lds_cdouble *row = ptab + r * H;
+          double rp = 0.0;
+          for (int i = 0; i < kk; i++) rp += row[s_req[i]] * invk;
+          s += read_log(rp) * cnt[r];
+        }
       }
     }
     return wave_sum(s);

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(64, 1) void denovo_fill_kernel(const SimtParams P) 
   const int32_t *mi = P.meta_i + (size_t)u * meta_i_stride(P.max_pos);
   const double *mf = P.meta_f + (size_t)u * meta_f_stride(P.max_ploidy, P.max_pos, P.max_allele);
   const int Mh = mi[META_I_MH];
+  const bool w01 = mi[META_I_W01] != 0;
   const int A = U.max_allele;
   const int bits = allele_bits(A);
   const uint32_t amask = (1u << bits) - 1u;
@@ -616,9 +617,16 @@ __global__ __launch_bounds__(64, 1) void denovo_fill_kernel(const SimtParams P) 
                   }
                 }
                 double blk = 0.0;
+                if (w01) {  // one logarithm for the block (read_log_sum: what every other kernel forms for these reads)
+                  double y[4];
 #pragma unroll
-                for (int x = 0; x < 4; x++)
-                  if (x < nb) blk += read_log(acc[x]) * cwv[x];
+                  for (int x = 0; x < 4; x++) y[x] = (x < nb && cwv[x] != 0.0) ? acc[x] : 1.0;
+                  blk = read_log_product<4>(y);
+                } else {
+#pragma unroll
+                  for (int x = 0; x < 4; x++)
+                    if (x < nb) blk += read_log(acc[x]) * cwv[x];
+                }
                 s_l[q] += blk;
               }
             }

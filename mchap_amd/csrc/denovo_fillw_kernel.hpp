@@ -224,6 +224,7 @@ struct FillwUnit {
   bool coded;
   bool has_gbp;
   bool has_tab, has_bpk;  // (explicit flags: an LDS pointer at offset 0 -- lane 0's `tab + lane` -- must not read as "no table")
+  bool w01;               // the unit's read weights are 0 / 1: one logarithm per lane and block of chunks (read_log_sum)
 };
 
 // prod[i] = product over the positions of haplotype word w, reads lane + 64 (cb + i), from the coded table (or the float64 rows)
@@ -286,10 +287,10 @@ __device__ __forceinline__ double fillw_block(const FillwUnit &U, const GWords<K
         acc[i] += (h == h1) ? p1[i] : ((h == h2) ? p2[i] : b);
       }
     }
-    double s = 0.0;
+    double wv[RPL];
 #pragma unroll
-    for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * U.cwl[i * WAVE];
-    return s;
+    for (int i = 0; i < RPL; i++) wv[i] = U.cwl[i * WAVE];
+    return read_log_sum<RPL>(acc, wv, U.w01);
   }
   if (DEEP && !FIRST && U.has_gbp) {
     // deep units: the products of the haplotypes the request did not change come from the chain's rows in the workspace (formed
@@ -308,10 +309,10 @@ __device__ __forceinline__ double fillw_block(const FillwUnit &U, const GWords<K
     for (int h = 0; h < KT; h++)
 #pragma unroll
       for (int i = 0; i < RPL; i++) acc[i] += ((h == h1) ? p1[i] : ((h == h2) ? p2[i] : bpv[h][i])) * invK;
-    double s = 0.0;
+    double wv[RPL];
 #pragma unroll
-    for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * U.cw[(size_t)(cb + i) * WAVE];
-    return s;
+    for (int i = 0; i < RPL; i++) wv[i] = U.cw[(size_t)(cb + i) * WAVE];
+    return read_log_sum<RPL>(acc, wv, U.w01);
   }
 #pragma unroll 1
   for (int h = 0; h < KT; h++) {
@@ -321,10 +322,10 @@ __device__ __forceinline__ double fillw_block(const FillwUnit &U, const GWords<K
 #pragma unroll
     for (int i = 0; i < RPL; i++) acc[i] += ph[i] * invK;
   }
-  double s = 0.0;
+  double wv[RPL];
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * U.cw[(size_t)(cb + i) * WAVE];
-  return s;
+  for (int i = 0; i < RPL; i++) wv[i] = U.cw[(size_t)(cb + i) * WAVE];
+  return read_log_sum<RPL>(acc, wv, U.w01);
 }
 
 template <int KT, bool FIRST, bool DEEP>
@@ -453,6 +454,7 @@ __global__ __launch_bounds__(FILLW_NT, MCHAP_FILLW_WPE) void denovo_fillw_kernel
   const bool use_tab = !flat && Mh * A <= tab_rows;
   FU.tab = (LDSP(const double))(tab + lane);
   FU.bpk = (LDSP(const double))(bp + lane);
+  FU.w01 = mi[META_I_W01] != 0;
   FU.has_tab = use_tab;
   FU.has_bpk = !flat;
   FU.cwl = (LDSP(const double))(cwl + lane);

@@ -286,6 +286,7 @@ struct Chain {
   uint64_t *cache;   // this chain's {tag, value} table or nullptr
   uint32_t cache_mask;
   int key_bits;      // bits per haplotype word actually used (Mh * bits)
+  bool w01;          // every read weight of the unit is 0 or 1: one logarithm per group of four chunks (read_log_sum_chunks)
 };
 
 // Likelihood cache: the reference memoises log_likelihood per genotype in an array-backed trie
@@ -329,10 +330,7 @@ __device__ __forceinline__ double eval_llk(const Chain &c, const uint64_t *hw, c
 #pragma unroll
     for (int i = 0; i < RPL; i++) acc[i] += prod[i] * c.invK;
   }
-  double s = 0.0;
-#pragma unroll
-  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cnt[i];
-  return wave_sum(s);
+  return wave_sum(read_log_sum_chunks<RPL>(acc, cnt, c.w01));
 }
 
 template <int RPL>
@@ -682,10 +680,15 @@ __global__ __launch_bounds__(64 * CHAINS_PER_BLOCK) void denovo_mcmc_kernel(cons
     const int r = lane + WAVE * i;
     cnt[i] = (r < R) ? (U.counts_off >= 0 ? (double)P.counts[U.counts_off + r] : 1.0) : 0.0;
   }
+  bool w01_l = true;
+#pragma unroll
+  for (int i = 0; i < RPL; i++) w01_l = w01_l && (cnt[i] == 0.0 || cnt[i] == 1.0);
+  const bool w01_u = __ballot(!w01_l) == 0ull;  // (as the prepare pass of the other kernels decides: META_I_W01)
   __syncthreads();
   if (chain >= P.chains) return;
 
   Chain c;
+  c.w01 = w01_u;
   c.rl = rl;
   c.w = reinterpret_cast<uint64_t *>(ws + L.w);
   c.pw = reinterpret_cast<uint64_t *>(ws + L.pw);
@@ -963,8 +966,12 @@ __global__ __launch_bounds__(256) void llk_batch_kernel(const double *reads, int
     const int r = lane + WAVE * i;
     cnt[i] = (r < R) ? (counts ? (double)counts[r] : 1.0) : 0.0;
   }
+  bool w01_l = true;
+#pragma unroll
+  for (int i = 0; i < RPL; i++) w01_l = w01_l && (cnt[i] == 0.0 || cnt[i] == 1.0);
   unsigned char *ws = smem + (size_t)MA * rpad * sizeof(double) + (size_t)wave * (8 * K + 4 * M + 64);
   Chain c;
+  c.w01 = __ballot(!w01_l) == 0ull;  // (the samplers' rule: one logarithm per group of four chunks where the weights are 0 / 1)
   c.rl = rl;
   c.pw = reinterpret_cast<uint64_t *>(ws);
   c.hetrow = reinterpret_cast<uint16_t *>(ws + 8 * K);

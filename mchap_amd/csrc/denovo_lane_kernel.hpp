@@ -807,7 +807,7 @@ __global__ __launch_bounds__(64, 1) void denovo_settle_kernel(const SimtParams P
     gp[GP_TRACE] = (uint64_t)(uintptr_t)(D.trace + U.trace_off + (size_t)chain * D.steps * KT);
     gp[GP_LLK] = (uint64_t)(uintptr_t)(D.llks + U.llk_off + (size_t)chain * D.steps);
     LL.nreads[ci] = (uint16_t)(c.alive ? U.n_reads : 0);
-    LL.ndict[ci] = (uint16_t)((c.alive && !(P.flags & 4)) ? mi[META_I_NDICT] : 0);
+    LL.ndict[ci] = (uint16_t)(((c.alive && !(P.flags & 4)) ? mi[META_I_NDICT] : 0) | ((c.alive && mi[META_I_W01] != 0) ? (int)ND_W01 : 0));
   }
   if (c.alive) {
     for (int j = sl; j < Mh; j += L) {

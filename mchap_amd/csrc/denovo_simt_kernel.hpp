@@ -25,8 +25,14 @@ constexpr int META_I_NDICT = 2;   // distinct values of the unit's table (0: mor
 constexpr int META_I_FLAT = 3;    // 1: every entry of the unit's table (existing alleles) is a gap -- a sample without reads
                                   // at the locus, which the reference samples all the same (assemble/mcmc.py:132-137): the
                                   // likelihood of every genotype is then the same number
-constexpr int META_I_COLS = 4;    // then [M]: column (j * A) of sampled position jj ; then [M]: n_alleles
-__host__ __device__ inline int meta_i_stride(int max_pos) { return 4 + 2 * max_pos; }
+constexpr int META_I_W01 = 4;     // 1: every read weight of the unit is 0 or 1 (no counts of de-duplicated rows): the lanes take ONE
+                                  // logarithm per group of up to four reads (read_log_sum, read_log.hpp); tuning flag 1048576: never
+constexpr int META_I_COLS = 5;    // then [M]: column (j * A) of sampled position jj ; then [M]: n_alleles
+__host__ __device__ inline int meta_i_stride(int max_pos) { return 5 + 2 * max_pos; }
+// SpecLds::ndict and its like hold the dictionary size with the unit's META_I_W01 in the top bit
+constexpr uint16_t ND_W01 = 0x8000u;
+__host__ __device__ inline int nd_count(uint16_t x) { return (int)(x & 0x7FFFu); }
+__host__ __device__ inline bool nd_w01(uint16_t x) { return (x & ND_W01) != 0; }
 // Coded read table (speculative sampler): a unit's table usually holds a few dozen distinct probabilities
 // (one per base quality, its error share, 1.0 for gaps), so it is also stored as uint8 codes into a per-unit
 // dictionary of float64 values: lossless, 8x smaller, and what the likelihood evaluation then streams stays in L2.
@@ -180,6 +186,13 @@ __global__ __launch_bounds__(64, MCHAP_PREP_WPE) void denovo_prepare_kernel(cons
     const int r = lane + WAVE * i;
     cnt[i] = (r < R) ? (U.counts_off >= 0 ? (double)D.counts[U.counts_off + r] : 1.0) : 0.0;
     cw[r] = cnt[i];
+  }
+  {
+    bool w01 = true;
+#pragma unroll
+    for (int i = 0; i < RPL; i++) w01 = w01 && (cnt[i] == 0.0 || cnt[i] == 1.0);
+    const bool all01 = __ballot(!w01) == 0ull;
+    if (lane == 0) mi[META_I_W01] = (all01 && !(P.flags & (1 << 20))) ? 1 : 0;
   }
   __syncthreads();
   // ---- dictionary + coded table ----
@@ -513,7 +526,8 @@ struct Lane {
   double invK, inbreeding;
   bool alive;            // lane owns a chain that is still running
   const double *rt;      // unit's transposed reads [ma][rpad]
-  const double *cw;      // unit's counts [rpad]
+  const double *cw;      // unit's counts [rpad]; bit 0 of the pointer: the unit's META_I_W01 (its weights are 0 / 1: one logarithm per
+                         // group of four chunks) -- a field of its own here made the 128-bit instantiation fault (round 5)
   ulonglong2 *cache;
   uint64_t *ckeys;  // words of the cached genotypes when they are wider than the tag (else nullptr)
   int key_words;
@@ -628,7 +642,7 @@ __device__ __forceinline__ W lane_interval_mask(const Lane &c, int start, int st
 // flight before the first multiply (one exposed memory latency per UNR pairs, not per pair)
 template <int RPL, class W>
 __device__ __forceinline__ double coop_body(const SimtLdsT<W> &S, int src, int K, int Mh, uint32_t amask, double invK,
-                                            const double *rt, const double *cw, int rpad, int lane) {
+                                            const double *rt, const double *cw, int rpad, int lane, bool grouped) {
   constexpr int UNR = RPL <= 4 ? 8 : (RPL == 8 ? 4 : 2);
   const int n_pairs = K * Mh;
   double acc[RPL], prod[RPL];
@@ -677,10 +691,10 @@ __device__ __forceinline__ double coop_body(const SimtLdsT<W> &S, int src, int K
       }
     }
   }
-  double s = 0.0;
+  double wv[RPL];
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
-  return wave_sum(s);
+  for (int i = 0; i < RPL; i++) wv[i] = cw[WAVE * i];
+  return wave_sum(read_log_sum_chunks<RPL>(acc, wv, grouped));
 }
 
 // Co-operative likelihood evaluation of the proposals S.pw[.][src] of every lane `src` with need set:
@@ -702,13 +716,14 @@ __device__ inline double coop_eval(bool need, const SimtLdsT<W> &S, const Lane &
     const unsigned long long rtb = __shfl((unsigned long long)(uintptr_t)c.rt, src, WAVE);
     const unsigned long long cwb = __shfl((unsigned long long)(uintptr_t)c.cw, src, WAVE);
     const double *rt = reinterpret_cast<const double *>((uintptr_t)rtb) + lane;
-    const double *cw = reinterpret_cast<const double *>((uintptr_t)cwb) + lane;
+    const double *cw = reinterpret_cast<const double *>((uintptr_t)(cwb & ~1ull)) + lane;
+    const bool grouped = (cwb & 1ull) != 0ull;
     double s;
-    if (nch == 4) s = coop_body<4, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
-    else if (nch == 1) s = coop_body<1, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
-    else if (nch == 2) s = coop_body<2, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
-    else if (nch == 8) s = coop_body<8, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
-    else s = coop_body<16, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane);
+    if (nch == 4) s = coop_body<4, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane, grouped);
+    else if (nch == 1) s = coop_body<1, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane, grouped);
+    else if (nch == 2) s = coop_body<2, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane, grouped);
+    else if (nch == 8) s = coop_body<8, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane, grouped);
+    else s = coop_body<16, W>(S, src, K, Mh, amask, invK, rt, cw, rpad, lane, grouped);
     if (lane == src) result = s;
   }
   return result;
@@ -1091,7 +1106,7 @@ __global__ __launch_bounds__(64) void denovo_simt_kernel(const SimtParams P) {
   c.inbreeding = U.inbreeding;
   c.key_bits = c.bits * c.Mh;
   c.rt = P.rt + (size_t)u * P.max_ma * rpad;
-  c.cw = P.cntw + (size_t)u * rpad;
+  c.cw = reinterpret_cast<const double *>((uintptr_t)(P.cntw + (size_t)u * rpad) | (uintptr_t)((c.alive && mi[META_I_W01] != 0) ? 1 : 0));
   c.cache = nullptr;
   c.cache_mask = 0;
   c.ckeys = nullptr;

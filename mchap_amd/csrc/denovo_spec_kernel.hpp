@@ -499,7 +499,7 @@ __device__ __forceinline__ void genotype_changed(Grp<KT> &c) {
 // ---- decision contexts per genotype (round 5) ----
 // A chain that never settles (phase-ambiguous samples, shallow pileups) keeps coming back to genotypes it has held before: at
 // docs/example's slowest units 98 % of the accepted moves lead to one of the last 64 ORDERED genotypes, at the shallow synthetic
-// units (40 reads of quality 3-20) 95 % to one of the last 32 (tests/analyze_moves.py: the oracle's sub-step log).  Everything a
+// units (40 reads of quality 3-20) 95 % to one of the last 32 (tests/aids/analyze_moves.py: the oracle's sub-step log).  Everything a
 // sub-step decides with is a pure function of the ordered genotype g it starts from (mutation.py:60-161): for sub-step e = (h, j)
 // the move probability pr(g, e) and the likelihood of the genotype the move leads to; for an interval step (structural.py:490-587)
 // the total move probability tot(g, type, start, stop).  Without contexts every accepted move starts a new speculation round --
@@ -634,7 +634,7 @@ __device__ __forceinline__ bool ctx_acquire(Grp<KT> &c, const SpecLds &S, int n,
 template <int KT, int RPL>
 __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
                                                  GLBP(const double) rt, GLBP(const double) cw, int rpad, int lane,
-                                                 int nrd) {
+                                                 int nrd, bool grouped) {
   // nrd: reads left from this block's first read on.  With -DMCHAP_MASK_PADDING lanes whose read is padding keep the
   // neutral 1.0 / count 0 without loading the padded tail of the row: 33 % fewer HBM bytes at config #2 (R = 200 in
   // rows of 256) but 2.5 % slower (a compare and an exec update per load), so it is off by default.
@@ -688,10 +688,10 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
       }
     }
   }
-  double s = 0.0;
+  double wv[RPL];
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * (MCHAP_PAD_LANE(lane + WAVE * i < nrd) ? cw[WAVE * i] : 0.0);
-  return s;  // per-lane partial sum; the caller reduces across the wave
+  for (int i = 0; i < RPL; i++) wv[i] = MCHAP_PAD_LANE(lane + WAVE * i < nrd) ? cw[WAVE * i] : 0.0;
+  return read_log_sum<RPL>(acc, wv, grouped);  // per-lane partial sum; the caller reduces across the wave
 }
 
 // The same evaluation from the coded table: one load per (haplotype, position) pair fetches the codes of the
@@ -699,7 +699,7 @@ __device__ __forceinline__ double spec_coop_body(const SpecLds &S, int src, int 
 // Same factors in the same order, hence the same value as spec_coop_body.
 template <int KT, int RPL, class CT, bool LT = false>
 __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
-                                                  typename TabPtr<LT>::u8 ct, typename TabPtr<LT>::f64 cw, int crow, int lane) {
+                                                  typename TabPtr<LT>::u8 ct, typename TabPtr<LT>::f64 cw, int crow, int lane, bool grouped) {
   // ct points at the lane's first code of the block of RPL chunks; cw at the lane's first read of the block;
   // crow = bytes per row of the coded table
   constexpr int UNR = MCHAP_CODED_UNR;
@@ -763,10 +763,10 @@ __device__ __forceinline__ double spec_coop_coded(const SpecLds &S, int src, int
       }
     }
   }
-  double s = 0.0;
+  double wv[RPL];
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
-  return s;
+  for (int i = 0; i < RPL; i++) wv[i] = cw[WAVE * i];
+  return read_log_sum<RPL>(acc, wv, grouped);
 }
 
 // ---- coded evaluation, one haplotype at a time ----
@@ -867,7 +867,7 @@ struct BaseProductsG {
 template <int KT, int RPL, class CT, bool LT = false, class BP>
 __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
                                                   typename TabPtr<LT>::u8 ct, typename TabPtr<LT>::f64 cw, int crow, int lane,
-                                                  const BP &bp, bool use_base) {
+                                                  const BP &bp, bool use_base, bool grouped) {
   LDSP(double) dict = S.dict + (size_t)sg * DICT_MAX;
   const double invK = 1.0 / (double)KT;
   const PairRows rows = spec_pair_rows<KT>(S.pw, WAVE, src, S, sg, mmax, Mh, amask, lane);
@@ -888,10 +888,10 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
 #pragma unroll
     for (int i = 0; i < RPL; i++) acc[i] += ph[i] * invK;
   }
-  double s = 0.0;
+  double wv[RPL];
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
-  return s;
+  for (int i = 0; i < RPL; i++) wv[i] = cw[WAVE * i];
+  return read_log_sum<RPL>(acc, wv, grouped);
 }
 // The same for a block of deep chunks, whose base products come from the workspace: the K x RPL loads of a block go out
 // together, ahead of everything else (behind the per-haplotype branches each would be a memory round trip of its own:
@@ -900,7 +900,7 @@ __device__ __forceinline__ double spec_coop_reuse(const SpecLds &S, int src, int
 template <int KT, int RPL, class CT, bool LT = false>
 __device__ __forceinline__ double spec_coop_reuse_g(const SpecLds &S, int src, int sg, int mmax, int Mh, uint32_t amask,
                                                     typename TabPtr<LT>::u8 ct, typename TabPtr<LT>::f64 cw, int crow, int lane,
-                                                    const BaseProductsG<KT> &bg) {
+                                                    const BaseProductsG<KT> &bg, bool grouped) {
   double bpv[KT][RPL];
 #pragma unroll
   for (int h = 0; h < KT; h++)
@@ -926,10 +926,10 @@ __device__ __forceinline__ double spec_coop_reuse_g(const SpecLds &S, int src, i
 #pragma unroll
     for (int i = 0; i < RPL; i++) acc[i] += ph[i] * invK;
   }
-  double s = 0.0;
+  double wv[RPL];
 #pragma unroll
-  for (int i = 0; i < RPL; i++) s += read_log(acc[i]) * cw[WAVE * i];
-  return s;
+  for (int i = 0; i < RPL; i++) wv[i] = cw[WAVE * i];
+  return read_log_sum<RPL>(acc, wv, grouped);
 }
 template <int KT, int RPL, class CT, bool LT = false, class BP>
 __device__ __forceinline__ void spec_base_products(const SpecLds &S, int sg, int mmax, int Mh, uint32_t amask,
@@ -1005,12 +1005,13 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
     if constexpr (LT) cw = lds_cw + lane;
     else cw = (GLBP(const double))(uintptr_t)gp[GP_CW] + lane;
     const int nrd = (int)nreads_tab[sg];
+    const bool grouped = nd_w01(ndict_tab[sg]);  // the unit's weights are 0 / 1: one logarithm per lane and block of chunks
     // read chunks of THIS unit: a batch is padded to its deepest unit, but the chunks beyond a unit's own reads hold
     // padding only -- weight 0, terms +-0.0, which every sum absorbs exactly -- so they are not evaluated (a ragged
     // batch of real pileups is mostly shallow units: docs/example has 2 to 534 read pairs per unit)
     const int nch = max(1, min(nch_batch, (nrd + WAVE - 1) / WAVE));
     const int cstride = crow / WAVE;  // code bytes per lane and row
-    if (MCHAP_REUSE_MAXK >= KT && ndict_tab[sg] != 0 && KT * Mh <= (MCHAP_SPEC_DEEP ? 3 : 2) * WAVE) {
+    if (MCHAP_REUSE_MAXK >= KT && nd_count(ndict_tab[sg]) != 0 && KT * Mh <= (MCHAP_SPEC_DEEP ? 3 : 2) * WAVE) {
       // coded table, one haplotype at a time; with use_base the haplotypes a request did not change are skipped.
       // The base products cover the first block of (up to) 4 chunks; deeper reads add their other blocks in full.
       const int nb0 = nch < 4 ? nch : 4;
@@ -1401,10 +1402,10 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
         const unsigned long long dups = (DEDUP ? spec_same_request<KT>(pwbuf, reqs, src, lane) : (1ull << src));
         reqs &= ~dups;
         double s = 0.0;
-        if (nb0 == 1) s += spec_coop_reuse<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
-        else if (nb0 == 2) s += spec_coop_reuse<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
-        else if (nb0 == 3) s += spec_coop_reuse<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
-        else s += spec_coop_reuse<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base);
+        if (nb0 == 1) s += spec_coop_reuse<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base, grouped);
+        else if (nb0 == 2) s += spec_coop_reuse<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base, grouped);
+        else if (nb0 == 3) s += spec_coop_reuse<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base, grouped);
+        else s += spec_coop_reuse<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct, cw, crow, lane, bp, use_base, grouped);
         for (int cb = 4; cb < nch; cb += 4) {
           const int rem = nch - cb;
           typename TabPtr<LT>::f64 cwb = cw + cb * WAVE;
@@ -1413,15 +1414,15 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
             bg.p = gbp;
             bg.rpad = rpad;
             bg.cb = cb;
-            if (rem >= 4) s += spec_coop_reuse_g<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg);
-            else if (rem == 3) s += spec_coop_reuse_g<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg);
-            else if (rem == 2) s += spec_coop_reuse_g<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg);
-            else s += spec_coop_reuse_g<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg);
+            if (rem >= 4) s += spec_coop_reuse_g<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, grouped);
+            else if (rem == 3) s += spec_coop_reuse_g<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, grouped);
+            else if (rem == 2) s += spec_coop_reuse_g<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, grouped);
+            else s += spec_coop_reuse_g<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, bg, grouped);
           } else {
-            if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-            else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-            else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-            else s += spec_coop_coded<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, grouped);
+            else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, grouped);
+            else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, grouped);
+            else s += spec_coop_coded<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, grouped);
           }
         }
         s = wave_sum(s);
@@ -1435,7 +1436,7 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
         // the lane's reads in blocks of at most 4 chunks of 64 (keeps the loads in flight, and the registers,
         // bounded whatever the read depth); the last block may hold 1-3 chunks
         double s = 0.0;
-        const bool coded = ndict_tab[sg] != 0;
+        const bool coded = nd_count(ndict_tab[sg]) != 0;
         typename TabPtr<LT>::u8 ct;
         if constexpr (LT) ct = lds_ct + (size_t)lane * cstride;
         else ct = (GLBP(const uint8_t))(uintptr_t)gp[GP_CT] + (size_t)lane * cstride;
@@ -1444,17 +1445,17 @@ __device__ __forceinline__ double spec_coop_all(unsigned long long todo, LDSP(ui
           const int rem = nch - cb;
           typename TabPtr<LT>::f64 cwb = cw + cb * WAVE;
           if (coded) {
-            if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-            else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-            else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
-            else s += spec_coop_coded<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane);
+            if (rem >= 4) s += spec_coop_coded<KT, 4, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, grouped);
+            else if (rem == 3) s += spec_coop_coded<KT, 3, uint32_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, grouped);
+            else if (rem == 2) s += spec_coop_coded<KT, 2, uint16_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, grouped);
+            else s += spec_coop_coded<KT, 1, uint8_t, LT>(S, src, sg, mmax, Mh, amask, ct + cb, cwb, crow, lane, grouped);
           } else {
             GLBP(const double) rtb = rt + cb * WAVE;
             GLBP(const double) cwgb = cwg + cb * WAVE;
-            if (rem >= 4) s += spec_coop_body<KT, 4>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE);
-            else if (rem == 3) s += spec_coop_body<KT, 3>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE);
-            else if (rem == 2) s += spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE);
-            else s += spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE);
+            if (rem >= 4) s += spec_coop_body<KT, 4>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE, grouped);
+            else if (rem == 3) s += spec_coop_body<KT, 3>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE, grouped);
+            else if (rem == 2) s += spec_coop_body<KT, 2>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE, grouped);
+            else s += spec_coop_body<KT, 1>(S, src, sg, mmax, Mh, amask, rtb, cwgb, rpad, lane, nrd - cb * WAVE, grouped);
           }
         }
         s = wave_sum(s);
@@ -2700,7 +2701,7 @@ __global__ __launch_bounds__(TW ? 64 * SPEC_TW_MAX : 64, TW ? 2 : MCHAP_SPEC_WPE
   if (gl == 0) S.nreads[gi] = (uint16_t)(c.alive ? U.n_reads : 0);
   {
     const int nd = (c.alive && !(P.flags & 4)) ? mi[META_I_NDICT] : 0;
-    if (gl == 0) S.ndict[gi] = (uint16_t)nd;
+    if (gl == 0) S.ndict[gi] = (uint16_t)(nd | ((c.alive && mi[META_I_W01] != 0) ? (int)ND_W01 : 0));
     const double *du = P.dict + (size_t)u * DICT_MAX;
     for (int i = gl; i < nd; i += G) S.dict[(size_t)gi * DICT_MAX + i] = du[i];
   }

@@ -144,6 +144,7 @@ struct ExactLds {
   double *lgf;    // [K+1]
   double *lfreq;  // [H]
   double *red;    // reduction scratch (the rest of the allocation)
+  bool w01;       // every read weight of the unit is 1: ONE logarithm per four consecutive reads (read_log_product, round 5)
 };
 // Builds P[r][h], the read weights and the prior tables of `unit` (whole workgroup; ends with a barrier).
 // (with P.Rcap < R only the first Rcap reads are tabulated here: exact_tile brings in the others, tile by tile)
@@ -175,6 +176,13 @@ __device__ __forceinline__ void exact_setup(const ExactParams &P, int unit, unsi
     E.ptab[q] = prod;
   }
   for (int r = threadIdx.x; r < R; r += blockDim.x) E.cnt[r] = P.counts ? (double)P.counts[(size_t)unit * P.R + r] : 1.0;
+  {
+    // (over ALL reads of the unit, not only the first tile's: the groups of four run through the tiles)
+    int weighted = 0;
+    if (P.counts)
+      for (int r = threadIdx.x; r < P.R; r += blockDim.x) weighted |= (P.counts[(size_t)unit * P.R + r] != 1) ? 1 : 0;
+    E.w01 = __syncthreads_or(weighted) == 0;
+  }
   double F = 0.0;
   const bool has_prior = P.has_prior != 0;
   const bool has_freqs = has_prior && P.freqs != nullptr;
@@ -220,7 +228,22 @@ __device__ __forceinline__ lds_cdouble *lds_table(const double *p) { return (lds
 __device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[MCHAP_MAX_PLOIDY], int R, int H, int K, double invK) {
   double llk = 0.0;
   lds_cdouble *ptab = lds_table(E.ptab), *cnt = lds_table(E.cnt);
-  for (int r = 0; r < R; r++) {
+  int r = 0;
+  if (E.w01) {  // unweighted reads: the sum over four consecutive reads as the logarithm of their product
+    for (; r + 4 <= R; r += 4) {
+      double rp[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        lds_cdouble *row = ptab + (r + t) * H;
+        rp[t] = 0.0;
+#pragma unroll
+        for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+          if (k < K) rp[t] += row[g[k]] * invK;
+      }
+      llk += read_log_product<4>(rp);
+    }
+  }
+  for (; r < R; r++) {
     lds_cdouble *row = ptab + r * H;
     double rp = 0.0;
 #pragma unroll
@@ -240,7 +263,27 @@ __device__ __forceinline__ void exact_llkn(const ExactLds &E, const int (&g)[NQ]
 #pragma unroll
   for (int q = 0; q < NQ; q++) l[q] = 0.0;
   lds_cdouble *ptab = lds_table(E.ptab), *cnt = lds_table(E.cnt);
-  for (int r = 0; r < R; r++) {
+  int r = 0;
+  if (E.w01) {  // (as exact_llk: groups of four consecutive reads, one logarithm each)
+    for (; r + 4 <= R; r += 4) {
+      double rp[NQ][4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        lds_cdouble *row = ptab + (r + t) * H;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) rp[q][t] = 0.0;
+#pragma unroll
+        for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+          if (k < K) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) rp[q][t] += row[g[q][k]] * invK;
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; q++) l[q] += read_log_product<4>(rp[q]);
+    }
+  }
+  for (; r < R; r++) {
     lds_cdouble *row = ptab + r * H;
     double rp[NQ];
 #pragma unroll
@@ -295,7 +338,23 @@ __device__ __forceinline__ void exact_llk_tiled(const ExactParams &P, int unit, 
         unrank_genotype(i, K, g);
         double acc = llk[t];
         lds_cdouble *ptab = lds_table(E.ptab), *cnt = lds_table(E.cnt);
-        for (int r = 0; r < rn; r++) {
+        int r = 0;
+        // (the host keeps the tile a multiple of four reads, so the groups of four are those of the untiled loop)
+        if (E.w01) {
+          for (; r + 4 <= rn; r += 4) {
+            double rp[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              lds_cdouble *row = ptab + (r + q) * H;
+              rp[q] = 0.0;
+#pragma unroll
+              for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+                if (k < K) rp[q] += row[g[k]] * invK;
+            }
+            acc += read_log_product<4>(rp);
+          }
+        }
+        for (; r < rn; r++) {
           lds_cdouble *row = ptab + r * H;
           double rp = 0.0;
 #pragma unroll

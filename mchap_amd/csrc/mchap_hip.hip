@@ -110,8 +110,9 @@ thread_local char g_err[512] = "";
 // Epochs of the likelihood caches: a fit whose packed genotypes leave the upper half of a cache tag free (ploidy x SNVs x bits per
 // allele <= 32: configs[1]) writes its epoch there instead of clearing the chains' tables first (0.33 GB of stores per 10 000 loci);
 // what an earlier call -- of any batch, on any stream -- left in a workspace carries another epoch and never matches.  The one
-// piece of process-wide state in the library: a counter, never read back by anything but the next fit.  After 2^31 - 1 fits the
-// tables are cleared again as before.
+// piece of process-wide state in the library: a counter, never read back by anything but the next fit -- and only used when the
+// caller does not name the call's epoch itself (mchap_denovo_cfg.cache_epoch).  After 2^31 - 2 fits the tables are cleared again
+// as before.
 std::atomic<uint64_t> g_cache_epoch{0};
 
 int fail(int code, const char *fmt, ...) {
@@ -1152,8 +1153,10 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
       uint64_t epoch = 0;
       if ((pl.kind == SAMPLER_PIPE || pl.kind == SAMPLER_SPEC) && !(T.flags & (64 | 65536)) &&
           B.max_ploidy * mchap::allele_bits(B.max_allele) * B.max_pos <= 32) {
-        epoch = g_cache_epoch.fetch_add(1) + 1;
-        if (epoch >= (1ull << 31)) epoch = 0;
+        // the caller's number (a property of the call: the Python host draws from one sequence for every library copy in the
+        // process -- two copies counting on their own could tag different data alike), else this copy's counter
+        epoch = cfg->cache_epoch > 0 ? (uint64_t)cfg->cache_epoch : g_cache_epoch.fetch_add(1) + 1;
+        if (epoch >= (1ull << 31) - 1) epoch = 0;
       }
       SP.cache_epoch = epoch << 33;
       if (!epoch)
@@ -1180,7 +1183,7 @@ static int fit_batch_device_impl(const mchap_denovo_cfg *cfg, int n_units, const
     SP.max_ploidy = B.max_ploidy;
     SP.max_ma = B.max_ma;
     SP.cstride = code_stride(rpl);
-    SP.flags = T.flags & (63 | 128 | 2048 | 4096 | 262144);  // (2048 / 4096: denovo_fillw_kernel without the cache probe / the LDS table)  // (256, 512: host only -- never the side-by-side instantiation / no deep-chunk product rows)
+    SP.flags = T.flags & (63 | 128 | 2048 | 4096 | 262144 | (1 << 20));  // (1 << 20: no grouped logarithms -- read_log_sum, META_I_W01)  // (2048 / 4096: denovo_fillw_kernel without the cache probe / the LDS table)  // (256, 512: host only -- never the side-by-side instantiation / no deep-chunk product rows)
     // the prepare pass keeps the transposed table in LDS when it fits, else it re-reads its own global copy
     SP.max_ugens_pad = (B.max_ugens + 8) & ~7;
     const size_t lds_dict = (size_t)mchap::DICT_HASH * (8 + 2) + 64;  // hash set of the dictionary pass
@@ -1368,6 +1371,46 @@ int mchap_read_log_batch(const double *x, int64_t n, double *out) {
   MCHAP_TRY(hc.up(d_x.p, x, (size_t)n * 8));
   hipLaunchKernelGGL(mchap::read_log_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, hc.stream,
                      d_x.as<double>(), (long long)n, d_o.as<double>());
+  HIP_TRY(hipGetLastError());
+  MCHAP_TRY(hc.down(out, d_o.p, (size_t)n * 8));
+  return hc.sync();
+}
+
+namespace mchap {
+static __global__ void read_log_product_kernel(const double *x, long long n, int group, double *out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double *g = x + i * group;
+    if (group == 4) {
+      const double y[4] = {g[0], g[1], g[2], g[3]};
+      out[i] = read_log_product<4>(y);
+    } else if (group == 3) {
+      const double y[3] = {g[0], g[1], g[2]};
+      out[i] = read_log_product<3>(y);
+    } else if (group == 2) {
+      const double y[2] = {g[0], g[1]};
+      out[i] = read_log_product<2>(y);
+    } else {
+      out[i] = read_log(g[0]);
+    }
+  }
+}
+}  // namespace mchap
+
+/* Test hook: read_log_product (csrc/read_log.hpp, round 5): out[i] = the logarithm of the product of x[i * group .. + group - 1]
+ * (group = 1..4) as the likelihood kernels form it for the reads of one lane where the read weights are 0 / 1.  Host pointers. */
+int mchap_read_log_product_batch(const double *x, int64_t n, int group, double *out) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (n <= 0) return MCHAP_OK;
+  if (!x || !out || group < 1 || group > 4) return fail(MCHAP_ERR_BAD_ARG, "NULL buffer or group not in 1..4");
+  DevBuf d_x, d_o;
+  HostCall hc;
+  MCHAP_TRY(hc.open());
+  HIP_TRY(hipMalloc(&d_x.p, (size_t)n * group * 8));
+  HIP_TRY(hipMalloc(&d_o.p, (size_t)n * 8));
+  MCHAP_TRY(hc.up(d_x.p, x, (size_t)n * group * 8));
+  hipLaunchKernelGGL(mchap::read_log_product_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, hc.stream,
+                     d_x.as<double>(), (long long)n, group, d_o.as<double>());
   HIP_TRY(hipGetLastError());
   MCHAP_TRY(hc.down(out, d_o.p, (size_t)n * 8));
   return hc.sync();

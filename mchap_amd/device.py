@@ -174,6 +174,7 @@ class DenovoDeviceBatch(_OwnBuffers):
         """Enqueue the sampler on torch's current stream (no synchronisation)."""
         L = _lib.lib()
         stream = self._begin().cuda_stream
+        self.cfg.cache_epoch = _lib.next_cache_epoch()  # (the call's own: one sequence for every library copy of the process)
         if self.d_reads is None:
             rc = L.mchap_denovo_fit_batch_calls_device(
                 C.byref(self.cfg), self.shape[0], self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_calls),
@@ -455,6 +456,7 @@ class DenovoRaggedBatch(_OwnBuffers):
         """The sampler launch on `stream` (a raw hipStream_t): from the float64 read tensors, or -- a batch built by from_calls --
         from int8 calls, the tensors formed on the device by the prepare pass (mchap_denovo_fit_batch_calls_device)."""
         L = _lib.lib()
+        self.cfg.cache_epoch = _lib.next_cache_epoch()
         if self.d_reads is None:
             _lib.check(L.mchap_denovo_fit_batch_calls_device(
                 C.byref(self.cfg), self.n_units, self._p(self.d_units), _lib.ptr(self.units_host), self._p(self.d_calls), None,

@@ -491,7 +491,7 @@ typedef struct {
   orc_stats *stats;
 } orc_ctx;
 
-/* Optional event log for tests/analyze_moves.py (only with -DORC_MOVE_LOG, a separate build: the shipped oracle has none of it).
+/* Optional event log for tests/aids/analyze_moves.py (only with -DORC_MOVE_LOG, a separate build: the shipped oracle has none of it).
    Entry = (FNV-1a hash of the ordered genotype bytes [+ step type, start, stop for kind 3]) << 2 | kind:
    0 step start, 1 accepted mutation, 2 accepted structural move, 3 interval step visited (with options). */
 #ifdef ORC_MOVE_LOG

@@ -4,8 +4,8 @@ a hash of the ordered genotype).  Sizes the per-genotype decision contexts of th
 distinct ordered genotypes per chain, hit rates of an LRU of N contexts, structural moves per step, distinct (genotype, interval)
 pairs.
 
-  python tests/analyze_moves.py example [locus015,locus012,...]     docs/example units (the pileup fixture)
-  python tests/analyze_moves.py moving 16|40 [units]                 bench.py's extra.moving shapes
+  python tests/aids/analyze_moves.py example [locus015,locus012,...]     docs/example units (the pileup fixture)
+  python tests/aids/analyze_moves.py moving 16|40 [units]                 bench.py's extra.moving shapes
 """
 import ctypes as C
 import os
@@ -15,7 +15,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import binding as orc  # noqa: E402
 

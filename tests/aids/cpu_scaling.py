@@ -1,6 +1,6 @@
 """Host-side check (not part of the product): scaling of the CPU oracle baseline with OpenMP threads."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import binding as orc
 from mchap_amd.assemble import break_table
 from mchap_amd.synth import synth_units

@@ -1,6 +1,6 @@
 """debug aid: docs/example units of one shape through several kernel settings against the oracle"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # repo root
 import numpy as np
 from oracle import binding as orc
 from tests.helpers import beta_break_table

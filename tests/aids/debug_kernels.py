@@ -1,7 +1,7 @@
 """Development aid: first step at which a sampler kernel's trace leaves the oracle's, for one of a few named cases.
     python tests/debug_kernels.py <kernel> <case> [flags]"""
 import os, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 from mchap_amd import DenovoMCMC

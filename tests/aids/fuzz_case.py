@@ -1,6 +1,6 @@
 """One explicit fuzz case for one kernel (development aid): python tests/fuzz_case.py kernel K M A R chains U T F steps lo seed cache p0 p1 p2 case"""
 import os, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 from mchap_amd import DenovoMCMC

@@ -348,3 +348,50 @@ def test_phased_sampler_equals_speculative_kernel_at_the_headline_shape(sampler_
     assert "phased" in out[0][3] and "phased" not in out[3][3]
     for a, c in zip(out[3][:3], out[0][:3]):
         assert np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("kernel", [2, 3, 5])
+@pytest.mark.parametrize("shape", [(4, 8, 200), (4, 8, 100), (6, 10, 500), (4, 6, 150)])
+def test_one_logarithm_per_group_of_reads(monkeypatch, kernel, shape):
+    """Round 5: where the read weights are 0 / 1 a lane takes ONE logarithm per block of (up to four) read chunks -- the logarithm of
+    the product of its reads' terms, mantissas multiplied and exponents summed (read_log.hpp read_log_product) -- instead of one
+    per read.  The log likelihoods then differ from the per-read sums in the last bits only (every kernel forms the same groups,
+    so the kernels stay bit-identical with each other: the other tests of this file); with flag 1048576 the kernels take a
+    logarithm per read as before: the same genotypes at every step, log likelihoods equal to 1e-13, and the oracle's."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import synth_units
+
+    K, M, R = shape
+    monkeypatch.setenv("MCHAP_HIP_KERNEL", str(kernel))
+    reads, _, _ = synth_units(6, ploidy=K, n_pos=M, n_reads=R, first_unit=900)
+    kw = dict(ploidy=K, n_alleles=[2] * M, steps=150, chains=2, random_seed=31)
+    monkeypatch.delenv("MCHAP_HIP_FLAGS", raising=False)
+    a = DenovoMCMC(**kw).fit_batch(list(reads))
+    monkeypatch.setenv("MCHAP_HIP_FLAGS", str(1 << 20))
+    b = DenovoMCMC(**kw).fit_batch(list(reads))
+    differ = 0
+    for x, y in zip(a, b):
+        assert np.array_equal(x.genotypes, y.genotypes)
+        np.testing.assert_allclose(x.llks, y.llks, rtol=1e-13)
+        differ += int((x.llks != y.llks).sum())
+    if R >= 200:
+        assert differ > 0  # (the grouping is in use: some last bits do differ; a small unit whose chains hold one or two likelihoods may show none)
+    monkeypatch.delenv("MCHAP_HIP_FLAGS", raising=False)
+    _check(DenovoMCMC(**kw), list(reads))
+
+
+def test_weighted_reads_keep_a_logarithm_per_read(monkeypatch):
+    """De-duplicated rows with counts: the weights are not 0 / 1, nothing is grouped -- the flag changes nothing at all."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.synth import dedup_unit, synth_units
+
+    reads, _, _ = synth_units(5, ploidy=4, n_pos=8, n_reads=200, first_unit=950, dedup=True)  # (phred ignored: equal rows do occur)
+    pairs = [dedup_unit(r) for r in reads]
+    assert all(int(p[1].max()) > 1 for p in pairs)
+    kw = dict(ploidy=4, n_alleles=[2] * 8, steps=120, chains=2, random_seed=5)
+    monkeypatch.delenv("MCHAP_HIP_FLAGS", raising=False)
+    a = DenovoMCMC(**kw).fit_batch([p[0] for p in pairs], [p[1] for p in pairs])
+    monkeypatch.setenv("MCHAP_HIP_FLAGS", str(1 << 20))
+    b = DenovoMCMC(**kw).fit_batch([p[0] for p in pairs], [p[1] for p in pairs])
+    for x, y in zip(a, b):
+        assert np.array_equal(x.genotypes, y.genotypes) and np.array_equal(x.llks, y.llks)

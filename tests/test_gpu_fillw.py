@@ -181,3 +181,51 @@ def test_a_workspace_reused_for_other_data_needs_no_clearing():
         finally:
             os.environ.pop("MCHAP_HIP_FLAGS", None)
         assert torch.equal(cleared.d_trace, reused.d_trace)
+
+
+def test_two_library_copies_never_tag_different_data_alike():
+    """The likelihood caches of packed genotypes are not cleared between fits: an entry carries the epoch of the fit that wrote it.
+    Until round 5 every loaded copy of the library counted its own epochs from 1 -- and the parity suite loads libmchap_hip.so and
+    libmchap_hip_test.so side by side while torch's allocator hands the same workspace block to both: the first fit of the second
+    copy then found the first copy's entries under its own epoch.  Now the epoch is a property of the call
+    (mchap_denovo_cfg.cache_epoch, one sequence per process: mchap_amd/_lib.py next_cache_epoch).  A fresh process: copy A fits
+    units X, its buffers go back to the allocator, copy B fits units Y of the same shape in the same block -- and must give what it
+    gives with the caches cleared (flag 65536)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys
+import numpy as np
+import torch
+from mchap_amd import DenovoMCMC, _lib
+from mchap_amd.device import DenovoDeviceBatch
+from mchap_amd.synth import synth_units
+
+kw = dict(ploidy=4, n_alleles=[2] * 8, steps=200, chains=2, random_seed=3)
+X, _, _ = synth_units(300, ploidy=4, n_pos=8, n_reads=40, qual=(3, 20), first_unit=0)
+Y, _, _ = synth_units(300, ploidy=4, n_pos=8, n_reads=40, qual=(3, 20), first_unit=5000)
+os.environ.pop("MCHAP_HIP_TEST_KERNELS", None)
+a = DenovoDeviceBatch(DenovoMCMC(**kw), X)
+a.run(); torch.cuda.synchronize()
+ptr_a = a.d_ws.data_ptr()
+del a
+os.environ["MCHAP_HIP_TEST_KERNELS"] = "1"
+b = DenovoDeviceBatch(DenovoMCMC(**kw), Y)
+same_block = b.d_ws.data_ptr() == ptr_a
+b.run(); torch.cuda.synchronize()
+wb = b.traces()[0].copy(); lb = b.traces()[2].copy()
+os.environ["MCHAP_HIP_FLAGS"] = "65536"
+c = DenovoDeviceBatch(DenovoMCMC(**kw), Y)
+c.run(); torch.cuda.synchronize()
+wc, lc = c.traces()[0], c.traces()[2]
+assert len(_lib._libs) == 2, list(_lib._libs)
+print("same_block", same_block, "equal", bool(np.array_equal(wb, wc) and np.array_equal(lb, lc)))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MCHAP_HIP_")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "equal True" in out.stdout, out.stdout[-500:]
+    assert "same_block True" in out.stdout, out.stdout[-500:]  # (the scenario did arise: the allocator recycled the block)

@@ -86,3 +86,50 @@ def test_wave_sum_tree():
         v = v + v[:, lanes ^ o]
     assert not np.isnan(out).any()  # (NaN: the lanes of a wavefront disagreed)
     assert np.array_equal(out.view(np.uint64), v[:, 0].view(np.uint64))
+
+
+@pytest.mark.parametrize("group", [2, 3, 4])
+def test_read_log_product_is_the_sum_of_the_logarithms(group):
+    """Round 5: where the read weights are 0 / 1 a lane takes ONE logarithm of the product of its (up to four) reads' terms --
+    mantissas multiplied, exponents summed, so nothing underflows (read_log.hpp read_log_product).  Against the sum of the
+    logarithms in long double: within two units in the last place of the result, over the range a likelihood sees -- products
+    of a few to a hundred probabilities, i.e. terms down to 1e-300 whose product no double holds --, with padding reads (factor
+    exactly 1) anywhere in the group, and 0 / NaN as the sum would give them."""
+    from mchap_amd import _lib
+
+    rng = np.random.default_rng(11 + group)
+    n = 300_000
+    x = np.concatenate([
+        rng.random((n // 3, group)),                                        # single probabilities
+        np.exp(rng.uniform(-690.0, 0.0, (n // 3, group))),                  # down to 1e-300: the plain product would underflow
+        np.prod(rng.random((n // 3, group, 6)), axis=2) / 4.0 + 1e-9,       # means of products
+    ])
+    pad = rng.random(x.shape) < 0.15
+    x[pad] = 1.0
+    out = np.empty(len(x))
+    _lib.check(_lib.lib().mchap_read_log_product_batch(_lib.ptr(np.ascontiguousarray(x)), C.c_int64(len(x)), group, _lib.ptr(out)))
+    true = np.log(x.astype(np.longdouble)).sum(axis=1)
+    ulp = np.spacing(np.abs(true.astype(np.float64))).astype(np.longdouble)
+    # two units in the last place of the result, plus the roundings of the (up to three) multiplications as an ABSOLUTE error:
+    # terms within 1e-14 of 1 lose relative accuracy in their product's logarithm, which is of no consequence in a sum of
+    # per-read terms of magnitude 0.1 .. 700
+    tol = 2.0 * ulp + np.longdouble(group - 1) * np.longdouble(2.0) ** -53
+    err = np.abs(out.astype(np.longdouble) - true)
+    assert bool((err <= tol).all()), float((err / tol).max())
+    # a group of padding reads around one real read is that read's logarithm, bit for bit
+    one = rng.random((1000, group))
+    keep = rng.integers(0, group, 1000)
+    mask = np.arange(group)[None, :] != keep[:, None]
+    one[mask] = 1.0
+    o1 = np.empty(1000)
+    _lib.check(_lib.lib().mchap_read_log_product_batch(_lib.ptr(np.ascontiguousarray(one)), C.c_int64(1000), group, _lib.ptr(o1)))
+    assert np.array_equal(o1, _read_log(one[np.arange(1000), keep]))
+    # special values
+    sp = np.ones((4, group))
+    sp[0, 0] = 0.0
+    sp[1, group - 1] = np.nan
+    sp[2, :] = 0.5
+    o2 = np.empty(4)
+    _lib.check(_lib.lib().mchap_read_log_product_batch(_lib.ptr(sp), C.c_int64(4), group, _lib.ptr(o2)))
+    assert o2[0] == -np.inf and np.isnan(o2[1]) and o2[3] == 0.0
+    assert abs(o2[2] - group * np.log(0.5)) < 1e-15
