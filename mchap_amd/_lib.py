@@ -19,7 +19,8 @@ SO = os.environ.get("MCHAP_HIP_LIB") or os.path.join(CSRC, "libmchap_hip.so")
 TEST_SO = os.path.join(CSRC, "libmchap_hip_test.so")
 
 MAX_TEMPS = 16
-MAX_PLOIDY = 8
+MAX_PLOIDY = 8          # the fast de novo samplers and the device posterior summary (include/mchap_hip.h MCHAP_MAX_PLOIDY)
+MAX_PLOIDY_GENERAL = 15  # the general de novo sampler, the exact caller and the call sampler (MCHAP_MAX_PLOIDY_DENOVO)
 MAX_ALLELE = 8
 MAX_READS = 4096
 

@@ -278,8 +278,14 @@ def _run_exact_groups(units, ploidy_of, inbreeding_of, full, backend=None):
             if has_prior:
                 Fs[i] = inbreeding_of(s)
                 frs[i] = locus.frequencies
-        batch = ExactDeviceBatch(reads, K, haps, counts, (Fs, frs) if has_prior else None)
-        batch.run(streaming=not full, arrays=full)
+        try:
+            batch = ExactDeviceBatch(reads, K, haps, counts, (Fs, frs) if has_prior else None)
+            batch.run(streaming=not full, arrays=full)
+        except NotImplementedError as e:
+            # a shape the library does not take (more than 2^62 genotypes, ploidy above 15, tables beyond the LDS): the records
+            # of this group are written with null genotypes and FILTER=LIMIT, the file goes on (round 5: used to raise mid-file)
+            _limit_units(units, members, "call-exact", "%d haplotypes x ploidy %d: %s" % (H, K, e))
+            continue
         if full:
             arr = batch.array_results(True)
             for i, key in enumerate(members):
@@ -290,6 +296,18 @@ def _run_exact_groups(units, ploidy_of, inbreeding_of, full, backend=None):
             for i, key in enumerate(members):
                 results[key] = dict(alleles=al[i], gprob=gp[i], sprob=sp[i], freqs=fq[i], occur=oc[i])
     return results
+
+
+def _limit_units(units, members, program, reason):
+    """Marks the records of `members` [(record index, sample)] as beyond a limit of the library: FILTER=LIMIT, null genotypes."""
+    import sys
+
+    for ri in sorted({ri for ri, _ in members}):
+        if units[ri].get("invalid") is None:
+            units[ri]["invalid"] = "LIMIT"
+            rec = units[ri]["rec"]
+            sys.stderr.write("mchap_amd %s: record %s:%s not called (written with FILTER=LIMIT): %s\n" % (
+                program, rec.get("chrom", "?"), rec.get("pos", "?"), reason))
 
 
 def _exact_one(calling, sr, haps, ploidy, prior, full):
@@ -1439,8 +1457,12 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
                         Fs[i] = inbreeding_of(s)
                         frs[i] = locus.frequencies[units[ri]["keep"]]
                 model = CallingMCMC(ploidy=K, haplotypes=haps[0], steps=steps, chains=chains, random_seed=seed, step_type=step_type)
-                traces = model.fit_batch(reads, counts, haplotypes=haps, prior=(Fs, frs) if has_prior else None,
-                                         stream_ids=np.zeros(U, dtype=np.uint64))
+                try:
+                    traces = model.fit_batch(reads, counts, haplotypes=haps, prior=(Fs, frs) if has_prior else None,
+                                             stream_ids=np.zeros(U, dtype=np.uint64))
+                except NotImplementedError as e:  # (a shape beyond the sampler's limits: FILTER=LIMIT records, the file goes on)
+                    _limit_units(units, members, "call", "%d haplotypes x ploidy %d: %s" % (H, K, e))
+                    continue
                 for key, tr in zip(members, traces):
                     results[key] = tr
         for ri, unit in enumerate(units):

@@ -143,7 +143,7 @@ __device__ inline double calling_log_prior_unsorted(const PriorTab &t, const int
 }
 
 __device__ __forceinline__ long long call_key(const int *g, int K) {
-  int s[MCHAP_MAX_PLOIDY];
+  int s[EXACT_KMAX];
   for (int i = 0; i < K; i++) s[i] = g[i];
   for (int a = 1; a < K; a++) {  // insertion sort
     const int v = s[a];
@@ -157,6 +157,8 @@ __device__ __forceinline__ long long call_key(const int *g, int K) {
   return rank_genotype(s, K);
 }
 
+// KM: the ploidy bound of the genotype arrays and unrolled loops (8, or EXACT_KMAX = 16 for ploidies 9 to 15: exact_kernel.hpp)
+template <int KM = 8>
 __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const CallParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   // (wave-uniform by construction; said so, or everything derived from it -- the chain, its pointers -- lives in vector registers)
@@ -184,14 +186,15 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
   double *o_prob = o_lpr + H;
   double *o_aux = o_prob + H;               // proposal ratios (Metropolis-Hastings)
   // Gibbs memo (call_memo_entries): keys (context rank + 1, 0 = empty), then per entry H probabilities and H likelihoods
-  const int n_memo = (P.step_type == 0) ? call_memo_entries(H) : 0;
+  // (the memo's key packs the K - 1 other alleles eight bits each: ploidies above 8 -- round 5 -- do without the memo)
+  const int n_memo = (P.step_type == 0 && 8 * (K - 1) <= 63) ? call_memo_entries(H) : 0;
   long long *memo_key = reinterpret_cast<long long *>(o_aux + H + 64);
   double *memo_val = reinterpret_cast<double *>(memo_key + CALL_MEMO);
   for (int i = lane; i < CALL_MEMO; i += WAVE) memo_key[i] = 0;
   int memo_next = 0;                        // (wave-uniform) the entry the next miss replaces
   __shared__ double s_acc_[CALL_WG_CHAINS], s_choice_llk_[CALL_WG_CHAINS];
-  __shared__ int s_g_[CALL_WG_CHAINS][MCHAP_MAX_PLOIDY];     // the chain's genotype (array order)
-  __shared__ int s_req_[CALL_WG_CHAINS][MCHAP_MAX_PLOIDY];   // alleles of the request being evaluated
+  __shared__ int s_g_[CALL_WG_CHAINS][KM];     // the chain's genotype (array order)
+  __shared__ int s_req_[CALL_WG_CHAINS][KM];   // alleles of the request being evaluated
   __shared__ double s_left;                 // Gibbs prior: lgamma(sum_alpha) - lgamma(1 + sum_alpha)   (shared)
   __shared__ int s_choice_[CALL_WG_CHAINS];
   __shared__ int s_full_[CALL_WG_CHAINS];
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
         double lprior = 0.0;
         if (has_prior) {
           // the prior of a genotype of ploidy i + 1: its tables depend on the ploidy (left term, lgamma(ploidy + 1))
-          int g[MCHAP_MAX_PLOIDY];
+          int g[KM];
           for (int q = 0; q <= i; q++) g[q] = s_req[q];
           const int kk = i + 1;
           if (F == 0.0) {
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
   auto option_llks = [&](int k, int a0) {
     const int a = a0 + lane;
     const bool act = a < H;
-    int g[MCHAP_MAX_PLOIDY];
+    int g[KM];
     for (int i = 0; i < K; i++) g[i] = s_g[i];
     g[k] = act ? a : g[k];
     double val = 0.0;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
 
   for (int step = 0; step < P.steps; step++) {
     // np.random.shuffle(arange(ploidy)) -- every lane the same
-    int order[MCHAP_MAX_PLOIDY];
+    int order[KM];
     for (int i = 0; i < K; i++) order[i] = i;
     for (int i = K - 1; i >= 1; i--) {
       const int j = (int)call_interval(st, ctr++, (uint32_t)i);
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
       int cur_copies = 1;
       if (P.step_type == 1) {
         // mh_options (calling/mcmc.py:15-140): likelihood and prior of the current genotype first
-        int g[MCHAP_MAX_PLOIDY];
+        int g[KM];
         for (int i = 0; i < K; i++) g[i] = s_g[i];
         cur_copies = 0;
         for (int i = 0; i < K; i++) cur_copies += g[i] == current ? 1 : 0;
@@ -492,15 +495,15 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
         // the multiset does; the genotype's rank would cost a chain of 64-bit divisions per sub-step.  Sorted by counting
         // (the place of an allele is the number of alleles before it in the order), all loops of constant extent: no
         // register array is indexed by a run-time value
-        int v[MCHAP_MAX_PLOIDY];
+        int v[KM];
 #pragma unroll
-        for (int i = 0; i < MCHAP_MAX_PLOIDY; i++) v[i] = i < K ? s_g[i] : 0;
+        for (int i = 0; i < KM; i++) v[i] = i < K ? s_g[i] : 0;
         unsigned long long packed = 0ull;
 #pragma unroll
-        for (int i = 0; i < MCHAP_MAX_PLOIDY; i++) {
+        for (int i = 0; i < KM; i++) {
           int place = 0;
 #pragma unroll
-          for (int j = 0; j < MCHAP_MAX_PLOIDY; j++)
+          for (int j = 0; j < KM; j++)
             place += (j < K && j != k && j != i && (v[j] < v[i] || (v[j] == v[i] && j < i))) ? 1 : 0;
           if (i < K && i != k) packed |= (unsigned long long)(v[i] & 255) << (8 * place);
         }
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
       for (int a0 = 0; a0 < H; a0 += WAVE) option_llks(k, a0);
       // priors (and proposal ratios) of the options
       for (int a = lane; a < H; a += WAVE) {
-        int g[MCHAP_MAX_PLOIDY];
+        int g[KM];
         for (int i = 0; i < K; i++) g[i] = s_g[i];
         g[k] = a;
         int copies = 0;

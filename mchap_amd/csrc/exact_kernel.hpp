@@ -12,6 +12,10 @@
 
 namespace mchap {
 
+// Ploidy bound of a kernel's genotype arrays and unrolled loops (template argument KM): 8 -- MCHAP_MAX_PLOIDY, what rounds 1-4
+// took -- for ploidies up to 8, and EXACT_KMAX = 16 for ploidies 9 to 15 (round 5: the shapes the de novo sampler's general kernel
+// assembles), so that the usual ploidies keep their code
+constexpr int EXACT_KMAX = 16;
 constexpr int EXACT_THREADS = 256;
 constexpr int EXACT_GENOS_PER_BLOCK = 4096;
 
@@ -50,10 +54,11 @@ __device__ __forceinline__ long long cwr(int n, int k) {
 }
 
 // jitutils.py:279-318: VCF index -> ascending alleles
-__device__ __forceinline__ void unrank_genotype(long long index, int K, int (&g)[MCHAP_MAX_PLOIDY]) {
+template <int KM>
+__device__ __forceinline__ void unrank_genotype(long long index, int K, int (&g)[KM]) {
   long long remainder = index;
 #pragma unroll
-  for (int p = MCHAP_MAX_PLOIDY; p >= 1; p--) {
+  for (int p = KM; p >= 1; p--) {
     if (p > K) {
       g[p - 1] = 0;
       continue;
@@ -225,7 +230,8 @@ typedef __attribute__((address_space(3))) const double lds_cdouble;
 __device__ __forceinline__ lds_cdouble *lds_table(const double *p) { return (lds_cdouble *)p; }
 
 // log likelihood of the genotype with ascending alleles g (calling/exact.py:252-263 via assemble/likelihood.py:17-70)
-__device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[MCHAP_MAX_PLOIDY], int R, int H, int K, double invK) {
+template <int KM>
+__device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[KM], int R, int H, int K, double invK) {
   double llk = 0.0;
   lds_cdouble *ptab = lds_table(E.ptab), *cnt = lds_table(E.cnt);
   int r = 0;
@@ -237,7 +243,7 @@ __device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[MC
         lds_cdouble *row = ptab + (r + t) * H;
         rp[t] = 0.0;
 #pragma unroll
-        for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+        for (int k = 0; k < KM; k++)
           if (k < K) rp[t] += row[g[k]] * invK;
       }
       llk += read_log_product<4>(rp);
@@ -247,7 +253,7 @@ __device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[MC
     lds_cdouble *row = ptab + r * H;
     double rp = 0.0;
 #pragma unroll
-    for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+    for (int k = 0; k < KM; k++)
       if (k < K) rp += row[g[k]] * invK;
     llk += read_log(rp) * cnt[r];
   }
@@ -257,8 +263,8 @@ __device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[MC
 // NQ genotypes of one thread at once: each sum runs over the reads in order as in exact_llk (same values); the NQ
 // chains of LDS reads, adds and logs are independent and hide each other's latency (two waves per SIMD is all the
 // 64 KB table leaves).  MI355X, config #4: pass 1 28.0 -> 21.8 (two) -> 20.4 ms (four at a time).
-template <int NQ>
-__device__ __forceinline__ void exact_llkn(const ExactLds &E, const int (&g)[NQ][MCHAP_MAX_PLOIDY], int R, int H, int K, double invK,
+template <int NQ, int KM>
+__device__ __forceinline__ void exact_llkn(const ExactLds &E, const int (&g)[NQ][KM], int R, int H, int K, double invK,
                                            double (&l)[NQ]) {
 #pragma unroll
   for (int q = 0; q < NQ; q++) l[q] = 0.0;
@@ -273,7 +279,7 @@ __device__ __forceinline__ void exact_llkn(const ExactLds &E, const int (&g)[NQ]
 #pragma unroll
         for (int q = 0; q < NQ; q++) rp[q][t] = 0.0;
 #pragma unroll
-        for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+        for (int k = 0; k < KM; k++)
           if (k < K) {
 #pragma unroll
             for (int q = 0; q < NQ; q++) rp[q][t] += row[g[q][k]] * invK;
@@ -289,7 +295,7 @@ __device__ __forceinline__ void exact_llkn(const ExactLds &E, const int (&g)[NQ]
 #pragma unroll
     for (int q = 0; q < NQ; q++) rp[q] = 0.0;
 #pragma unroll
-    for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+    for (int k = 0; k < KM; k++)
       if (k < K) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) rp[q] += row[g[q][k]] * invK;
@@ -321,6 +327,7 @@ __device__ __forceinline__ void exact_tile(const ExactParams &P, int unit, const
 // The log likelihoods of the thread's genotypes lo + threadIdx.x + t * blockDim.x (t < NGT) when the reads do not fit
 // the LDS at once: tile by tile, every genotype's sum continued in read order -- the values of the untiled loop.
 constexpr int EXACT_NGT = EXACT_GENOS_PER_BLOCK / EXACT_THREADS;
+template <int KM>
 __device__ __forceinline__ void exact_llk_tiled(const ExactParams &P, int unit, const ExactLds &E, long long lo, long long hi,
                                                 double (&llk)[EXACT_NGT]) {
   const int H = P.H, K = P.K, cap = P.Rcap;
@@ -334,7 +341,7 @@ __device__ __forceinline__ void exact_llk_tiled(const ExactParams &P, int unit, 
     for (int t = 0; t < EXACT_NGT; t++) {
       const long long i = lo + threadIdx.x + (long long)t * EXACT_THREADS;
       if (i < hi) {
-        int g[MCHAP_MAX_PLOIDY];
+        int g[KM];
         unrank_genotype(i, K, g);
         double acc = llk[t];
         lds_cdouble *ptab = lds_table(E.ptab), *cnt = lds_table(E.cnt);
@@ -348,7 +355,7 @@ __device__ __forceinline__ void exact_llk_tiled(const ExactParams &P, int unit, 
               lds_cdouble *row = ptab + (r + q) * H;
               rp[q] = 0.0;
 #pragma unroll
-              for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+              for (int k = 0; k < KM; k++)
                 if (k < K) rp[q] += row[g[k]] * invK;
             }
             acc += read_log_product<4>(rp);
@@ -358,7 +365,7 @@ __device__ __forceinline__ void exact_llk_tiled(const ExactParams &P, int unit, 
           lds_cdouble *row = ptab + r * H;
           double rp = 0.0;
 #pragma unroll
-          for (int k = 0; k < MCHAP_MAX_PLOIDY; k++)
+          for (int k = 0; k < KM; k++)
             if (k < K) rp += row[g[k]] * invK;
           acc += read_log(rp) * cnt[r];
         }
@@ -368,7 +375,7 @@ __device__ __forceinline__ void exact_llk_tiled(const ExactParams &P, int unit, 
   }
 }
 
-template <bool TILED>
+template <bool TILED, int KM = 8>
 __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int unit = blockIdx.y;
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
   double best = -INFINITY, best_llk = -INFINITY;
   long long best_idx = 0x7fffffffffffffffll;
   double lse_m = -INFINITY, lse_s = 0.0;  // running log-sum-exp: max and scaled sum
-  auto visit = [&](long long i, const int (&g)[MCHAP_MAX_PLOIDY], double llk) {
+  auto visit = [&](long long i, const int (&g)[KM], double llk) {
     const size_t o = (size_t)unit * G + i;
     if (P.llk32) P.llk32[o] = (float)llk;  // calling/exact.py:254 float32 store
     if (P.llk64) P.llk64[o] = llk;
@@ -410,12 +417,12 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
   };
   if constexpr (TILED) {
     double tl[EXACT_NGT];
-    exact_llk_tiled(P, unit, E, lo, hi, tl);
+    exact_llk_tiled<KM>(P, unit, E, lo, hi, tl);
 #pragma unroll
     for (int t = 0; t < EXACT_NGT; t++) {
       const long long i = lo + threadIdx.x + (long long)t * EXACT_THREADS;
       if (i < hi) {
-        int g[MCHAP_MAX_PLOIDY];
+        int g[KM];
         unrank_genotype(i, K, g);
         visit(i, g, tl[t]);
       }
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
     // the thread's genotypes i, i + 256, ... two at a time (visited in index order: the first maximum stays the first)
     long long i = lo + threadIdx.x;
     for (; i + 3 * (long long)blockDim.x < hi; i += 4 * (long long)blockDim.x) {
-      int g4[4][MCHAP_MAX_PLOIDY];
+      int g4[4][KM];
       double l4[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) unrank_genotype(i + (long long)q * blockDim.x, K, g4[q]);
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
       for (int q = 0; q < 4; q++) visit(i + (long long)q * blockDim.x, g4[q], l4[q]);
     }
     for (; i + (long long)blockDim.x < hi; i += 2 * (long long)blockDim.x) {
-      int g2[2][MCHAP_MAX_PLOIDY];
+      int g2[2][KM];
       double l2[2];
       unrank_genotype(i, K, g2[0]);
       unrank_genotype(i + blockDim.x, K, g2[1]);
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass1_kernel(const ExactP
       visit(i + blockDim.x, g2[1], l2[1]);
     }
     if (i < hi) {
-      int g[MCHAP_MAX_PLOIDY];
+      int g[KM];
       unrank_genotype(i, K, g);
       visit(i, g, exact_llk(E, g, R, H, K, invK));
     }
@@ -489,6 +496,7 @@ struct ExactModeParams {
   double *mode_llk, *mode_prob, *total;   // [U]
 };
 __global__ __launch_bounds__(64) void exact_mode_kernel(const ExactModeParams P) {
+  constexpr int KM = EXACT_KMAX;
   const ExactParams &E = P.e;
   const int unit = blockIdx.x;
   if (threadIdx.x != 0) return;
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(64) void exact_mode_kernel(const ExactModeParams P)
     }
     total = add_log_prob(total, E.part_lse[o]);
   }
-  int g[MCHAP_MAX_PLOIDY];
+  int g[KM];
   unrank_genotype(bi, E.K, g);
   for (int k = 0; k < E.K; k++) P.mode_alleles[(size_t)unit * E.K + k] = g[k];
   if (P.mode_llk) P.mode_llk[unit] = bl;
@@ -522,7 +530,7 @@ inline size_t exact_pass2_lds(int R, int H, int K, int threads) {
 }
 // HAVE_LJ: pass 1 left llk + log prior of every genotype in P.ljoint (the caller's workspace had room for U * G
 // doubles): the pass then reads them back instead of forming every likelihood a second time -- same values, same sums.
-template <bool TILED, bool HAVE_LJ = false>
+template <bool TILED, bool HAVE_LJ = false, int KM = 8>
 __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int unit = blockIdx.y;
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
   for (int i = threadIdx.x; i < nw * NS; i += nt) acc[i] = 0.0;
   __syncthreads();
   const double total = P.unit_total[unit];
-  int ms[MCHAP_MAX_PLOIDY], ns = 0;  // distinct alleles of the mode, ascending
+  int ms[KM], ns = 0;  // distinct alleles of the mode, ascending
   for (int k = 0; k < K; k++) {
     const int a = (int)P.unit_mode[(size_t)unit * K + k];
     if (k == 0 || a != ms[ns - 1]) ms[ns++] = a;
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
       tl[t] = i < hi ? P.ljoint[(size_t)unit * G + i] : 0.0;
     }
   } else if constexpr (TILED) {
-    exact_llk_tiled(P, unit, E, lo, hi, tl);  // (nt == EXACT_THREADS: thread t's genotypes lo + t + 256 q)
+    exact_llk_tiled<KM>(P, unit, E, lo, hi, tl);  // (nt == EXACT_THREADS: thread t's genotypes lo + t + 256 q)
   } else {
     // the likelihoods of the thread's genotypes, four at a time (exact_llkn), ahead of the accounting loop
 #pragma unroll
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
 #pragma unroll
       for (int q = 0; q < 4; q++) tl[tqq + q] = 0.0;
       if (ia + 3 * (long long)nt < hi) {
-        int g4[4][MCHAP_MAX_PLOIDY];
+        int g4[4][KM];
         double l4[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) unrank_genotype(ia + (long long)q * nt, K, g4[q]);
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           if (ia + (long long)q * nt < hi) {
-            int ga[MCHAP_MAX_PLOIDY];
+            int ga[KM];
             unrank_genotype(ia + (long long)q * nt, K, ga);
             tl[tqq + q] = exact_llk(E, ga, R, H, K, invK);
           }
@@ -594,9 +602,9 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
     const long long i0 = lo + (long long)wave * 64 + (long long)tqq * nt;  // wave-uniform
     if (i0 >= hi) continue;
     const long long i = i0 + lane;
-    int g[MCHAP_MAX_PLOIDY];
+    int g[KM];
 #pragma unroll
-    for (int k = 0; k < MCHAP_MAX_PLOIDY; k++) g[k] = -1;
+    for (int k = 0; k < KM; k++) g[k] = -1;
     double prob = 0.0;
     bool support = false;
     if (i < hi) {
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void exact_pass2_kernel(const ExactP
     for (int a = 0; a < H; a++) {
       int cnt = 0;
 #pragma unroll
-      for (int k = 0; k < MCHAP_MAX_PLOIDY; k++) cnt += (k < K && g[k] == a) ? 1 : 0;
+      for (int k = 0; k < KM; k++) cnt += (k < K && g[k] == a) ? 1 : 0;
       const double c1 = wave_sum(prob * (double)cnt);         // allele count
       const double c2 = wave_sum(cnt > 0 ? prob : 0.0);       // allele occurrence
       if (lane == 0) {
@@ -677,6 +685,7 @@ constexpr int EXACT_ARRAY_THREADS = 1024;
 inline size_t exact_array_lds(int H, int K, int nacc) {
   return ((size_t)H * (K + 1) + (K + 1) + H + 2 * (size_t)EXACT_ARRAY_THREADS + (size_t)(2 * H + 1) * nacc) * 8;
 }
+template <int KM = 8>
 __global__ __launch_bounds__(EXACT_ARRAY_THREADS) void exact_array_kernel(const ExactArrayParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int unit = blockIdx.x;
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(EXACT_ARRAY_THREADS) void exact_array_kernel(const 
     double *out = P.post + (size_t)unit * G;
     double m = -INFINITY, sacc = 0.0;
     for (long long i = threadIdx.x; i < G; i += nt) {
-      int g[MCHAP_MAX_PLOIDY];
+      int g[KM];
       unrank_genotype(i, K, g);
       const double lpr = P.has_prior ? calling_log_prior(pt, g, K) : 0.0;
       double j;
@@ -797,10 +806,10 @@ __global__ __launch_bounds__(EXACT_ARRAY_THREADS) void exact_array_kernel(const 
     }
     __syncthreads();
   }
-  int mg[MCHAP_MAX_PLOIDY];
+  int mg[KM];
   unrank_genotype(s_mode, K, mg);
   if (P.mode_alleles && threadIdx.x < K) P.mode_alleles[(size_t)unit * K + threadIdx.x] = mg[threadIdx.x];
-  int ms[MCHAP_MAX_PLOIDY], ns = 0;
+  int ms[KM], ns = 0;
   for (int k = 0; k < K; k++)
     if (k == 0 || mg[k] != mg[k - 1]) ms[ns++] = mg[k];
   // ---- sums over the genotypes: P.nacc accumulating threads (an LDS column each), summed in thread order ----
@@ -808,7 +817,7 @@ __global__ __launch_bounds__(EXACT_ARRAY_THREADS) void exact_array_kernel(const 
   if ((int)threadIdx.x < na) {
     for (int h = 0; h < 2 * H + 1; h++) acc[(size_t)h * na + threadIdx.x] = 0.0;
     for (long long i = threadIdx.x; i < G; i += na) {
-      int g[MCHAP_MAX_PLOIDY];
+      int g[KM];
       unrank_genotype(i, K, g);
       const double prob = post[i];
       int nd = 0;

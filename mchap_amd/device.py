@@ -302,6 +302,12 @@ class ExactDeviceBatch:
                 fr = np.array(np.broadcast_to(np.asarray(prior[1], dtype=np.float64), (U, H)))
                 self.d_fr = torch.from_numpy(fr.reshape(-1)).to(dev)
         self.ws_bytes = int(_lib.lib().mchap_exact_workspace_bytes(U, H, int(ploidy)))
+        free, _ = torch.cuda.mem_get_info()
+        if self.ws_bytes < 0 or self.ws_bytes > free:
+            # beyond what the exact caller enumerates here (the reference has no limit but time): the programs write such a record
+            # with FILTER=LIMIT (application._run_exact_groups)
+            raise NotImplementedError("mchap_hip: ploidy %d over %d haplotypes: %s genotypes are beyond this build's exact caller "
+                                      "(2^62 indices; the workspace must fit the device)" % (int(ploidy), H, self.G))
         if cache_joint:
             # room for llk + log prior of every genotype between the two passes of the streaming form (8 bytes each)
             # (taken only when it fits comfortably: else the plain workspace, whose second pass forms the values again)

@@ -15,6 +15,9 @@ FILTERS = [
 # `assemble` only, not a reference filter: a target beyond the library's shape limits (README: SNVs per target, bits of sampled
 # alleles per haplotype) is written with null genotypes and this filter instead of being left out of the file
 LIMIT_FILTER = ("LIMIT", "Target not assembled: beyond the shape limits of this build (record kept with null genotypes)")
+# (the call programs: a record whose units the exact caller / call sampler does not take -- more than 2^62 genotypes, more than
+# 256 known haplotypes for the sampler, tables beyond the LDS -- is written with null genotypes and this filter, round 5)
+LIMIT_FILTER_CALL = ("LIMIT", "Record not called: beyond the shape limits of this build (record kept with null genotypes)")
 
 # (id, Number, Type, Description); the order is the order of the header and of the INFO column
 INFO_FIELDS = [
@@ -87,7 +90,7 @@ def header_lines(program, command, samples, contigs, report=(), random_seed=None
            "##source=mchap_amd v%s (%s)" % (version or __version__, program), "##phasing=None", "##commandline=%s" % cmd,
            "##randomseed=%s" % random_seed]
     out += ["##contig=<ID=%s,length=%d>" % (n, l) for n, l in contigs]
-    out += ['##FILTER=<ID=%s,Description="%s">' % f for f in FILTERS + ([LIMIT_FILTER] if program == "assemble" else [])]
+    out += ['##FILTER=<ID=%s,Description="%s">' % f for f in FILTERS + ([LIMIT_FILTER] if program == "assemble" else [LIMIT_FILTER_CALL])]
     info_opt, fmt_opt = report_fields(report)
     for fid, num, typ, descr in INFO_FIELDS:
         out.append('##INFO=<ID=%s,Number=%s,Type=%s,Description="%s">' % (fid, num, typ, descr))

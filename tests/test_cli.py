@@ -9,7 +9,9 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refer
 
 
 def _decl(lines):
-    return [ln for ln in lines if ln.startswith(("##FILTER", "##INFO", "##FORMAT", "##contig", "##fileformat", "##phasing", "#CHROM"))]
+    # (the FILTER=LIMIT declaration is this build's own: records beyond its shape limits, which the reference does not have)
+    return [ln for ln in lines if ln.startswith(("##FILTER", "##INFO", "##FORMAT", "##contig", "##fileformat", "##phasing", "#CHROM"))
+            and not ln.startswith("##FILTER=<ID=LIMIT,")]
 
 
 @pytest.mark.parametrize("golden,report", [

@@ -25,8 +25,10 @@ def _inputs(U, K, H, M, R, seed, qual=(5, 25)):
 
 
 @pytest.mark.parametrize("step_type", ["Gibbs", "Metropolis-Hastings"])
-@pytest.mark.parametrize("K,H,M,R", [(4, 6, 6, 40), (2, 9, 5, 20), (6, 5, 4, 70), (3, 12, 6, 130), (4, 18, 6, 1400)],
-                         ids=["K4", "K2", "K6", "K3", "tables-in-workspace"])  # the last: 202 KB of products per chain
+@pytest.mark.parametrize("K,H,M,R", [(4, 6, 6, 40), (2, 9, 5, 20), (6, 5, 4, 70), (3, 12, 6, 130), (4, 18, 6, 1400),  # 202 KB of products per chain
+                                     (10, 6, 6, 50), (12, 5, 5, 90), (15, 4, 6, 40), (9, 7, 100, 60)],
+                         # (round 5: ploidies 9 to 15, and known haplotypes of 100 SNVs)
+                         ids=["K4", "K2", "K6", "K3", "tables-in-workspace", "K10", "K12", "K15", "K9-100snvs"])
 def test_traces_match_oracle_step_for_step(step_type, K, H, M, R):
     from mchap_amd.calling_mcmc import CallingMCMC
 

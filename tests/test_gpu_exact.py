@@ -49,8 +49,10 @@ def test_against_reference_goldens(golden_dir):
 
 
 @pytest.mark.parametrize("K,H,M,R,U", [(4, 8, 8, 120, 3), (6, 10, 10, 200, 2), (2, 30, 6, 64, 2), (8, 5, 5, 40, 2),
-                                       (4, 24, 6, 1500, 2)],  # the last: 288 KB of products -- the passes tile the reads
-                         ids=["K4", "K6", "K2-H30", "K8", "tiled-reads"])
+                                       (4, 24, 6, 1500, 2),  # 288 KB of products -- the passes tile the reads
+                                       (10, 6, 8, 90, 2), (12, 5, 7, 130, 2), (15, 4, 6, 60, 2), (9, 6, 100, 70, 2)],
+                         # (round 5: ploidies 9 to 15 -- what the general de novo sampler assembles --, and haplotypes of 100 SNVs)
+                         ids=["K4", "K6", "K2-H30", "K8", "tiled-reads", "K10", "K12", "K15", "K9-100snvs"])
 def test_batch_against_oracle(K, H, M, R, U):
     from mchap_amd import calling
     from mchap_amd.synth import synth_units

@@ -62,7 +62,7 @@ def test_targets_beyond_the_limits_are_written_with_a_filter(capsys):
     from mchap_amd import vcfheader
 
     assert any(ln.startswith("##FILTER=<ID=LIMIT,") for ln in vcfheader.header_lines("assemble", "x", ["S1"], [("c1", 9000)]))
-    assert not any("LIMIT" in ln for ln in vcfheader.header_lines("call-exact", "x", ["S1"], [("c1", 9000)]))
+    assert any(ln.startswith("##FILTER=<ID=LIMIT,") for ln in vcfheader.header_lines("call-exact", "x", ["S1"], [("c1", 9000)]))  # (round 5)
 
 
 @pytest.mark.parametrize("block_path", [None, False])
@@ -95,3 +95,35 @@ def test_a_deep_wide_target_is_a_limit_record_not_an_abort(capsys, block_path):
     assert "target deepwide" in err and "distinct read rows" in err and "1024" in err
     alone = list(application.assemble(None, variants, {"c1": _NSeq()}, source, targets=[targets[0], targets[2], targets[3]], **kw))
     assert alone == [lines[0], lines[2], lines[3]]
+
+
+def test_call_programs_write_limit_records_instead_of_raising(capsys):
+    """Round 5: the exact caller and the call sampler take ploidies up to 15; what they still do not take -- here ploidy 15 over
+    120 known haplotypes: 10^19 genotypes, beyond the int64 indices -- used to raise out of the program in the middle of a file.
+    Now the record is marked (FILTER=LIMIT, null genotypes: `invalid`), a warning names it, and the other records are called."""
+    from types import SimpleNamespace
+
+    from mchap_amd import application, calling
+
+    rng = np.random.default_rng(3)
+    M = 6
+
+    def unit(H, K, pos):
+        haps = rng.integers(0, 2, size=(H, M)).astype(np.int8)
+        reads = rng.dirichlet(np.ones(2), size=(20, M))
+        locus = SimpleNamespace(haplotypes=haps, frequencies=np.full(H, 1.0 / H), n_alleles=[2] * M, mask_reference_allele=False)
+        return dict(rec=dict(chrom="c1", pos=pos), locus=locus, invalid=None, needs_kernel=True,
+                    reads={"S1": dict(dists=reads, counts=np.ones(20, dtype=np.int64))})
+
+    with pytest.raises(NotImplementedError, match="2\\^62"):
+        calling.posterior_mode_batch(rng.dirichlet(np.ones(2), size=(1, 20, M)), 15, rng.integers(0, 2, size=(120, M)).astype(np.int8))
+    units = [unit(5, 4, 100), unit(120, 15, 200), unit(6, 12, 300)]   # (ploidy 12 over 6 haplotypes: 6 188 genotypes -- runs since round 5)
+    # (ploidy is per sample in the programs; three one-record calls keep the test simple)
+    out = {}
+    for u, K in zip(units, (4, 15, 12)):
+        out.update({(u["rec"]["pos"], k[1]): v for k, v in application._run_exact_groups([u], lambda s, K=K: K, lambda s: None, False).items()})
+    assert units[0]["invalid"] is None and units[2]["invalid"] is None and units[1]["invalid"] == "LIMIT"
+    assert (100, "S1") in out and (300, "S1") in out and (200, "S1") not in out
+    assert len(out[(300, "S1")]["alleles"]) == 12
+    err = capsys.readouterr().err
+    assert "record c1:200 not called" in err and "FILTER=LIMIT" in err
