@@ -565,9 +565,8 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
         }
       }
       }  // (memo miss)
-      if (lane == 0) {
-        if (P.step_type == 0) {
-        } else {
+      if (P.step_type != 0) {
+        if (lane == 0) {
           double sum = 0.0;
           for (int a = 0; a < H; a++) {
             const double r = ((o_llk[a] - cur_llk) + (o_lpr[a] - cur_lprior)) + o_aux[a];
@@ -578,7 +577,12 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
           for (int a = 0; a < H; a++) sum += o_prob[a];
           o_prob[current] = 1.0 - sum;
         }
-        // random_choice: searchsorted(cumsum(p), u, side="right")
+        call_sync();
+      }
+      // random_choice: searchsorted(cumsum(p), u, side="right") -- lane 0 walks the cumulative sum and stops at the choice (a settled
+      // chain's mass sits on the first few alleles: two or three reads; forming all H sums in every lane by v_readlane was
+      // measured slower, round 5: 118.9 -> 134.2 ms)
+      if (lane == 0) {
         const double u = call_double(st, ctr);
         double cacc = 0.0;
         int ch = H;
@@ -599,6 +603,8 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
       choice = s_choice;
     }
     // genotype_alleles.sort(); the step's llk is that of the last choice
+    // (tried in round 5 and not kept: the sort by counting, one lane per allele -- 118.9 -> 121.5 ms; the serial part of a sub-step
+    // is not where its time goes)
     if (lane == 0) {
       for (int a = 1; a < K; a++) {
         const int v = s_g[a];

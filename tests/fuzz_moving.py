@@ -1,5 +1,6 @@
-"""Differential fuzz of shallow low-quality units (chains that never settle; at most 64 reads: requests evaluated side by side
-from the code table in LDS, up to 24 K rows) of random shapes against the oracle, the phased and the speculative sampler.
+"""Differential fuzz of low-quality units (chains that never settle; mostly at most 64 reads: requests evaluated side by side
+from the code table in LDS, up to 24 K rows; the resumed chains of the phased sampler keep decision contexts per genotype) of
+random shapes against the oracle, the phased and the speculative sampler.
 Needs a GPU; test infrastructure, like tests/fuzz_kernels.py.
     python tests/fuzz_moving.py [cases] [first_seed]"""
 import os
@@ -25,9 +26,10 @@ def run(cases=40, seed0=9000):
         A = int(rng.choice([2, 2, 2, 3]))
         bits = 1 if A == 2 else 2
         M = int(rng.integers(5, min(24, 44, 192 // K, 64 // bits) + 1))
-        R = int(rng.integers(4, 65))
+        R = int(rng.integers(4, 65)) if rng.random() < 0.75 else int(rng.integers(65, 300))  # (round 5: now and then beyond one read chunk)
         F = [None, 0.0, 0.2][int(rng.integers(0, 3))]
-        steps = int(rng.integers(150, 450))
+        steps = int(rng.integers(150, 450)) if rng.random() < 0.6 else int(rng.integers(450, 1400))  # (... and long enough for the decision
+        # contexts of the resumed chains to be replaced, paused and tried again)
         units = int(rng.integers(2, 7))
         first = int(rng.integers(0, 10 ** 6))
         reads, _, _ = synth_units(units, ploidy=K, n_pos=M, n_reads=R, n_alleles=A, qual=(3, int(rng.integers(8, 25))), window=(min(4, M), M),
