@@ -178,15 +178,17 @@ def resolve_seed(seed):
     return int(seed)
 
 
-def device_unit_budget(bytes_per_unit, fraction=0.5, least=1, most=1 << 20):
+def device_unit_budget(bytes_per_unit, fraction=0.5, least=1, most=1 << 20, reserve=0):
     """How many units of `bytes_per_unit` device bytes a launch may hold: a share of the free HBM (the reference streams
-    record by record; here a file is processed in blocks of records, each block one launch per shape)."""
+    record by record; here a file is processed in blocks of records, each block one launch per shape).  `reserve`: bytes
+    the launches take whatever the number of units (at most three quarters of the free memory are set aside for them)."""
     try:
         import torch
 
         free, _ = torch.cuda.mem_get_info()
     except Exception:
         free = 8 << 30
+    free = max(free - int(reserve), free // 4)
     return int(max(least, min(most, (free * fraction) // max(1, int(bytes_per_unit)))))
 
 
@@ -809,12 +811,15 @@ def assemble(bed_path, variants_vcf_path, reference_sequences, sample_bams, ploi
         return bool(getattr(reference_sequences[contig], "known", True))
     by_contig = _variants_by_contig(variants)
     if units_per_block is None:
-        # device bytes of one unit: its traces (chains x steps x (ploidy words + llk)), the per-chain likelihood cache and
-        # tables of the workspace, a typical read tensor; two blocks are resident at a time (below).  A block is at most
+        # device bytes of one unit: its traces (chains x steps x (ploidy words + llk)), the floor of the per-chain likelihood
+        # cache (1024 entries of 16 bytes) and the tables of the workspace, a typical read tensor; two blocks are resident at a
+        # time (below), each with up to four sampler passes whose caches and decision contexts grow into fixed budgets of 4 + 6
+        # GiB (csrc/mchap_hip.hip CACHE_BUDGET, CTX_BUDGET; each at most an eighth of what is free): set aside.  A block is at most
         # 32 768 units: large enough that its launch is set by the average chain and not by its slowest, small enough that
         # a big job is several blocks whose host and device work overlap
         kmax = max(int(ploidy_of(s_)) for s_ in samples)
-        units_per_block = min(32768, device_unit_budget(chains * steps * (kmax + 1) * 8 + chains * 1024 * 16 * 2 + (256 << 10), fraction=0.2))
+        units_per_block = min(32768, device_unit_budget(chains * steps * (kmax + 1) * 8 + chains * 1024 * 16 + (256 << 10), fraction=0.2,
+                                                             reserve=2 * 4 * (10 << 30)))
     loci_per_block = max(1, units_per_block // max(1, len(samples)))
 
     def start_block(block, stream):

@@ -505,14 +505,23 @@ constexpr int PIPE_MAX_ROUNDS = 6;  // resume rounds of the phased sampler (coun
 // Unless the caller names a size, the tables therefore take what CACHE_BUDGET bytes over the batch's chains allow, between 1024
 // and 65536 entries: 880 chains of wide genotypes get 65536 each, 20 000 chains of configs[1] 8192.
 constexpr size_t CACHE_BUDGET = (size_t)4 << 30;
+// (a budget never takes more than 1/frac of the memory the device has free right now: several passes in flight on a shared or
+// partly used device each ask for theirs; the tables only save work, any size gives the same results)
+size_t budget_on_device(size_t cap, size_t frac) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / frac < cap) return free_b / frac;
+  return cap;
+}
 int cache_slots_of(const mchap_denovo_cfg *cfg, const Tune &T, const Plan &pl, int n_units, const BatchDims &B) {
   if (!cfg->llk_cache) return 0;
   if (!T.cache_auto) return T.cache_slots;
   const size_t ncc = (size_t)n_units * cfg->chains * (size_t)(pl.kind == SAMPLER_SPEC ? cfg->n_temps : 1);
   const bool keyed = B.max_ploidy * mchap::allele_bits(B.max_allele) * B.max_pos > 63;
   const size_t entry = 16 + (keyed ? (size_t)B.max_ploidy * (pl.wide ? 2 : 1) * 8 : 0);
+  const size_t budget = budget_on_device(CACHE_BUDGET, 8);
   int slots = 1024;
-  while (slots < 65536 && ncc * (size_t)(2 * slots) * entry <= CACHE_BUDGET) slots *= 2;
+  while (slots > 32 && ncc * (size_t)slots * entry > budget) slots >>= 1;  // (a nearly full device: below the usual floor)
+  while (slots < 65536 && ncc * (size_t)(2 * slots) * entry <= budget) slots *= 2;
   return slots;
 }
 
@@ -530,9 +539,7 @@ int ctx_slots_for(size_t bytes, size_t n_chains, size_t slot_bytes) {
 }
 int ctx_slots_of(const mchap_denovo_cfg *cfg, const Tune &T, const Plan &pl, int n_units, const BatchDims &B) {
   if (!ctx_shape(pl, B, T)) return 0;
-  size_t budget = CTX_BUDGET, free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 8 < budget) budget = free_b / 8;
-  return ctx_slots_for(budget, (size_t)n_units * cfg->chains, ctx_slot_bytes(pl, B));
+  return ctx_slots_for(budget_on_device(CTX_BUDGET, 8), (size_t)n_units * cfg->chains, ctx_slot_bytes(pl, B));
 }
 
 SimtCarve simt_carve(const mchap_denovo_cfg *cfg, const Plan &pl, int n_units, const BatchDims &B, int rpad, int cache_slots, int ctx_n = 0) {

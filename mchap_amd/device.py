@@ -543,8 +543,17 @@ class DenovoRaggedBatch(_OwnBuffers):
         self._begin()
         status = self.d_status.cpu().numpy()
         fixed = self.d_fixed.cpu().numpy()
-        trace = self.d_trace.cpu().numpy().view(np.uint64)
-        llks = self.d_llks.cpu().numpy()
+        # a few units asked for (the program's records whose summary the device pass could not give): their slices only
+        whole = only is None or 4 * len(only) >= self.n_units
+        trace = self.d_trace.cpu().numpy().view(np.uint64) if whole else None
+        llks = self.d_llks.cpu().numpy() if whole else None
+
+        def piece(host, dev, lo, n, view=None):
+            if host is not None:
+                return host[lo: lo + n]
+            a = dev[lo: lo + n].cpu().numpy()
+            return a.view(view) if view is not None else a
+
         out = []
         for u in (range(self.n_units) if only is None else only):
             D = self.units_host[u]
@@ -560,9 +569,9 @@ class DenovoRaggedBatch(_OwnBuffers):
                 out.append(dict(status=st, limit="more than 128 bits of sampled alleles per haplotype"))
                 continue
             fx = fixed[int(D["fixed_off"]): int(D["fixed_off"]) + M]
-            w = trace[int(D["trace_off"]): int(D["trace_off"]) + self.Cn * self.S * Ku * 2].reshape(self.Cn, self.S, Ku, 2)
+            w = piece(trace, self.d_trace, int(D["trace_off"]), self.Cn * self.S * Ku * 2, np.uint64).reshape(self.Cn, self.S, Ku, 2)
             g = unpack_trace(w, fx, A, 2)
-            lk = llks[int(D["llk_off"]): int(D["llk_off"]) + self.Cn * self.S].reshape(self.Cn, self.S)
+            lk = piece(llks, self.d_llks, int(D["llk_off"]), self.Cn * self.S).reshape(self.Cn, self.S)
             tr = GenotypeMultiTrace._from_sorted(g, lk).burn(self.burn)
             post = tr.posterior()
             sup = post.mode_genotype_support()

@@ -675,7 +675,9 @@ _AUX_SIZE = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
 
 
 def _aux_rg(buf, o, end):
-    """The value of a record's RG:Z tag found by walking its aux fields (SAM specification 4.2.4), or None."""
+    """The value of a record's RG:Z tag found by walking its aux fields (SAM specification 4.2.4), or None -- on malformed aux data
+    exactly what the native walk gives (csrc/bam_columns.cpp find_rg): None for an unterminated string, an unknown type or B
+    sub-type, a negative count, a truncated B header -- so that a sample's reads do not depend on which of the two walks ran."""
     while o + 3 <= end:
         tag, typ = bytes(buf[o:o + 2]), chr(buf[o + 2])
         o += 3
@@ -683,18 +685,72 @@ def _aux_rg(buf, o, end):
             z = o
             while z < end and buf[z] != 0:
                 z += 1
+            if z >= end:
+                return None  # no terminating NUL
             if tag == b"RG" and typ == "Z":
                 return bytes(buf[o:z]).decode()
             o = z + 1
         elif typ == "B":
-            sub = chr(buf[o])
+            if o + 5 > end:
+                return None
+            size = _AUX_SIZE.get(chr(buf[o]))
             (cnt,) = struct.unpack_from("<i", buf, o + 1)
-            o += 5 + cnt * _AUX_SIZE.get(sub, 1)
+            if size is None or cnt < 0:
+                return None
+            o += 5 + cnt * size
         elif typ in _AUX_SIZE:
             o += _AUX_SIZE[typ]
         else:
             return None
     return None
+
+
+def _aux_rg_all(b, tag_off, rec_end):
+    """_aux_rg for every record at once: the records walk their aux fields in lockstep (one numpy step per field index).  Returns
+    (start, length) of each record's RG:Z value in `b`, start -1 where the walk finds none or gives up."""
+    n = len(tag_off)
+    start, length = np.full(n, -1, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    if n == 0:
+        return start, length
+    size_of = np.zeros(256, dtype=np.int64)
+    for k, v in _AUX_SIZE.items():
+        size_of[ord(k)] = v
+    nul = np.flatnonzero(b == 0)
+    p = np.asarray(tag_off, dtype=np.int64).copy()
+    end = np.asarray(rec_end, dtype=np.int64)
+    act = np.flatnonzero(p + 3 <= end)
+    while len(act):
+        q, e = p[act], end[act]
+        t0, t1, ty = b[q], b[q + 1], b[q + 2]
+        q = q + 3
+        nxt = np.full(len(act), -1, dtype=np.int64)  # -1: the walk of this record is over
+        is_s = (ty == ord("Z")) | (ty == ord("H"))
+        if is_s.any():
+            qs, es = q[is_s], e[is_s]
+            j = np.searchsorted(nul, qs)  # the first NUL at or after the value's start
+            z = np.where(j < len(nul), nul[np.minimum(j, max(len(nul) - 1, 0))] if len(nul) else 0, np.int64(1) << 62)
+            closed = z < es
+            hit = closed & (t0[is_s] == ord("R")) & (t1[is_s] == ord("G")) & (ty[is_s] == ord("Z"))
+            rows = act[is_s]
+            start[rows[hit]], length[rows[hit]] = qs[hit], (z - qs)[hit]
+            nxt[is_s] = np.where(closed & ~hit, z + 1, -1)
+        is_b = ty == ord("B")
+        if is_b.any():
+            qb = q[is_b]
+            room = qb + 5 <= e[is_b]
+            at = np.where(room, qb, 0)
+            at = np.minimum(at, max(len(b) - 5, 0))
+            size = size_of[b[at]]
+            cnt = np.ascontiguousarray(b[(at + 1)[:, None] + np.arange(4)]).view("<i4").reshape(-1).astype(np.int64) if len(b) >= 5 else np.zeros(len(at), np.int64)
+            nxt[is_b] = np.where(room & (size > 0) & (cnt >= 0), qb + 5 + cnt * size, -1)
+        is_f = ~is_s & ~is_b
+        if is_f.any():
+            size = size_of[ty[is_f]]
+            nxt[is_f] = np.where(size > 0, q[is_f] + size, -1)
+        go = (nxt >= 0) & (nxt + 3 <= e)
+        p[act[go]] = nxt[go]
+        act = act[go]
+    return start, length
 
 
 class AlignmentColumns:
@@ -731,33 +787,19 @@ class AlignmentColumns:
             self.qname = np.unique(np.ascontiguousarray(nm).view("S%d" % width).reshape(n), return_inverse=True)[1].astype(np.int64)
         else:
             self.qname = np.zeros(0, dtype=np.int64)
-        # read groups from the RG:Z tag: every "RGZ" in the buffer, kept when it lies in a record's tag bytes (the first one
-        # of a record), then its NUL-terminated value matched with the header's read-group ids
+        # read groups: the RG:Z field found by walking each record's aux fields in order (what pysam's read.get_tag("RG") does;
+        # "RGZ" bytes inside another field's payload are not a field), its value matched with the header's read-group ids
         rg_names = list(rg_table)
         self.rg_samples = [rg_table[k] if id_field == "SM" else k for k in rg_names]
         rgi = np.full(n, -1, dtype=np.int64)
-        if n and rg_names and len(b) >= 4:
-            at = np.flatnonzero((b[:-3] == ord("R")) & (b[1:-2] == ord("G")) & (b[2:-1] == ord("Z")))
-            ri = np.searchsorted(offs, at, side="right") - 1
-            keep = (ri >= 0)
-            keep[keep] &= (at[keep] >= tag_off[ri[keep]]) & (at[keep] + 3 < rec_end[ri[keep]])
-            at, ri = at[keep], ri[keep]
-            firsts = np.r_[True, ri[1:] != ri[:-1]] if len(ri) else np.zeros(0, bool)
-            n_cand = np.bincount(ri, minlength=n)
-            at, ri = at[firsts], ri[firsts]
+        if n and rg_names:
+            v0, vlen = _aux_rg_all(b, tag_off, rec_end)
             for gi, key in enumerate(rg_names):
-                kb = np.frombuffer(key.encode() + b"\0", dtype=np.uint8)
-                room = at + 3 + len(kb) <= rec_end[ri]
-                m = room.copy()
-                m[room] = (b[(at[room] + 3)[:, None] + np.arange(len(kb))] == kb).all(axis=1)
-                rgi[ri[m]] = gi
-            # "RGZ" can also occur inside another tag's payload (a Z / H string, a B array, integer bytes): records with more than
-            # one candidate, or whose first candidate named no header read group, are settled by walking their aux fields
-            # (what pysam's read.get_tag("RG") does)
-            index_of = {k: i for i, k in enumerate(rg_names)}
-            for r in np.flatnonzero((n_cand > 1) | ((n_cand == 1) & (rgi < 0))):
-                v = _aux_rg(buf, int(tag_off[r]), int(rec_end[r]))
-                rgi[r] = index_of.get(v, -1)
+                kb = np.frombuffer(key.encode(), dtype=np.uint8)
+                m = (v0 >= 0) & (vlen == len(kb)) & (rgi < 0)
+                if len(kb):
+                    m[m] = (b[v0[m][:, None] + np.arange(len(kb))] == kb).all(axis=1)
+                rgi[m] = gi
         self.rg = rgi
         # CIGAR operations, flattened: record, op, length, reference / read offset at the start of the op
         total = int(n_cig.sum())

@@ -132,6 +132,8 @@ def write_bam(path, contigs, read_groups, records, index=True):
         for i, c in enumerate(seq):
             packed[i >> 1] |= seq_code[c] << (4 if i % 2 == 0 else 0)
         tags = r.get("tags_before", b"") + b"RGZ" + r["rg"].encode() + b"\0"  # (tags_before: raw aux bytes ahead of RG, for tests)
+        if "tags" in r:
+            tags = r["tags"]  # (the whole aux block as given, malformed ones included: tests)
         end = r["pos"] + max(ref_len, 1)
         b = _reg2bin(r["pos"], end)
         body = struct.pack("<iiBBHHHiiii", r["ref"], r["pos"], len(name), r["mapq"], b, len(r["cigar"]), r["flag"], len(seq), -1, -1, 0) + \

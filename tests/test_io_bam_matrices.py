@@ -182,6 +182,45 @@ def test_native_record_walk_equals_the_array_construction(tmp_path):
     assert n_files >= 8
 
 
+def test_malformed_aux_fields_read_the_same_in_both_walks(tmp_path):
+    """Aux data that breaks the SAM specification's layout ahead of (or inside) the RG field: the array construction (io._aux_rg) and
+    the library's walk (bam_columns.cpp find_rg) both give 'no read group' -- which reads a sample gets does not depend on whether
+    the library loaded."""
+    import struct
+
+    from mchap_amd import synth
+
+    ok = b"RGZg\0"
+    cases = {
+        "unknown B sub-type": b"XBBz" + struct.pack("<i", 2) + b"\1\2" + ok,
+        "negative B count": b"XBBc" + struct.pack("<i", -1) + ok,
+        "truncated B header": b"XBBc\1",
+        "unterminated RG": b"RGZg",
+        "unterminated string before RG": b"XAZabc",
+        "unknown type": b"XAq\0" + ok,
+        "fine": b"XAi" + struct.pack("<i", 7) + ok,
+    }
+    recs = [dict(qname="r%d" % i, flag=0, ref=0, pos=100 + i, mapq=60, cigar=[(20, "M")], seq="A" * 20, qual=[30] * 20, rg="g", tags=t)
+            for i, t in enumerate(cases.values())]
+    path = str(tmp_path / "bad_aux.bam")
+    synth.write_bam(path, [("chrS", 1000)], {"g": "X"}, recs)
+    bf = io.BamFile(path)
+    payload = b"".join(io.bgzf_inflate(bf.data, bf.blocks))
+    offsets, o = [], bf.header_end
+    while o + 4 <= len(payload):
+        (block,) = struct.unpack_from("<i", payload, o)
+        offsets.append(o)
+        o += 4 + block
+    a = io.AlignmentColumns(bf.refs, bf.rg, payload, offsets)
+    b = io.AlignmentColumns.native(bf.refs, bf.rg, payload, bf.header_end)
+    assert b is not None and a.n == b.n == len(cases)
+    np.testing.assert_array_equal(a.rg, b.rg)
+    assert (a.rg[:-1] < 0).all() and a.rg[-1] >= 0, dict(zip(cases, a.rg.tolist()))
+    for (name, t) in cases.items():
+        got = io._aux_rg(memoryview(t), 0, len(t))
+        assert got == ("g" if name == "fine" else None), name
+
+
 def test_native_record_walk_on_truncated_and_empty_payloads(tmp_path):
     """A payload cut in the middle of a record (a region's last block) yields the complete records before it; one without any
     record yields empty columns; a record whose own fields overrun its length is refused."""
