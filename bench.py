@@ -631,7 +631,7 @@ def call_mcmc_workload(U):
 def call_mcmc_roofline(U, S, Cn, K, ms):
     """VALU issue of call_mcmc_kernel from the committed SQ counter passes of this workload at 4096 units (static figures of an
     earlier rocprofv3 --pmc run, scaled per allele sub-step), priced per instruction class; None while no such profile exists."""
-    c, src, kname = sq_counters_of("*_call_sq_counters.json", ("call_mcmc_kernel", "mchap::call_mcmc_kernel"))
+    c, src, kname = sq_counters_of("*_call_sq_counters.json", ("call_mcmc_kernel", "mchap::call_mcmc_kernel", "call_coast_kernel", "mchap::call_coast_kernel"))
     if c is None:
         return None
     ref = 4096.0 * 2 * 2000 * 4
@@ -642,10 +642,11 @@ def call_mcmc_roofline(U, S, Cn, K, ms):
            "frac": cyc * sub / (ms * 1e-3) / SIMD_CYCLES_PER_S, "valu_insts_per_allele_sub_step": float(c["SQ_INSTS_VALU"]) / ref,
            "issue_cycles_per_allele_sub_step": cyc, "per_class_complete": w["per_class_complete"],
            "counters": "%s (%s; static: an earlier rocprofv3 --pmc run)" % (src, kname),
-           "note": "one wavefront per (unit, chain), the chains of a unit in one workgroup over shared LDS tables (two wavefronts per SIMD; a table "
-                   "per chain left one): a sub-step is bookkeeping on a handful of lanes (a categorical draw over 16 options from remembered "
-                   "likelihoods), so the issue slots it uses are a small fraction of the chip's; what bounds it is the dependent latency of "
-                   "that bookkeeping at the occupancy the LDS tables allow"}
+           "note": "a chain starts on a wavefront of its own (call_mcmc_kernel: the likelihoods of its first contexts, lanes over reads) and, once a "
+                   "step met only remembered contexts, runs a lane per chain (call_coast_kernel: a sub-step is a key, a look-up among eight, "
+                   "a Philox draw and a search over 16 running sums); a step is a serial program of about a thousand instructions whatever the "
+                   "lanes in use, so the launch lasts steps x that program and the chip's issue slots are mostly idle at 8 192 chains -- "
+                   "throughput grows with the batch until the LDS (a chain's memo: 2.1 KB) is full at 60 chains a compute unit"}
     if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
         out["wait_any_frac_of_wave_cycles"] = float(c["SQ_WAIT_ANY"]) / float(c["SQ_WAVE_CYCLES"])
     return out
@@ -673,7 +674,7 @@ def bench_call_mcmc(args):
     ms = e0.elapsed_time(e1) / n
     assert (d_st.cpu().numpy() == 0).all()
     out = {"workload": "%d units: tetraploid, %d known haplotypes x %d SNVs, %d reads, Gibbs steps, %d steps x %d chains, prior (0.1, flat); HBM resident" % (U, H, M, R, S, Cn),
-           "value": U / (ms * 1e-3), "unit": "units/s", "kernel": "call_mcmc_kernel", "kernel_ms": ms,
+           "value": U / (ms * 1e-3), "unit": "units/s", "kernel": "call_mcmc_kernel + call_coast_kernel", "kernel_ms": ms,
            "allele_steps_per_s": U * Cn * S * K / (ms * 1e-3), "roofline": call_mcmc_roofline(U, S, Cn, K, ms)}
     if not args.no_cpu_baseline:
         from oracle import binding as orc

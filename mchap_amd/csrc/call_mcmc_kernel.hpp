@@ -58,7 +58,19 @@ struct CallParams {
   int64_t *genotypes;        // [U][chains][steps][K] sorted alleles
   double *llks;              // [U][chains][steps]
   int32_t *status;           // [U]: 0 ok, MCHAP_ERR_LIMIT if a table filled up
+  // settled chains on their own kernel (call_coast_kernel below): the chain's hand-over record in the workspace, or null
+  uint64_t *state;           // [U * chains][state_stride] words (call_state_words)
+  int state_stride;
+  int phase;                 // 0: a chain's start; 1: the chains call_coast_kernel handed back (CALL_RESUME)
+  int last;                  // run every chain to its end: no hand-over
+  int n_units;
 };
+
+// A chain's hand-over record: word 0 = next step | flag << 32, word 1 = entry the next memo miss replaces, words 2-5 the genotype
+// at that step's start (eight alleles of 32 bits), then the Gibbs memo as it sits in LDS: CALL_MEMO keys, the entries' H
+// probabilities and H likelihoods.
+constexpr int CALL_STATE_HDR = 6;
+constexpr unsigned CALL_START = 0u, CALL_COAST = 1u, CALL_RESUME = 2u, CALL_DONE = 3u;
 
 // Memo of Gibbs sub-steps (round 3): the option probabilities of a sub-step are a function of the OTHER K - 1 alleles of the
 // genotype alone -- the likelihood table never forgets or changes an entry, the priors are tables -- and normalising them is
@@ -72,6 +84,7 @@ __host__ __device__ inline int call_memo_entries(int H) {
   const int n = 16384 / per;
   return n > CALL_MEMO ? CALL_MEMO : n;
 }
+__host__ __device__ inline int call_state_words(int H) { return CALL_STATE_HDR + CALL_MEMO + call_memo_entries(H) * 2 * H; }
 // A workgroup is up to CALL_WG_CHAINS wavefronts: the chains of ONE unit, which share the unit's tables (product table, read
 // weights, prior tables: 28 of the 32 KB a chain needed at the `mchap call` bench shape -- the LDS, not the registers, set the
 // occupancy: 4 wavefronts per CU with a table per chain, 8 with two chains per table).  Each chain keeps its own option arrays,
@@ -157,6 +170,18 @@ __device__ __forceinline__ long long call_key(const int *g, int K) {
   return rank_genotype(s, K);
 }
 
+// Key of a Gibbs context over at most sixteen known haplotypes: how many copies of each the other K - 1 <= 7 alleles hold, four
+// bits a haplotype -- one-to-one on the multiset, never 0 for K >= 2 (0 marks an empty memo entry), and a handful of shifts
+// where sorting the alleles costs a network
+template <int KM, typename Get>
+__device__ __forceinline__ unsigned long long call_ctx_counts(Get allele, int K, int k) {
+  unsigned long long key = 0ull;
+#pragma unroll
+  for (int i = 0; i < KM; i++)
+    if (i < K && i != k) key += 1ull << (4 * (allele(i) & 15));
+  return key;
+}
+
 // KM: the ploidy bound of the genotype arrays and unrolled loops (8, or EXACT_KMAX = 16 for ploidies 9 to 15: exact_kernel.hpp)
 template <int KM = 8>
 __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const CallParams P) {
@@ -177,6 +202,12 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
   EP.Rcap = 0;  // the whole product table (the sampler does not tile the reads)
   // (a table in the workspace is a table per chain: the host then launches one chain per workgroup)
   EP.ptab_ext = P.ptab_ext ? P.ptab_ext + ((size_t)unit * P.chains + chain) * ((size_t)R * H + R) : nullptr;
+  if (P.phase == 1) {  // resume launch: a workgroup none of whose chains was handed back has nothing to do (uniform over the workgroup)
+    bool any = false;
+    for (int c = (int)blockIdx.x * nwv; c < ((int)blockIdx.x + 1) * nwv && c < P.chains; c++)
+      any |= (unsigned)(P.state[((size_t)unit * P.chains + c) * P.state_stride] >> 32) == CALL_RESUME;
+    if (!any) return;
+  }
   ExactLds E;
   PriorTab pt;
   exact_setup(EP, unit, smem, E, pt);       // (all wavefronts of the workgroup together)
@@ -190,7 +221,10 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
   const int n_memo = (P.step_type == 0 && 8 * (K - 1) <= 63) ? call_memo_entries(H) : 0;
   long long *memo_key = reinterpret_cast<long long *>(o_aux + H + 64);
   double *memo_val = reinterpret_cast<double *>(memo_key + CALL_MEMO);
-  for (int i = lane; i < CALL_MEMO; i += WAVE) memo_key[i] = 0;
+  uint64_t *state = P.state ? P.state + ((size_t)unit * P.chains + (chain < P.chains ? chain : 0)) * P.state_stride : nullptr;
+  const bool resumed = P.phase == 1;
+  if (!resumed)
+    for (int i = lane; i < CALL_MEMO; i += WAVE) memo_key[i] = 0;
   int memo_next = 0;                        // (wave-uniform) the entry the next miss replaces
   __shared__ double s_acc_[CALL_WG_CHAINS], s_choice_llk_[CALL_WG_CHAINS];
   __shared__ int s_g_[CALL_WG_CHAINS][KM];     // the chain's genotype (array order)
@@ -230,6 +264,16 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
   }
   __syncthreads();  // (the last workgroup-wide barrier: from here on every wavefront runs its chain alone)
   if (chain >= P.chains) return;
+  int first_step = 0;
+  if (resumed) {
+    const uint64_t w0 = state[0];
+    if ((unsigned)(w0 >> 32) != CALL_RESUME) return;
+    first_step = __builtin_amdgcn_readfirstlane((int)(unsigned)w0);
+    memo_next = __builtin_amdgcn_readfirstlane((int)state[1]);
+    const int nw = CALL_MEMO + n_memo * 2 * H;  // keys and entries: one run of words in the record and in LDS
+    uint64_t *dst = reinterpret_cast<uint64_t *>(memo_key);
+    for (int i = lane; i < nw; i += WAVE) dst[i] = state[CALL_STATE_HDR + i];
+  }
   const double invK_full = 1.0 / (double)K;
   ulonglong2 *cache = P.cache + ((size_t)unit * P.chains + chain) * (size_t)P.cache_slots;
   const unsigned long long cmask = (unsigned long long)P.cache_slots - 1ull;
@@ -280,8 +324,11 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
   };
   (void)invK_full;
 
-  // ---- initial genotype: the caller's, or greedy_caller (calling/mcmc.py:393-453) ----
-  if (P.initial) {
+  // ---- initial genotype: the handed-back chain's, the caller's, or greedy_caller (calling/mcmc.py:393-453) ----
+  if (resumed) {
+    if (lane < K) s_g[lane] = (int)reinterpret_cast<const uint32_t *>(state + 2)[lane];
+    call_sync();
+  } else if (P.initial) {
     if (lane < K) s_g[lane] = (int)P.initial[(size_t)unit * K + lane];
     call_sync();
   } else {
@@ -378,7 +425,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
   st.k1 = (uint32_t)(P.seed >> 32) ^ (uint32_t)(P.stream_ids[unit] >> 32);
   st.c2 = ((uint32_t)chain << 16) | SLOT_CALL;
   st.c3 = (uint32_t)P.stream_ids[unit];
-  uint64_t ctr = 0;
+  uint64_t ctr = (uint64_t)first_step * (uint64_t)(2 * K - 1);  // (K - 1 shuffle draws and K uniforms per step)
   int64_t *gout = P.genotypes + (((size_t)unit * P.chains + chain) * P.steps) * K;
   double *lout = P.llks + ((size_t)unit * P.chains + chain) * P.steps;
 
@@ -444,7 +491,10 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
     if (act) o_llk[a] = val;
   };
 
-  for (int step = 0; step < P.steps; step++) {
+  const bool hand_over = state != nullptr && !P.last && n_memo > 0;
+  bool handed = false;
+  for (int step = first_step; step < P.steps; step++) {
+    bool all_known = true;  // every sub-step of this step found its context in the memo
     // np.random.shuffle(arange(ploidy)) -- every lane the same
     int order[KM];
     for (int i = 0; i < K; i++) order[i] = i;
@@ -491,10 +541,14 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
       long long ctx = 0;
       int memo_hit = -1;
       if (n_memo > 0) {
-        // key of the context: the other alleles sorted, eight bits each (H <= 256, K - 1 <= 7) -- any one-to-one function of
+        // key of the context: up to sixteen known haplotypes, the copies of each among the other alleles, four bits a haplotype
+        // (call_ctx_counts); more: the other alleles sorted, eight bits each (H <= 256, K - 1 <= 7) -- any one-to-one function of
         // the multiset does; the genotype's rank would cost a chain of 64-bit divisions per sub-step.  Sorted by counting
         // (the place of an allele is the number of alleles before it in the order), all loops of constant extent: no
         // register array is indexed by a run-time value
+        if (H <= 16 && K >= 2) {
+          ctx = (long long)call_ctx_counts<KM>([&](int i) { return s_g[i]; }, K, k);
+        } else {
         int v[KM];
 #pragma unroll
         for (int i = 0; i < KM; i++) v[i] = i < K ? s_g[i] : 0;
@@ -508,6 +562,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
           if (i < K && i != k) packed |= (unsigned long long)(v[i] & 255) << (8 * place);
         }
         ctx = (long long)((packed << 1) | 1ull);  // (never 0: 0 marks an empty entry)
+        }
         const unsigned long long m = __ballot(lane < n_memo && memo_key[lane] == ctx);
         memo_hit = m ? __ffsll((long long)m) - 1 : -1;
       }
@@ -515,6 +570,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
         use_prob = memo_val + (size_t)memo_hit * 2 * H;
         use_llk = use_prob + H;
       } else {
+      all_known = false;
       for (int a0 = 0; a0 < H; a0 += WAVE) option_llks(k, a0);
       // priors (and proposal ratios) of the options
       for (int a = lane; a < H; a += WAVE) {
@@ -620,8 +676,235 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
     call_sync();
     if (lane < K) gout[(size_t)step * K + lane] = s_g[lane];
     call_sync();
+    // A step that met only remembered contexts: the chain has settled -- its record to the workspace, the rest of its steps to
+    // call_coast_kernel (a lane per chain; it hands the chain back at the first context it does not know)
+    if (hand_over && all_known && step + 1 < P.steps) {
+      const int nw = CALL_MEMO + n_memo * 2 * H;
+      const uint64_t *src = reinterpret_cast<const uint64_t *>(memo_key);
+      for (int i = lane; i < nw; i += WAVE) state[CALL_STATE_HDR + i] = src[i];
+      if (lane < 8) reinterpret_cast<uint32_t *>(state + 2)[lane] = lane < K ? (uint32_t)s_g[lane] : 0u;
+      if (lane == 0) {
+        state[1] = (uint64_t)memo_next;
+        state[0] = (uint64_t)(unsigned)(step + 1) | ((uint64_t)CALL_COAST << 32);
+      }
+      handed = true;
+      break;
+    }
   }
+  if (state && !handed && lane == 0) state[0] = (uint64_t)(unsigned)P.steps | ((uint64_t)CALL_DONE << 32);
   if (lane == 0 && s_full) atomicMin(&P.status[unit], MCHAP_ERR_LIMIT);
+}
+
+// ---- settled chains: a lane per chain ----
+// A chain of `mchap call` that has settled meets the same K contexts step after step, and a sub-step in a remembered context is a
+// table look-up and a draw: nothing in it needs a wavefront.  call_mcmc_kernel hands such a chain over after its first step of
+// remembered contexts only (the record of call_state_words); here `chains_per_wave` chains run side by side, one per lane, their
+// memos in LDS, each until its last step or the first context its memo does not hold -- that step is left undone and the chain
+// goes back to call_mcmc_kernel (phase 1), which finds the draws of a step by its number.  The same draws (Philox counters by
+// step), the same probabilities (the memo's doubles), the same sequential cumulative sum: the same traces.
+
+// sorting network of eight (19 compare-exchanges)
+__device__ __forceinline__ void call_cx(unsigned &a, unsigned &b) {
+  const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+__device__ __forceinline__ void call_sort8(unsigned (&v)[8]) {
+  call_cx(v[0], v[1]); call_cx(v[2], v[3]); call_cx(v[4], v[5]); call_cx(v[6], v[7]);
+  call_cx(v[0], v[2]); call_cx(v[1], v[3]); call_cx(v[4], v[6]); call_cx(v[5], v[7]);
+  call_cx(v[1], v[2]); call_cx(v[5], v[6]); call_cx(v[0], v[4]); call_cx(v[3], v[7]);
+  call_cx(v[1], v[5]); call_cx(v[2], v[6]);
+  call_cx(v[1], v[4]); call_cx(v[3], v[6]);
+  call_cx(v[2], v[4]); call_cx(v[3], v[5]);
+  call_cx(v[3], v[4]);
+}
+// Philox draws of a lane's stream with the last block kept (two draws a block: philox.hpp)
+struct CallDraws {
+  CallStream s;
+  uint64_t blk;
+  uint32_t o[4];
+  __device__ __forceinline__ void words(uint64_t n, uint32_t &a, uint32_t &b) {
+    if ((n >> 1) != blk) {
+      blk = n >> 1;
+      philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), s.c2, s.c3, s.k0, s.k1, o);
+    }
+    a = (n & 1) ? o[2] : o[0];
+    b = (n & 1) ? o[3] : o[1];
+  }
+};
+
+// Lane l of wavefront w (CALL_COAST_WAVES of them a workgroup: one per SIMD of a compute unit) runs chain w * chains_per_wave + l
+// (unit-major, as the records lie); lds_stride: 8-byte words of a chain's memo in LDS (odd: the lanes' accesses spread over the
+// banks).  A step is a serial program of ~1300 instructions whatever the number of lanes in use, so a batch is spread as thin as
+// the chip allows: few lanes per wavefront, a wavefront per SIMD (the host picks chains_per_wave).
+constexpr int CALL_COAST_WAVES = 4;
+__global__ __launch_bounds__(64 * CALL_COAST_WAVES) void call_coast_kernel(const CallParams P, const int chains_per_wave, const int lds_stride) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  typedef __attribute__((address_space(3))) uint64_t lds_u64;
+  typedef __attribute__((address_space(3))) const double lds_f64c;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  lds_u64 *cm = (lds_u64 *)reinterpret_cast<uint64_t *>(smem) + wv * chains_per_wave * lds_stride;
+  const int lane = (int)(threadIdx.x & 63);
+  const int H = P.H, K = P.K;
+  const int n_memo = call_memo_entries(H);
+  const int nw = CALL_MEMO + n_memo * 2 * H;
+  const long long n_all = (long long)P.n_units * P.chains;
+  const long long c0 = ((long long)blockIdx.x * CALL_COAST_WAVES + wv) * chains_per_wave;
+  const long long ci = c0 + lane;
+  bool live = lane < chains_per_wave && ci < n_all;
+  uint64_t *state = P.state + (size_t)(live ? ci : 0) * P.state_stride;
+  int step = 0;
+  if (live) {
+    const uint64_t w0 = state[0];
+    live = (unsigned)(w0 >> 32) == CALL_COAST;
+    step = (int)(unsigned)w0;
+  }
+  const unsigned long long mine = __ballot(live);
+  if (!mine) return;
+  // the memos of this wavefront's chains into LDS, a chain at a time (the record's words are contiguous)
+  for (int l = 0; l < chains_per_wave; l++) {
+    if (!((mine >> l) & 1ull)) continue;
+    const uint64_t *src = P.state + (size_t)(c0 + l) * P.state_stride + CALL_STATE_HDR;
+    for (int i = lane; i < nw; i += WAVE) cm[l * lds_stride + i] = src[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+  __builtin_amdgcn_wave_barrier();
+  lds_u64 *keys = cm + lane * lds_stride;
+  lds_f64c *vals = (lds_f64c *)(keys + CALL_MEMO);
+  // ... and each entry's probabilities turned into their running sums, added in allele order as random_choice's cumsum adds them:
+  // the draw is then the number of sums not above u (they never decrease) -- a search instead of a walk
+  if (live) {
+    typedef __attribute__((address_space(3))) double lds_f64;
+    for (int e = 0; e < n_memo; e++) {
+      lds_f64 *pr = (lds_f64 *)(keys + CALL_MEMO) + (size_t)e * 2 * H;
+      double acc = 0.0;
+      for (int x = 0; x < H; x++) {
+        acc += pr[x];
+        pr[x] = acc;
+      }
+    }
+  }
+  // the genotype: eight alleles of eight bits (the memo's key holds K - 1 <= 7 of them: K <= 8, H <= 256)
+  uint64_t gp = 0;
+  if (live)
+    for (int i = 0; i < 8; i++) gp |= (uint64_t)(reinterpret_cast<const uint32_t *>(state + 2)[i] & 255u) << (8 * i);
+  const bool few = H <= 16 && K >= 2;
+  // (few: the copies of each haplotype in the genotype, four bits each -- call_ctx_counts of a context is this less one allele)
+  uint64_t counts = 0;
+  if (few)
+    for (int i = 0; i < K; i++) counts += 1ull << (4 * (int)((gp >> (8 * i)) & 15ull));
+  const int unit = live ? (int)(ci / P.chains) : 0, chain = live ? (int)(ci % P.chains) : 0;
+  CallDraws D;
+  D.s.k0 = (uint32_t)P.seed;
+  D.s.k1 = (uint32_t)(P.seed >> 32) ^ (uint32_t)(P.stream_ids[unit] >> 32);
+  D.s.c2 = ((uint32_t)chain << 16) | SLOT_CALL;
+  D.s.c3 = (uint32_t)P.stream_ids[unit];
+  D.blk = ~0ull;
+  int64_t *gout = P.genotypes + ((size_t)(live ? ci : 0) * P.steps) * K;
+  double *lout = P.llks + (size_t)(live ? ci : 0) * P.steps;
+  const int per_step = 2 * K - 1;
+  int search_rounds = 0;  // of the binary search over H sums
+  while ((1 << search_rounds) <= H) search_rounds++;
+
+  while (__ballot(live)) {
+    if (live) {
+      uint64_t ctr = (uint64_t)step * (uint64_t)per_step;
+      // np.random.shuffle(arange(ploidy)): positions four bits each
+      uint32_t order = 0x76543210u;
+      for (int i = K - 1; i >= 1; i--) {
+        uint32_t a, b;
+        D.words(ctr++, a, b);
+        const int j = (int)__umulhi(a, (uint32_t)i + 1u);
+        const uint32_t oi = (order >> (4 * i)) & 15u, oj = (order >> (4 * j)) & 15u;
+        order = (order & ~(15u << (4 * i))) | (oj << (4 * i));
+        order = (order & ~(15u << (4 * j))) | (oi << (4 * j));
+      }
+      uint64_t g = gp, cn = counts;
+      double choice_llk = 0.0;
+      bool known = true;
+      for (int jj = 0; jj < K; jj++) {
+        const int k = (int)((order >> (4 * jj)) & 15u);
+        // the context's key as call_mcmc_kernel forms it
+        uint64_t ctx;
+        if (few) {
+          ctx = cn - (1ull << (4 * (int)((g >> (8 * k)) & 15ull)));
+        } else {
+          unsigned v[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) v[i] = (i < K && i != k) ? (unsigned)((g >> (8 * i)) & 255ull) : 0x1FFu;
+          call_sort8(v);
+          unsigned long long packed = 0ull;
+#pragma unroll
+          for (int i = 0; i < 7; i++)
+            if (i < K - 1) packed |= (unsigned long long)v[i] << (8 * i);
+          ctx = (packed << 1) | 1ull;
+        }
+        int hit = -1;
+#pragma unroll
+        for (int e = 0; e < CALL_MEMO; e++)  // (entries the memo does not use keep the key 0)
+          if (keys[e] == ctx) hit = e;
+        if (hit < 0) {
+          known = false;
+          break;
+        }
+        lds_f64c *pr = vals + (size_t)hit * 2 * H;
+        uint32_t a, b;
+        D.words(ctr++, a, b);
+        const double u = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+        // random_choice: searchsorted(cumsum(p), u, side="right") = how many of the running sums are not above u (beyond the
+        // last: the last allele, as call_mcmc_kernel)
+        int ch = 0;
+        if (few) {
+          double q[16];
+#pragma unroll
+          for (int x = 0; x < 16; x++) q[x] = pr[x < H ? x : H - 1];
+#pragma unroll
+          for (int x = 0; x < 16; x++) ch += (x < H && !(q[x] > u)) ? 1 : 0;
+        } else {
+          int lo = 0, hi = H;  // the first sum above u lies in [lo, hi]
+          for (int r = 0; r < search_rounds; r++) {
+            const int mid = (lo + hi) >> 1;
+            const double c = pr[mid < H ? mid : H - 1];
+            if (lo < hi) {
+              if (c > u) hi = mid;
+              else lo = mid + 1;
+            }
+          }
+          ch = lo;
+        }
+        if (ch > H - 1) ch = H - 1;
+        choice_llk = pr[H + ch];
+        g = (g & ~(255ull << (8 * k))) | ((uint64_t)ch << (8 * k));
+        if (few) cn = ctx + (1ull << (4 * ch));
+      }
+      if (!known) {
+        // this step is call_mcmc_kernel's: the record keeps the genotype of the step's start (the memo is as it was)
+        for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(state + 2)[i] = (uint32_t)((gp >> (8 * i)) & 255ull);
+        state[0] = (uint64_t)(unsigned)step | ((uint64_t)CALL_RESUME << 32);
+        live = false;
+      } else {
+        // genotype_alleles.sort(); the step's llk is that of the last choice
+        unsigned v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = i < K ? (unsigned)((g >> (8 * i)) & 255ull) : 0x1FFu;
+        call_sort8(v);
+        gp = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          if (i < K) {
+            gp |= (uint64_t)v[i] << (8 * i);
+            gout[(size_t)step * K + i] = (int64_t)v[i];
+          }
+        lout[step] = choice_llk;
+        counts = cn;
+        step++;
+        if (step >= P.steps) {
+          state[0] = (uint64_t)(unsigned)P.steps | ((uint64_t)CALL_DONE << 32);
+          live = false;
+        }
+      }
+    }
+  }
 }
 
 }  // namespace mchap

@@ -102,3 +102,30 @@ def test_gibbs_and_mh_agree_with_the_exact_posterior(prior):
         model = CallingMCMC(ploidy=K, haplotypes=haps[0], prior=prior, steps=25000, chains=2, random_seed=11, step_type=step_type)
         post = model.fit(reads[0]).burn(1000).posterior().as_array(H)
         assert np.abs(post - exact).max() < 0.015, step_type
+
+
+@pytest.mark.parametrize("lanes", ["default", "0", "1", "5", "13"])
+@pytest.mark.parametrize("shape", ["settled", "wandering", "octoploid", "many-haplotypes"])
+def test_settled_chains_a_lane_each_give_the_same_traces(shape, lanes, monkeypatch):
+    """Round 5: a chain whose step met only remembered contexts goes to call_coast_kernel (a lane per chain) and comes back at the
+    first context it does not know -- settled chains (no coming back), chains of few low-quality reads that keep moving (every
+    round used up, the last launch finishes them), ploidy 8 (seven alleles in a context's key), 40 known haplotypes; whatever
+    the number of lanes in use per wavefront (MCHAP_HIP_CALL_LANES; 0: no hand-over), the oracle's traces step for step."""
+    from mchap_amd.calling_mcmc import CallingMCMC
+
+    K, H, M, R, qual, steps = {"settled": (4, 16, 8, 200, (5, 25), 400), "wandering": (4, 8, 6, 12, (2, 8), 700),
+                               "octoploid": (8, 6, 5, 60, (5, 25), 300), "many-haplotypes": (3, 40, 8, 30, (3, 12), 300)}[shape]
+    if lanes != "default":
+        monkeypatch.setenv("MCHAP_HIP_CALL_LANES", lanes)
+    U = 5
+    reads, haps, counts, rng = _inputs(U, K, H, M, R, seed=7 * K + H, qual=qual)
+    traces = CallingMCMC(ploidy=K, haplotypes=haps[0], prior=None, steps=steps, chains=3, random_seed=23).fit_batch(
+        reads, None, haplotypes=haps, prior=(np.full(U, 0.1), None))
+    moves = 0
+    for u in range(U):
+        g, l = orc.call_mcmc(reads[u], haps[u], K, steps=steps, chains=3, step_type=0, prior=(0.1, None), rng_kind=orc.RNG_PHILOX, seed=23, stream_id=u)
+        assert np.array_equal(traces[u].genotypes, g), u
+        np.testing.assert_allclose(traces[u].llks, l, rtol=1e-10, atol=1e-9)
+        moves += int((g[:, 1:] != g[:, :-1]).any(axis=-1).sum())
+    if shape == "wandering":
+        assert moves > U * 3 * steps // 10, moves  # (the shape does what its name says)
