@@ -199,6 +199,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
   EP.freqs = P.freqs;
   EP.R = R; EP.M = P.M; EP.A = P.A; EP.H = H; EP.K = K;
   EP.has_prior = P.has_prior;
+  EP.ptab_scale = 1.0;
   EP.Rcap = 0;  // the whole product table (the sampler does not tile the reads)
   // (a table in the workspace is a table per chain: the host then launches one chain per workgroup)
   EP.ptab_ext = P.ptab_ext ? P.ptab_ext + ((size_t)unit * P.chains + chain) * ((size_t)R * H + R) : nullptr;

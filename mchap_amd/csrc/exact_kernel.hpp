@@ -31,6 +31,10 @@ struct ExactParams {
   int nblk;
   int Rcap;                 // rows of the LDS product table (0: all R; less: the passes tile the reads, exact_tile)
   double *ptab_ext;         // product table + read weights of THIS workgroup in global memory instead of LDS, or null
+  double ptab_scale;        // the table holds product * ptab_scale: 1 / ploidy for the exact caller -- the factor every term of a read's sum
+                            // over a genotype's haplotypes carries (likelihood.py:60-66), applied once per table entry instead of once per
+                            // (genotype, read, haplotype): the same products, a third of the arithmetic less -- 1 for the call sampler (its
+                            // greedy start divides by the partial ploidies)
   // outputs / workspace
   float *llk32;             // [U][G] or null
   double *llk64;            // [U][G] or null
@@ -178,7 +182,7 @@ __device__ __forceinline__ void exact_setup(const ExactParams &P, int unit, unsi
       const double v = reads[((size_t)r * M + j) * A + haps[h * M + j]];
       if (!isnan(v)) prod *= v;  // assemble/likelihood.py:54-59
     }
-    E.ptab[q] = prod;
+    E.ptab[q] = prod * P.ptab_scale;
   }
   for (int r = threadIdx.x; r < R; r += blockDim.x) E.cnt[r] = P.counts ? (double)P.counts[(size_t)unit * P.R + r] : 1.0;
   {
@@ -244,7 +248,7 @@ __device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[KM
         rp[t] = 0.0;
 #pragma unroll
         for (int k = 0; k < KM; k++)
-          if (k < K) rp[t] += row[g[k]] * invK;
+          if (k < K) rp[t] += row[g[k]];
       }
       llk += read_log_product<4>(rp);
     }
@@ -254,7 +258,7 @@ __device__ __forceinline__ double exact_llk(const ExactLds &E, const int (&g)[KM
     double rp = 0.0;
 #pragma unroll
     for (int k = 0; k < KM; k++)
-      if (k < K) rp += row[g[k]] * invK;
+      if (k < K) rp += row[g[k]];
     llk += read_log(rp) * cnt[r];
   }
   return llk;
@@ -282,7 +286,7 @@ __device__ __forceinline__ void exact_llkn(const ExactLds &E, const int (&g)[NQ]
         for (int k = 0; k < KM; k++)
           if (k < K) {
 #pragma unroll
-            for (int q = 0; q < NQ; q++) rp[q][t] += row[g[q][k]] * invK;
+            for (int q = 0; q < NQ; q++) rp[q][t] += row[g[q][k]];
           }
       }
 #pragma unroll
@@ -298,7 +302,7 @@ __device__ __forceinline__ void exact_llkn(const ExactLds &E, const int (&g)[NQ]
     for (int k = 0; k < KM; k++)
       if (k < K) {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) rp[q] += row[g[q][k]] * invK;
+        for (int q = 0; q < NQ; q++) rp[q] += row[g[q][k]];
       }
     const double w = cnt[r];
 #pragma unroll
@@ -319,7 +323,7 @@ __device__ __forceinline__ void exact_tile(const ExactParams &P, int unit, const
       const double v = reads[((size_t)r * M + j) * A + haps[h * M + j]];
       if (!isnan(v)) prod *= v;
     }
-    E.ptab[q] = prod;
+    E.ptab[q] = prod * P.ptab_scale;
   }
   for (int r = threadIdx.x; r < rn; r += blockDim.x) E.cnt[r] = P.counts ? (double)P.counts[(size_t)unit * P.R + r0 + r] : 1.0;
   __syncthreads();
@@ -356,7 +360,7 @@ __device__ __forceinline__ void exact_llk_tiled(const ExactParams &P, int unit, 
               rp[q] = 0.0;
 #pragma unroll
               for (int k = 0; k < KM; k++)
-                if (k < K) rp[q] += row[g[k]] * invK;
+                if (k < K) rp[q] += row[g[k]];
             }
             acc += read_log_product<4>(rp);
           }
@@ -366,7 +370,7 @@ __device__ __forceinline__ void exact_llk_tiled(const ExactParams &P, int unit, 
           double rp = 0.0;
 #pragma unroll
           for (int k = 0; k < KM; k++)
-            if (k < K) rp += row[g[k]] * invK;
+            if (k < K) rp += row[g[k]];
           acc += read_log(rp) * cnt[r];
         }
         llk[t] = acc;
