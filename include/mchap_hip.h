@@ -265,6 +265,29 @@ int mchap_trace_incongruence_listed_device(int n_list, const int32_t *unit_list_
                                            int burn, const uint64_t *trace_words, int cap, int ploidy_max, double threshold, int32_t *mci,
                                            void *stream);
 
+/* The four summaries above for traces of `words_per_haplotype` 64-bit words per haplotype: 1 (the entry points above), or 2 for a
+ * batch that ran on the general sampler (mchap_denovo_trace_words_per_haplotype: units of more than 64 bits per haplotype, ploidies 9
+ * to MCHAP_MAX_PLOIDY_DENOVO) -- round 5, so that no shape `assemble` samples needs its traces on the host.  A state is then
+ * ploidy x 2 words (a haplotype's words adjacent, genotypes sorted by haplotype as the sampler writes them) and the rows of
+ * post_words / mode_words hold ploidy_max x 2 words; a batch launch keeps min(512, mchap_trace_posterior_max_states_wph) states. */
+int mchap_trace_posterior_batch_wph_device(int n_units, const mchap_unit *units_dev, int steps, int chains, int burn,
+                                           const uint64_t *trace_words, int max_states, int ploidy_max, int words_per_haplotype,
+                                           uint64_t *post_words, int32_t *post_counts, int32_t *post_n,
+                                           double *mode_stats, int32_t *mode_index, uint64_t *mode_words,
+                                           int32_t *mode_count, void *stream);
+int mchap_trace_posterior_max_states_wph(int ploidy_max, int words_per_haplotype);
+int mchap_trace_posterior_listed_wph_device(int n_list, const int32_t *unit_list_dev, const mchap_unit *units_dev, int steps, int chains,
+                                            int burn, const uint64_t *trace_words, int cap, int ploidy_max, int words_per_haplotype,
+                                            uint64_t *post_words, int32_t *post_counts, int32_t *post_n, double *mode_stats,
+                                            int32_t *mode_index, uint64_t *mode_words, int32_t *mode_count, void *stream);
+int mchap_trace_incongruence_batch_wph_device(int n_units, const mchap_unit *units_dev, int steps, int chains, int burn,
+                                              const uint64_t *trace_words, int ploidy_max, int words_per_haplotype, double threshold,
+                                              int32_t *mci, void *stream);
+int mchap_trace_incongruence_listed_wph_device(int n_list, const int32_t *unit_list_dev, const mchap_unit *units_dev, int steps, int chains,
+                                               int burn, const uint64_t *trace_words, int cap, int ploidy_max, int words_per_haplotype,
+                                               double threshold, int32_t *mci, void *stream);
+
+
 /* Exact caller for a batch of units that share (n_reads, n_pos, max_allele, n_haps, ploidy), everything resident on the
  * device: what application/call_exact.py:126-179 asks of calling/exact.py per sample, for all samples of a chunk of
  * loci at once.  Every output is optional (NULL = not wanted):

@@ -251,6 +251,11 @@ EXPORTS = [
     "mchap_trace_posterior_listed_device",
     "mchap_trace_incongruence_listed_device",
     "mchap_trace_incongruence_batch_device",
+    "mchap_trace_posterior_batch_wph_device",
+    "mchap_trace_posterior_max_states_wph",
+    "mchap_trace_posterior_listed_wph_device",
+    "mchap_trace_incongruence_batch_wph_device",
+    "mchap_trace_incongruence_listed_wph_device",
     "mchap_exact_genotype_likelihoods",
     "mchap_exact_genotype_posteriors",
     "mchap_exact_posterior_mode_batch",

@@ -23,6 +23,9 @@ struct PosteriorParams {
   const uint64_t *trace;
   int steps, chains, burn;
   int max_states, ploidy_max;
+  int wph;                   // 64-bit words per haplotype of the traces: 1, or 2 for a batch of the general sampler (units of more than
+                             // 64 bits per haplotype, ploidies 9 to 15): a state is ploidy x wph words, and so are the rows of
+                             // post_words / mode_words (ploidy_max x wph words each)
   int cap;                   // distinct states the LDS table holds (POST_CAP for a whole batch; up to posterior_max_cap for a list)
   const int32_t *unit_list;  // null: workgroup b summarises unit b; else unit unit_list[b], its states written to row b
   uint64_t *post_words;
@@ -35,15 +38,24 @@ struct PosteriorParams {
 };
 
 // Distinct states of chains [ch_lo, ch_hi) after burn-in, ranked, with support labels and the mode support.
-// LDS: uw [POST_CAP][K], ucount / order / label [POST_CAP].  Every lane returns the same n_u, overflow, best, best_r.
+// LDS: uw [POST_CAP][K * W], ucount / order / label [POST_CAP].  Every lane returns the same n_u, overflow, best, best_r.
+// SW: the bound of a state's words (8: the fast samplers' traces; 32: ploidies up to 15 at W = 2 words per haplotype -- round 5)
 struct PostSummary {
   int n_u, overflow, best_r;
   double best;  // probability of the mode support (SPM)
 };
 
+__device__ __forceinline__ bool post_hap_eq(const uint64_t *a, const uint64_t *b, int W) {
+  bool eq = a[0] == b[0];
+  if (W > 1) eq = eq && a[1] == b[1];
+  return eq;
+}
+template <int SW>
 __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, const mchap_unit &U, int S, int burn, int ch_lo,
-                                                      int ch_hi, uint64_t *uw, int *ucount, int *order, int *label, const int CAP) {
-  const int K = U.ploidy;
+                                                      int ch_hi, uint64_t *uw, int *ucount, int *order, int *label, const int CAP,
+                                                      const int W) {
+  const int Kh = U.ploidy;   // haplotypes of a state
+  const int K = Kh * W;      // words of a state
   const int lane = threadIdx.x;
   const int per_chain = S - burn;
   const int N = (ch_hi - ch_lo) * per_chain;
@@ -55,22 +67,22 @@ __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, con
   for (int base = 0; base < N; base += WAVE) {
     const int n = base + lane;
     const bool active = n < N;
-    uint64_t st[MCHAP_MAX_PLOIDY];
+    uint64_t st[SW];
     if (active) {
       const int ch = ch_lo + n / per_chain, s = burn + n % per_chain;
       const uint64_t *src = trace + U.trace_off + ((size_t)ch * S + s) * K;
 #pragma unroll
-      for (int h = 0; h < MCHAP_MAX_PLOIDY; h++) st[h] = h < K ? src[h] : 0ull;
+      for (int h = 0; h < SW; h++) st[h] = h < K ? src[h] : 0ull;
     } else {
 #pragma unroll
-      for (int h = 0; h < MCHAP_MAX_PLOIDY; h++) st[h] = 0ull;
+      for (int h = 0; h < SW; h++) st[h] = 0ull;
     }
     // match against the distinct states found so far
     int found = -1;
     for (int e = 0; e < n_u; e++) {
       bool eq = true;
 #pragma unroll
-      for (int h = 0; h < MCHAP_MAX_PLOIDY; h++)
+      for (int h = 0; h < SW; h++)
         if (h < K) eq = eq && (uw[(size_t)e * K + h] == st[h]);
       if (eq && found < 0) found = e;
     }
@@ -80,7 +92,7 @@ __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, con
       const int leader = __ffsll((long long)pending) - 1;
       bool eq = true;
 #pragma unroll
-      for (int h = 0; h < MCHAP_MAX_PLOIDY; h++) {
+      for (int h = 0; h < SW; h++) {
         if (h < K) {
           const uint64_t lw = __shfl(st[h], leader, WAVE);
           eq = eq && (lw == st[h]);
@@ -115,21 +127,22 @@ __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, con
     int lab = r;
     for (int q = 0; q < r; q++) {
       const uint64_t *b = uw + (size_t)order[q] * K;
-      // sorted words: equal supports <=> equal sequences of distinct words
+      // sorted haplotypes (W words each): equal supports <=> equal sequences of distinct haplotypes
       int ia = 0, ib = 0;
       bool same = true;
-      while (same && (ia < K || ib < K)) {
-        if (ia >= K || ib >= K) {
+      while (same && (ia < Kh || ib < Kh)) {
+        if (ia >= Kh || ib >= Kh) {
           same = false;
           break;
         }
-        if (a[ia] != b[ib]) {
+        if (!post_hap_eq(a + ia * W, b + ib * W, W)) {
           same = false;
           break;
         }
-        const uint64_t v = a[ia];
-        while (ia < K && a[ia] == v) ia++;
-        while (ib < K && b[ib] == v) ib++;
+        const uint64_t *v = a + ia * W;
+        const int ia0 = ia;
+        while (ia < Kh && post_hap_eq(a + ia * W, a + ia0 * W, W)) ia++;
+        while (ib < Kh && post_hap_eq(b + ib * W, v, W)) ib++;
       }
       if (same) {
         lab = q;
@@ -176,16 +189,19 @@ __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, con
   return R;
 }
 
+template <int SW>
 __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int row = blockIdx.x;                                   // row of the per-state outputs
   const int unit = P.unit_list ? P.unit_list[row] : row;        // index of the per-unit outputs
   const mchap_unit U = P.units[unit];
-  const int K = U.ploidy;
+  const int W = P.wph;
+  const int K = U.ploidy * W;          // words of a state
+  const int KWmax = P.ploidy_max * W;  // ... and of an output row
   const int lane = threadIdx.x;
   const int N = P.chains * (P.steps - P.burn);
   const int CAP = P.cap;
-  if (K > P.ploidy_max || K < 1) {  // the LDS tables are sized for ploidy_max: refuse instead of overrunning them
+  if (U.ploidy > P.ploidy_max || U.ploidy < 1 || K > SW) {  // the LDS tables are sized for ploidy_max: refuse instead of overrunning them
     if (lane == 0) {
       P.post_n[unit] = INT_MIN;
       P.mode_stats[2 * (size_t)unit + 0] = NAN;
@@ -199,19 +215,19 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
   int *ucount = reinterpret_cast<int *>(smem + (size_t)CAP * K * 8);  // [CAP]
   int *order = ucount + CAP;                                          // [CAP] rank -> unique index
   int *label = order + CAP;                                           // [CAP] support label by rank
-  const PostSummary R = post_summarise(P.trace, U, P.steps, P.burn, 0, P.chains, uw, ucount, order, label, CAP);
+  const PostSummary R = post_summarise<SW>(P.trace, U, P.steps, P.burn, 0, P.chains, uw, ucount, order, label, CAP, W);
   const int n_u = R.n_u;
   for (int r = lane; r < n_u; r += WAVE) {
     if (r < P.max_states) {
       const int e = order[r];
-      uint64_t *dst = P.post_words + ((size_t)row * P.max_states + r) * P.ploidy_max;
-      for (int h = 0; h < P.ploidy_max; h++) dst[h] = h < K ? uw[(size_t)e * K + h] : 0ull;
+      uint64_t *dst = P.post_words + ((size_t)row * P.max_states + r) * KWmax;
+      for (int h = 0; h < KWmax; h++) dst[h] = h < K ? uw[(size_t)e * K + h] : 0ull;
       P.post_counts[(size_t)row * P.max_states + r] = ucount[e];
     }
   }
   for (int r = n_u + lane; r < P.max_states; r += WAVE) {
-    uint64_t *dst = P.post_words + ((size_t)row * P.max_states + r) * P.ploidy_max;
-    for (int h = 0; h < P.ploidy_max; h++) dst[h] = 0ull;
+    uint64_t *dst = P.post_words + ((size_t)row * P.max_states + r) * KWmax;
+    for (int h = 0; h < KWmax; h++) dst[h] = 0ull;
     P.post_counts[(size_t)row * P.max_states + r] = 0;
   }
   if (lane == 0) {
@@ -221,8 +237,8 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
       P.mode_stats[2 * (size_t)unit + 1] = (double)ucount[order[R.best_r]] / (double)N;       // GPM
       P.mode_index[unit] = R.best_r;
       if (P.mode_words)
-        for (int h = 0; h < P.ploidy_max; h++)
-          P.mode_words[(size_t)unit * P.ploidy_max + h] = h < K ? uw[(size_t)order[R.best_r] * K + h] : 0ull;
+        for (int h = 0; h < KWmax; h++)
+          P.mode_words[(size_t)unit * KWmax + h] = h < K ? uw[(size_t)order[R.best_r] * K + h] : 0ull;
       if (P.mode_count) P.mode_count[unit] = ucount[order[R.best_r]];
     } else {
       if (P.mode_count) P.mode_count[unit] = 0;
@@ -244,19 +260,22 @@ struct IncongruenceParams {
   int steps, chains, burn;
   double threshold;
   int ploidy_max;
+  int wph;                   // as PosteriorParams::wph
   int cap;                   // as PosteriorParams::cap
   const int32_t *unit_list;  // null, or the units to summarise (mci is indexed by unit)
   int32_t *mci;
 };
 
+template <int SW>
 __global__ __launch_bounds__(64) void trace_incongruence_kernel(const IncongruenceParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int unit = P.unit_list ? P.unit_list[blockIdx.x] : (int)blockIdx.x;
   const mchap_unit U = P.units[unit];
-  const int K = U.ploidy;
+  const int W = P.wph;
+  const int Kh = U.ploidy, K = Kh * W;  // haplotypes / words of a state
   const int lane = threadIdx.x;
   const int CAP = P.cap;
-  if (K > P.ploidy_max || K < 1) {
+  if (Kh > P.ploidy_max || Kh < 1 || K > SW) {
     if (lane == 0) P.mci[unit] = -1;
     return;
   }
@@ -264,18 +283,22 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
   int *ucount = reinterpret_cast<int *>(smem + (size_t)CAP * K * 8);
   int *order = ucount + CAP;
   int *label = order + CAP;
-  uint64_t *sets = reinterpret_cast<uint64_t *>(smem + (((size_t)CAP * K * 8 + (size_t)CAP * 12 + 7) & ~(size_t)7));  // [chains][K] distinct words of the chain's mode support
-  int *nset = reinterpret_cast<int *>(sets + (size_t)POST_MAX_CHAINS * MCHAP_MAX_PLOIDY);  // [chains] size, 0 = below threshold
+  // [chains][SW] words: the distinct haplotypes of the chain's mode support, W words each
+  uint64_t *sets = reinterpret_cast<uint64_t *>(smem + (((size_t)CAP * K * 8 + (size_t)CAP * 12 + 7) & ~(size_t)7));
+  int *nset = reinterpret_cast<int *>(sets + (size_t)POST_MAX_CHAINS * SW);  // [chains] size, 0 = below threshold
   int bad = 0;
   for (int ch = 0; ch < P.chains; ch++) {
-    const PostSummary R = post_summarise(P.trace, U, P.steps, P.burn, ch, ch + 1, uw, ucount, order, label, CAP);
+    const PostSummary R = post_summarise<SW>(P.trace, U, P.steps, P.burn, ch, ch + 1, uw, ucount, order, label, CAP, W);
     if (R.overflow) bad = 1;
     if (lane == 0) {
       int n = 0;
       if (R.n_u > 0 && R.best >= P.threshold) {
-        const uint64_t *g = uw + (size_t)order[R.best_r] * K;  // sorted words
-        for (int h = 0; h < K; h++)
-          if (h == 0 || g[h] != g[h - 1]) sets[(size_t)ch * MCHAP_MAX_PLOIDY + n++] = g[h];
+        const uint64_t *g = uw + (size_t)order[R.best_r] * K;  // sorted haplotypes
+        for (int h = 0; h < Kh; h++)
+          if (h == 0 || !post_hap_eq(g + h * W, g + (h - 1) * W, W)) {
+            for (int w = 0; w < W; w++) sets[(size_t)ch * SW + n * W + w] = g[h * W + w];
+            n++;
+          }
       }
       nset[ch] = n;
     }
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
       for (int b = 0; b < a && !seen; b++) {
         if (nset[b] != nset[a]) continue;
         bool eq = true;
-        for (int i = 0; i < nset[a]; i++) eq = eq && sets[(size_t)a * MCHAP_MAX_PLOIDY + i] == sets[(size_t)b * MCHAP_MAX_PLOIDY + i];
+        for (int i = 0; i < nset[a] * W; i++) eq = eq && sets[(size_t)a * SW + i] == sets[(size_t)b * SW + i];
         seen = eq;
       }
       if (!seen) modes++;
@@ -303,10 +326,10 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
       int total = 0;
       for (int a = 0; a < P.chains; a++)
         for (int i = 0; i < nset[a]; i++) {
-          const uint64_t w = sets[(size_t)a * MCHAP_MAX_PLOIDY + i];
+          const uint64_t *w = sets + (size_t)a * SW + i * W;
           bool dup = false;
           for (int b = 0; b < a && !dup; b++)
-            for (int q = 0; q < nset[b] && !dup; q++) dup = sets[(size_t)b * MCHAP_MAX_PLOIDY + q] == w;
+            for (int q = 0; q < nset[b] && !dup; q++) dup = post_hap_eq(sets + (size_t)b * SW + q * W, w, W);
           if (!dup) total++;
         }
       // the reference compares with the size of the FIRST qualifying chain's allele set, not with the ploidy
@@ -317,14 +340,16 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
   }
 }
 
-inline size_t posterior_lds_bytes(int K, int cap = POST_CAP) { return (((size_t)cap * K * 8 + (size_t)cap * 4 * 3) + 7) & ~(size_t)7; }
-inline size_t incongruence_lds_bytes(int K, int cap = POST_CAP) {
-  return posterior_lds_bytes(K, cap) + (size_t)POST_MAX_CHAINS * MCHAP_MAX_PLOIDY * 8 + (size_t)POST_MAX_CHAINS * 4;
+// (kw: words of a state = ploidy bound x words per haplotype; sw: the kernels' SW)
+inline size_t posterior_lds_bytes(int kw, int cap = POST_CAP) { return (((size_t)cap * kw * 8 + (size_t)cap * 4 * 3) + 7) & ~(size_t)7; }
+inline size_t incongruence_lds_bytes(int kw, int cap = POST_CAP, int sw = MCHAP_MAX_PLOIDY) {
+  return posterior_lds_bytes(kw, cap) + (size_t)POST_MAX_CHAINS * sw * 8 + (size_t)POST_MAX_CHAINS * 4;
 }
-// the largest table (distinct states) a workgroup's 160 KB of LDS holds at this ploidy, beside the incongruence kernel's sets
-inline int posterior_max_cap(int K) {
-  const size_t fixed = (size_t)POST_MAX_CHAINS * MCHAP_MAX_PLOIDY * 8 + (size_t)POST_MAX_CHAINS * 4 + 64;
-  return (int)((160 * 1024 - fixed) / ((size_t)K * 8 + 12));
+// the largest table (distinct states) a workgroup's 160 KB of LDS holds at this state width, beside the incongruence kernel's sets
+inline int posterior_max_cap(int kw, int sw = MCHAP_MAX_PLOIDY) {
+  const size_t fixed = (size_t)POST_MAX_CHAINS * sw * 8 + (size_t)POST_MAX_CHAINS * 4 + 64;
+  return (int)((160 * 1024 - fixed) / ((size_t)kw * 8 + 12));
 }
+constexpr int POST_SW_WIDE = 32;  // ploidies up to 15 at two words per haplotype
 
 }  // namespace mchap

@@ -527,85 +527,63 @@ class DenovoRaggedBatch(_OwnBuffers):
         self.d_ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
         return self
 
-    def _run_wide(self, burn, incongruence_threshold):
-        """A batch with a unit wider than 64 bits per haplotype (two words per haplotype in the traces): the sampler only; the
-        posterior summaries of such batches are formed by the host classes in results()."""
-        stream = self._begin().cuda_stream
-        type(self).n_runs += 1
-        self._fit(stream)
-        self.burn = int(burn)
-        self.incongruence_threshold = float(incongruence_threshold)
-        self._end()
-
-    def _results_wide(self, raise_on_limit, only=None):
+    def _host_summary(self, u, st, fixed, cache):
+        """The summary of unit u by the host classes on its downloaded traces (assemble/classes.py:280-376 as the reference runs
+        them): only for a unit whose chains visited more distinct genotypes than even the listed launch's LDS table holds --
+        tens of thousands of steps.  cache: dict holding the batch's traces once most of its units come this way."""
         from .classes import GenotypeMultiTrace
 
-        self._begin()
-        status = self.d_status.cpu().numpy()
-        fixed = self.d_fixed.cpu().numpy()
-        # a few units asked for (the program's records whose summary the device pass could not give): their slices only
-        whole = only is None or 4 * len(only) >= self.n_units
-        trace = self.d_trace.cpu().numpy().view(np.uint64) if whole else None
-        llks = self.d_llks.cpu().numpy() if whole else None
+        D = self.units_host[u]
+        Ku, M, A, W = int(D["ploidy"]), int(D["n_pos"]), int(D["max_allele"]), self.wph
+        fx = fixed[int(D["fixed_off"]): int(D["fixed_off"]) + M]
 
-        def piece(host, dev, lo, n, view=None):
-            if host is not None:
-                return host[lo: lo + n]
+        def piece(name, dev, lo, n, view=None):
+            if cache.get("whole"):
+                if name not in cache:
+                    a = dev.cpu().numpy()
+                    cache[name] = a.view(view) if view is not None else a
+                return cache[name][lo: lo + n]
             a = dev[lo: lo + n].cpu().numpy()
             return a.view(view) if view is not None else a
 
-        out = []
-        for u in (range(self.n_units) if only is None else only):
-            D = self.units_host[u]
-            Ku, M, A = int(D["ploidy"]), int(D["n_pos"]), int(D["max_allele"])
-            st = int(status[u])
-            if st == _lib.UNIT_NAN_LLK:
-                raise ValueError("Encountered log likelihood of nan")
-            if st == _lib.UNIT_BREAKS:
-                raise ValueError("breaks must be smaller then n")
-            if st < 0:
-                if raise_on_limit:
-                    raise NotImplementedError("mchap_hip: unit %d exceeds the packed haplotype width" % u)
-                out.append(dict(status=st, limit="more than 128 bits of sampled alleles per haplotype"))
-                continue
-            fx = fixed[int(D["fixed_off"]): int(D["fixed_off"]) + M]
-            w = piece(trace, self.d_trace, int(D["trace_off"]), self.Cn * self.S * Ku * 2, np.uint64).reshape(self.Cn, self.S, Ku, 2)
-            g = unpack_trace(w, fx, A, 2)
-            lk = piece(llks, self.d_llks, int(D["llk_off"]), self.Cn * self.S).reshape(self.Cn, self.S)
-            tr = GenotypeMultiTrace._from_sorted(g, lk).burn(self.burn)
-            post = tr.posterior()
-            sup = post.mode_genotype_support()
-            mg, gp = sup.mode_genotype()
-            out.append(dict(genotypes=post.genotypes, probabilities=post.probabilities, spm=float(sup.probabilities.sum()),
-                            gpm=float(gp), mode_genotype=mg, mci=int(tr.replicate_incongruence(self.incongruence_threshold)), status=st))
-        return out
+        w = piece("trace", self.d_trace, int(D["trace_off"]), self.Cn * self.S * Ku * W, np.uint64)
+        w = w.reshape((self.Cn, self.S, Ku) + ((W,) if W > 1 else ()))
+        g = unpack_trace(w, fx, A, W)
+        lk = piece("llks", self.d_llks, int(D["llk_off"]), self.Cn * self.S).reshape(self.Cn, self.S)
+        tr = GenotypeMultiTrace._from_sorted(g, lk).burn(self.burn)
+        post = tr.posterior()
+        sup = post.mode_genotype_support()
+        mg, gp = sup.mode_genotype()
+        return dict(genotypes=post.genotypes, probabilities=post.probabilities, spm=float(sup.probabilities.sum()), gpm=float(gp),
+                    mode_genotype=mg, mci=int(tr.replicate_incongruence(self.incongruence_threshold)), status=st)
 
     def run(self, burn, max_states=512, incongruence_threshold=0.6):
         """Sampler, posterior summary and incongruence code, all enqueued on torch's current stream."""
-        if self.wph > 1:
-            return self._run_wide(burn, incongruence_threshold)
         torch = self.torch
         dev = self.device
-        U, K = self.n_units, self.Kmax
+        U, K, W = self.n_units, self.Kmax, self.wph  # (W = 2: a batch of the general sampler, two words per haplotype -- round 5)
         stream = self._begin().cuda_stream
         L = _lib.lib()
         type(self).n_runs += 1
         self._fit(stream)
         self.max_states = max_states
-        self.p_words = torch.empty(U * max_states * K, dtype=torch.int64, device=dev)
+        if W > 1:  # (wider states: the batch launch's table is what the LDS holds of them)
+            max_states = min(int(max_states), int(L.mchap_trace_posterior_max_states_wph(K, W)))
+            self.max_states = max_states
+        self.p_words = torch.empty(U * max_states * K * W, dtype=torch.int64, device=dev)
         self.p_counts = torch.empty(U * max_states, dtype=torch.int32, device=dev)
         self.p_n = torch.empty(U, dtype=torch.int32, device=dev)
         self.p_stats = torch.empty(U * 2, dtype=torch.float64, device=dev)
         self.p_mode = torch.empty(U, dtype=torch.int32, device=dev)
-        self.p_mode_words = torch.empty(U * K, dtype=torch.int64, device=dev)
+        self.p_mode_words = torch.empty(U * K * W, dtype=torch.int64, device=dev)
         self.p_mode_count = torch.empty(U, dtype=torch.int32, device=dev)
         self.p_mci = torch.empty(U, dtype=torch.int32, device=dev)
-        _lib.check(L.mchap_trace_posterior_batch_device(
-            U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), int(max_states), K, self._p(self.p_words),
+        _lib.check(L.mchap_trace_posterior_batch_wph_device(
+            U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), int(max_states), K, W, self._p(self.p_words),
             self._p(self.p_counts), self._p(self.p_n), self._p(self.p_stats), self._p(self.p_mode), self._p(self.p_mode_words),
             self._p(self.p_mode_count), C.c_void_p(stream)))
-        _lib.check(L.mchap_trace_incongruence_batch_device(
-            U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), K, C.c_double(float(incongruence_threshold)),
+        _lib.check(L.mchap_trace_incongruence_batch_wph_device(
+            U, self._p(self.d_units), self.S, self.Cn, int(burn), self._p(self.d_trace), K, W, C.c_double(float(incongruence_threshold)),
             self._p(self.p_mci), C.c_void_p(stream)))
         self.burn = int(burn)
         self.incongruence_threshold = float(incongruence_threshold)
@@ -613,24 +591,24 @@ class DenovoRaggedBatch(_OwnBuffers):
 
     def _summarise_listed(self, over):
         """The units `over` (int32 indices) summarised again with a table of chains x (steps - burn) states (as many as the LDS
-        holds): their entries of p_n / p_stats / p_mode_words / p_mci are rewritten; returns (words int64 [len(over) * cap * K],
+        holds): their entries of p_n / p_stats / p_mode_words / p_mci are rewritten; returns (words int64 [len(over) * cap * K * wph],
         counts int32 [len(over) * cap] on the device, cap)."""
         torch = self.torch
         L = _lib.lib()
-        K = self.Kmax
+        K, W = self.Kmax, self.wph
         total = self.Cn * (self.S - self.burn)
-        cap = min(total, int(L.mchap_trace_posterior_max_states(K)))
+        cap = min(total, int(L.mchap_trace_posterior_max_states_wph(K, W)))
         stream = torch.cuda.current_stream().cuda_stream
         d_list = torch.from_numpy(np.ascontiguousarray(over, dtype=np.int32)).to(self.device)
-        o_words = torch.empty(len(over) * cap * K, dtype=torch.int64, device=self.device)
+        o_words = torch.empty(len(over) * cap * K * W, dtype=torch.int64, device=self.device)
         o_counts = torch.empty(len(over) * cap, dtype=torch.int32, device=self.device)
-        _lib.check(L.mchap_trace_posterior_listed_device(
-            len(over), self._p(d_list), self._p(self.d_units), self.S, self.Cn, self.burn, self._p(self.d_trace), cap, K,
+        _lib.check(L.mchap_trace_posterior_listed_wph_device(
+            len(over), self._p(d_list), self._p(self.d_units), self.S, self.Cn, self.burn, self._p(self.d_trace), cap, K, W,
             self._p(o_words), self._p(o_counts), self._p(self.p_n), self._p(self.p_stats), self._p(self.p_mode),
             self._p(self.p_mode_words), self._p(self.p_mode_count), C.c_void_p(stream)))
-        _lib.check(L.mchap_trace_incongruence_listed_device(
+        _lib.check(L.mchap_trace_incongruence_listed_wph_device(
             len(over), self._p(d_list), self._p(self.d_units), self.S, self.Cn, self.burn, self._p(self.d_trace),
-            min(self.S - self.burn, cap), K, C.c_double(self.incongruence_threshold), self._p(self.p_mci), C.c_void_p(stream)))
+            min(self.S - self.burn, cap), K, W, C.c_double(self.incongruence_threshold), self._p(self.p_mci), C.c_void_p(stream)))
         return o_words, o_counts, cap
 
     def summary_arrays(self):
@@ -684,17 +662,14 @@ class DenovoRaggedBatch(_OwnBuffers):
         summarised by a second, listed launch with a table of chains x (steps - burn) states (as many as the LDS holds).
         A unit beyond the library's packed haplotype width raises NotImplementedError, or with raise_on_limit=False comes
         back as dict(status, limit=reason)."""
-        from .classes import GenotypeMultiTrace
-
-        if self.wph > 1:
-            return self._results_wide(raise_on_limit, only)
-        U, K, ms = self.n_units, self.Kmax, self.max_states
+        U, K, ms, W = self.n_units, self.Kmax, self.max_states, self.wph
+        wshape = (W,) if W > 1 else ()   # (a haplotype of a wide batch is two words: unpack_trace(..., W))
         self._begin()  # (the pass may have been issued on another stream)
-        words = self.p_words.cpu().numpy().view(np.uint64).reshape(U, ms, K)
+        words = self.p_words.cpu().numpy().view(np.uint64).reshape((U, ms, K) + wshape)
         counts = self.p_counts.cpu().numpy().reshape(U, ms)
         n = self.p_n.cpu().numpy()
         stats = self.p_stats.cpu().numpy().reshape(U, 2)
-        mode_words = self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K)
+        mode_words = self.p_mode_words.cpu().numpy().view(np.uint64).reshape((U, K) + wshape)
         mci = self.p_mci.cpu().numpy()
         status = self.d_status.cpu().numpy()
         fixed = self.d_fixed.cpu().numpy()
@@ -710,14 +685,15 @@ class DenovoRaggedBatch(_OwnBuffers):
             o_words, o_counts, cap = self._summarise_listed(over)
             n = self.p_n.cpu().numpy()
             stats = self.p_stats.cpu().numpy().reshape(U, 2)
-            mode_words = self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K)
+            mode_words = self.p_mode_words.cpu().numpy().view(np.uint64).reshape((U, K) + wshape)
             mci = self.p_mci.cpu().numpy()
-            ow = o_words.cpu().numpy().view(np.uint64).reshape(len(over), cap, K)
+            ow = o_words.cpu().numpy().view(np.uint64).reshape((len(over), cap, K) + wshape)
             oc = o_counts.cpu().numpy().reshape(len(over), cap)
             over_row = {int(u): (ow[i], oc[i], cap) for i, u in enumerate(over)}
         out = []
-        trace = llks = None
-        for u in (range(U) if only is None else only):
+        wanted = range(U) if only is None else only
+        host_cache = {"whole": 4 * len(wanted) >= U}  # (traces for _host_summary: the batch's at once, or a unit's slice at a time)
+        for u in wanted:
             D = self.units_host[u]
             Ku, M, A = int(D["ploidy"]), int(D["n_pos"]), int(D["max_allele"])
             fx = fixed[int(D["fixed_off"]): int(D["fixed_off"]) + M]
@@ -729,32 +705,21 @@ class DenovoRaggedBatch(_OwnBuffers):
             if st < 0:
                 if raise_on_limit:
                     raise NotImplementedError("mchap_hip: unit %d exceeds the packed haplotype width" % u)
-                out.append(dict(status=st, limit="more than 64 bits of sampled alleles per haplotype (one bit per biallelic, two per "
-                                                 "tri- / tetra-allelic SNV that is not fixed as homozygous)"))
+                out.append(dict(status=st, limit="more than %d bits of sampled alleles per haplotype (one bit per biallelic, two per "
+                                                 "tri- / tetra-allelic SNV that is not fixed as homozygous)" % (128 if W > 1 else 64)))
                 continue
             if u in over_row and 0 <= n[u] <= over_row[u][2] and mci[u] >= 0:
                 w_, c_, _ = over_row[u]
                 k = int(n[u])
-                out.append(dict(genotypes=unpack_trace(w_[:k, :Ku], fx, A), probabilities=c_[:k] / total, spm=float(stats[u, 0]),
-                                gpm=float(stats[u, 1]), mode_genotype=unpack_trace(mode_words[u, :Ku], fx, A), mci=int(mci[u]), status=st))
+                out.append(dict(genotypes=unpack_trace(w_[:k, :Ku], fx, A, W), probabilities=c_[:k] / total, spm=float(stats[u, 0]),
+                                gpm=float(stats[u, 1]), mode_genotype=unpack_trace(mode_words[u, :Ku], fx, A, W), mci=int(mci[u]), status=st))
                 continue
             if n[u] < 0 or n[u] > ms or mci[u] < 0:
                 # (more distinct states than even the LDS holds -- tens of thousands of steps: the host classes on the trace)
-                if trace is None:
-                    trace = self.d_trace.cpu().numpy().view(np.uint64)
-                    llks = self.d_llks.cpu().numpy()
-                w = trace[int(D["trace_off"]): int(D["trace_off"]) + self.Cn * self.S * Ku].reshape(self.Cn, self.S, Ku)
-                g = unpack_trace(w, fx, A)
-                lk = llks[int(D["llk_off"]): int(D["llk_off"]) + self.Cn * self.S].reshape(self.Cn, self.S)
-                tr = GenotypeMultiTrace._from_sorted(g, lk).burn(self.burn)
-                post = tr.posterior()
-                sup = post.mode_genotype_support()
-                mg, gp = sup.mode_genotype()
-                out.append(dict(genotypes=post.genotypes, probabilities=post.probabilities, spm=float(sup.probabilities.sum()),
-                                gpm=float(gp), mode_genotype=mg, mci=int(tr.replicate_incongruence(self.incongruence_threshold)), status=st))
+                out.append(self._host_summary(u, st, fixed, host_cache))
                 continue
             k = int(n[u])
-            out.append(dict(genotypes=unpack_trace(words[u, :k, :Ku], fx, A), probabilities=counts[u, :k] / total,
-                            spm=float(stats[u, 0]), gpm=float(stats[u, 1]), mode_genotype=unpack_trace(mode_words[u, :Ku], fx, A),
+            out.append(dict(genotypes=unpack_trace(words[u, :k, :Ku], fx, A, W), probabilities=counts[u, :k] / total,
+                            spm=float(stats[u, 0]), gpm=float(stats[u, 1]), mode_genotype=unpack_trace(mode_words[u, :Ku], fx, A, W),
                             mci=int(mci[u]), status=st))
         return out

@@ -91,3 +91,53 @@ def test_beyond_the_widest_sampler_is_still_refused_by_name():
     reads, _, _ = synth_units(1, ploidy=16, n_pos=4, n_reads=20, window=(2, 4))
     with pytest.raises(NotImplementedError):
         DenovoMCMC(ploidy=16, n_alleles=[2] * 4, steps=5, chains=1, random_seed=1).fit_batch(list(reads))
+
+
+@pytest.mark.parametrize("case", ["tetraploid-80-snvs", "triploid-50-triallelic", "decaploid-6-snvs", "dodecaploid-wandering", "tetraploid-70-snvs-wandering",
+                                  "mixed-ploidies-3-and-11"])
+def test_device_summary_of_wide_batches_equals_the_host_classes(case):
+    """Round 5: the posterior summary and the replicate incongruence of a batch on the general sampler (two words per haplotype:
+    mchap_trace_posterior_*_wph_device, trace_posterior_kernel<32>) against the host classes on the same traces
+    (GenotypeMultiTrace.burn().posterior(), mode_genotype_support(), replicate_incongruence(): assemble/classes.py:87-128,
+    194-205, 280-376 -- pinned to the reference's vectors in tests/test_classes.py): distinct genotypes in the reference's
+    order, probabilities, SPM / GPM, mode genotype, MCI.  Settled units stay with the batch launch; chains of four reads wander
+    through more than 512 genotypes and go to the listed launch (ploidy 4: its table holds every state) or beyond it to the
+    host classes (ploidy 12: 762 states of 24 words fit the LDS)."""
+    from mchap_amd import DenovoMCMC
+    from mchap_amd.device import DenovoRaggedBatch
+    from mchap_amd.synth import synth_units
+
+    shapes = {"tetraploid-80-snvs": [(4, 80, 60, 2, dict(window=(20, 80)))] * 3, "triploid-50-triallelic": [(3, 50, 40, 3, dict(window=(10, 50)))] * 3,
+              "decaploid-6-snvs": [(10, 6, 60, 2, dict(window=(3, 6)))] * 3,
+              "dodecaploid-wandering": [(12, 5, 4, 2, dict(window=(2, 5), qual=(2, 8)))] * 2 + [(12, 5, 80, 2, dict(window=(2, 5)))],
+              "tetraploid-70-snvs-wandering": [(4, 70, 4, 2, dict(window=(10, 40), qual=(2, 8)))] * 2 + [(4, 70, 60, 2, dict(window=(20, 70)))],
+              "mixed-ploidies-3-and-11": [(3, 66, 50, 2, dict(window=(20, 66))), (11, 4, 40, 2, dict(window=(2, 4))), (3, 8, 30, 2, dict(window=(3, 8)))]}[case]
+    steps, burn = (600, 100) if "wandering" in case else (120, 40)
+    units = []
+    for u, (K, M, R, A, skw) in enumerate(shapes):
+        reads, _, _ = synth_units(1, ploidy=K, n_pos=M, n_reads=R, n_alleles=A, first_unit=940 + u, **skw)
+        units.append(dict(reads=reads[0], counts=None, n_alleles=[A] * M, ploidy=K, inbreeding=None, stream_id=u))
+    model = DenovoMCMC(ploidy=4, n_alleles=[2], steps=steps, chains=2, random_seed=8)
+    batch = DenovoRaggedBatch(model, units)
+    assert batch.wph == 2
+    batch.run(burn)
+    got = batch.results()
+    n = batch.p_n.cpu().numpy()
+    status, fixed = batch.d_status.cpu().numpy(), batch.d_fixed.cpu().numpy()
+    for u in range(len(units)):
+        want = batch._host_summary(u, int(status[u]), fixed, {"whole": True})
+        assert np.array_equal(got[u]["genotypes"], want["genotypes"]), u
+        np.testing.assert_array_equal(got[u]["probabilities"], want["probabilities"])
+        # (SPM: the device adds a support's probabilities one after the other in ranked order, numpy's sum pairwise: 1e-12 as in
+        # tests/test_gpu_posterior.py)
+        assert abs(got[u]["spm"] - want["spm"]) < 1e-12 and abs(got[u]["gpm"] - want["gpm"]) < 1e-15 and got[u]["mci"] == want["mci"], (u, got[u]["spm"], want["spm"])
+        assert np.array_equal(got[u]["mode_genotype"], want["mode_genotype"])
+    if "wandering" in case:
+        k = [len(g["probabilities"]) for g in got]
+        assert max(k[:2]) > 512 and k[2] <= 512, k          # the listed launch (or the host classes beyond it) did the first two
+        assert (n[2] == k[2]) and (case.startswith("dodeca") or (n[:2] == np.array(k[:2])).all()), (n, k)
+    else:
+        assert (n == [len(g["probabilities"]) for g in got]).all()
+    # a part of the units only (the programs' slow records)
+    only = batch.results(only=[len(units) - 1])
+    assert len(only) == 1 and np.array_equal(only[0]["genotypes"], got[-1]["genotypes"]) and only[0]["mci"] == got[-1]["mci"]
