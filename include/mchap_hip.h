@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define MCHAP_MAX_TEMPS 16
-#define MCHAP_MAX_PLOIDY 8   /* the fast de novo samplers (nibble-packed labels) and the device posterior summary; reference has no limit */
+#define MCHAP_MAX_PLOIDY 8   /* the fast de novo samplers (nibble-packed labels) and the one-word forms of the device posterior summary; reference has no limit */
 #define MCHAP_MAX_PLOIDY_DENOVO 15  /* ... the de novo sampler: ploidies 9 to 15 run on the general lanes-over-chains kernel (packs of
                                        sixteen nibbles; a dose of 16 does not fit one), with two trace words per haplotype */
 #define MCHAP_MAX_POS 126    /* SNVs per unit.  Up to 62 SNVs and 64 bits of sampled alleles per haplotype (1 bit per biallelic, 2 per
