@@ -822,6 +822,7 @@ __global__ __launch_bounds__(64 * CALL_COAST_WAVES) void call_coast_kernel(const
       }
       uint64_t g = gp, cn = counts;
       double choice_llk = 0.0;
+      lds_f64c *llk_at = vals;
       bool known = true;
       for (int jj = 0; jj < K; jj++) {
         const int k = (int)((order >> (4 * jj)) & 15u);
@@ -874,10 +875,11 @@ __global__ __launch_bounds__(64 * CALL_COAST_WAVES) void call_coast_kernel(const
           ch = lo;
         }
         if (ch > H - 1) ch = H - 1;
-        choice_llk = pr[H + ch];
+        llk_at = pr + H + ch;  // (the step's llk is that of its last choice: read once, after the sub-steps)
         g = (g & ~(255ull << (8 * k))) | ((uint64_t)ch << (8 * k));
         if (few) cn = ctx + (1ull << (4 * ch));
       }
+      if (known) choice_llk = *llk_at;
       if (!known) {
         // this step is call_mcmc_kernel's: the record keeps the genotype of the step's start (the memo is as it was)
         for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(state + 2)[i] = (uint32_t)((gp >> (8 * i)) & 255ull);
