@@ -45,6 +45,12 @@ struct PostSummary {
   double best;  // probability of the mode support (SPM)
 };
 
+// slots of the hash index beside a table of `cap` states: the power of two at or above 2 cap
+__host__ __device__ inline int post_hash_slots(int cap) {
+  int hs = 64;
+  while (hs < 2 * cap) hs <<= 1;
+  return hs;
+}
 __device__ __forceinline__ bool post_hap_eq(const uint64_t *a, const uint64_t *b, int W) {
   bool eq = a[0] == b[0];
   if (W > 1) eq = eq && a[1] == b[1];
@@ -53,14 +59,19 @@ __device__ __forceinline__ bool post_hap_eq(const uint64_t *a, const uint64_t *b
 template <int SW>
 __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, const mchap_unit &U, int S, int burn, int ch_lo,
                                                       int ch_hi, uint64_t *uw, int *ucount, int *order, int *label, const int CAP,
-                                                      const int W) {
+                                                      const int W, int *hidx, const int HS) {
   const int Kh = U.ploidy;   // haplotypes of a state
   const int K = Kh * W;      // words of a state
+  // hidx [HS] (HS a power of two >= 2 CAP): open-addressing index of the distinct states by a hash of their words -- a state of
+  // the trace is matched by a probe instead of a walk over everything seen so far (round 5: the walk was quadratic in the distinct
+  // states, 20 ms for docs/example's 24 wandering units)
+  for (int i = (int)threadIdx.x; i < HS; i += WAVE) hidx[i] = -1;
   const int lane = threadIdx.x;
   const int per_chain = S - burn;
   const int N = (ch_hi - ch_lo) * per_chain;
   for (int i = lane; i < CAP; i += WAVE) ucount[i] = 0;
   __syncthreads();
+  const unsigned hmask = (unsigned)HS - 1u;
 
   int n_u = 0;        // wave-uniform
   int overflow = 0;
@@ -77,14 +88,28 @@ __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, con
 #pragma unroll
       for (int h = 0; h < SW; h++) st[h] = 0ull;
     }
-    // match against the distinct states found so far
-    int found = -1;
-    for (int e = 0; e < n_u; e++) {
-      bool eq = true;
+    // match against the distinct states found so far: probe from the hash of the state's words
+    uint64_t hv = 0x9E3779B97F4A7C15ull;
 #pragma unroll
-      for (int h = 0; h < SW; h++)
-        if (h < K) eq = eq && (uw[(size_t)e * K + h] == st[h]);
-      if (eq && found < 0) found = e;
+    for (int h = 0; h < SW; h++)
+      if (h < K) hv = (hv ^ st[h]) * 0xFF51AFD7ED558CCDull + (hv >> 29);
+    const unsigned home = (unsigned)(hv >> 32) & hmask;
+    int found = -1;
+    if (active) {
+      unsigned slot = home;
+      for (int tries = 0; tries < HS; tries++) {
+        const int e = hidx[slot];
+        if (e < 0) break;
+        bool eq = true;
+#pragma unroll
+        for (int h = 0; h < SW; h++)
+          if (h < K) eq = eq && (uw[(size_t)e * K + h] == st[h]);
+        if (eq) {
+          found = e;
+          break;
+        }
+        slot = (slot + 1) & hmask;
+      }
     }
     // unresolved states become new distinct states in lane (= appearance) order
     unsigned long long pending = __ballot(active && found < 0);
@@ -100,6 +125,11 @@ __device__ __forceinline__ PostSummary post_summarise(const uint64_t *trace, con
         }
       }
       if (active && found < 0 && eq) found = n_u < CAP ? n_u : CAP;
+      if (lane == leader && n_u < CAP) {  // (one lane at a time writes the index: no race; the states beyond CAP are not indexed)
+        unsigned slot = home;
+        while (hidx[slot] >= 0) slot = (slot + 1) & hmask;
+        hidx[slot] = n_u;
+      }
       if (n_u < CAP) n_u++;
       else overflow++;
       pending = __ballot(active && found < 0);
@@ -215,7 +245,9 @@ __global__ __launch_bounds__(64) void trace_posterior_kernel(const PosteriorPara
   int *ucount = reinterpret_cast<int *>(smem + (size_t)CAP * K * 8);  // [CAP]
   int *order = ucount + CAP;                                          // [CAP] rank -> unique index
   int *label = order + CAP;                                           // [CAP] support label by rank
-  const PostSummary R = post_summarise<SW>(P.trace, U, P.steps, P.burn, 0, P.chains, uw, ucount, order, label, CAP, W);
+  const int HS = post_hash_slots(CAP);
+  int *hidx = label + CAP;                                            // [HS] hash index of the distinct states
+  const PostSummary R = post_summarise<SW>(P.trace, U, P.steps, P.burn, 0, P.chains, uw, ucount, order, label, CAP, W, hidx, HS);
   const int n_u = R.n_u;
   for (int r = lane; r < n_u; r += WAVE) {
     if (r < P.max_states) {
@@ -283,12 +315,14 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
   int *ucount = reinterpret_cast<int *>(smem + (size_t)CAP * K * 8);
   int *order = ucount + CAP;
   int *label = order + CAP;
+  const int HS = post_hash_slots(CAP);
+  int *hidx = label + CAP;
   // [chains][SW] words: the distinct haplotypes of the chain's mode support, W words each
-  uint64_t *sets = reinterpret_cast<uint64_t *>(smem + (((size_t)CAP * K * 8 + (size_t)CAP * 12 + 7) & ~(size_t)7));
+  uint64_t *sets = reinterpret_cast<uint64_t *>(smem + (((size_t)CAP * K * 8 + (size_t)CAP * 12 + (size_t)HS * 4 + 7) & ~(size_t)7));
   int *nset = reinterpret_cast<int *>(sets + (size_t)POST_MAX_CHAINS * SW);  // [chains] size, 0 = below threshold
   int bad = 0;
   for (int ch = 0; ch < P.chains; ch++) {
-    const PostSummary R = post_summarise<SW>(P.trace, U, P.steps, P.burn, ch, ch + 1, uw, ucount, order, label, CAP, W);
+    const PostSummary R = post_summarise<SW>(P.trace, U, P.steps, P.burn, ch, ch + 1, uw, ucount, order, label, CAP, W, hidx, HS);
     if (R.overflow) bad = 1;
     if (lane == 0) {
       int n = 0;
@@ -341,14 +375,18 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
 }
 
 // (kw: words of a state = ploidy bound x words per haplotype; sw: the kernels' SW)
-inline size_t posterior_lds_bytes(int kw, int cap = POST_CAP) { return (((size_t)cap * kw * 8 + (size_t)cap * 4 * 3) + 7) & ~(size_t)7; }
+inline size_t posterior_lds_bytes(int kw, int cap = POST_CAP) {
+  return (((size_t)cap * kw * 8 + (size_t)cap * 4 * 3 + (size_t)post_hash_slots(cap) * 4) + 7) & ~(size_t)7;
+}
 inline size_t incongruence_lds_bytes(int kw, int cap = POST_CAP, int sw = MCHAP_MAX_PLOIDY) {
   return posterior_lds_bytes(kw, cap) + (size_t)POST_MAX_CHAINS * sw * 8 + (size_t)POST_MAX_CHAINS * 4;
 }
 // the largest table (distinct states) a workgroup's 160 KB of LDS holds at this state width, beside the incongruence kernel's sets
 inline int posterior_max_cap(int kw, int sw = MCHAP_MAX_PLOIDY) {
   const size_t fixed = (size_t)POST_MAX_CHAINS * sw * 8 + (size_t)POST_MAX_CHAINS * 4 + 64;
-  return (int)((160 * 1024 - fixed) / ((size_t)kw * 8 + 12));
+  int cap = (int)((160 * 1024 - fixed) / ((size_t)kw * 8 + 12 + 8));  // (+ the hash index: two slots a state, up to four ...)
+  while (cap > 1 && posterior_lds_bytes(kw, cap) + fixed > 160 * 1024) cap--;  // ... when 2 cap is just above a power of two
+  return cap;
 }
 constexpr int POST_SW_WIDE = 32;  // ploidies up to 15 at two words per haplotype
 

@@ -102,7 +102,7 @@ def test_device_summary_of_wide_batches_equals_the_host_classes(case):
     194-205, 280-376 -- pinned to the reference's vectors in tests/test_classes.py): distinct genotypes in the reference's
     order, probabilities, SPM / GPM, mode genotype, MCI.  Settled units stay with the batch launch; chains of four reads wander
     through more than 512 genotypes and go to the listed launch (ploidy 4: its table holds every state) or beyond it to the
-    host classes (ploidy 12: 762 states of 24 words fit the LDS)."""
+    host classes (ploidy 12: 721 states of 24 words fit the LDS)."""
     from mchap_amd import DenovoMCMC
     from mchap_amd.device import DenovoRaggedBatch
     from mchap_amd.synth import synth_units
