@@ -353,9 +353,12 @@ int mchap_exact_posterior_mode_batch(int n_units, const double *reads, int n_rea
  * The workspace holds, per chain, the counterpart of the reference's llk dict (calling/likelihood.py:36-78), which never
  * forgets an entry.  Device pointers; enqueues on `stream`. */
 int64_t mchap_call_mcmc_workspace_bytes(int n_units, int n_haps, int ploidy, int steps, int chains);
-/* The same plus, when n_reads x n_haps x 8 B exceeds the LDS, room for every chain's product table P[r][h] (the sampler
- * then reads it from the workspace: slower, but no limit on the read depth).  mchap_call_mcmc_batch_device needs this
- * many bytes; for shapes that fit the LDS it equals mchap_call_mcmc_workspace_bytes. */
+/* The same plus the chains' hand-over records (round 5: Gibbs steps at ploidies up to 8 -- a chain that has settled runs the
+ * rest of its steps one lane of call_coast_kernel, csrc/call_mcmc_kernel.hpp; 2.2 KB a chain at 16 known haplotypes) and, when
+ * n_reads x n_haps x 8 B exceeds the LDS, room for every chain's product table P[r][h] (the sampler then reads it from the
+ * workspace: slower, but no limit on the read depth).  mchap_call_mcmc_batch_device needs this many bytes.  Environment
+ * MCHAP_HIP_CALL_LANES (measurement): 0 = every chain on its own wavefront to the end, as before round 5; n = chains per
+ * wavefront of call_coast_kernel.  The traces are the same either way. */
 int64_t mchap_call_mcmc_workspace_bytes_for(int n_units, int n_reads, int n_haps, int ploidy, int steps, int chains);
 int mchap_call_mcmc_batch_device(int n_units, const double *reads, int n_reads, int n_pos, int max_allele,
                                  const int64_t *read_counts, const int8_t *haplotypes, int n_haps, int ploidy, int has_prior,
