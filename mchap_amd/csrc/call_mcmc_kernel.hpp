@@ -467,6 +467,7 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
       if (miss && !slot) s_full = 1;
     }
     unsigned long long todo = __ballot(miss);
+    const bool any_miss = todo != 0ull;
     while (todo) {
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
@@ -474,21 +475,32 @@ __global__ __launch_bounds__(64 * CALL_WG_CHAINS, 2) void call_mcmc_kernel(const
         for (int i = 0; i < K; i++) s_req[i] = g[i];
       call_sync();
       const double v = coop_llk(K);
-      if (lane == src) {
-        val = v;
-        // The lanes probed together: two of them (different keys) may have ended their probes on the same empty slot.
-        // The table never forgets an entry -- the reference's dict keeps the value of whichever allele order was
-        // evaluated first (calling/likelihood.py:36-78), and a lost key would be evaluated again later in a possibly
-        // different order -- so the slot is looked up again now, behind the entries the earlier lanes of this loop wrote.
-        double seen;
-        ulonglong2 *free_slot = nullptr;
-        if (!probe(key, seen, free_slot)) {
-          if (free_slot) *free_slot = make_ulonglong2((unsigned long long)key + 1ull, (unsigned long long)__double_as_longlong(v));
-          else s_full = 1;
+      if (lane == src) val = v;
+    }
+    // The lanes' new entries go into the table together (round 5; until then one after the other, a probe and a fence over global
+    // memory each: 4 of a miss's 8 us): a lane claims the first empty slot of its probe sequence by compare-and-swap on the key
+    // word, then stores the value -- two lanes that end on the same empty slot are told apart by the swap, and nobody reads the
+    // table before the fence below.  Which slot a key lands in depends on the race; its value does not (the keys of a round
+    // differ: the options differ in the allele at k).  The table never forgets an entry -- the reference's dict keeps the value of
+    // whichever allele order was evaluated first (calling/likelihood.py:36-78).
+    if (miss && slot) {
+      unsigned long long h = (unsigned long long)key * 0x9E3779B97F4A7C15ull;
+      unsigned long long i = (h >> 20) & cmask;
+      bool placed = false;
+      for (long long tries = 0; tries < P.cache_slots && !placed; tries++) {
+        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&cache[i].x), 0ull, (unsigned long long)key + 1ull);
+        if (old == 0ull) {
+          cache[i].y = (unsigned long long)__double_as_longlong(val);
+          placed = true;
+        } else if (old == (unsigned long long)key + 1ull) {
+          placed = true;
+        } else {
+          i = (i + 1) & cmask;
         }
       }
-      call_sync_global();  // (the next lane of this loop probes behind this entry)
+      if (!placed) s_full = 1;
     }
+    if (any_miss) call_sync_global();  // (the next sub-step's probes read behind these entries)
     if (act) o_llk[a] = val;
   };
 
