@@ -238,6 +238,20 @@ int mchap_trace_posterior_listed_device(int n_list, const int32_t *unit_list_dev
                                         int32_t *post_counts, int32_t *post_n, double *mode_stats, int32_t *mode_index,
                                         uint64_t *mode_words, int32_t *mode_count, void *stream);
 
+/* `mchap call`: the sampler's traces summarised on the device (round 5).  The traces of mchap_call_mcmc_batch_device -- int64
+ * genotypes [U][chains][steps][ploidy], alleles ascending -- are states of `ploidy` words, so GenotypeAllelesMultiTrace.burn(n)
+ * .posterior() and PosteriorGenotypeAllelesDistribution.mode(genotype_support=True) (calling/classes.py:180-196, 303-362) are
+ * mchap_trace_posterior_batch_device / _listed_device above as they stand (units: ploidy and trace_off = u * chains * steps *
+ * ploidy; post_words are allele indices), ploidy <= MCHAP_MAX_PLOIDY.  The calling classes' replicate_incongruence
+ * (calling/classes.py:231-263) differs from the assembler's: chains whose mode support reaches the threshold are compared by their
+ * mode GENOTYPES, and the code is 2 when those genotypes together hold more distinct alleles than the ploidy.  mci int32 [n_units]:
+ * 0 / 1 / 2, -1 if a chain visited more distinct genotypes than the table holds (then the listed form with a larger table). */
+int mchap_call_incongruence_batch_device(int n_units, const mchap_unit *units_dev, int steps, int chains, int burn,
+                                         const int64_t *genotypes, int ploidy_max, double threshold, int32_t *mci, void *stream);
+int mchap_call_incongruence_listed_device(int n_list, const int32_t *unit_list_dev, const mchap_unit *units_dev, int steps, int chains,
+                                          int burn, const int64_t *genotypes, int cap, int ploidy_max, double threshold, int32_t *mci,
+                                          void *stream);
+
 /* Exact caller: replaces calling.exact.genotype_likelihoods (calling/exact.py:266-292): llks_out float32 [G] as the
  * reference stores them and / or llks64_out float64 [G] (the unrounded values), G = C(n_haps + ploidy - 1, ploidy) genotypes in
  * VCF order; either may be NULL.  Host pointers, one unit. */

@@ -256,6 +256,8 @@ EXPORTS = [
     "mchap_trace_posterior_listed_wph_device",
     "mchap_trace_incongruence_batch_wph_device",
     "mchap_trace_incongruence_listed_wph_device",
+    "mchap_call_incongruence_batch_device",
+    "mchap_call_incongruence_listed_device",
     "mchap_exact_genotype_likelihoods",
     "mchap_exact_genotype_posteriors",
     "mchap_exact_posterior_mode_batch",

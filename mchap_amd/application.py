@@ -1409,7 +1409,7 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
     blocks; the (record x sample) units of a block are grouped by shape and each group is one launch of the sampler kernel
     (CallingMCMC.fit_batch), cut into several when its traces and per-chain likelihood tables would not fit the free HBM.
     As in the reference every unit restarts from the same seed."""
-    from .calling_mcmc import CallingMCMC, GenotypeAllelesMultiTrace
+    from .calling_mcmc import CallingMCMC, CallSummary, GenotypeAllelesMultiTrace
     from . import _lib, calling
 
     source = _source(sample_bams, base_error_rate, use_base_phred_scores, read_kw)
@@ -1463,8 +1463,10 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
                         frs[i] = locus.frequencies[units[ri]["keep"]]
                 model = CallingMCMC(ploidy=K, haplotypes=haps[0], steps=steps, chains=chains, random_seed=seed, step_type=step_type)
                 try:
-                    traces = model.fit_batch(reads, counts, haplotypes=haps, prior=(Fs, frs) if has_prior else None,
-                                             stream_ids=np.zeros(U, dtype=np.uint64))
+                    # (the traces stay on the device: what a record reads off them is summarised there -- round 5)
+                    traces = model.fit_batch_summaries(reads, counts, haplotypes=haps, prior=(Fs, frs) if has_prior else None,
+                                                       stream_ids=np.zeros(U, dtype=np.uint64), burn=burn,
+                                                       incongruence_threshold=incongruence_threshold)
                 except NotImplementedError as e:  # (a shape beyond the sampler's limits: FILTER=LIMIT records, the file goes on)
                     _limit_units(units, members, "call", "%d haplotypes x ploidy %d: %s" % (H, K, e))
                     continue
@@ -1479,20 +1481,18 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
                     K = int(ploidy_of(s))
                     if M == 0:
                         trace = GenotypeAllelesMultiTrace(np.zeros((chains, steps, K), np.int8), np.full((chains, steps), np.nan), 1)
+                        summ = CallSummary.of_trace(trace.burn(burn), incongruence_threshold)
                     else:
-                        trace = results[(ri, s)]
-                    trace = trace.burn(burn)
+                        summ = results[(ri, s)]
                     if not unit["keep"].all() and M > 0:
-                        trace = trace.relabel(np.flatnonzero(unit["keep"]))
-                    post = trace.posterior()
-                    alleles, gprob, sprob = post.mode(genotype_support=True)
-                    f0, _, o0 = trace.posterior_frequencies()  # over the alleles the trace knows: pad to the record's
+                        summ = summ.relabel(np.flatnonzero(unit["keep"]))
+                    f0, _, o0 = summ.posterior_frequencies()  # over the alleles the trace knows: pad to the record's
                     freqs, occur = np.zeros(H), np.zeros(H)
                     freqs[: len(f0)], occur[: len(o0)] = f0[:H], o0[:H]
-                    r = dict(alleles=np.asarray(alleles), gprob=float(gprob), sprob=float(sprob), freqs=freqs, occur=occur,
-                             mci=int(trace.replicate_incongruence(threshold=incongruence_threshold)))
+                    r = dict(alleles=np.asarray(summ.alleles), gprob=float(summ.gprob), sprob=float(summ.sprob), freqs=freqs, occur=occur,
+                             mci=int(summ.mci))
                     if "GP" in report or "FORMAT/GP" in report:
-                        r["GP"] = post.as_array(H)
+                        r["GP"] = summ.posterior().as_array(H)
                     if "GL" in report or "FORMAT/GL" in report:
                         sr = unit["reads"][s]
                         r["GL"] = calling.genotype_likelihoods(sr["dists"], K, locus.haplotypes, read_counts=sr["counts"]).astype(np.float64) / np.log(10)

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 from .classes import Assembler, unique_counts
 
-__all__ = ["CallingMCMC", "GenotypeAllelesMultiTrace", "PosteriorGenotypeAllelesDistribution"]
+__all__ = ["CallingMCMC", "CallSummary", "GenotypeAllelesMultiTrace", "PosteriorGenotypeAllelesDistribution"]
 
 _STEP_TYPES = {"Gibbs": 0, "Metropolis-Hastings": 1}
 
@@ -101,6 +101,170 @@ class CallingMCMC(Assembler):
         if (status != 0).any():
             raise _lib.MchapLibraryError("mchap_hip: the table of remembered likelihoods of a chain filled up")
         return [GenotypeAllelesMultiTrace(g[u].astype(np.int32), l[u], H) for u in range(U)]
+
+    def fit_batch_summaries(self, reads, read_counts=None, initial=None, haplotypes=None, prior=None, stream_ids=None, burn=0,
+                            incongruence_threshold=0.6, max_states=512):
+        """`fit_batch` with everything `mchap call` reads off a trace taken on the device (round 5): the sampler's traces stay in
+        HBM and trace_posterior_kernel / trace_incongruence_kernel summarise them -- GenotypeAllelesMultiTrace.burn(burn)
+        .posterior(), PosteriorGenotypeAllelesDistribution.mode(genotype_support=True) and replicate_incongruence
+        (calling/classes.py:166-263, 303-362) -- so that a unit comes back as a few hundred bytes instead of its trace.
+        Arguments as fit_batch.  Returns one CallSummary per unit."""
+        from .device import _torch
+
+        reads = np.ascontiguousarray(reads, dtype=np.float64)
+        U, R, M, A = reads.shape
+        haps = np.asarray(self.haplotypes if haplotypes is None else haplotypes, dtype=np.int8)
+        if haps.ndim == 2:
+            haps = np.broadcast_to(haps, (U,) + haps.shape)
+        haps = np.ascontiguousarray(haps)
+        H = haps.shape[1]
+        K, S, Cn = int(self.ploidy), int(self.steps), int(self.chains)
+        burn = int(burn)
+        if self.step_type not in _STEP_TYPES:
+            raise ValueError('MCMC step type must be "Gibbs" or "Metropolis-Hastings"')
+        n_obs = Cn * (S - burn)
+        if M == 0 or K > _lib.MAX_PLOIDY:
+            # (no variants: the constant trace; a ploidy beyond the device summary's: the host classes on the traces)
+            return [CallSummary.of_trace(t.burn(burn), incongruence_threshold)
+                    for t in self.fit_batch(reads, read_counts, initial, haplotypes, prior, stream_ids)]
+        if R == 0:
+            reads = np.full((U, 1, M, A), np.nan)
+            read_counts = None
+            R = 1
+        torch = _torch()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        L = _lib.lib()
+        pr = self.prior if prior is None else prior
+        has = 0 if pr is None else 1
+        F = fr = None
+        if pr is not None:
+            F = np.array(np.broadcast_to(np.asarray(pr[0], dtype=np.float64), (U,)))
+            if pr[1] is not None:
+                fr = np.array(np.broadcast_to(np.asarray(pr[1], dtype=np.float64), (U, H)))
+        up = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        d_reads, d_rc, d_haps = up(reads, np.float64), up(read_counts, np.int64), up(haps, np.int8)
+        d_F, d_fr, d_ini = up(F, np.float64), up(fr, np.float64), up(initial, np.int64)
+        if initial is not None:
+            assert tuple(d_ini.shape) == (U, K)
+        sid = np.ascontiguousarray(np.arange(U, dtype=np.uint64) if stream_ids is None else stream_ids, dtype=np.uint64)
+        d_sid = torch.from_numpy(sid.view(np.int64)).to(dev)
+        seed = self.random_seed
+        if seed is None:
+            seed = int(np.random.randint(0, 2**31 - 1))
+        d_g = torch.empty(U * Cn * S * K, dtype=torch.int64, device=dev)
+        d_l = torch.empty(U * Cn * S, dtype=torch.float64, device=dev)
+        d_st = torch.empty(U, dtype=torch.int32, device=dev)
+        ws = int(L.mchap_call_mcmc_workspace_bytes_for(U, R, H, K, S, Cn))
+        d_ws = torch.empty(max(ws, 16), dtype=torch.uint8, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.mchap_call_mcmc_batch_device(U, p(d_reads), R, M, A, p(d_rc), p(d_haps), H, K, has, p(d_F), p(d_fr), p(d_ini), p(d_sid), S, Cn,
+                                                  _STEP_TYPES[self.step_type], C.c_uint64(int(seed) & (2**64 - 1)), p(d_g), p(d_l), p(d_st), p(d_ws),
+                                                  C.c_int64(ws), stream))
+        units = np.zeros(U, dtype=_lib.UNIT_DTYPE)
+        units["ploidy"] = K
+        units["trace_off"] = np.arange(U, dtype=np.int64) * (Cn * S * K)
+        d_units = torch.from_numpy(units.view(np.uint8).reshape(-1)).to(dev)
+        ms = int(max_states)
+        d_words = torch.empty(U * ms * K, dtype=torch.int64, device=dev)
+        d_counts = torch.empty(U * ms, dtype=torch.int32, device=dev)
+        d_n = torch.empty(U, dtype=torch.int32, device=dev)
+        d_stats = torch.empty(U * 2, dtype=torch.float64, device=dev)
+        d_mode = torch.empty(U, dtype=torch.int32, device=dev)
+        d_mw = torch.empty(U * K, dtype=torch.int64, device=dev)
+        d_mc = torch.empty(U, dtype=torch.int32, device=dev)
+        d_mci = torch.empty(U, dtype=torch.int32, device=dev)
+        thr = C.c_double(float(incongruence_threshold))
+        _lib.check(L.mchap_trace_posterior_batch_device(U, p(d_units), S, Cn, burn, p(d_g), ms, K, p(d_words), p(d_counts), p(d_n), p(d_stats),
+                                                        p(d_mode), p(d_mw), p(d_mc), stream))
+        _lib.check(L.mchap_call_incongruence_batch_device(U, p(d_units), S, Cn, burn, p(d_g), K, thr, p(d_mci), stream))
+        status = d_st.cpu().numpy()
+        if (status != 0).any():
+            raise _lib.MchapLibraryError("mchap_hip: the table of remembered likelihoods of a chain filled up")
+        n, mci = d_n.cpu().numpy(), d_mci.cpu().numpy()
+        # chains that wander through more genotypes than the batch launches keep: again with a table of every state (as many as
+        # the LDS holds), a launch over those units only
+        over = np.flatnonzero((n < 0) | (n > ms) | (mci < 0)).astype(np.int32)
+        over_rows = {}
+        if len(over):
+            cap = min(n_obs, int(L.mchap_trace_posterior_max_states(K)))
+            d_list = torch.from_numpy(over).to(dev)
+            o_words = torch.empty(len(over) * cap * K, dtype=torch.int64, device=dev)
+            o_counts = torch.empty(len(over) * cap, dtype=torch.int32, device=dev)
+            _lib.check(L.mchap_trace_posterior_listed_device(len(over), p(d_list), p(d_units), S, Cn, burn, p(d_g), cap, K, p(o_words), p(o_counts),
+                                                             p(d_n), p(d_stats), p(d_mode), p(d_mw), p(d_mc), stream))
+            _lib.check(L.mchap_call_incongruence_listed_device(len(over), p(d_list), p(d_units), S, Cn, burn, p(d_g), min(S - burn, cap), K, thr,
+                                                               p(d_mci), stream))
+            n, mci = d_n.cpu().numpy(), d_mci.cpu().numpy()
+            ow = o_words.cpu().numpy().reshape(len(over), cap, K)
+            oc = o_counts.cpu().numpy().reshape(len(over), cap)
+            over_rows = {int(u): (ow[i], oc[i], cap) for i, u in enumerate(over)}
+        words = d_words.cpu().numpy().reshape(U, ms, K)
+        counts = d_counts.cpu().numpy().reshape(U, ms)
+        stats = d_stats.cpu().numpy().reshape(U, 2)
+        mw = d_mw.cpu().numpy().reshape(U, K)
+        out = []
+        for u in range(U):
+            w_, c_, cap_u = over_rows.get(u, (words[u], counts[u], ms))
+            if n[u] < 0 or n[u] > cap_u or mci[u] < 0:
+                # (more distinct genotypes than even the LDS holds: the host classes on this unit's trace)
+                g = d_g[u * Cn * S * K: (u + 1) * Cn * S * K].cpu().numpy().reshape(Cn, S, K).astype(np.int32)
+                lk = d_l[u * Cn * S: (u + 1) * Cn * S].cpu().numpy().reshape(Cn, S)
+                out.append(CallSummary.of_trace(GenotypeAllelesMultiTrace(g, lk, H).burn(burn), incongruence_threshold))
+                continue
+            k = int(n[u])
+            out.append(CallSummary(genotypes=w_[:k].astype(np.int32), counts=c_[:k].astype(np.int64), n_obs=n_obs, alleles=mw[u].astype(np.int32),
+                                   gprob=float(stats[u, 1]), sprob=float(stats[u, 0]), mci=int(mci[u]), n_allele=H))
+        return out
+
+
+@dataclass
+class CallSummary(object):
+    """What `mchap call` reads off a unit's trace (application/call.py:95-160): the distinct genotypes after burn-in, most
+    frequent first (ties as GenotypeAllelesMultiTrace.posterior), with their counts; the mode genotype of the mode support with
+    its probability and the support's; the replicate incongruence code."""
+
+    genotypes: np.ndarray   # int [n, ploidy], alleles ascending
+    counts: np.ndarray      # int [n] occurrences among the n_obs recorded steps
+    n_obs: int
+    alleles: np.ndarray     # the mode genotype
+    gprob: float
+    sprob: float
+    mci: int
+    n_allele: int
+
+    @classmethod
+    def of_trace(cls, trace, threshold):
+        """The same from a (burnt) trace on the host, by the classes below."""
+        post = trace.posterior()
+        alleles, gprob, sprob = post.mode(genotype_support=True)
+        n_obs = trace.genotypes.shape[0] * trace.genotypes.shape[1]
+        counts = np.rint(np.asarray(post.probabilities) * n_obs).astype(np.int64)
+        return cls(genotypes=np.asarray(post.genotypes), counts=counts, n_obs=n_obs, alleles=np.asarray(alleles), gprob=float(gprob),
+                   sprob=float(sprob), mci=int(trace.replicate_incongruence(threshold=threshold)), n_allele=trace.n_allele)
+
+    def relabel(self, labels):
+        """Alleles renamed labels[a] (an increasing map: genotypes stay ascending)."""
+        labels = np.asarray(labels)
+        return type(self)(labels[self.genotypes], self.counts, self.n_obs, labels[self.alleles], self.gprob, self.sprob, self.mci, int(labels.max()) + 1)
+
+    def posterior(self):
+        return PosteriorGenotypeAllelesDistribution(self.genotypes, self.counts / np.sum(self.counts))
+
+    def posterior_frequencies(self):
+        """GenotypeAllelesMultiTrace.posterior_frequencies from the distinct genotypes: the same whole-number sums (every
+        recorded step counts once), divided as there."""
+        g = np.asarray(self.genotypes, dtype=np.int64)
+        ploidy = g.shape[1]
+        w = np.repeat(self.counts.astype(float)[:, None], ploidy, axis=1)
+        counts = np.bincount(g.reshape(-1), weights=w.reshape(-1), minlength=self.n_allele)
+        first = np.ones(g.shape, dtype=bool)
+        for i in range(1, ploidy):
+            first[:, i] = (g[:, i: i + 1] != g[:, :i]).all(axis=1)
+        occur = np.bincount(g[first], weights=w[first], minlength=self.n_allele)
+        counts /= self.n_obs
+        occur /= self.n_obs
+        return counts / ploidy, counts, occur
 
 
 @dataclass

@@ -293,6 +293,9 @@ struct IncongruenceParams {
   double threshold;
   int ploidy_max;
   int wph;                   // as PosteriorParams::wph
+  int calling;               // 1: the traces are `mchap call`'s (a word = an allele index) and the code is the calling classes'
+                             // (calling/classes.py:231-263): chains are compared by their mode GENOTYPES, and the code is 2 when the
+                             // genotypes together hold more distinct alleles than the ploidy
   int cap;                   // as PosteriorParams::cap
   const int32_t *unit_list;  // null, or the units to summarise (mci is indexed by unit)
   int32_t *mci;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
       if (R.n_u > 0 && R.best >= P.threshold) {
         const uint64_t *g = uw + (size_t)order[R.best_r] * K;  // sorted haplotypes
         for (int h = 0; h < Kh; h++)
-          if (h == 0 || !post_hap_eq(g + h * W, g + (h - 1) * W, W)) {
+          if (P.calling || h == 0 || !post_hap_eq(g + h * W, g + (h - 1) * W, W)) {  // (calling: the genotype itself, copies included)
             for (int w = 0; w < W; w++) sets[(size_t)ch * SW + n * W + w] = g[h * W + w];
             n++;
           }
@@ -364,6 +367,7 @@ __global__ __launch_bounds__(64) void trace_incongruence_kernel(const Incongruen
           bool dup = false;
           for (int b = 0; b < a && !dup; b++)
             for (int q = 0; q < nset[b] && !dup; q++) dup = post_hap_eq(sets + (size_t)b * SW + q * W, w, W);
+          for (int q = 0; q < i && !dup; q++) dup = post_hap_eq(sets + (size_t)a * SW + q * W, w, W);  // (copies within a genotype: calling)
           if (!dup) total++;
         }
       // the reference compares with the size of the FIRST qualifying chain's allele set, not with the ploidy

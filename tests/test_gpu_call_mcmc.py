@@ -129,3 +129,41 @@ def test_settled_chains_a_lane_each_give_the_same_traces(shape, lanes, monkeypat
         moves += int((g[:, 1:] != g[:, :-1]).any(axis=-1).sum())
     if shape == "wandering":
         assert moves > U * 3 * steps // 10, moves  # (the shape does what its name says)
+
+
+@pytest.mark.parametrize("shape", ["settled", "wandering", "octoploid", "one-chain", "ploidy-10"])
+def test_device_summaries_of_call_traces_equal_the_host_classes(shape):
+    """Round 5: CallingMCMC.fit_batch_summaries leaves the traces in HBM and summarises them there (trace_posterior_kernel; the
+    calling classes' replicate incongruence by mchap_call_incongruence_*_device) -- against GenotypeAllelesMultiTrace.burn()
+    .posterior(), .mode(genotype_support=True), .replicate_incongruence(), .posterior_frequencies() of fit_batch's traces of the
+    same seed (calling/classes.py:166-284, 303-362): genotype order, probabilities, mode genotype, its probability, the
+    support's, MCI, allele frequencies / counts / occurrence, and the GP array.  Chains of few poor reads visit more genotypes
+    than the batch launch keeps (listed launch); ploidy 10 takes the host classes (the device summary's ploidy bound is 8)."""
+    from mchap_amd.calling_mcmc import CallingMCMC
+
+    K, H, M, R, qual, steps, chains = {"settled": (4, 12, 8, 150, (5, 25), 300, 2), "wandering": (4, 30, 6, 3, (2, 6), 900, 3),
+                                       "octoploid": (8, 6, 5, 20, (3, 12), 300, 2), "one-chain": (3, 7, 5, 40, (5, 25), 200, 1),
+                                       "ploidy-10": (10, 4, 4, 30, (5, 25), 120, 2)}[shape]
+    U, burn = 4, steps // 3
+    reads, haps, counts, rng = _inputs(U, K, H, M, R, seed=11 * K + H, qual=qual)
+    model = CallingMCMC(ploidy=K, haplotypes=haps[0], prior=None, steps=steps, chains=chains, random_seed=29)
+    kw = dict(haplotypes=haps, prior=(np.full(U, 0.15), None))
+    got = model.fit_batch_summaries(reads, None, burn=burn, incongruence_threshold=0.6, **kw)
+    traces = model.fit_batch(reads, None, **kw)
+    most = 0
+    for u in range(U):
+        tr = traces[u].burn(burn)
+        post = tr.posterior()
+        assert np.array_equal(got[u].genotypes, post.genotypes), u
+        np.testing.assert_array_equal(got[u].counts / got[u].n_obs, post.probabilities)
+        alleles, gprob, sprob = post.mode(genotype_support=True)
+        assert np.array_equal(got[u].alleles, alleles) and abs(got[u].gprob - gprob) < 1e-15 and abs(got[u].sprob - sprob) < 1e-12
+        assert got[u].mci == tr.replicate_incongruence(threshold=0.6)
+        for a, b in zip(got[u].posterior_frequencies(), tr.posterior_frequencies()):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(got[u].posterior().as_array(H), post.as_array(H))
+        labels = np.arange(H) * 2 + 1   # (--filter-input-haplotypes: alleles renamed by an increasing map)
+        np.testing.assert_array_equal(got[u].relabel(labels).posterior_frequencies()[2], tr.relabel(labels).posterior_frequencies()[2])
+        most = max(most, len(post.probabilities))
+    if shape == "wandering":
+        assert most > 512, most

@@ -117,3 +117,25 @@ def test_programs_sharded_over_two_ranks_write_the_same_vcf(tmp_path):
         assert _records(r.stdout) == _records(single.getvalue()) and len(_records(r.stdout)) >= 2
         head = [ln for ln in r.stdout.splitlines() if ln.startswith("#CHROM")]
         assert len(head) == 1  # one header: only rank 0 writes
+
+
+def test_call_program_with_device_summaries_writes_the_records_of_the_host_classes(monkeypatch):
+    """Round 5: `mchap call` reads GT / GPM / SPM / MCI / AFP / AOP / GP off summaries taken on the device
+    (CallingMCMC.fit_batch_summaries); with the summaries formed by the host classes on the downloaded traces instead -- what the
+    program did before, and what the reference does (application/call.py:95-160) -- every record line is the same string."""
+    from mchap_amd import cli
+    from mchap_amd.calling_mcmc import CallingMCMC, CallSummary
+
+    argv = (["mchap_amd", "call", "--bam"] + [os.path.join(HERE, f) for f in DEEP] + ["--ploidy", "4", "--haplotypes",
+            os.path.join(HERE, "simple.output.deep.assemble.vcf"), "--mcmc-steps", "500", "--mcmc-burn", "120", "--mcmc-seed", "5",
+            "--report", "AFP", "AOP", "GP"])
+    a, b = _io.StringIO(), _io.StringIO()
+    cli.run(argv, a)
+
+    def by_host(self, reads, read_counts=None, initial=None, haplotypes=None, prior=None, stream_ids=None, burn=0, incongruence_threshold=0.6, max_states=512):
+        return [CallSummary.of_trace(t.burn(burn), incongruence_threshold) for t in self.fit_batch(reads, read_counts, initial, haplotypes, prior, stream_ids)]
+
+    monkeypatch.setattr(CallingMCMC, "fit_batch_summaries", by_host)
+    cli.run(argv, b)
+    ra, rb = _records(a.getvalue()), _records(b.getvalue())
+    assert len(ra) == len(rb) > 0 and ra == rb
