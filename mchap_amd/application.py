@@ -1138,8 +1138,6 @@ class _BlockState:
         from . import blockpath as bp
 
         run = self.run
-        if getattr(batch, "wph", 1) != 1:
-            return None
         arr = batch.summary_arrays()
         plain = arr["plain"]
         if not plain.any():
@@ -1148,7 +1146,18 @@ class _BlockState:
         M, total = u["n_pos"], arr["total"]
         n = np.where(plain, arr["n"], 0).astype(np.int64)
         gu, gi = bp._ragged_arange(n)
-        W = arr["words"][:, :K]
+        wide = getattr(batch, "wph", 1) != 1
+        if wide:
+            # a batch of the general sampler (round 5): a haplotype is two words -- the distinct pairs of the batch are numbered,
+            # everything below compares and groups the numbers, and unpack_words gets the pairs back
+            pu_ = np.flatnonzero(plain)
+            pairs = np.concatenate([arr["words"][:, :K].reshape(-1, 2), arr["mode_words"][pu_, :K].reshape(-1, 2)])
+            upairs, inv = np.unique(pairs, axis=0, return_inverse=True)
+            inv = inv.reshape(-1).astype(np.uint64)
+            W = inv[: len(arr["words"]) * K].reshape(len(arr["words"]), K)
+            mode_ids = inv[len(arr["words"]) * K:].reshape(len(pu_), K)
+        else:
+            W = arr["words"][:, :K]
         p = arr["counts"] / total
         # allele_frequencies(dosage=True) of every unit (classes.py): one term per (genotype, distinct haplotype), summed in
         # genotype order; haplotypes in order of first appearance
@@ -1173,7 +1182,10 @@ class _BlockState:
         listed = occur >= run["threshold"]
         lu, lw, lwt = hap_u[listed], hap_w[listed], weight[listed]
         pu = np.flatnonzero(plain)
-        words = np.concatenate([lw, arr["mode_words"][pu, :K].reshape(-1)])
+        if wide:
+            words = upairs[np.concatenate([lw, mode_ids.reshape(-1)]).astype(np.int64)]   # [n, 2]
+        else:
+            words = np.concatenate([lw, arr["mode_words"][pu, :K].reshape(-1)])
         unit = np.concatenate([lu, np.repeat(pu, K)])
         fixed_off = batch.units_host["fixed_off"].astype(np.int64)
         flat, cell_of = bp.unpack_words(words, unit, arr["fixed"], fixed_off, M, u["bits"])

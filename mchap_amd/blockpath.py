@@ -294,6 +294,7 @@ def unpack_words(words, unit, fixed, fixed_off, M, bits):
     word's unit), fixed int8 (the batch's fixed-allele templates, unit u at fixed_off[u] .. + M[u]), bits [U] bits per sampled
     position.  Returns (alleles int8 flat, first cell of every word): assemble.unpack_trace, ragged."""
     words = np.asarray(words, dtype=np.uint64)
+    wide = words.ndim == 2   # [n, 2]: haplotypes of a batch of the general sampler
     n = len(words)
     Mw = M[unit]
     cell_of = np.cumsum(Mw) - Mw
@@ -310,5 +311,18 @@ def unpack_words(words, unit, fixed, fixed_off, M, bits):
     mh_w = np.zeros(n, dtype=np.int64)
     mh_w[Mw > 0] = mh
     sh = (bits[u] * (mh_w[w] - 1 - jj)).clip(0).astype(np.uint64)
-    val = ((words[w] >> sh) & ((np.uint64(1) << bits[u].astype(np.uint64)) - np.uint64(1))).astype(np.int8)
+    mask = (np.uint64(1) << bits[u].astype(np.uint64)) - np.uint64(1)
+    if wide:
+        # two words per haplotype, the more significant first (assemble.unpack_trace(..., 2)): a field lies in the low word, in
+        # the high one, or across both
+        hi, lo = words[w, 0], words[w, 1]
+        low = sh < 64
+        s_lo = np.where(low, sh, 0).astype(np.uint64)
+        across = low & (sh > 0)
+        up = np.where(across, np.uint64(64) - s_lo, 0).astype(np.uint64)
+        v_low = (lo >> s_lo) | np.where(across, hi << up, np.uint64(0))
+        v_high = hi >> np.where(low, 0, sh - np.uint64(64)).astype(np.uint64)
+        val = (np.where(low, v_low, v_high) & mask).astype(np.int8)
+    else:
+        val = ((words[w] >> sh) & mask).astype(np.int8)
     return np.where(het, val, fx).astype(np.int8), cell_of

@@ -616,11 +616,12 @@ class DenovoRaggedBatch(_OwnBuffers):
         genotypes of each unit, plain [U] bool: the unit's summary is complete in these arrays -- the others (more distinct
         states than max_states, beyond a limit) go through results(only=...); words uint64 [N, K] / counts int32 [N]: the
         packed distinct genotypes of the plain units, unit after unit, most probable first (N = n[plain].sum(): only these
-        rows leave the device); stats float64 [U, 2] (SPM, GPM), mode_words uint64 [U, K], mci [U], status [U], fixed int8
+        rows leave the device; [N, K, 2] / [U, K, 2] for a batch of the general sampler: two words per haplotype); stats float64 [U, 2]
+        (SPM, GPM), mode_words uint64 [U, K], mci [U], status [U], fixed int8
         flat (unit u at units_host['fixed_off'][u]), total = the steps a probability is a count of)."""
-        assert self.wph == 1
         torch = self.torch
-        U, K, ms = self.n_units, self.Kmax, self.max_states
+        U, K, ms, Wp = self.n_units, self.Kmax, self.max_states, self.wph
+        KW = K * Wp   # words of a state (a batch of the general sampler: two words per haplotype, the more significant first)
         self._begin()
         status, n, mci = self.d_status.cpu().numpy(), self.p_n.cpu().numpy(), self.p_mci.cpu().numpy()
         # units with more distinct genotypes than the batch kernels keep (samples with few or no reads: their chains wander):
@@ -630,7 +631,9 @@ class DenovoRaggedBatch(_OwnBuffers):
         if len(over):
             o_words, o_counts, cap = self._summarise_listed(over)
             n, mci = self.p_n.cpu().numpy(), self.p_mci.cpu().numpy()
-        out = dict(n=n, stats=self.p_stats.cpu().numpy().reshape(U, 2), mode_words=self.p_mode_words.cpu().numpy().view(np.uint64).reshape(U, K),
+        wshape = (Wp,) if Wp > 1 else ()
+        out = dict(n=n, stats=self.p_stats.cpu().numpy().reshape(U, 2),
+                   mode_words=self.p_mode_words.cpu().numpy().view(np.uint64).reshape((U, K) + wshape),
                    mci=mci, status=status, fixed=self.d_fixed.cpu().numpy(), total=self.Cn * (self.S - self.burn))
         is_over = np.zeros(U, dtype=bool)
         is_over[over] = True
@@ -643,17 +646,17 @@ class DenovoRaggedBatch(_OwnBuffers):
             k_ = nn[sel]
             rows = np.repeat(table_row - (np.cumsum(k_) - k_), k_) + np.arange(int(k_.sum()), dtype=np.int64)
             d_rows = torch.from_numpy(rows).to(self.device)
-            return words.view(-1, K)[d_rows].cpu().numpy().view(np.uint64), counts[d_rows].cpu().numpy(), np.repeat(first[sel] - (np.cumsum(k_) - k_), k_) + np.arange(int(k_.sum()), dtype=np.int64)
+            return words.view(-1, KW)[d_rows].cpu().numpy().view(np.uint64), counts[d_rows].cpu().numpy(), np.repeat(first[sel] - (np.cumsum(k_) - k_), k_) + np.arange(int(k_.sum()), dtype=np.int64)
 
         N = int(nn.sum())
-        W, Cc = np.empty((N, K), dtype=np.uint64), np.empty(N, dtype=np.int32)
+        W, Cc = np.empty((N, KW), dtype=np.uint64), np.empty(N, dtype=np.int32)
         reg = np.flatnonzero(~is_over)
         w_, c_, dst = gather(reg, reg.astype(np.int64) * ms, self.p_words, self.p_counts)
         W[dst], Cc[dst] = w_, c_
         if len(over):
             w_, c_, dst = gather(over.astype(np.int64), np.arange(len(over), dtype=np.int64) * cap, o_words, o_counts)
             W[dst], Cc[dst] = w_, c_
-        out["words"], out["counts"] = W, Cc
+        out["words"], out["counts"] = W.reshape((N, K) + wshape), Cc
         return out
 
     def results(self, raise_on_limit=True, only=None):

@@ -59,6 +59,11 @@ def test_targets_beyond_the_limits_are_written_with_a_filter(capsys):
     alone = list(application.assemble(None, variants, {"c1": _NSeq()}, source, ploidy=4, steps=120, burn=60, chains=2, seed=3,
                                       targets=[targets[0], targets[3], targets[4], targets[5]]))
     assert alone == [lines[0], lines[3], lines[4], lines[5]]
+    # ... nor on the host path: the block path formats units of the general sampler from the summary arrays (two words per
+    # haplotype: round 5), the per-locus path through results() -- the same record lines
+    per_locus = list(application.assemble(None, variants, {"c1": _NSeq()}, source, ploidy=4, steps=120, burn=60, chains=2, seed=3, targets=targets,
+                                          block_path=False))
+    assert per_locus == lines
     from mchap_amd import vcfheader
 
     assert any(ln.startswith("##FILTER=<ID=LIMIT,") for ln in vcfheader.header_lines("assemble", "x", ["S1"], [("c1", 9000)]))
