@@ -1451,6 +1451,7 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
             for s in samples:
                 groups.setdefault((M, int(max(locus.n_alleles)), int(keep.sum()), int(ploidy_of(s))), []).append((ri, s))
         results = {}
+        pending = []
         for (M, A, H, K), all_members in groups.items():
             Rmax = max(max(len(units[ri]["reads"][s]["dists"]), 1) for ri, s in all_members)
             # device bytes per unit: reads, traces, and the chains' tables of remembered likelihoods (the workspace)
@@ -1475,15 +1476,18 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
                         frs[i] = locus.frequencies[units[ri]["keep"]]
                 model = CallingMCMC(ploidy=K, haplotypes=haps[0], steps=steps, chains=chains, random_seed=seed, step_type=step_type)
                 try:
-                    # (the traces stay on the device: what a record reads off them is summarised there -- round 5)
-                    traces = model.fit_batch_summaries(reads, counts, haplotypes=haps, prior=(Fs, frs) if has_prior else None,
-                                                       stream_ids=np.zeros(U, dtype=np.uint64), burn=burn,
-                                                       incongruence_threshold=incongruence_threshold)
+                    # (the traces stay on the device: what a record reads off them is summarised there; the shapes of a block of
+                    # records are enqueued on streams of their own and waited for together -- round 5)
+                    handle = model.start_batch_summaries(reads, counts, haplotypes=haps, prior=(Fs, frs) if has_prior else None,
+                                                         stream_ids=np.zeros(U, dtype=np.uint64), burn=burn,
+                                                         incongruence_threshold=incongruence_threshold, stream=_call_stream(len(pending)))
                 except NotImplementedError as e:  # (a shape beyond the sampler's limits: FILTER=LIMIT records, the file goes on)
                     _limit_units(units, members, "call", "%d haplotypes x ploidy %d: %s" % (H, K, e))
                     continue
-                for key, tr in zip(members, traces):
-                    results[key] = tr
+                pending.append((model, handle, members))
+        for model, handle, members in pending:
+            for key, tr in zip(members, model.finish_batch_summaries(handle)):
+                results[key] = tr
         for ri, unit in enumerate(units):
             rec, locus = unit["rec"], unit["locus"]
             H, M = locus.haplotypes.shape
@@ -1522,6 +1526,23 @@ def call(vcf_path, sample_bams, ploidy=2, report=(), base_error_rate=0.0024, use
             alts = unit["locus"].sequences[1:]  # (the input's, minus the alleles --filter-input-haplotypes removed)
             alt = ",".join(alts) if alts else "."
             yield "\t".join([rec["chrom"], str(rec["pos"]), rec["id"], rec["ref"], alt, ".", flt, info, fmt] + [cols[s] for s in samples])
+
+
+_CALL_STREAMS = []
+
+
+def _call_stream(i):
+    """One of four side streams (made on first use) for the i-th batch of a block of records; None without a GPU runtime."""
+    try:
+        import torch
+
+        if not torch.cuda.is_available():
+            return None
+        while len(_CALL_STREAMS) < 4:
+            _CALL_STREAMS.append(torch.cuda.Stream())
+        return _CALL_STREAMS[i % 4]
+    except Exception:
+        return None
 
 
 class _Forced(dict):

@@ -19,6 +19,14 @@ __all__ = ["CallingMCMC", "CallSummary", "GenotypeAllelesMultiTrace", "Posterior
 _STEP_TYPES = {"Gibbs": 0, "Metropolis-Hastings": 1}
 
 
+class _null_context(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def _vcf_index(genotypes):
     """VCF order index of every row of ascending alleles [n, K]: sum_i C(g_i + i, i + 1)."""
     g = np.asarray(genotypes, dtype=np.int64)
@@ -109,6 +117,14 @@ class CallingMCMC(Assembler):
         .posterior(), PosteriorGenotypeAllelesDistribution.mode(genotype_support=True) and replicate_incongruence
         (calling/classes.py:166-263, 303-362) -- so that a unit comes back as a few hundred bytes instead of its trace.
         Arguments as fit_batch.  Returns one CallSummary per unit."""
+        return self.finish_batch_summaries(self.start_batch_summaries(reads, read_counts, initial, haplotypes, prior, stream_ids, burn,
+                                                                      incongruence_threshold, max_states))
+
+    def start_batch_summaries(self, reads, read_counts=None, initial=None, haplotypes=None, prior=None, stream_ids=None, burn=0,
+                              incongruence_threshold=0.6, max_states=512, stream=None):
+        """The first half of fit_batch_summaries: uploads, the sampler and the summary launches enqueued on `stream` (a
+        torch.cuda.Stream; default: the current one) without waiting for them -- several batches (the shapes of a block of
+        records) then run side by side.  Returns the handle finish_batch_summaries takes."""
         from .device import _torch
 
         reads = np.ascontiguousarray(reads, dtype=np.float64)
@@ -125,59 +141,80 @@ class CallingMCMC(Assembler):
         n_obs = Cn * (S - burn)
         if M == 0 or K > _lib.MAX_PLOIDY:
             # (no variants: the constant trace; a ploidy beyond the device summary's: the host classes on the traces)
-            return [CallSummary.of_trace(t.burn(burn), incongruence_threshold)
-                    for t in self.fit_batch(reads, read_counts, initial, haplotypes, prior, stream_ids)]
+            return dict(done=[CallSummary.of_trace(t.burn(burn), incongruence_threshold)
+                              for t in self.fit_batch(reads, read_counts, initial, haplotypes, prior, stream_ids)])
         if R == 0:
             reads = np.full((U, 1, M, A), np.nan)
             read_counts = None
             R = 1
         torch = _torch()
         dev = torch.device("cuda", torch.cuda.current_device())
-        L = _lib.lib()
-        pr = self.prior if prior is None else prior
-        has = 0 if pr is None else 1
-        F = fr = None
-        if pr is not None:
-            F = np.array(np.broadcast_to(np.asarray(pr[0], dtype=np.float64), (U,)))
-            if pr[1] is not None:
-                fr = np.array(np.broadcast_to(np.asarray(pr[1], dtype=np.float64), (U, H)))
-        up = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
-        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        d_reads, d_rc, d_haps = up(reads, np.float64), up(read_counts, np.int64), up(haps, np.int8)
-        d_F, d_fr, d_ini = up(F, np.float64), up(fr, np.float64), up(initial, np.int64)
-        if initial is not None:
-            assert tuple(d_ini.shape) == (U, K)
-        sid = np.ascontiguousarray(np.arange(U, dtype=np.uint64) if stream_ids is None else stream_ids, dtype=np.uint64)
-        d_sid = torch.from_numpy(sid.view(np.int64)).to(dev)
-        seed = self.random_seed
-        if seed is None:
-            seed = int(np.random.randint(0, 2**31 - 1))
-        d_g = torch.empty(U * Cn * S * K, dtype=torch.int64, device=dev)
-        d_l = torch.empty(U * Cn * S, dtype=torch.float64, device=dev)
-        d_st = torch.empty(U, dtype=torch.int32, device=dev)
-        ws = int(L.mchap_call_mcmc_workspace_bytes_for(U, R, H, K, S, Cn))
-        d_ws = torch.empty(max(ws, 16), dtype=torch.uint8, device=dev)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(L.mchap_call_mcmc_batch_device(U, p(d_reads), R, M, A, p(d_rc), p(d_haps), H, K, has, p(d_F), p(d_fr), p(d_ini), p(d_sid), S, Cn,
-                                                  _STEP_TYPES[self.step_type], C.c_uint64(int(seed) & (2**64 - 1)), p(d_g), p(d_l), p(d_st), p(d_ws),
-                                                  C.c_int64(ws), stream))
-        units = np.zeros(U, dtype=_lib.UNIT_DTYPE)
-        units["ploidy"] = K
-        units["trace_off"] = np.arange(U, dtype=np.int64) * (Cn * S * K)
-        d_units = torch.from_numpy(units.view(np.uint8).reshape(-1)).to(dev)
-        ms = int(max_states)
-        d_words = torch.empty(U * ms * K, dtype=torch.int64, device=dev)
-        d_counts = torch.empty(U * ms, dtype=torch.int32, device=dev)
-        d_n = torch.empty(U, dtype=torch.int32, device=dev)
-        d_stats = torch.empty(U * 2, dtype=torch.float64, device=dev)
-        d_mode = torch.empty(U, dtype=torch.int32, device=dev)
-        d_mw = torch.empty(U * K, dtype=torch.int64, device=dev)
-        d_mc = torch.empty(U, dtype=torch.int32, device=dev)
-        d_mci = torch.empty(U, dtype=torch.int32, device=dev)
-        thr = C.c_double(float(incongruence_threshold))
-        _lib.check(L.mchap_trace_posterior_batch_device(U, p(d_units), S, Cn, burn, p(d_g), ms, K, p(d_words), p(d_counts), p(d_n), p(d_stats),
-                                                        p(d_mode), p(d_mw), p(d_mc), stream))
-        _lib.check(L.mchap_call_incongruence_batch_device(U, p(d_units), S, Cn, burn, p(d_g), K, thr, p(d_mci), stream))
+        with (torch.cuda.stream(stream) if stream is not None else _null_context()):
+            L = _lib.lib()
+            pr = self.prior if prior is None else prior
+            has = 0 if pr is None else 1
+            F = fr = None
+            if pr is not None:
+                F = np.array(np.broadcast_to(np.asarray(pr[0], dtype=np.float64), (U,)))
+                if pr[1] is not None:
+                    fr = np.array(np.broadcast_to(np.asarray(pr[1], dtype=np.float64), (U, H)))
+            up = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
+            p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+            d_reads, d_rc, d_haps = up(reads, np.float64), up(read_counts, np.int64), up(haps, np.int8)
+            d_F, d_fr, d_ini = up(F, np.float64), up(fr, np.float64), up(initial, np.int64)
+            if initial is not None:
+                assert tuple(d_ini.shape) == (U, K)
+            sid = np.ascontiguousarray(np.arange(U, dtype=np.uint64) if stream_ids is None else stream_ids, dtype=np.uint64)
+            d_sid = torch.from_numpy(sid.view(np.int64)).to(dev)
+            seed = self.random_seed
+            if seed is None:
+                seed = int(np.random.randint(0, 2**31 - 1))
+            d_g = torch.empty(U * Cn * S * K, dtype=torch.int64, device=dev)
+            d_l = torch.empty(U * Cn * S, dtype=torch.float64, device=dev)
+            d_st = torch.empty(U, dtype=torch.int32, device=dev)
+            ws = int(L.mchap_call_mcmc_workspace_bytes_for(U, R, H, K, S, Cn))
+            d_ws = torch.empty(max(ws, 16), dtype=torch.uint8, device=dev)
+            t_stream = torch.cuda.current_stream()
+            stream = C.c_void_p(t_stream.cuda_stream)
+            _lib.check(L.mchap_call_mcmc_batch_device(U, p(d_reads), R, M, A, p(d_rc), p(d_haps), H, K, has, p(d_F), p(d_fr), p(d_ini), p(d_sid), S, Cn,
+                                                      _STEP_TYPES[self.step_type], C.c_uint64(int(seed) & (2**64 - 1)), p(d_g), p(d_l), p(d_st), p(d_ws),
+                                                      C.c_int64(ws), stream))
+            units = np.zeros(U, dtype=_lib.UNIT_DTYPE)
+            units["ploidy"] = K
+            units["trace_off"] = np.arange(U, dtype=np.int64) * (Cn * S * K)
+            d_units = torch.from_numpy(units.view(np.uint8).reshape(-1)).to(dev)
+            ms = int(max_states)
+            d_words = torch.empty(U * ms * K, dtype=torch.int64, device=dev)
+            d_counts = torch.empty(U * ms, dtype=torch.int32, device=dev)
+            d_n = torch.empty(U, dtype=torch.int32, device=dev)
+            d_stats = torch.empty(U * 2, dtype=torch.float64, device=dev)
+            d_mode = torch.empty(U, dtype=torch.int32, device=dev)
+            d_mw = torch.empty(U * K, dtype=torch.int64, device=dev)
+            d_mc = torch.empty(U, dtype=torch.int32, device=dev)
+            d_mci = torch.empty(U, dtype=torch.int32, device=dev)
+            thr = C.c_double(float(incongruence_threshold))
+            _lib.check(L.mchap_trace_posterior_batch_device(U, p(d_units), S, Cn, burn, p(d_g), ms, K, p(d_words), p(d_counts), p(d_n), p(d_stats),
+                                                            p(d_mode), p(d_mw), p(d_mc), stream))
+            _lib.check(L.mchap_call_incongruence_batch_device(U, p(d_units), S, Cn, burn, p(d_g), K, thr, p(d_mci), stream))
+            return dict(torch=torch, stream=t_stream, dev=dev, L=L, p=p, U=U, K=K, S=S, Cn=Cn, H=H, burn=burn, n_obs=n_obs, ms=ms, thr=thr,
+                        incongruence_threshold=incongruence_threshold, d_units=d_units, d_g=d_g, d_l=d_l, d_st=d_st, d_words=d_words,
+                        d_counts=d_counts, d_n=d_n, d_stats=d_stats, d_mode=d_mode, d_mw=d_mw, d_mc=d_mc, d_mci=d_mci,
+                        keep=(d_reads, d_rc, d_haps, d_F, d_fr, d_ini, d_sid, d_ws))
+
+    def finish_batch_summaries(self, h):
+        """The second half: waits for the batch, settles the units that need the listed launch (or, beyond it, the host classes) and
+        returns one CallSummary per unit."""
+        if "done" in h:
+            return h["done"]
+        with h["torch"].cuda.stream(h["stream"]):
+            return self._finish(dict(h, stream=C.c_void_p(h["stream"].cuda_stream)))
+
+    def _finish(self, v):
+        torch, L, p, dev, stream = v["torch"], v["L"], v["p"], v["dev"], v["stream"]
+        U, K, S, Cn, H, burn, n_obs, ms, thr = v["U"], v["K"], v["S"], v["Cn"], v["H"], v["burn"], v["n_obs"], v["ms"], v["thr"]
+        incongruence_threshold = v["incongruence_threshold"]
+        d_units, d_g, d_l, d_st, d_words, d_counts = v["d_units"], v["d_g"], v["d_l"], v["d_st"], v["d_words"], v["d_counts"]
+        d_n, d_stats, d_mode, d_mw, d_mc, d_mci = v["d_n"], v["d_stats"], v["d_mode"], v["d_mw"], v["d_mc"], v["d_mci"]
         status = d_st.cpu().numpy()
         if (status != 0).any():
             raise _lib.MchapLibraryError("mchap_hip: the table of remembered likelihoods of a chain filled up")

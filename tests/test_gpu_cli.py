@@ -132,10 +132,11 @@ def test_call_program_with_device_summaries_writes_the_records_of_the_host_class
     a, b = _io.StringIO(), _io.StringIO()
     cli.run(argv, a)
 
-    def by_host(self, reads, read_counts=None, initial=None, haplotypes=None, prior=None, stream_ids=None, burn=0, incongruence_threshold=0.6, max_states=512):
-        return [CallSummary.of_trace(t.burn(burn), incongruence_threshold) for t in self.fit_batch(reads, read_counts, initial, haplotypes, prior, stream_ids)]
+    def by_host(self, reads, read_counts=None, initial=None, haplotypes=None, prior=None, stream_ids=None, burn=0, incongruence_threshold=0.6, max_states=512,
+                stream=None):
+        return dict(done=[CallSummary.of_trace(t.burn(burn), incongruence_threshold) for t in self.fit_batch(reads, read_counts, initial, haplotypes, prior, stream_ids)])
 
-    monkeypatch.setattr(CallingMCMC, "fit_batch_summaries", by_host)
+    monkeypatch.setattr(CallingMCMC, "start_batch_summaries", by_host)
     cli.run(argv, b)
     ra, rb = _records(a.getvalue()), _records(b.getvalue())
     assert len(ra) == len(rb) > 0 and ra == rb

@@ -17,14 +17,15 @@ try:
     cli.run(["mchap_amd", "assemble", "--bam"] + job["bams"] + ["--targets", job["bed"], "--variants", job["vcf"], "--reference", job["fasta"], "--ploidy", "4"], out)
     open(vcf, "w").write(out.getvalue())
     argv = ["mchap_amd", "call", "--bam"] + job["bams"] + ["--haplotypes", vcf, "--ploidy", "4"]
-    device = CallingMCMC.fit_batch_summaries
+    device = CallingMCMC.start_batch_summaries
 
-    def by_host(self, reads, read_counts=None, initial=None, haplotypes=None, prior=None, stream_ids=None, burn=0, incongruence_threshold=0.6, max_states=512):
-        return [CallSummary.of_trace(t.burn(burn), incongruence_threshold) for t in self.fit_batch(reads, read_counts, initial, haplotypes, prior, stream_ids)]
+    def by_host(self, reads, read_counts=None, initial=None, haplotypes=None, prior=None, stream_ids=None, burn=0, incongruence_threshold=0.6, max_states=512,
+                stream=None):
+        return dict(done=[CallSummary.of_trace(t.burn(burn), incongruence_threshold) for t in self.fit_batch(reads, read_counts, initial, haplotypes, prior, stream_ids)])
 
     texts = {}
     for name, fn in (("device summaries", device), ("host classes", by_host), ("device summaries", device)):
-        CallingMCMC.fit_batch_summaries = fn
+        CallingMCMC.start_batch_summaries = fn
         o = _io.StringIO()
         t0 = time.perf_counter()
         cli.run(argv, o)
